@@ -1,0 +1,73 @@
+"""ctypes binding of libmodex_hip.so (the C ABI declared in include/modex_hip.h).
+
+No fallback: if the shared library is missing, or a call returns a non-zero status, this raises.
+Device pointers are borrowed from torch tensors; launches go to torch's current HIP stream.
+"""
+import ctypes
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "_lib", "libmodex_hip.so")
+ABI_VERSION = 1
+
+_ERR = {-1: "MX_ERR_ARG (bad argument)", -2: "MX_ERR_UNSUPPORTED (size not supported)",
+        -3: "MX_ERR_LAUNCH (HIP launch error)"}
+
+_P, _I64, _I32, _F32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_float
+
+# name -> argtypes; must list every symbol include/modex_hip.h declares (tests check this)
+SIGNATURES = {
+    "mx_abi_version": [],
+    "mx_lfo_synth": [_P, _P, _P, _P, _P, _I64, _I64, _I64, _F32, _P, _P],
+    "mx_interp_linear": [_P, _I64, _I64, _I64, _P, _P],
+    "mx_flanger_fwd": [_P, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _I32, _P, _I64, _I64, _I64,
+                       _P, _P, _P, _P, _P],
+}
+
+_lib: Optional[ctypes.CDLL] = None
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+def load() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(SO_PATH):
+            raise HipLibraryError(
+                f"{SO_PATH} not found: build it with `python -m mod_extraction_amd.build` "
+                "(there is no CPU fallback)")
+        lib = ctypes.CDLL(SO_PATH)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
+            fn.argtypes = argtypes
+            fn.restype = ctypes.c_int
+        if lib.mx_abi_version() != ABI_VERSION:
+            raise HipLibraryError(f"ABI mismatch: library {lib.mx_abi_version()} != binding {ABI_VERSION}")
+        _lib = lib
+    return _lib
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    """Device pointer of a contiguous CUDA(HIP) tensor, or NULL for None."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise HipLibraryError("mod_extraction_amd ops need tensors on a HIP device (no CPU fallback)")
+    if not t.is_contiguous():
+        raise HipLibraryError("non-contiguous tensor passed to a HIP kernel")
+    return t.data_ptr()
+
+
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name: str, *args) -> None:
+    rc = getattr(load(), name)(*args)
+    if rc != 0:
+        raise HipLibraryError(f"{name} failed: {_ERR.get(rc, rc)}")

@@ -1,0 +1,120 @@
+"""Host mirror of mod_extraction/fx.py: same class, constructor and forward signature
+(fx.py:25-44,121-130); the per-sample delay-line recurrence runs in the ``mx_flanger_fwd`` HIP
+kernel (one wavefront per clip, delay line in LDS) instead of 88 200 python iterations.
+"""
+from typing import Dict, Optional, Union
+
+import torch
+from torch import Tensor as T, nn
+
+from . import _hip
+
+Param = Union[float, T]
+
+
+def delay_samples(ms: float, sr: float) -> int:
+    """fx.py:40-41."""
+    return int(((ms / 1000.0) * sr) + 0.5)
+
+
+def apply_tremolo(x: T, mod_sig: T, mix: Param = 1.0) -> T:
+    """fx.py:13-22 (a single fused elementwise expression; torch-on-HIP plumbing, not a kernel)."""
+    assert x.ndim == 3 and x.size(0) == mod_sig.size(0) and x.size(-1) == mod_sig.size(-1)
+    if mod_sig.ndim == 2:
+        mod_sig = mod_sig.unsqueeze(1).expand(-1, x.size(1), -1)
+    if isinstance(mix, T):
+        assert mix.size(0) == x.size(0)
+    return ((1.0 - mix) * x) + (mix * mod_sig * x)
+
+
+def _check_param(param: Param, bs: int, can_be_one: bool = True) -> None:
+    """fx.py:46-70: all parameters >= 0; feedback < 1 strictly, the others <= 1."""
+    if isinstance(param, T):
+        assert param.shape == (bs,)
+        lo, hi = float(param.min()), float(param.max())
+    else:
+        lo = hi = float(param)
+    assert lo >= 0
+    if can_be_one:
+        assert hi <= 1.0
+    else:
+        assert hi < 1.0
+
+
+def derive_clip_constants(bs: int, device: torch.device, max_min_delay_samples: int,
+                          max_lfo_delay_samples: int, feedback: Param, min_delay_width: Param,
+                          width: Param, depth: Param, mix: Param, check: bool = True) -> Dict[str, T]:
+    """Per-clip fp32 constants of fx.py:98-99,114-117, rounded where the reference rounds them: a
+    tensor parameter meets the integer sample count in fp32, a python float meets it in double."""
+    if check:
+        _check_param(feedback, bs, can_be_one=False)
+        for p in (min_delay_width, width, depth, mix):
+            _check_param(p, bs)
+
+    def vec(p: Param) -> T:
+        if isinstance(p, T):
+            return p.to(device=device, dtype=torch.float32).contiguous()
+        return torch.full((bs,), float(p), device=device, dtype=torch.float32)
+
+    def times_int(p: Param, k: int) -> T:
+        if isinstance(p, T):
+            return (vec(p) * float(k)).contiguous()
+        return torch.full((bs,), float(p) * k, device=device, dtype=torch.float32)
+
+    mix_v = vec(mix)
+    omm = (1.0 - mix_v) if isinstance(mix, T) else torch.full((bs,), 1.0 - float(mix), device=device,
+                                                             dtype=torch.float32)
+    return {"lfo_scale": times_int(width, max_lfo_delay_samples),
+            "min_delay": times_int(min_delay_width, max_min_delay_samples),
+            "feedback": vec(feedback), "depth": vec(depth), "mix": mix_v, "one_minus_mix": omm.contiguous()}
+
+
+def flanger_forward(x: T, mod_sig: T, consts: Dict[str, T], max_delay: T, max_delay_max: int,
+                    rows: Optional[T] = None, out: Optional[T] = None, mod_up: Optional[T] = None,
+                    dbg_prev: Optional[T] = None, dbg_frac: Optional[T] = None) -> T:
+    """Launch mx_flanger_fwd.  x (B,N) fp32, mod_sig (B,n_mod) fp32, max_delay (B,) int32."""
+    B, N = x.shape
+    y = out if out is not None else torch.empty_like(x)
+    _hip.call("mx_flanger_fwd", _hip.ptr(x), _hip.ptr(mod_sig), mod_sig.size(-1),
+              _hip.ptr(consts["lfo_scale"]), _hip.ptr(consts["min_delay"]), _hip.ptr(consts["feedback"]),
+              _hip.ptr(consts["depth"]), _hip.ptr(consts["mix"]), _hip.ptr(consts["one_minus_mix"]),
+              _hip.ptr(max_delay), int(max_delay_max), _hip.ptr(rows), 0 if rows is None else rows.numel(),
+              B, N, _hip.ptr(y), _hip.ptr(mod_up), _hip.ptr(dbg_prev), _hip.ptr(dbg_frac), _hip.stream())
+    return y
+
+
+class MonoFlangerChorusModule(nn.Module):
+    def __init__(self, batch_size: int, n_ch: int, n_samples: int, sr: float,
+                 max_min_delay_ms: float, max_lfo_delay_ms: float) -> None:
+        super().__init__()
+        if n_ch != 1:
+            raise NotImplementedError("mono only (every reference call site uses n_ch=1)")
+        self.batch_size = batch_size
+        self.n_ch = n_ch
+        self.n_samples = n_samples
+        self.sr = sr
+        self.max_min_delay_ms = max_min_delay_ms
+        self.max_lfo_delay_ms = max_lfo_delay_ms
+        self.max_min_delay_samples = delay_samples(max_min_delay_ms, sr)
+        self.max_lfo_delay_samples = delay_samples(max_lfo_delay_ms, sr)
+        self.max_delay_samples = self.max_min_delay_samples + self.max_lfo_delay_samples
+        # the reference registers delay_buf / out_buf buffers (fx.py:43-44); here the delay line
+        # lives in LDS for the duration of the kernel and the output is the returned tensor.
+
+    def forward(self, x: T, mod_sig: T, feedback: Param = 0.0, min_delay_width: Param = 1.0,
+                width: Param = 1.0, depth: Param = 1.0, mix: Param = 1.0) -> T:
+        assert x.ndim == 3
+        bs, n_ch, n = x.shape
+        assert n_ch == 1
+        assert mod_sig.size(0) == bs
+        if mod_sig.ndim == 3:
+            assert mod_sig.size(1) == 1
+        with torch.no_grad():
+            consts = derive_clip_constants(bs, x.device, self.max_min_delay_samples,
+                                           self.max_lfo_delay_samples, feedback, min_delay_width,
+                                           width, depth, mix)
+            md = torch.full((bs,), self.max_delay_samples, device=x.device, dtype=torch.int32)
+            xc = x.reshape(bs, n).contiguous().float()
+            mc = mod_sig.reshape(bs, -1).contiguous().float()
+            y = flanger_forward(xc, mc, consts, md, self.max_delay_samples)
+        return y.view(bs, 1, n)

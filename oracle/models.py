@@ -1,0 +1,142 @@
+"""Oracle restatement of mod_extraction/models.py (TEST INFRASTRUCTURE ONLY), torch on the CPU.
+
+* ``mel_frontend`` restates ``torchaudio.transforms.MelSpectrogram`` (torchaudio==0.13.1, absent
+  from /root/reference and from this image) as used at models.py:170-181,199-208 -- from its
+  published algorithm: ``torch.stft`` (hann periodic window, centre, reflect pad) -> ``abs().pow(2)``
+  -> HTK triangular filter bank without normalisation -> optional SpecAugment masks -> clip -> log.
+  The STFT is torch's own (pinned); the filter-bank construction and masking are PARITY UNPINNED.
+* ``Spectral2DCNN`` restates models.py:128-215 with the same ``torch.nn`` modules in the same
+  ``nn.Sequential`` positions, so state-dict keys match the reference
+  (``cnn.{1,5,..}.weight|bias``, ``cnn.{3,7,..}.weight``, ``output.weight|bias`` and the buffers
+  ``spectrogram.spectrogram.window``, ``spectrogram.mel_scale.fb``).  Pinned against the
+  reference's own ``models.Spectral2DCNN.cnn``/``output`` stack (imported with a name-only
+  torchaudio stub) by tests/golden/make_golden_nn.py.
+* ``LSTMEffectModel`` restates models.py:292-339; pinned with the 7 shipped LSTM-64 weight files.
+"""
+import math
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+from torch import Tensor as T, nn
+
+
+# ---- torchaudio.functional.melscale_fbanks(norm=None, mel_scale="htk") -----------------------
+def htk_mel_filterbank(n_freqs: int, f_min: float, f_max: float, n_mels: int, sample_rate: int) -> T:
+    all_freqs = torch.linspace(0, sample_rate // 2, n_freqs)
+    m_lo = 2595.0 * math.log10(1.0 + (f_min / 700.0))
+    m_hi = 2595.0 * math.log10(1.0 + (f_max / 700.0))
+    m_pts = torch.linspace(m_lo, m_hi, n_mels + 2)
+    f_pts = 700.0 * (10.0 ** (m_pts / 2595.0) - 1.0)
+    f_diff = f_pts[1:] - f_pts[:-1]
+    slopes = f_pts.unsqueeze(0) - all_freqs.unsqueeze(1)          # (n_freqs, n_mels + 2)
+    down = (-1.0 * slopes[:, :-2]) / f_diff[:-1]
+    up = slopes[:, 2:] / f_diff[1:]
+    return torch.max(torch.zeros(1), torch.min(down, up))         # (n_freqs, n_mels)
+
+
+def specaugment_bounds(size: int, mask_param: int) -> Tuple[int, int]:
+    """torchaudio.functional.mask_along_axis (one mask for the whole batch): two torch.rand(1)
+    draws, ``value`` then ``min_value``; masked range is [int(min_value), int(min_value)+int(value))."""
+    value = torch.rand(1) * mask_param
+    min_value = torch.rand(1) * (size - value)
+    start = int(min_value.long())
+    return start, start + int(value.long())
+
+
+class _Holder(nn.Module):
+    """Namespace module so buffers get the torchaudio key names."""
+
+
+class MelFrontEnd(nn.Module):
+    def __init__(self, sr: int, n_fft: int, hop_len: int, n_mels: int) -> None:
+        super().__init__()
+        self.n_fft, self.hop_len, self.n_mels = n_fft, hop_len, n_mels
+        self.spectrogram = _Holder()
+        self.spectrogram.register_buffer("window", torch.hann_window(n_fft))
+        self.mel_scale = _Holder()
+        self.mel_scale.register_buffer("fb", htk_mel_filterbank(n_fft // 2 + 1, 0.0, float(sr // 2), n_mels, sr))
+
+    def forward(self, x: T) -> T:
+        shape = x.shape
+        spec = torch.stft(x.reshape(-1, shape[-1]), self.n_fft, self.hop_len, self.n_fft,
+                          self.spectrogram.window, center=True, pad_mode="reflect", normalized=False,
+                          onesided=True, return_complex=True)
+        power = spec.abs().pow(2.0)
+        power = power.reshape(shape[:-1] + power.shape[-2:])       # (B, C, n_freqs, frames)
+        return torch.matmul(power.transpose(-1, -2), self.mel_scale.fb).transpose(-1, -2)
+
+
+class Spectral2DCNN(nn.Module):
+    def __init__(self, in_ch: int = 1, n_samples: int = 88200, sr: float = 44100, n_fft: int = 1024,
+                 hop_len: int = 256, n_mels: int = 256, kernel_size: Tuple[int, int] = (5, 13),
+                 out_channels: Optional[List[int]] = None, bin_dilations: Optional[List[int]] = None,
+                 temp_dilations: Optional[List[int]] = None, pool_size: Tuple[int, int] = (3, 1),
+                 latent_dim: int = 1, freq_mask_amount: float = 0.0, time_mask_amount: float = 0.0,
+                 use_ln: bool = True, eps: float = 1e-7) -> None:
+        super().__init__()
+        out_channels = [64] * 5 if out_channels is None else list(out_channels)
+        bin_dilations = [1] * len(out_channels) if bin_dilations is None else list(bin_dilations)
+        temp_dilations = [2 ** i for i in range(len(out_channels))] if temp_dilations is None else list(temp_dilations)
+        assert pool_size[1] == 1 and len(out_channels) == len(bin_dilations) == len(temp_dilations)
+        self.eps, self.latent_dim = eps, latent_dim
+        self.n_frames = n_samples // hop_len + 1
+        self.freq_mask_param = int(freq_mask_amount * n_mels)
+        self.time_mask_param = int(time_mask_amount * self.n_frames)
+        self.freq_mask_amount, self.time_mask_amount = freq_mask_amount, time_mask_amount
+        self.spectrogram = MelFrontEnd(int(sr), n_fft, hop_len, n_mels)
+        stack, bins, c_in = [], n_mels, in_ch
+        for c_out, bd, td in zip(out_channels, bin_dilations, temp_dilations):
+            if use_ln:
+                stack.append(nn.LayerNorm([bins, self.n_frames], elementwise_affine=False))
+            stack += [nn.Conv2d(c_in, c_out, tuple(kernel_size), stride=(1, 1), dilation=(bd, td), padding="same"),
+                      nn.MaxPool2d(kernel_size=tuple(pool_size)), nn.PReLU(num_parameters=c_out)]
+            c_in, bins = c_out, bins // pool_size[0]
+        self.cnn = nn.Sequential(*stack)
+        self.output = nn.Conv1d(out_channels[-1], latent_dim, kernel_size=(1,))
+
+    def log_mel(self, x: T, masks: Optional[Sequence[int]] = None) -> T:
+        """models.py:199-208.  ``masks`` = (f0, f1, t0, t1) injects the SpecAugment ranges (tests);
+        None in training mode draws them like torchaudio does."""
+        m = self.spectrogram(x)
+        if masks is None and self.training:
+            f0 = f1 = t0 = t1 = 0
+            if self.freq_mask_amount > 0:
+                f0, f1 = specaugment_bounds(m.size(-2), self.freq_mask_param)
+            if self.time_mask_amount > 0:
+                t0, t1 = specaugment_bounds(m.size(-1), self.time_mask_param)
+            masks = (f0, f1, t0, t1)
+        if masks is not None:
+            f0, f1, t0, t1 = masks
+            m = m.clone()
+            m[..., f0:f1, :] = 0.0
+            m[..., :, t0:t1] = 0.0
+        return torch.log(torch.clip(m, min=self.eps))
+
+    def forward(self, x: T, masks: Optional[Sequence[int]] = None) -> Tuple[T, T]:
+        assert x.ndim == 3
+        latent = torch.mean(self.cnn(self.log_mel(x, masks)), dim=-2)      # models.py:209-211
+        return torch.sigmoid(self.output(latent)), latent                 # models.py:213-215
+
+
+class LSTMEffectModel(nn.Module):
+    """models.py:292-339 (HiddenStateModel + LSTMEffectModel)."""
+
+    def __init__(self, in_ch: int = 1, out_ch: int = 1, n_hidden: int = 64, latent_dim: int = 1) -> None:
+        super().__init__()
+        self.in_ch, self.out_ch, self.n_hidden, self.latent_dim = in_ch, out_ch, n_hidden, latent_dim
+        self.lstm = nn.LSTM(in_ch + latent_dim, n_hidden, batch_first=True)
+        self.fc = nn.Linear(n_hidden, out_ch)
+        self.hidden: Optional[Tuple[T, T]] = None
+
+    def clear_hidden(self) -> None:
+        self.hidden = None
+
+    def detach_hidden(self) -> None:
+        if self.hidden is not None:
+            self.hidden = tuple(h.detach().clone() for h in self.hidden)
+
+    def forward(self, x: T, latent: T) -> T:
+        assert x.ndim == 3 and latent.shape == (x.size(0), self.latent_dim, x.size(-1))
+        seq = torch.cat([latent, x], dim=1).swapaxes(1, 2)               # LFO first, audio second
+        out, self.hidden = self.lstm(seq, self.hidden)
+        return torch.tanh(self.fc(out).swapaxes(1, 2) + x)

@@ -1,0 +1,112 @@
+"""CPU: the oracle restatements reproduce the golden vectors captured from the real reference
+(tests/golden/make_golden.py).  Bit-exact unless stated."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import fx as ofx, modulations as omod, util as outil
+
+SHAPES = ["cos", "rect_cos", "inv_rect_cos", "tri", "saw", "rsaw", "sqr"]
+
+
+def load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def test_lfo_bit_exact(golden_dir):
+    g = load(golden_dir, "lfo.npz")
+    for i in range(len(g["n"])):
+        y = omod.make_mod_signal(int(g["n"][i]), float(g["sr"][i]), float(g["freq"][i]), float(g["phase"][i]),
+                                 SHAPES[int(g["shape"][i])], float(g["exp"][i])).numpy()
+        assert np.array_equal(y, g[f"y{i}"], equal_nan=True), (i, SHAPES[int(g["shape"][i])])
+
+
+def test_lfo_phaser_ground_truth(golden_dir):
+    g = load(golden_dir, "lfo_phaser_gt.npz")
+    for i in range(len(g["rate"])):
+        full = omod.make_mod_signal(int(g["proc_n"][i]), 44100, float(g["rate"][i]), math.pi / 2, "cos")
+        s = int(g["start"][i])
+        crop = outil.linear_interpolate_last_dim(full[s:s + 88200], 882).numpy()
+        assert np.array_equal(crop, g["y"][i])
+
+
+def test_interp_bit_exact(golden_dir):
+    g = load(golden_dir, "interp.npz")
+    i = 0
+    while f"x{i}" in g:
+        a, b = g[f"n{i}"]
+        y = outil.linear_interpolate_last_dim_np(g[f"x{i}"], int(b))
+        if f"y{i}_idx" in g:
+            assert np.array_equal(y[:, g[f"y{i}_idx"]], g[f"y{i}"])
+            assert np.array_equal(y.astype(np.float64).sum(-1), g[f"y{i}_sum"])
+        else:
+            assert np.array_equal(y, g[f"y{i}"])
+        i += 1
+    assert i == 6
+
+
+def _params(g, ci, pi):
+    is_t = bool(g[f"p_{ci}_{pi}_is_tensor"])
+    p = {}
+    for k in ("feedback", "min_delay_width", "width", "depth", "mix"):
+        v = g[f"p_{ci}_{pi}_{k}"]
+        p[k] = torch.from_numpy(v.astype(np.float32)) if is_t else float(v)
+    return p
+
+
+def test_flanger_bit_exact(golden_dir):
+    g = load(golden_dir, "flanger.npz")
+    for ci in range(int(g["n_cases"])):
+        x = torch.from_numpy(g[f"x_{ci}"]).unsqueeze(1)
+        mod = torch.from_numpy(g[f"mod_{ci}"])
+        mm, ml = g[f"ms_{ci}"]
+        fl = ofx.MonoFlangerChorusModule(x.size(0), 1, x.size(-1), 44100, float(mm), float(ml))
+        for pi in range(int(g["n_psets"])):
+            y = fl(x, mod, **_params(g, ci, pi)).numpy()[:, 0]
+            assert np.array_equal(y, g[f"y_{ci}_{pi}"]), (ci, pi)
+
+
+def test_flanger_full_length(golden_dir):
+    g = load(golden_dir, "flanger_full.npz")
+    torch.manual_seed(int(g["seed"]))
+    x = torch.rand(2, 1, 88200) * 2 - 1
+    assert np.array_equal(x.numpy()[:, 0, ::89], g["x_sub"])
+    lfo = torch.stack([omod.make_mod_signal(882, 441.0, float(f), float(p), SHAPES[int(s)])
+                       for f, p, s in zip(g["freq"], g["phase"], g["shape"])])
+    assert np.array_equal(lfo.numpy(), g["lfo882"])
+    mod = outil.linear_interpolate_last_dim(lfo, 88200)
+    p = {k: torch.from_numpy(g[f"p_{k}"]) for k in ("feedback", "min_delay_width", "width", "depth", "mix")}
+    y = ofx.MonoFlangerChorusModule(2, 1, 88200, 44100, 1.0, 10.0)(x, mod, **p)
+    assert np.array_equal(y.numpy()[:, 0, ::89], g["y_sub"])
+    assert np.array_equal(y.double().sum(-1).numpy()[:, 0], g["y_sum"])
+
+
+@pytest.mark.parametrize("k", [0, 4, 8])
+def test_corner_bookkeeping_bit_exact(golden_dir, k):
+    g = load(golden_dir, "corners.npz")
+    m = torch.from_numpy(g["mod_sig"])
+    ms = omod.smoothen(m, k)
+    assert np.array_equal(ms.numpy(), g[f"smooth_{k}"])
+    top, bot = omod.find_corners(ms)
+    assert np.array_equal(top.numpy().astype(np.int8), g[f"top_{k}"])
+    assert np.array_equal(bot.numpy().astype(np.int8), g[f"bot_{k}"])
+    for mx in (16, 4):
+        s = omod.stretch_corners(ms.clone(), mx, 0).numpy()
+        assert np.array_equal(s, g[f"stretch_{k}_{mx}"], equal_nan=True)
+    assert omod.find_valid_mod_sig_indices(ms) == g[f"valid_{k}"].tolist()
+
+
+def test_param_stream(golden_dir):
+    g = load(golden_dir, "param_stream.npz")
+    torch.manual_seed(43)
+    np.random.seed(43)
+    for i in range(8):
+        assert outil.sample_log_uniform(0.5, 3.0) == g["rate"][i]
+        assert outil.sample_uniform(0.0, 2 * math.pi) == g["phase"][i]
+        assert SHAPES.index(outil.choice(["cos", "rect_cos", "inv_rect_cos", "tri", "saw", "rsaw"])) == g["shape"][i]
+    for name, (lo, hi) in (("feedback", (0.0, 0.7)), ("min_delay_width", (0.0, 1.0)), ("width", (0.25, 1.0)),
+                           ("depth", (0.25, 1.0)), ("mix", (0.25, 1.0))):
+        assert np.array_equal(outil.sample_uniform(lo, hi, n=8).numpy(), g[name])
