@@ -63,6 +63,82 @@ int mx_flanger_fwd(const float *x, const float *mod, int64_t n_mod, const float 
                    int32_t max_delay_max, const int32_t *rows, int64_t n_rows, int64_t B, int64_t N,
                    float *y, float *mod_up, int64_t *dbg_prev, float *dbg_frac, void *stream);
 
+/* ---- K4: log-mel front end -- mod_extraction/models.py:170-181,199-208
+ * (torchaudio MelSpectrogram: n_fft 1024, hann, centre/reflect, power 2, mel filter bank `fb`)
+ * x (planes, N), planes = B*in_ch; window (n_fft,); twiddle (n_fft, 2) = exp(-2 pi i m / n_fft);
+ * fb (n_fft/2+1, n_mels) row-major; band_lo/band_hi (n_mels,) int32 non-zero row range per mel band.
+ * out (planes, n_mels, out_pitch) = log(clip(mel, eps)); out_pitch >= n_frames (352 for 345);
+ * columns >= n_frames are zero.  SpecAugment: mel rows [f0,f1) and frames [t0,t1) are set to 0
+ * before clip/log (0,0 = no mask). */
+int mx_logmel_fwd(const float *x, int64_t planes, int64_t N, const float *window, const float *twiddle,
+                  const float *fb, const int32_t *band_lo, const int32_t *band_hi, int64_t n_fft,
+                  int64_t hop, int64_t n_mels, int64_t n_frames, int64_t out_pitch, float eps, int32_t f0,
+                  int32_t f1, int32_t t0, int32_t t1, float *out, void *stream);
+
+/* ---- K5/K6: one Spectral2DCNN block -- mod_extraction/models.py:183-195
+ * Activation planes are (B, C, H, 352) fp32 (345 valid columns).  Weight packing:
+ * flip=0: (Cout,Cin,5,13) -> [ci][kh][kw][co] (forward); flip=1 -> [co][4-kh][12-kw][ci] (dgrad). */
+int mx_conv_pack_weights(const float *W, int64_t Cout, int64_t Cin, int32_t flip, float *wt, void *stream);
+
+/* mean / rstd (eps inside the sqrt, biased variance) of f(x) per (b,c) plane over H x Wv;
+ * f = PReLU(slope[c]) if slope != NULL else identity.  stats (B, C, 2). */
+int mx_plane_stats(const float *x, const float *slope, int64_t B, int64_t C, int64_t H, int64_t Wv,
+                   float eps, float *stats, void *stream);
+
+/* LayerNorm -> Conv2d(5x13, dilation (1,dilation), same) -> +bias -> MaxPool(2,1), fused.
+ * in (B,Cin,H,352): log-mel (first_layer=1) or the previous block's pooled pre-activations (their
+ * PReLU, slope (Cin,), is applied on the fly).  out (B,64,H/2,352) pooled PRE-activations,
+ * out_amax (B,64,H/2,352) uint8 = which of the two pooled rows won (first max on ties). */
+int mx_conv_block_fwd(const float *in, const float *stats, const float *slope, const float *wt,
+                      const float *bias, int64_t B, int64_t Cin, int64_t H, int64_t Wv, int32_t dilation,
+                      int32_t first_layer, float *out, uint8_t *out_amax, void *stream);
+
+/* data gradient of the block's convolution: G (B,64,H/2,352) = dL/d(pooled pre-activation),
+ * routed through amax; wt_flipped = weights packed with flip=1; dxhat (B,64,H,352). */
+int mx_conv_block_dgrad(const float *G, const uint8_t *amax, const float *wt_flipped, int64_t B, int64_t H,
+                        int64_t Wv, int32_t dilation, float *dxhat, void *stream);
+
+/* weight gradient: x (B,Cin,H,352) = block input before PReLU/LayerNorm (Cin = 64, or 2 for the
+ * first block with slope = NULL); part = workspace of ceil(B*H/rows_per_slab)*65*64*Cin floats;
+ * dW (64,Cin,5,13) torch layout, overwritten. */
+int mx_conv_block_wgrad(const float *G, const uint8_t *amax, const float *x, const float *stats,
+                        const float *slope, int64_t B, int64_t Cin, int64_t H, int64_t Wv, int32_t dilation,
+                        int64_t rows_per_slab, float *part, float *dW, void *stream);
+
+/* LayerNorm backward fused with the backward of the PReLU in front of it.  p (B,C,H,352): input of
+ * that PReLU; dxhat_inout: in = grad w.r.t. the normalised tensor, out = G = dL/dp (in place);
+ * dslope_part (B*C,) per-plane partial of dL/dslope. */
+int mx_ln_prelu_bwd(const float *p, float *dxhat_inout, const float *stats, const float *slope, int64_t B,
+                    int64_t C, int64_t H, int64_t Wv, float *dslope_part, void *stream);
+
+/* out[c] (+)= sum_r part[r*C + c]  (fp64 accumulate; deterministic) */
+int mx_reduce_rows(const float *part, int64_t R, int64_t C, int32_t accumulate, float *out, void *stream);
+
+/* out[plane] = sum over the H x Wv valid region of each (H,352) plane (bias gradients). */
+int mx_plane_sum(const float *x, int64_t planes, int64_t H, int64_t Wv, float *out, void *stream);
+
+/* ---- K7: head -- mod_extraction/models.py:209-215: PReLU -> mean over bins -> Conv1d(C->L,k=1) ->
+ * sigmoid.  p6 (B,C,Hl,352); latent (B,C,Wv) and out (B,L,Wv) dense.  L <= 4. */
+int mx_head_fwd(const float *p6, const float *slope, const float *wout, const float *bout, int64_t B,
+                int64_t C, int64_t Hl, int64_t Wv, int64_t L, float *latent, float *out, void *stream);
+int mx_head_bwd(const float *p6, const float *slope, const float *wout, const float *latent,
+                const float *out, const float *d_out, const float *d_latent, int64_t B, int64_t C,
+                int64_t Hl, int64_t Wv, int64_t L, float *G6, float *dwout_part, float *dbout_part,
+                float *dslope_part, void *stream);
+
+/* ---- K8: LFO loss -- mod_extraction/lightning.py:33-62 + losses.py:70-102 (l1, fdl1, sdl1, mse,
+ * 'mean' reductions).  y_hat, y (B,n), n <= 2048; part (B,4) workspace; losses (5,) = l1, fdl1,
+ * sdl1, mse, weighted total (weights <= 0 are logged but not added); grad (B,n) or NULL. */
+int mx_lfo_loss(const float *y_hat, const float *y, int64_t B, int64_t n, float w_l1, float w_fdl1,
+                float w_sdl1, float w_mse, float *part, float *losses, float *grad, void *stream);
+
+/* ---- K12: AdamW -- torch.optim.AdamW (configs/opt/adam_w.yml), flat fp32 buffers of n elements;
+ * step = 1-based step index; grad_scale multiplies the gradient first (1/world after a sum
+ * all-reduce). */
+int mx_adamw_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n,
+                  int64_t step, float lr, float beta1, float beta2, float eps, float weight_decay,
+                  float grad_scale, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

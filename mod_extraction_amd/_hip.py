@@ -25,6 +25,20 @@ SIGNATURES = {
     "mx_interp_linear": [_P, _I64, _I64, _I64, _P, _P],
     "mx_flanger_fwd": [_P, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _I32, _P, _I64, _I64, _I64,
                        _P, _P, _P, _P, _P],
+    "mx_logmel_fwd": [_P, _I64, _I64, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _F32, _I32, _I32,
+                      _I32, _I32, _P, _P],
+    "mx_conv_pack_weights": [_P, _I64, _I64, _I32, _P, _P],
+    "mx_plane_stats": [_P, _P, _I64, _I64, _I64, _I64, _F32, _P, _P],
+    "mx_conv_block_fwd": [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I32, _I32, _P, _P, _P],
+    "mx_conv_block_dgrad": [_P, _P, _P, _I64, _I64, _I64, _I32, _P, _P],
+    "mx_conv_block_wgrad": [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I32, _I64, _P, _P, _P],
+    "mx_ln_prelu_bwd": [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _P, _P],
+    "mx_reduce_rows": [_P, _I64, _I64, _I32, _P, _P],
+    "mx_plane_sum": [_P, _I64, _I64, _I64, _P, _P],
+    "mx_head_fwd": [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _P, _P, _P],
+    "mx_head_bwd": [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _P, _P, _P, _P, _P],
+    "mx_lfo_loss": [_P, _P, _I64, _I64, _F32, _F32, _F32, _F32, _P, _P, _P, _P],
+    "mx_adamw_step": [_P, _P, _P, _P, _I64, _I64, _F32, _F32, _F32, _F32, _F32, _F32, _P],
 }
 
 _lib: Optional[ctypes.CDLL] = None

@@ -1,0 +1,257 @@
+// conv2d.hip -- K5+K6: LayerNorm -> Conv2d(5x13, dil (1,T), same) -> (+bias, MaxPool(2,1)) of one
+// Spectral2DCNN block as a single implicit-GEMM kernel on the fp32 matrix cores, and the data
+// gradient of the same convolution (reference: mod_extraction/models.py:183-195; torch.nn
+// LayerNorm / Conv2d / MaxPool2d / PReLU semantics).
+//
+// GEMM view per workgroup:  D[co (64)] [w (352)]  for 2 adjacent output rows h0, h0+1
+//     D = sum over (ci, kh, kw) of  Wt[ci][kh][kw][co] * Xhat[ci][h + kh - 2][w + (kw - 6) T]
+// 4 waves = (co tile of 32) x (output row); each wave owns 11 accumulators of 32x32
+// (v_mfma_f32_32x32x2_f32: exact fp32, k-ordered fma chain -- no reduced precision anywhere).
+// The K loop runs over pairs of input channels ("stages"): per stage the 2 x 6 x (352 + 2 HALO)
+// input patch and the 2 x 65 x 64 weight slab are staged in LDS (51-59 KB, two workgroups per CU so
+// one stages while the other multiplies); the two lane halves of a wave read the two channels of
+// the pair, so every LDS fragment read is 32 consecutive floats (conflict free).
+//
+// The input transform is fused into the staging step, so normalised activations never exist in
+// HBM:   forward l>=2:  xhat = (prelu(p_prev) - mean) * rstd   (PReLU of the previous block and
+//                       LayerNorm of this block; zero outside the image = "same" padding of xhat)
+//        forward l=1 :  xhat = (logmel - mean) * rstd
+//        dgrad       :  dz[h][w] = (argmax[h/2][w] == h&1) ? G[h/2][w] : 0   (max-pool routing)
+// Epilogues: forward adds the bias, max-pools the two rows (first-max wins, like torch) and stores
+// the pooled PRE-activation p plus a 1-byte argmax; dgrad stores the two rows of dxhat.
+//
+// Roofline: MFMA-bound (fp32 matrix peak 157 TFLOP/s).  Useful flops per launch are
+// 2*64*Cin*65*H*345 per clip; padded columns 345..351 cost 2 %.
+#include "conv_common.h"
+
+enum { IN_LOGMEL = 0, IN_PRELU = 1, IN_ROUTE = 2 };
+enum { OUT_POOL = 0, OUT_PLAIN = 1 };
+
+struct ConvArgs {
+    const float *in;            // (B, Cin, Hin, PITCH): Hin = H (forward) or H/2 (dgrad: pooled grads G)
+    const unsigned char *amax;  // dgrad: (B, Cin, H/2, PITCH) argmax row of the forward pool
+    const float *stats;         // forward: (B, Cin, 2) = mean, rstd of the (transformed) input plane
+    const float *slope;         // forward l>=2: (Cin,) PReLU slopes of the previous block
+    const float *wt;            // packed weights (Cin, 5, 13, 64): [ci][kh][kw][co]
+    const float *bias;          // forward: (64,)
+    float *out;                 // forward: (B, 64, H/2, PITCH) pooled pre-activations; dgrad: (B, 64, H, PITCH)
+    unsigned char *out_amax;    // forward: (B, 64, H/2, PITCH)
+    int Cin, H, Wv;             // H = conv-domain height (rows of xhat / dz), Wv = valid width (345)
+};
+
+template <int T, int INMODE, int OUTMODE>
+__global__ __launch_bounds__(256, 2) void conv_kernel(ConvArgs a)
+{
+    constexpr int HALO = cv_halo(T);
+    constexpr int PW = CV_PITCH + 2 * HALO;      // patch row length (floats)
+    constexpr int PW4 = PW / 4;
+    constexpr int PROWS = 6;
+    constexpr int PATCH = 2 * PROWS * PW;
+    constexpr int WSLAB = 2 * CV_TAPS * CV_CO;   // 8320 floats
+    __shared__ __attribute__((aligned(16))) float lds[PATCH + WSLAB];
+    float *patch = lds;
+    float *wl = lds + PATCH;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int mt = wave & 1, row = wave >> 1;
+    const int half = lane >> 5, l32 = lane & 31;
+    const int b = blockIdx.y, h0 = blockIdx.x * 2;
+    const int Hin = (INMODE == IN_ROUTE) ? (a.H >> 1) : a.H;
+
+    floatx16 acc[CV_WT];
+#pragma unroll
+    for (int i = 0; i < CV_WT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+
+    const int n_stage = a.Cin >> 1;
+    for (int s = 0; s < n_stage; ++s) {
+        __syncthreads();
+        // ---- stage the weight slab of channels (2s, 2s+1): contiguous 33 KB ----
+        {
+            const floatx4 *src = reinterpret_cast<const floatx4 *>(a.wt + (size_t)s * WSLAB);
+            floatx4 *dst = reinterpret_cast<floatx4 *>(wl);
+            for (int i = tid; i < WSLAB / 4; i += 256) dst[i] = src[i];
+        }
+        // ---- stage the input patch with the fused transform ----
+        for (int i = tid; i < 2 * PROWS * PW4; i += 256) {
+            const int rowid = i / PW4, c4 = i - rowid * PW4;
+            const int cl = rowid / PROWS, r = rowid - cl * PROWS;
+            const int h = h0 - 2 + r;
+            const int w0 = c4 * 4 - HALO;
+            const int ci = 2 * s + cl;
+            floatx4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (h >= 0 && h < a.H && w0 >= 0 && w0 < CV_PITCH) {
+                const int hin = (INMODE == IN_ROUTE) ? (h >> 1) : h;
+                const size_t off = (((size_t)b * a.Cin + ci) * Hin + hin) * CV_PITCH + w0;
+                v = *reinterpret_cast<const floatx4 *>(a.in + off);
+                if (INMODE == IN_ROUTE) {
+                    const uchar4 am = *reinterpret_cast<const uchar4 *>(a.amax + off);
+                    const unsigned want = (unsigned)(h & 1);
+                    v[0] = am.x == want ? v[0] : 0.0f;
+                    v[1] = am.y == want ? v[1] : 0.0f;
+                    v[2] = am.z == want ? v[2] : 0.0f;
+                    v[3] = am.w == want ? v[3] : 0.0f;
+                } else {
+                    const float mean = a.stats[((size_t)b * a.Cin + ci) * 2];
+                    const float rstd = a.stats[((size_t)b * a.Cin + ci) * 2 + 1];
+                    const float sl = (INMODE == IN_PRELU) ? a.slope[ci] : 1.0f;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float x = v[e];
+                        if (INMODE == IN_PRELU) x = x > 0.0f ? x : sl * x;
+                        v[e] = (x - mean) * rstd;
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (w0 + e >= a.Wv) v[e] = 0.0f;
+            }
+            *reinterpret_cast<floatx4 *>(patch + rowid * PW + c4 * 4) = v;
+        }
+        __syncthreads();
+        // ---- 65 k-steps (one tap each, both channels of the pair), 11 MFMAs per k-step ----
+        const float *wbase = wl + half * (CV_TAPS * CV_CO) + mt * 32 + l32;
+        const float *pbase = patch + half * (PROWS * PW) + row * PW + HALO + l32 - 6 * T;
+#pragma unroll 1
+        for (int kh = 0; kh < CV_KH; ++kh) {
+#pragma unroll 1
+            for (int kw = 0; kw < CV_KW; ++kw) {
+                const float av = wbase[(kh * CV_KW + kw) * CV_CO];
+                const float *pp = pbase + kh * PW + kw * T;
+                float bv[CV_WT];
+#pragma unroll
+                for (int i = 0; i < CV_WT; ++i) bv[i] = pp[i * 32];
+#pragma unroll
+                for (int i = 0; i < CV_WT; ++i) acc[i] = mfma32(av, bv[i], acc[i]);
+            }
+        }
+    }
+
+    // ---- epilogue ----
+    if (OUTMODE == OUT_PLAIN) {
+        const int h = h0 + row;
+#pragma unroll
+        for (int i = 0; i < CV_WT; ++i) {
+            const int w = i * 32 + l32;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = mt * 32 + mfma_row(r, lane);
+                a.out[(((size_t)b * CV_CO + co) * a.H + h) * CV_PITCH + w] = w < a.Wv ? acc[i][r] : 0.0f;
+            }
+        }
+    } else {
+        // max-pool the two rows: row-1 waves hand their accumulators to the row-0 waves through LDS,
+        // 4 w-tiles at a time (2 co tiles x 4 x 16 regs x 64 lanes x 4 B = 32 KB, fits the staging LDS)
+        float *xch = lds;
+        const int hp = h0 >> 1, Hp = a.H >> 1;
+#pragma unroll
+        for (int c0 = 0; c0 < CV_WT; c0 += 4) {
+            __syncthreads();
+            if (row == 1) {
+#pragma unroll
+                for (int i = c0; i < c0 + 4 && i < CV_WT; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) xch[((mt * 4 + (i - c0)) * 16 + r) * 64 + lane] = acc[i][r];
+            }
+            __syncthreads();
+            if (row == 0) {
+#pragma unroll
+                for (int i = c0; i < c0 + 4 && i < CV_WT; ++i) {
+                    const int w = i * 32 + l32;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int co = mt * 32 + mfma_row(r, lane);
+                        const float top = acc[i][r];
+                        const float bot = xch[((mt * 4 + (i - c0)) * 16 + r) * 64 + lane];
+                        const bool take_bot = bot > top;                 // ties keep the first row (torch)
+                        const float m = (take_bot ? bot : top) + a.bias[co];
+                        const size_t off = (((size_t)b * CV_CO + co) * Hp + hp) * CV_PITCH + w;
+                        a.out[off] = w < a.Wv ? m : 0.0f;
+                        a.out_amax[off] = take_bot ? 1 : 0;
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int T>
+static int launch_conv(int inmode, int outmode, const ConvArgs &a, int B, hipStream_t st)
+{
+    dim3 grid(a.H / 2, B), block(256);
+    if (inmode == IN_LOGMEL && outmode == OUT_POOL)
+        hipLaunchKernelGGL((conv_kernel<T, IN_LOGMEL, OUT_POOL>), grid, block, 0, st, a);
+    else if (inmode == IN_PRELU && outmode == OUT_POOL)
+        hipLaunchKernelGGL((conv_kernel<T, IN_PRELU, OUT_POOL>), grid, block, 0, st, a);
+    else if (inmode == IN_ROUTE && outmode == OUT_PLAIN)
+        hipLaunchKernelGGL((conv_kernel<T, IN_ROUTE, OUT_PLAIN>), grid, block, 0, st, a);
+    else
+        return MX_ERR_ARG;
+    return mx_launch_status();
+}
+
+static int dispatch_conv(int T, int inmode, int outmode, const ConvArgs &a, int B, hipStream_t st)
+{
+    switch (T) {
+    case 1: return launch_conv<1>(inmode, outmode, a, B, st);
+    case 2: return launch_conv<2>(inmode, outmode, a, B, st);
+    case 4: return launch_conv<4>(inmode, outmode, a, B, st);
+    case 8: return launch_conv<8>(inmode, outmode, a, B, st);
+    case 16: return launch_conv<16>(inmode, outmode, a, B, st);
+    default: return MX_ERR_UNSUPPORTED;
+    }
+}
+
+// ---- weight packing: torch (Cout, Cin, 5, 13) -> kernel layout --------------------------------
+//   flip == 0 (forward):  wt[ci][kh][kw][co] = W[co][ci][kh][kw]                    (Cin x 65 x Cout)
+//   flip == 1 (dgrad):    wt[co][kh][kw][ci] = W[co][ci][4-kh][12-kw]                (Cout x 65 x Cin)
+__global__ void pack_weights_kernel(const float *__restrict__ W, int Cout, int Cin, int flip,
+                                    float *__restrict__ wt)
+{
+    const int total = Cout * Cin * CV_TAPS;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        int kw = i % CV_KW, kh = (i / CV_KW) % CV_KH, ci = (i / CV_TAPS) % Cin, co = i / (CV_TAPS * Cin);
+        const float v = W[i];
+        if (!flip)
+            wt[((size_t)(ci * CV_KH + kh) * CV_KW + kw) * Cout + co] = v;
+        else
+            wt[((size_t)(co * CV_KH + (CV_KH - 1 - kh)) * CV_KW + (CV_KW - 1 - kw)) * Cin + ci] = v;
+    }
+}
+
+MX_EXPORT int mx_conv_pack_weights(const float *W, int64_t Cout, int64_t Cin, int32_t flip, float *wt,
+                                   void *stream)
+{
+    if (!W || !wt || Cout <= 0 || Cin <= 0) return MX_ERR_ARG;
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, W, (int)Cout, (int)Cin,
+                       (int)flip, wt);
+    return mx_launch_status();
+}
+
+// ---- forward block: LayerNorm (stats given) -> conv -> +bias -> maxpool(2,1) ------------------
+// in (B,Cin,H,352): log-mel (first_layer=1) or the previous block's pooled pre-activations (PReLU
+// with `slope` applied on the fly); stats (B,Cin,2) from mx_plane_stats; wt = packed forward
+// weights; out (B,64,H/2,352) pooled pre-activations; out_amax (B,64,H/2,352) uint8.
+MX_EXPORT int mx_conv_block_fwd(const float *in, const float *stats, const float *slope, const float *wt,
+                                const float *bias, int64_t B, int64_t Cin, int64_t H, int64_t Wv,
+                                int32_t dilation, int32_t first_layer, float *out, uint8_t *out_amax,
+                                void *stream)
+{
+    if (!in || !stats || !wt || !bias || !out || !out_amax || (!first_layer && !slope)) return MX_ERR_ARG;
+    if (B <= 0 || B > 65535 || Cin < 2 || (Cin & 1) || H < 2 || (H & 1) || Wv <= 0 || Wv > CV_PITCH)
+        return MX_ERR_UNSUPPORTED;
+    ConvArgs a{in, nullptr, stats, slope, wt, bias, out, out_amax, (int)Cin, (int)H, (int)Wv};
+    return dispatch_conv(dilation, first_layer ? IN_LOGMEL : IN_PRELU, OUT_POOL, a, (int)B, (hipStream_t)stream);
+}
+
+// ---- data gradient: G (B,64,H/2,352) pooled grads + argmax -> dxhat (B,Cin_orig=64,H,352) ------
+// wt = weights packed with flip=1.  (Not needed for the first block: the log-mel input needs no grad.)
+MX_EXPORT int mx_conv_block_dgrad(const float *G, const uint8_t *amax, const float *wt_flipped, int64_t B,
+                                  int64_t H, int64_t Wv, int32_t dilation, float *dxhat, void *stream)
+{
+    if (!G || !amax || !wt_flipped || !dxhat) return MX_ERR_ARG;
+    if (B <= 0 || B > 65535 || H < 2 || (H & 1) || Wv <= 0 || Wv > CV_PITCH) return MX_ERR_UNSUPPORTED;
+    ConvArgs a{G, amax, nullptr, nullptr, wt_flipped, nullptr, dxhat, nullptr, CV_CO, (int)H, (int)Wv};
+    return dispatch_conv(dilation, IN_ROUTE, OUT_PLAIN, a, (int)B, (hipStream_t)stream);
+}

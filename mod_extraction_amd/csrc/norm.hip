@@ -1,0 +1,155 @@
+// norm.hip -- K5: LayerNorm([bins, frames], elementwise_affine=False) statistics and backward,
+// fused with the PReLU that precedes the norm (reference: mod_extraction/models.py:186-189,
+// torch.nn.LayerNorm eps=1e-5 biased variance; torch.nn.PReLU per-channel slope).
+//
+// The normalised tensor itself is never materialised: the conv kernels apply (x - mean) * rstd
+// while staging.  These kernels are pure HBM streams (one read of the plane for the statistics;
+// two reads + one write for the backward); sums are accumulated in fp64 so the result does not
+// depend on the reduction order.
+#include "conv_common.h"
+
+__device__ __forceinline__ void block_sum2(double &a, double &b, double *sh)
+{
+    a = wave_sum_f64(a);
+    b = wave_sum_f64(b);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) { sh[wave * 2] = a; sh[wave * 2 + 1] = b; }
+    __syncthreads();
+    a = 0.0; b = 0.0;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) { a += sh[i * 2]; b += sh[i * 2 + 1]; }
+}
+
+// stats[plane] = (mean, rstd) of f(x) over the H x Wv valid region, f = PReLU(slope[c]) or identity.
+__global__ __launch_bounds__(256) void plane_stats_kernel(const float *__restrict__ x,
+                                                          const float *__restrict__ slope, int C, int H,
+                                                          int Wv, float eps, float *__restrict__ stats)
+{
+    __shared__ double sh[8];
+    const int plane = blockIdx.x;
+    const float sl = slope ? slope[plane % C] : 1.0f;
+    const floatx4 *p = reinterpret_cast<const floatx4 *>(x + (size_t)plane * H * CV_PITCH);
+    double s = 0.0, ss = 0.0;
+    const int n4 = H * (CV_PITCH / 4);
+    for (int i = threadIdx.x; i < n4; i += 256) {
+        const int w0 = (i % (CV_PITCH / 4)) * 4;
+        floatx4 v = p[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (w0 + e < Wv) {
+                float t = v[e];
+                if (slope) t = t > 0.0f ? t : sl * t;
+                s += (double)t;
+                ss += (double)t * (double)t;
+            }
+        }
+    }
+    block_sum2(s, ss, sh);
+    if (threadIdx.x == 0) {
+        const double n = (double)H * (double)Wv;
+        const double mean = s / n;
+        double var = ss / n - mean * mean;
+        var = var > 0.0 ? var : 0.0;
+        stats[plane * 2] = (float)mean;
+        stats[plane * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+}
+
+MX_EXPORT int mx_plane_stats(const float *x, const float *slope, int64_t B, int64_t C, int64_t H, int64_t Wv,
+                             float eps, float *stats, void *stream)
+{
+    if (!x || !stats || B <= 0 || C <= 0 || H <= 0 || Wv <= 0 || Wv > CV_PITCH) return MX_ERR_ARG;
+    hipLaunchKernelGGL(plane_stats_kernel, dim3((unsigned)(B * C)), dim3(256), 0, (hipStream_t)stream, x, slope,
+                       (int)C, (int)H, (int)Wv, eps, stats);
+    return mx_launch_status();
+}
+
+// LayerNorm backward fused with the backward of the PReLU in front of it.
+//   p      (B,C,H,352): pooled pre-activations of the previous block (input of PReLU)
+//   dxhat  (B,C,H,352): gradient w.r.t. the normalised tensor (from mx_conv_block_dgrad); overwritten
+//                       IN PLACE with G = dL/dp
+//   stats  (B,C,2), slope (C,)
+//   dslope_part (B*C,): per-plane partial of dL/dslope (summed over B by mx_reduce_rows)
+// LN backward:  dx = rstd * (dxhat - mean(dxhat) - xhat * mean(dxhat * xhat))
+// PReLU bwd  :  G = dx * (p > 0 ? 1 : slope);  dslope += dx * (p > 0 ? 0 : p)
+__global__ __launch_bounds__(256) void ln_prelu_bwd_kernel(const float *__restrict__ p, float *__restrict__ dxhat,
+                                                           const float *__restrict__ stats,
+                                                           const float *__restrict__ slope, int C, int H, int Wv,
+                                                           float *__restrict__ dslope_part)
+{
+    __shared__ double sh[8];
+    const int plane = blockIdx.x;
+    const float sl = slope[plane % C];
+    const float mean = stats[plane * 2], rstd = stats[plane * 2 + 1];
+    const floatx4 *pp = reinterpret_cast<const floatx4 *>(p + (size_t)plane * H * CV_PITCH);
+    floatx4 *gp = reinterpret_cast<floatx4 *>(dxhat + (size_t)plane * H * CV_PITCH);
+    const int n4 = H * (CV_PITCH / 4);
+    double s1 = 0.0, s2 = 0.0;
+    for (int i = threadIdx.x; i < n4; i += 256) {
+        const int w0 = (i % (CV_PITCH / 4)) * 4;
+        floatx4 pv = pp[i], gv = gp[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (w0 + e < Wv) {
+                float x = pv[e] > 0.0f ? pv[e] : sl * pv[e];
+                float xh = (x - mean) * rstd;
+                s1 += (double)gv[e];
+                s2 += (double)gv[e] * (double)xh;
+            }
+        }
+    }
+    block_sum2(s1, s2, sh);
+    const double n = (double)H * (double)Wv;
+    const float m1 = (float)(s1 / n), m2 = (float)(s2 / n);
+    double ds = 0.0, dummy = 0.0;
+    for (int i = threadIdx.x; i < n4; i += 256) {
+        const int w0 = (i % (CV_PITCH / 4)) * 4;
+        floatx4 pv = pp[i], gv = gp[i], o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float r = 0.0f;
+            if (w0 + e < Wv) {
+                const bool pos = pv[e] > 0.0f;
+                float x = pos ? pv[e] : sl * pv[e];
+                float xh = (x - mean) * rstd;
+                float dx = rstd * (gv[e] - m1 - xh * m2);
+                r = pos ? dx : sl * dx;
+                if (!pos) ds += (double)dx * (double)pv[e];
+            }
+            o[e] = r;
+        }
+        gp[i] = o;
+    }
+    block_sum2(ds, dummy, sh);
+    if (threadIdx.x == 0) dslope_part[plane] = (float)ds;
+}
+
+MX_EXPORT int mx_ln_prelu_bwd(const float *p, float *dxhat_inout, const float *stats, const float *slope,
+                              int64_t B, int64_t C, int64_t H, int64_t Wv, float *dslope_part, void *stream)
+{
+    if (!p || !dxhat_inout || !stats || !slope || !dslope_part || B <= 0 || C <= 0 || H <= 0 || Wv <= 0 ||
+        Wv > CV_PITCH)
+        return MX_ERR_ARG;
+    hipLaunchKernelGGL(ln_prelu_bwd_kernel, dim3((unsigned)(B * C)), dim3(256), 0, (hipStream_t)stream, p,
+                       dxhat_inout, stats, slope, (int)C, (int)H, (int)Wv, dslope_part);
+    return mx_launch_status();
+}
+
+// out[c] (+)= sum over r of part[r*C + c]   (deterministic column sum of a small (R, C) matrix)
+__global__ __launch_bounds__(256) void reduce_rows_kernel(const float *__restrict__ part, int R, int C,
+                                                          int accumulate, float *__restrict__ out)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int r = 0; r < R; ++r) s += (double)part[(size_t)r * C + c];
+    out[c] = accumulate ? out[c] + (float)s : (float)s;
+}
+
+MX_EXPORT int mx_reduce_rows(const float *part, int64_t R, int64_t C, int32_t accumulate, float *out, void *stream)
+{
+    if (!part || !out || R <= 0 || C <= 0) return MX_ERR_ARG;
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       part, (int)R, (int)C, (int)accumulate, out);
+    return mx_launch_status();
+}

@@ -1,0 +1,91 @@
+"""Host mirror of mod_extraction/losses.py.
+
+``get_loss_func_by_name`` (losses.py:142-160) returns ``nn.Module``s with the reference's names and
+call signature; l1 / fdl1 / sdl1 / mse -- the LFO-extraction losses -- are evaluated by the fused
+``mx_lfo_loss`` HIP kernel (all four terms and d/d(y_hat) in one launch).  ``lfo_loss`` is the fused
+weighted form that ``lightning.LFOExtraction`` uses (lightning.py:33-62).
+"""
+from typing import Dict, Tuple
+
+import torch
+from torch import Tensor as T, nn
+
+from . import _hip
+
+_LFO_TERMS = ("l1", "fdl1", "sdl1", "mse")
+
+
+class _LFOLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y_hat: T, y: T, w_l1: float, w_fd: float, w_sd: float, w_mse: float):
+        assert y_hat.shape == y.shape
+        n = y_hat.size(-1)
+        yh = y_hat.reshape(-1, n).contiguous().float()
+        yt = y.reshape(-1, n).contiguous().float()
+        B = yh.size(0)
+        part = torch.empty((B, 4), device=yh.device, dtype=torch.float32)
+        losses = torch.empty(5, device=yh.device, dtype=torch.float32)
+        grad = torch.empty_like(yh)
+        _hip.call("mx_lfo_loss", _hip.ptr(yh), _hip.ptr(yt), B, n, float(w_l1), float(w_fd), float(w_sd),
+                  float(w_mse), _hip.ptr(part), _hip.ptr(losses), _hip.ptr(grad), _hip.stream())
+        ctx.save_for_backward(grad)
+        ctx.shape = y_hat.shape
+        return losses
+
+    @staticmethod
+    def backward(ctx, g: T):
+        (grad,) = ctx.saved_tensors
+        return (grad * g[4]).view(ctx.shape), None, None, None, None, None
+
+
+def lfo_loss(y_hat: T, y: T, weights: Dict[str, float]) -> Tuple[T, Dict[str, T]]:
+    """Weighted LFO loss: returns (total, {name: term}); only weights > 0 enter the total
+    (lightning.py:48-52) but every named term is reported."""
+    for k in weights:
+        if k not in _LFO_TERMS:
+            raise KeyError(k)
+    w = [float(weights.get(k, 0.0)) for k in _LFO_TERMS]
+    losses = _LFOLossFn.apply(y_hat, y, *w)
+    return losses[4], {k: losses[i].detach() for i, k in enumerate(_LFO_TERMS) if k in weights}
+
+
+class _SingleTerm(nn.Module):
+    term = "l1"
+
+    def forward(self, input: T, target: T) -> T:
+        return lfo_loss(input, target, {self.term: 1.0})[0]
+
+
+class L1Loss(_SingleTerm):
+    term = "l1"
+
+
+class FirstDerivativeL1Loss(_SingleTerm):
+    term = "fdl1"
+
+
+class SecondDerivativeL1Loss(_SingleTerm):
+    term = "sdl1"
+
+
+class MSELoss(_SingleTerm):
+    term = "mse"
+
+
+def get_loss_func_by_name(name: str) -> nn.Module:
+    if name == "l1":
+        return L1Loss()
+    elif name == "fdl1":
+        return FirstDerivativeL1Loss()
+    elif name == "sdl1":
+        return SecondDerivativeL1Loss()
+    elif name == "mse":
+        return MSELoss()
+    elif name in ("esr", "dc"):
+        from .effect_losses import get_effect_loss
+        return get_effect_loss(name)
+    elif name == "mrstft":
+        from .effect_losses import get_effect_loss
+        return get_effect_loss(name)
+    else:
+        raise KeyError

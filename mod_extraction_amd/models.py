@@ -1,0 +1,313 @@
+"""Host mirror of mod_extraction/models.py: same classes, constructor arguments, forward signatures
+and state-dict keys; every forward/backward runs hand-written HIP kernels through the C ABI.
+
+* ``Spectral2DCNN`` (models.py:128-215): log-mel front end (``mx_logmel_fwd``) and six fused
+  LayerNorm -> Conv2d(5x13) -> MaxPool(2,1) -> PReLU blocks on the fp32 matrix cores
+  (``mx_conv_block_{fwd,dgrad,wgrad}``, ``mx_plane_stats``, ``mx_ln_prelu_bwd``), head
+  (``mx_head_{fwd,bwd}``), wired into autograd by one ``torch.autograd.Function``.
+  The ``torch.nn`` layer objects inside ``self.cnn`` / ``self.output`` are parameter holders only
+  (they give the reference's state-dict keys and default initialisation); they are never called.
+* ``LSTMEffectModel`` / ``HiddenStateModel`` (models.py:292-339) and ``RandomLFO`` (models.py:19-69).
+"""
+import math
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+from torch import Tensor as T, nn
+
+from . import _hip
+
+DEBUG_TAP = None       # set to a dict to capture backward intermediates (tools/debug_cnn_bwd.py)
+PITCH = 352            # activation row pitch (floats); 345 frames + pad (csrc/conv_common.h)
+LN_EPS = 1e-5          # torch.nn.LayerNorm default
+
+
+# ---------------------------------------------------------------------------------------------
+# mel front-end constants (torchaudio 0.13.1 MelSpectrogram defaults as used at models.py:170-175)
+# ---------------------------------------------------------------------------------------------
+def htk_mel_filterbank(n_freqs: int, f_min: float, f_max: float, n_mels: int, sample_rate: int) -> T:
+    """torchaudio.functional.melscale_fbanks(norm=None, mel_scale='htk'): triangular filters."""
+    all_freqs = torch.linspace(0, sample_rate // 2, n_freqs)
+    m_min = 2595.0 * math.log10(1.0 + (f_min / 700.0))
+    m_max = 2595.0 * math.log10(1.0 + (f_max / 700.0))
+    m_pts = torch.linspace(m_min, m_max, n_mels + 2)
+    f_pts = 700.0 * (10.0 ** (m_pts / 2595.0) - 1.0)
+    f_diff = f_pts[1:] - f_pts[:-1]
+    slopes = f_pts.unsqueeze(0) - all_freqs.unsqueeze(1)
+    down_slopes = (-1.0 * slopes[:, :-2]) / f_diff[:-1]
+    up_slopes = slopes[:, 2:] / f_diff[1:]
+    return torch.max(torch.zeros(1), torch.min(down_slopes, up_slopes))
+
+
+def _band_limits(fb: T) -> Tuple[T, T]:
+    nz = fb != 0
+    any_nz = nz.any(dim=0)
+    idx = torch.arange(fb.size(0)).unsqueeze(1).expand_as(fb)
+    lo = torch.where(nz, idx, torch.full_like(idx, fb.size(0))).min(dim=0).values
+    hi = torch.where(nz, idx + 1, torch.zeros_like(idx)).max(dim=0).values
+    lo = torch.where(any_nz, lo, torch.zeros_like(lo))
+    return lo.to(torch.int32), hi.to(torch.int32)
+
+
+class _Buffers(nn.Module):
+    """Plain namespace module (gives buffers their torchaudio state-dict key prefixes)."""
+
+
+class MelSpectrogramHIP(nn.Module):
+    """State-dict compatible stand-in for torchaudio's MelSpectrogram (keys
+    ``spectrogram.window`` and ``mel_scale.fb``); the transform itself is the HIP kernel."""
+
+    def __init__(self, sample_rate: int, n_fft: int, hop_length: int, n_mels: int) -> None:
+        super().__init__()
+        if n_fft != 1024:
+            raise NotImplementedError("mx_logmel_fwd is built for n_fft = 1024")
+        self.sample_rate, self.n_fft, self.hop_length, self.n_mels = sample_rate, n_fft, hop_length, n_mels
+        self.spectrogram = _Buffers()
+        self.spectrogram.register_buffer("window", torch.hann_window(n_fft))
+        self.mel_scale = _Buffers()
+        self.mel_scale.register_buffer("fb", htk_mel_filterbank(n_fft // 2 + 1, 0.0, float(sample_rate // 2),
+                                                                n_mels, sample_rate))
+        k = torch.arange(n_fft, dtype=torch.float64) * (-2.0 * math.pi / n_fft)
+        self.register_buffer("twiddle", torch.stack([torch.cos(k), torch.sin(k)], dim=1).float(), persistent=False)
+        self._bands: Optional[Tuple[T, T, int]] = None
+
+    def bands(self) -> Tuple[T, T]:
+        fb = self.mel_scale.fb
+        if self._bands is None or self._bands[2] != fb._version or self._bands[0].device != fb.device:
+            lo, hi = _band_limits(fb.detach().cpu())
+            self._bands = (lo.to(fb.device), hi.to(fb.device), fb._version)
+        return self._bands[0], self._bands[1]
+
+    def log_mel(self, x: T, n_frames: int, eps: float, masks: Sequence[int] = (0, 0, 0, 0)) -> T:
+        """x (B, C, N) -> (B, C, n_mels, PITCH) = log(clip(mel, eps)) with SpecAugment ranges."""
+        B, C, N = x.shape
+        xc = x.contiguous().float()
+        out = torch.empty((B, C, self.n_mels, PITCH), device=x.device, dtype=torch.float32)
+        lo, hi = self.bands()
+        f0, f1, t0, t1 = (int(v) for v in masks)
+        _hip.call("mx_logmel_fwd", _hip.ptr(xc), B * C, N, _hip.ptr(self.spectrogram.window), _hip.ptr(self.twiddle),
+                  _hip.ptr(self.mel_scale.fb), _hip.ptr(lo), _hip.ptr(hi), self.n_fft, self.hop_length, self.n_mels,
+                  n_frames, PITCH, float(eps), f0, f1, t0, t1, _hip.ptr(out), _hip.stream())
+        return out
+
+
+def specaugment_bounds(size: int, mask_param: int) -> Tuple[int, int]:
+    """torchaudio.functional.mask_along_axis: one mask per batch; two host ``torch.rand(1)`` draws
+    (value, then min_value); masked range [int(min_value), int(min_value) + int(value))."""
+    value = torch.rand(1) * mask_param
+    min_value = torch.rand(1) * (size - value)
+    start = int(min_value.long())
+    return start, start + int(value.long())
+
+
+# ---------------------------------------------------------------------------------------------
+# the CNN stack as one autograd node
+# ---------------------------------------------------------------------------------------------
+def _pack(w: T, flip: int) -> T:
+    out = torch.empty(w.numel(), device=w.device, dtype=torch.float32)
+    _hip.call("mx_conv_pack_weights", _hip.ptr(w.contiguous()), w.size(0), w.size(1), flip, _hip.ptr(out),
+              _hip.stream())
+    return out
+
+
+def _reduce_rows(part: T, rows: int, cols: int) -> T:
+    out = torch.empty(cols, device=part.device, dtype=torch.float32)
+    _hip.call("mx_reduce_rows", _hip.ptr(part), rows, cols, 0, _hip.ptr(out), _hip.stream())
+    return out
+
+
+class _CNNStack(torch.autograd.Function):
+    """logmel (B,Cin,H,PITCH) -> (sigmoid output (B,L,W), latent (B,64,W)).
+    params: [w1,b1,a1, ..., w6,b6,a6, wout, bout]."""
+
+    @staticmethod
+    def forward(ctx, logmel: T, n_frames: int, dilations: Tuple[int, ...], *params: T):
+        n_blocks = len(dilations)
+        B, cin, H, _ = logmel.shape
+        dev = logmel.device
+        st = _hip.stream()
+        cur, slope = logmel, None
+        saved: List[T] = []
+        for l in range(n_blocks):
+            w, b, a = params[3 * l], params[3 * l + 1], params[3 * l + 2]
+            stats = torch.empty((B, cin, 2), device=dev, dtype=torch.float32)
+            _hip.call("mx_plane_stats", _hip.ptr(cur), _hip.ptr(slope), B, cin, H, n_frames, LN_EPS,
+                      _hip.ptr(stats), st)
+            wt = _pack(w, 0)
+            p = torch.empty((B, 64, H // 2, PITCH), device=dev, dtype=torch.float32)
+            amax = torch.empty((B, 64, H // 2, PITCH), device=dev, dtype=torch.uint8)
+            _hip.call("mx_conv_block_fwd", _hip.ptr(cur), _hip.ptr(stats), _hip.ptr(slope), _hip.ptr(wt),
+                      _hip.ptr(b.contiguous()), B, cin, H, n_frames, int(dilations[l]), 1 if l == 0 else 0,
+                      _hip.ptr(p), _hip.ptr(amax), st)
+            saved += [cur, stats, amax]
+            cur, slope, cin, H = p, a.contiguous(), 64, H // 2
+        wout, bout = params[3 * n_blocks], params[3 * n_blocks + 1]
+        L = wout.size(0)
+        latent = torch.empty((B, 64, n_frames), device=dev, dtype=torch.float32)
+        out = torch.empty((B, L, n_frames), device=dev, dtype=torch.float32)
+        _hip.call("mx_head_fwd", _hip.ptr(cur), _hip.ptr(slope), _hip.ptr(wout.contiguous()),
+                  _hip.ptr(bout.contiguous()), B, 64, H, n_frames, L, _hip.ptr(latent), _hip.ptr(out), st)
+        ctx.save_for_backward(*saved, cur, latent, out, *params)
+        ctx.meta = (n_frames, tuple(dilations), n_blocks)
+        return out, latent
+
+    @staticmethod
+    def backward(ctx, d_out: Optional[T], d_latent: Optional[T]):
+        n_frames, dilations, n_blocks = ctx.meta
+        tensors = ctx.saved_tensors
+        saved, p_last, latent, out = tensors[:3 * n_blocks], tensors[3 * n_blocks], tensors[3 * n_blocks + 1], \
+            tensors[3 * n_blocks + 2]
+        params = tensors[3 * n_blocks + 3:]
+        dev = out.device
+        st = _hip.stream()
+        B, L = out.size(0), out.size(1)
+        wout = params[3 * n_blocks]
+        grads: List[Optional[T]] = [None] * len(params)
+        if d_out is None:
+            d_out = torch.zeros_like(out)
+        d_out = d_out.contiguous()
+        d_latent = d_latent.contiguous() if d_latent is not None else None
+        Hl = p_last.size(2)
+        G = torch.empty_like(p_last)
+        dw_part = torch.empty((B, L * 64), device=dev, dtype=torch.float32)
+        db_part = torch.empty((B, L), device=dev, dtype=torch.float32)
+        ds_part = torch.empty((B, 64), device=dev, dtype=torch.float32)
+        slope_last = params[3 * (n_blocks - 1) + 2].contiguous()
+        _hip.call("mx_head_bwd", _hip.ptr(p_last), _hip.ptr(slope_last), _hip.ptr(wout.contiguous()),
+                  _hip.ptr(latent), _hip.ptr(out), _hip.ptr(d_out), _hip.ptr(d_latent), B, 64, Hl, n_frames, L,
+                  _hip.ptr(G), _hip.ptr(dw_part), _hip.ptr(db_part), _hip.ptr(ds_part), st)
+        grads[3 * n_blocks] = _reduce_rows(dw_part, B, L * 64).view_as(wout)
+        grads[3 * n_blocks + 1] = _reduce_rows(db_part, B, L)
+        grads[3 * (n_blocks - 1) + 2] = _reduce_rows(ds_part, B, 64)
+        for l in range(n_blocks - 1, -1, -1):
+            x_in, stats, amax = saved[3 * l], saved[3 * l + 1], saved[3 * l + 2]
+            w = params[3 * l]
+            cin, H = x_in.size(1), x_in.size(2)
+            slope_prev = params[3 * (l - 1) + 2].contiguous() if l > 0 else None
+            # bias gradient: sum of G over (b, h, w)
+            if DEBUG_TAP is not None:
+                DEBUG_TAP[f"G{l}"] = G.clone()
+                DEBUG_TAP[f"amax{l}"] = amax.clone()
+                DEBUG_TAP[f"p{l}"] = (p_last if l == n_blocks - 1 else saved[3 * (l + 1)]).clone()
+            bsum = torch.empty((B, 64), device=dev, dtype=torch.float32)
+            _hip.call("mx_plane_sum", _hip.ptr(G), B * 64, H // 2, n_frames, _hip.ptr(bsum), st)
+            grads[3 * l + 1] = _reduce_rows(bsum, B, 64)
+            # weight gradient
+            rows = B * H
+            rps = max(1, -(-rows // (256 if cin == 64 else 1024)))
+            n_slabs = -(-rows // rps)
+            part = torch.empty(n_slabs * 65 * 64 * cin, device=dev, dtype=torch.float32)
+            dW = torch.empty_like(w)
+            _hip.call("mx_conv_block_wgrad", _hip.ptr(G), _hip.ptr(amax), _hip.ptr(x_in), _hip.ptr(stats),
+                      _hip.ptr(slope_prev), B, cin, H, n_frames, int(dilations[l]), rps, _hip.ptr(part),
+                      _hip.ptr(dW), st)
+            grads[3 * l] = dW
+            del part
+            if l > 0:
+                wt_f = _pack(w, 1)
+                dxhat = torch.empty((B, 64, H, PITCH), device=dev, dtype=torch.float32)
+                _hip.call("mx_conv_block_dgrad", _hip.ptr(G), _hip.ptr(amax), _hip.ptr(wt_f), B, H, n_frames,
+                          int(dilations[l]), _hip.ptr(dxhat), st)
+                if DEBUG_TAP is not None:
+                    DEBUG_TAP[f"dxhat{l}"] = dxhat.clone()
+                ds_part = torch.empty((B, 64), device=dev, dtype=torch.float32)
+                _hip.call("mx_ln_prelu_bwd", _hip.ptr(x_in), _hip.ptr(dxhat), _hip.ptr(stats), _hip.ptr(slope_prev),
+                          B, 64, H, n_frames, _hip.ptr(ds_part), st)
+                grads[3 * (l - 1) + 2] = _reduce_rows(ds_part, B, 64)
+                G = dxhat
+        return (None, None, None, *grads)
+
+
+class Spectral2DCNN(nn.Module):
+    def __init__(self,
+                 in_ch: int = 1,
+                 n_samples: int = 88200,
+                 sr: float = 44100,
+                 n_fft: int = 1024,
+                 hop_len: int = 256,
+                 n_mels: int = 256,
+                 kernel_size: Tuple[int, int] = (5, 13),
+                 out_channels: Optional[List[int]] = None,
+                 bin_dilations: Optional[List[int]] = None,
+                 temp_dilations: Optional[List[int]] = None,
+                 pool_size: Tuple[int, int] = (3, 1),
+                 latent_dim: int = 1,
+                 freq_mask_amount: float = 0.0,
+                 time_mask_amount: float = 0.0,
+                 use_ln: bool = True,
+                 eps: float = 1e-7) -> None:
+        super().__init__()
+        if out_channels is None:
+            out_channels = [64] * 5
+        if bin_dilations is None:
+            bin_dilations = [1] * len(out_channels)
+        if temp_dilations is None:
+            temp_dilations = [2 ** idx for idx in range(len(out_channels))]
+        assert len(out_channels) == len(bin_dilations) == len(temp_dilations)
+        assert pool_size[1] == 1
+        self.sr, self.n_fft, self.hop_len, self.n_mels = sr, n_fft, hop_len, n_mels
+        self.kernel_size, self.pool_size, self.latent_dim = tuple(kernel_size), tuple(pool_size), latent_dim
+        self.freq_mask_amount, self.time_mask_amount = freq_mask_amount, time_mask_amount
+        self.use_ln, self.eps = use_ln, eps
+        self.out_channels, self.bin_dilations, self.temp_dilations = list(out_channels), list(bin_dilations), \
+            list(temp_dilations)
+        self.in_ch = in_ch
+        self.n_frames = n_samples // hop_len + 1
+        # what the gfx950 kernels are built for (the only configuration the reference ships):
+        unsupported = (self.kernel_size != (5, 13) or self.pool_size != (2, 1) or not use_ln
+                       or any(c != 64 for c in out_channels) or any(d != 1 for d in bin_dilations)
+                       or any(d not in (1, 2, 4, 8, 16) for d in temp_dilations) or in_ch not in (1, 2)
+                       or self.n_frames > PITCH or n_mels % (2 ** len(out_channels)) != 0 or latent_dim > 4)
+        if unsupported:
+            raise NotImplementedError("Spectral2DCNN HIP kernels support the shipped spectral_2dcnn.yml family: "
+                                      "5x13 kernels, 64 channels, pool (2,1), LayerNorm, temp dilations in "
+                                      "{1,2,4,8,16}, in_ch <= 2, <= 352 frames")
+        self.spectrogram = MelSpectrogramHIP(int(sr), n_fft, hop_len, n_mels)
+        self.freq_mask_param = int(freq_mask_amount * n_mels)
+        self.time_mask_param = int(time_mask_amount * self.n_frames)
+        layers: List[nn.Module] = []
+        n_bins, c_in = n_mels, in_ch
+        for out_ch, b_dil, t_dil in zip(out_channels, bin_dilations, temp_dilations):
+            layers.append(nn.LayerNorm([n_bins, self.n_frames], elementwise_affine=False))
+            layers.append(nn.Conv2d(c_in, out_ch, self.kernel_size, stride=(1, 1), dilation=(b_dil, t_dil),
+                                    padding="same"))
+            layers.append(nn.MaxPool2d(kernel_size=self.pool_size))
+            layers.append(nn.PReLU(num_parameters=out_ch))
+            c_in, n_bins = out_ch, n_bins // self.pool_size[0]
+        self.cnn = nn.Sequential(*layers)       # parameter holders; never called
+        self.output = nn.Conv1d(out_channels[-1], latent_dim, kernel_size=(1,))
+
+    def _stack_params(self) -> List[T]:
+        ps: List[T] = []
+        for i in range(len(self.out_channels)):
+            conv, prelu = self.cnn[4 * i + 1], self.cnn[4 * i + 3]
+            w = conv.weight
+            if i == 0 and self.in_ch == 1:      # pad the single input channel to the 2-channel kernel
+                w = torch.cat([w, torch.zeros_like(w)], dim=1)
+            ps += [w, conv.bias, prelu.weight]
+        ps += [self.output.weight.view(self.latent_dim, -1), self.output.bias]
+        return ps
+
+    def draw_masks(self) -> Tuple[int, int, int, int]:
+        f0 = f1 = t0 = t1 = 0
+        if self.training:
+            if self.freq_mask_amount > 0:
+                f0, f1 = specaugment_bounds(self.n_mels, self.freq_mask_param)
+            if self.time_mask_amount > 0:
+                t0, t1 = specaugment_bounds(self.n_frames, self.time_mask_param)
+        return f0, f1, t0, t1
+
+    def log_mel(self, x: T, masks: Optional[Sequence[int]] = None) -> T:
+        assert x.ndim == 3
+        n_frames = x.size(-1) // self.hop_len + 1
+        assert n_frames == self.n_frames, "clip length does not match the LayerNorm shape"
+        masks = self.draw_masks() if masks is None else masks
+        if self.in_ch == 1:
+            x = torch.cat([x, torch.zeros_like(x)], dim=1)
+        with torch.no_grad():
+            return self.spectrogram.log_mel(x, self.n_frames, self.eps, masks)
+
+    def forward(self, x: T, masks: Optional[Sequence[int]] = None) -> (T, T):
+        logmel = self.log_mel(x, masks)
+        out, latent = _CNNStack.apply(logmel, self.n_frames, tuple(self.temp_dilations), *self._stack_params())
+        return out, latent

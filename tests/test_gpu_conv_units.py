@@ -1,0 +1,90 @@
+"""GPU parity, kernel by kernel: the fused conv block forward, its data gradient and its weight
+gradient against torch's CPU Conv2d / LayerNorm / MaxPool2d / PReLU autograd (fp32), for every
+temporal dilation the model family uses and for full (345) and short (88) frame counts."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+PITCH = 352
+
+
+def to_planes(x, dev):
+    """(B,C,H,W) cpu -> (B,C,H,352) device, zero padded."""
+    out = torch.zeros(x.shape[:-1] + (PITCH,), dtype=x.dtype)
+    out[..., :x.size(-1)] = x
+    return out.to(dev).contiguous()
+
+
+def ref_block(x_in, slope_prev, w, b, T, first):
+    """torch CPU reference of one block up to the pooled pre-activation; returns (p, z, xhat)."""
+    x = x_in if first else F.prelu(x_in, slope_prev)
+    xhat = F.layer_norm(x, x.shape[-2:], eps=1e-5)
+    z = F.conv2d(xhat, w, b, dilation=(1, T), padding="same")
+    return F.max_pool2d(z, (2, 1)), z, xhat
+
+
+def rel(a, b):
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+@pytest.mark.parametrize("T", [1, 2, 4, 8, 16])
+@pytest.mark.parametrize("W,H,cin", [(345, 8, 64), (88, 16, 64), (345, 12, 2), (88, 6, 2)])
+def test_block_fwd_dgrad_wgrad(dev, T, W, H, cin):
+    from mod_extraction_amd import _hip, models as am
+    torch.manual_seed(100 * T + W + H)
+    B = 2
+    first = cin == 2
+    x_in = torch.randn(B, cin, H, W) * (1.0 if first else 0.7) + 0.1
+    slope_prev = None if first else torch.rand(cin) * 0.4 + 0.05
+    w = (torch.randn(64, cin, 5, 13) / np.sqrt(cin * 65)).requires_grad_(True)
+    b = (torch.randn(64) * 0.1).requires_grad_(True)
+    x_req = x_in.clone().requires_grad_(True)
+    p_r, z_r, xhat_r = ref_block(x_req, slope_prev, w, b, T, first)
+    xhat_r.retain_grad()
+    Gc = torch.randn_like(p_r)
+    (p_r * Gc).sum().backward()
+
+    st = _hip.stream()
+    x_d = to_planes(x_in, dev)
+    sl_d = slope_prev.to(dev) if slope_prev is not None else None
+    stats = torch.empty((B, cin, 2), device=dev)
+    _hip.call("mx_plane_stats", _hip.ptr(x_d), _hip.ptr(sl_d), B, cin, H, W, 1e-5, _hip.ptr(stats), st)
+    wt = am._pack(w.detach().to(dev), 0)
+    p = torch.empty((B, 64, H // 2, PITCH), device=dev)
+    amax = torch.empty((B, 64, H // 2, PITCH), device=dev, dtype=torch.uint8)
+    _hip.call("mx_conv_block_fwd", _hip.ptr(x_d), _hip.ptr(stats), _hip.ptr(sl_d), _hip.ptr(wt),
+              _hip.ptr(b.detach().to(dev)), B, cin, H, W, T, 1 if first else 0, _hip.ptr(p), _hip.ptr(amax), st)
+    assert rel(p.cpu()[..., :W], p_r.detach()) < 5e-6
+    am_r = (z_r[:, :, 1::2] > z_r[:, :, 0::2]).to(torch.uint8)
+    mism = amax.cpu()[..., :W] != am_r
+    # a mismatch is only acceptable where the two pooled rows are equal to fp32 rounding
+    if mism.any():
+        gap = (z_r[:, :, 1::2] - z_r[:, :, 0::2]).abs()[mism]
+        assert float(gap.max()) < 1e-5
+
+    # use the oracle's argmax for the gradient checks so that routing is identical on both sides
+    amax_d = to_planes(am_r, dev)
+    G_d = to_planes(Gc, dev)
+    rows = B * H
+    rps = 3
+    n_slabs = -(-rows // rps)
+    part = torch.empty(n_slabs * 65 * 64 * cin, device=dev)
+    dW = torch.empty((64, cin, 5, 13), device=dev)
+    _hip.call("mx_conv_block_wgrad", _hip.ptr(G_d), _hip.ptr(amax_d), _hip.ptr(x_d), _hip.ptr(stats), _hip.ptr(sl_d),
+              B, cin, H, W, T, rps, _hip.ptr(part), _hip.ptr(dW), st)
+    assert rel(dW.cpu(), w.grad) < 1e-5, ("wgrad", rel(dW.cpu(), w.grad))
+    bsum = torch.empty(B * 64, device=dev)
+    _hip.call("mx_plane_sum", _hip.ptr(G_d), B * 64, H // 2, W, _hip.ptr(bsum), st)
+    assert rel(bsum.view(B, 64).sum(0).cpu(), b.grad) < 1e-5
+    if not first:
+        wt_f = am._pack(w.detach().to(dev), 1)
+        dxhat = torch.empty((B, 64, H, PITCH), device=dev)
+        _hip.call("mx_conv_block_dgrad", _hip.ptr(G_d), _hip.ptr(amax_d), _hip.ptr(wt_f), B, H, W, T, _hip.ptr(dxhat), st)
+        assert rel(dxhat.cpu()[..., :W], xhat_r.grad) < 1e-5, ("dgrad", rel(dxhat.cpu()[..., :W], xhat_r.grad))
+        assert bool((dxhat[..., W:] == 0).all())
+        ds_part = torch.empty(B * 64, device=dev)
+        _hip.call("mx_ln_prelu_bwd", _hip.ptr(x_d), _hip.ptr(dxhat), _hip.ptr(stats), _hip.ptr(sl_d), B, 64, H, W,
+                  _hip.ptr(ds_part), st)
+        assert rel(dxhat.cpu()[..., :W], x_req.grad) < 1e-5, ("ln_prelu_bwd", rel(dxhat.cpu()[..., :W], x_req.grad))
