@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""Headline benchmark: 44.1 kHz audio-seconds per second of the LFO-extraction TRAIN STEP on the
+interwoven flanger / chorus / phaser batch (BASELINE.json: train_lfo_interwoven_all, bs = 256 x 2 s
+per GPU, fp32), one process per GPU.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One step = on-device batch synthesis (LFO synth, flanger/chorus, phaser; inputs are generated in HBM)
+-> log-mel -> 6-block 2D-CNN forward -> L1 + 5*FDL1 + 10*SDL1 loss -> backward -> gradient all-reduce
+(RCCL) -> AdamW.  Nothing is skipped or cached inside the timed region.  Rank 0 prints ONE JSON line.
+
+Extra objects in the JSON line:
+  roofline      the dominant kernel: conv_kernel<1,1,0> = block-2 forward (LayerNorm + 5x13 conv +
+                bias + max-pool on the fp32 matrix cores); algorithmic flops of that launch / its
+                HIP-event duration measured live on the launch stream, vs the 157.3 TFLOP/s fp32
+                MFMA peak.  `kernels` lists the other conv launches the same way.
+  cpu_baseline  the CPU oracle (oracle/: torch fp32 CNN step + C effects, "port") timed on this
+                host's cores on a bounded sample (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SR, N_SAMPLES, BATCH = 44100, 88200, 256
+LOSS = {"l1": 1.0, "fdl1": 5.0, "sdl1": 10.0, "mse": 0.0}
+CNN_CFG = dict(in_ch=2, n_samples=N_SAMPLES, sr=SR, n_fft=1024, hop_len=256, n_mels=256, kernel_size=(5, 13),
+               out_channels=[64] * 6, temp_dilations=[1, 1, 2, 4, 8, 16], pool_size=(2, 1), latent_dim=1,
+               freq_mask_amount=0.25, time_mask_amount=0.25, use_ln=True)       # configs/models/spectral_2dcnn.yml
+KINDS = ("flanger", "chorus", "phaser")                                         # configs/data/interwoven_idmt_all.yml
+FP32_MFMA_PEAK_TFLOPS = 157.3                                                   # MI355X_MICROARCH.md
+W_FRAMES = N_SAMPLES // 256 + 1
+# useful flops of one conv launch: 2 * Cout * Cin * 65 taps * H * W per clip
+BLOCK_H = [256, 128, 64, 32, 16, 8]
+BLOCK_CIN = [2, 64, 64, 64, 64, 64]
+
+
+def conv_flops(block: int, batch: int) -> float:
+    return 2.0 * 64 * BLOCK_CIN[block] * 65 * BLOCK_H[block] * W_FRAMES * batch
+
+
+def build_job(device, rank, batch):
+    from mod_extraction_amd import data_modules, lightning, models, optim
+    torch.manual_seed(43 + rank)
+    import numpy as np
+    np.random.seed(43 + rank)
+    model = models.Spectral2DCNN(**CNN_CFG)
+    module = lightning.LFOExtraction(model, sr=SR, use_dry=True, model_smooth_n_frames=0, should_stretch=False,
+                                     loss_dict=LOSS).to(device)
+    module.train()
+    opt = optim.FlatAdamW(module.parameters(), lr=1e-4, betas=(0.8, 0.99))
+    batcher = data_modules.SyntheticFxBatcher(batch, N_SAMPLES, SR, KINDS, device, audio_seed=43 + rank)
+    return module, opt, batcher
+
+
+def cpu_baseline(batch_cpu: int = 8, steps: int = 2):
+    """The CPU oracle's version of the same step, on all host cores, bounded sample."""
+    import numpy as np
+    from oracle import lightning as ol, models as om
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(43)
+    np.random.seed(43)
+    model = om.Spectral2DCNN(**CNN_CFG)
+    model.train()
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, betas=(0.8, 0.99))
+    from mod_extraction_amd.data_modules import SyntheticFxBatcher
+    sampler = SyntheticFxBatcher.__new__(SyntheticFxBatcher)       # host-side parameter draws only
+    SyntheticFxBatcher.__init__(sampler, batch_cpu, N_SAMPLES, SR, KINDS, torch.device("cpu"))
+    kinds = sampler.kinds
+    times = []
+    for it in range(steps + 1):
+        t0 = time.perf_counter()
+        p = sampler.sample_params()
+        src = (torch.rand(batch_cpu, N_SAMPLES + sampler.max_lead) * 2 - 1).mul_(sampler.peak).numpy()
+        dry, wet, mod = ol.synth_batch(p, kinds, src, N_SAMPLES, SR, {"flanger": 1.0, "chorus": 30.0})
+        ol.lfo_train_step(model, opt, dry, wet, mod, LOSS)
+        times.append(time.perf_counter() - t0)
+    t = sum(times[1:]) / steps
+    return {"value": batch_cpu * N_SAMPLES / SR / t, "unit": "audio-seconds/s", "cores": cores, "kind": "port",
+            "sample": f"{steps} train steps (after 1 warm-up) of the CPU oracle on {batch_cpu} clips x 2 s, same "
+                      f"interwoven recipe; torch fp32 CNN on {cores} threads, C effects single-threaded"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=BATCH, help="clips per GPU (default: the BASELINE config)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from mod_extraction_amd import _hip, trainer as tr
+    env = tr.init_distributed()
+    rank, world = env["rank"], env["world_size"]
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    device = torch.device("cuda", env["local_rank"])
+    torch.cuda.set_device(device)
+    module, opt, batcher = build_job(device, rank, args.batch)
+    runner = tr.Trainer(log_fn=None)
+
+    def step():
+        return runner.train_step(module, opt, batcher.next_batch())
+
+    def fence():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    module.logged.clear()
+
+    def key(name, a):
+        # (Cin, H) of the launch: positions of B, Cin, H in each entry point's argument list
+        if name == "mx_conv_block_fwd":
+            return f"{a[6]}x{a[7]}"
+        if name == "mx_conv_block_dgrad":
+            return f"64x{a[4]}"
+        return f"{a[6]}x{a[7]}"
+
+    fence()
+    t0 = time.perf_counter()
+    with _hip.KernelTimer({"mx_conv_block_fwd", "mx_conv_block_dgrad", "mx_conv_block_wgrad"}, key) as kt:
+        for _ in range(args.steps):
+            loss = step()
+    fence()
+    dt = time.perf_counter() - t0
+    dt_t = torch.tensor([dt], dtype=torch.float64, device=device)
+    if world > 1:
+        torch.distributed.all_reduce(dt_t, op=torch.distributed.ReduceOp.MAX)
+    dt = float(dt_t)
+    timings = kt.results()
+
+    if rank == 0:
+        audio_s = world * args.batch * (N_SAMPLES / SR) * args.steps
+        kernels = {}
+        for tag, ms in sorted(timings.items()):
+            name, shape = tag.split("#")
+            cin, h = (int(v) for v in shape.split("x"))
+            blk = BLOCK_H.index(h)
+            avg = sum(ms) / len(ms)
+            kernels[f"{name[3:]}[block{blk + 1}]"] = {"avg_ms": round(avg, 3),
+                                                     "tflops": round(conv_flops(blk, args.batch) / (avg * 1e-3) / 1e12, 2)}
+        dom = kernels.get("conv_block_fwd[block2]", {"avg_ms": None, "tflops": None})
+        mfma_ms = sum(sum(ms) for ms in timings.values()) / args.steps
+        out = {
+            "metric": "44.1 kHz audio-seconds/sec (train step), interwoven ph/fl/ch",
+            "value": audio_s / dt, "unit": "audio-seconds/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"train_lfo_interwoven_all: 2D-CNN LFO extractor train step, bs={args.batch} x 2 s "
+                                   f"@44.1 kHz per GPU, flanger/chorus/phaser interleaved, fp32",
+                       "global_batch": world * args.batch, "n_samples": N_SAMPLES, "parallelism": f"dp{world}"},
+            "roofline": {"bound": "mfma", "kernel": "conv_kernel<1,1,0> (block-2 forward: LayerNorm+conv5x13+bias+maxpool)",
+                         "achieved": dom["tflops"], "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": None if dom["tflops"] is None else round(dom["tflops"] / FP32_MFMA_PEAK_TFLOPS, 4),
+                         "avg_launch_ms": dom["avg_ms"], "flops_per_launch": conv_flops(1, args.batch), "traffic": None},
+            "kernels": kernels,
+            "conv_ms_per_step": round(mfma_ms, 2),
+            "final_loss": None if loss is None else float(loss),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -47,21 +47,36 @@ int mx_interp_linear(const float *x, int64_t rows, int64_t n_in, int64_t n_out, 
                      void *stream);
 
 /* ---- K2: flanger / chorus -- mod_extraction/fx.py:72-119 (MonoFlangerChorusModule.apply_effect)
- * x (B,N) mono clips; mod (B,n_mod), n_mod == N or shorter (resampled in-kernel).
+ * x: mono clips, row b at x + b*x_stride (N samples each; x_stride = N for a dense (B,N) tensor);
+ * mod (B,n_mod), n_mod == N or shorter (resampled in-kernel).
  * Per-clip float32 constants, each (B,):
  *   lfo_scale     = max_lfo_delay_samples * width            (fx.py:99)
  *   min_delay     = min_delay_width * max_min_delay_samples  (fx.py:98)
  *   feedback, depth, mix, one_minus_mix                      (fx.py:114-117)
  * max_delay (B,) int32: delay-line length M per clip (fx.py:42), max_delay_max = max over the
  * batch (<= 40000).  rows/n_rows: optional subset of clip indices to process (NULL = all B).
- * y (B,N) out, clipped to [-1,1].  Optional (NULL to skip): mod_up (B,N) resampled LFO,
+ * y: row b at y + b*y_stride, N samples, clipped to [-1,1].  Optional (NULL to skip): mod_up (B,N) resampled LFO,
  * dbg_prev (B,N) int64 and dbg_frac (B,N) = prev_idx_all / delay_read_fraction_all of
  * fx.py:101-102 for index-parity tests. */
-int mx_flanger_fwd(const float *x, const float *mod, int64_t n_mod, const float *lfo_scale,
+int mx_flanger_fwd(const float *x, int64_t x_stride, const float *mod, int64_t n_mod, const float *lfo_scale,
                    const float *min_delay, const float *feedback, const float *depth,
                    const float *mix, const float *one_minus_mix, const int32_t *max_delay,
                    int32_t max_delay_max, const int32_t *rows, int64_t n_rows, int64_t B, int64_t N,
-                   float *y, float *mod_up, int64_t *dbg_prev, float *dbg_frac, void *stream);
+                   float *y, int64_t y_stride, float *mod_up, int64_t *dbg_prev, float *dbg_frac, void *stream);
+
+/* ---- K3: phaser -- call site mod_extraction/datasets.py:455-482 (pedalboard==0.7.3 Phaser = JUCE
+ * dsp::Phaser<float>: 6 first-order TPT all-pass stages + feedback, sine LFO at sr/4 on a log
+ * frequency axis, linear dry/wet mix), then clip to [-1,1] (datasets.py:472).  Third-party
+ * algorithm restated from its published source: parity unpinned.
+ * x: source audio, row b at x + b*x_stride holding lead[b] + N samples; rate, depth, centre,
+ * feedback, mix (B,) fp32; lead (B,) int32 = samples rendered before the output window (the
+ * reference renders n + sr/rate samples and crops at a random offset, datasets.py:428-449), NULL = 0;
+ * rows/n_rows: optional subset of clips.  y: row b at y + b*y_stride = processed[lead:lead+N];
+ * dry_out (optional, same stride): the matching crop of x. */
+int mx_phaser_fwd(const float *x, int64_t x_stride, const float *rate, const float *depth,
+                  const float *centre, const float *feedback, const float *mix, const int32_t *lead,
+                  const int32_t *rows, int64_t n_rows, int64_t B, int64_t N, double sr, float *y,
+                  int64_t y_stride, float *dry_out, void *stream);
 
 /* ---- K4: log-mel front end -- mod_extraction/models.py:170-181,199-208
  * (torchaudio MelSpectrogram: n_fft 1024, hann, centre/reflect, power 2, mel filter bank `fb`)
@@ -131,6 +146,20 @@ int mx_head_bwd(const float *p6, const float *slope, const float *wout, const fl
  * sdl1, mse, weighted total (weights <= 0 are logged but not added); grad (B,n) or NULL. */
 int mx_lfo_loss(const float *y_hat, const float *y, int64_t B, int64_t n, float w_l1, float w_fdl1,
                 float w_sdl1, float w_mse, float *part, float *losses, float *grad, void *stream);
+
+/* ---- K9: LFO post-processing -- mod_extraction/modulations.py:219-363; all bit-exact fp32.
+ * x (rows, n) dense. */
+/* smoothen (modulations.py:359-363): out (rows, n-k+1) = moving average over k frames. */
+int mx_smoothen(const float *x, int64_t rows, int64_t n, int64_t k, float *out, void *stream);
+/* find_corners (modulations.py:219-238): top/bot (rows, n) float maps. */
+int mx_find_corners(const float *x, int64_t rows, int64_t n, float *top, float *bot, void *stream);
+/* stretch_corners after smoothing (modulations.py:260-307): out (rows, n). */
+int mx_stretch_corners(const float *x, int64_t rows, int64_t n, int64_t max_n_corners, float *out,
+                       void *stream);
+/* check_mod_sig (modulations.py:311-343) per row: valid (rows,) int32 0/1;
+ * min_gap = int(min_fraction_between_corners * n). */
+int mx_check_mod_sig(const float *x, int64_t rows, int64_t n, int32_t min_top, int32_t max_top,
+                     int32_t min_bot, int32_t max_bot, int32_t min_gap, int32_t *valid, void *stream);
 
 /* ---- K12: AdamW -- torch.optim.AdamW (configs/opt/adam_w.yml), flat fp32 buffers of n elements;
  * step = 1-based step index; grad_scale multiplies the gradient first (1/world after a sum

@@ -16,15 +16,16 @@ ABI_VERSION = 1
 _ERR = {-1: "MX_ERR_ARG (bad argument)", -2: "MX_ERR_UNSUPPORTED (size not supported)",
         -3: "MX_ERR_LAUNCH (HIP launch error)"}
 
-_P, _I64, _I32, _F32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_float
+_P, _I64, _I32, _F32, _F64 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_float, ctypes.c_double
 
 # name -> argtypes; must list every symbol include/modex_hip.h declares (tests check this)
 SIGNATURES = {
     "mx_abi_version": [],
     "mx_lfo_synth": [_P, _P, _P, _P, _P, _I64, _I64, _I64, _F32, _P, _P],
     "mx_interp_linear": [_P, _I64, _I64, _I64, _P, _P],
-    "mx_flanger_fwd": [_P, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _I32, _P, _I64, _I64, _I64,
-                       _P, _P, _P, _P, _P],
+    "mx_flanger_fwd": [_P, _I64, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _I32, _P, _I64, _I64, _I64,
+                       _P, _I64, _P, _P, _P, _P],
+    "mx_phaser_fwd": [_P, _I64, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _F64, _P, _I64, _P, _P],
     "mx_logmel_fwd": [_P, _I64, _I64, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _F32, _I32, _I32,
                       _I32, _I32, _P, _P],
     "mx_conv_pack_weights": [_P, _I64, _I64, _I32, _P, _P],
@@ -38,6 +39,10 @@ SIGNATURES = {
     "mx_head_fwd": [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _P, _P, _P],
     "mx_head_bwd": [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _P, _P, _P, _P, _P],
     "mx_lfo_loss": [_P, _P, _I64, _I64, _F32, _F32, _F32, _F32, _P, _P, _P, _P],
+    "mx_smoothen": [_P, _I64, _I64, _I64, _P, _P],
+    "mx_find_corners": [_P, _I64, _I64, _P, _P, _P],
+    "mx_stretch_corners": [_P, _I64, _I64, _I64, _P, _P],
+    "mx_check_mod_sig": [_P, _I64, _I64, _I32, _I32, _I32, _I32, _I32, _P, _P],
     "mx_adamw_step": [_P, _P, _P, _P, _I64, _I64, _F32, _F32, _F32, _F32, _F32, _F32, _P],
 }
 
@@ -81,7 +86,44 @@ def stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+class KernelTimer:
+    """Optional per-entry-point device timing with HIP events on the launch stream (bench.py).
+
+    ``with KernelTimer({"mx_conv_block_fwd"}) as kt: ...`` records an event pair around every call of
+    the selected C-ABI entry points (they launch on torch's current stream, so ``torch.cuda.Event``
+    brackets exactly the kernel(s) of that call); ``kt.results()`` synchronises and returns
+    ``{tag: [ms, ...]}`` where tag = ``name`` or ``name#<key>`` if ``key_fn(name, args)`` is given."""
+
+    active: Optional["KernelTimer"] = None
+
+    def __init__(self, names, key_fn=None) -> None:
+        self.names, self.key_fn = set(names), key_fn
+        self.pairs = []
+
+    def __enter__(self) -> "KernelTimer":
+        KernelTimer.active = self
+        return self
+
+    def __exit__(self, *exc) -> None:
+        KernelTimer.active = None
+
+    def results(self):
+        torch.cuda.synchronize()
+        out = {}
+        for tag, a, b in self.pairs:
+            out.setdefault(tag, []).append(a.elapsed_time(b))
+        return out
+
+
 def call(name: str, *args) -> None:
-    rc = getattr(load(), name)(*args)
+    kt = KernelTimer.active
+    if kt is not None and name in kt.names:
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        rc = getattr(load(), name)(*args)
+        b.record()
+        kt.pairs.append((name if kt.key_fn is None else f"{name}#{kt.key_fn(name, args)}", a, b))
+    else:
+        rc = getattr(load(), name)(*args)
     if rc != 0:
         raise HipLibraryError(f"{name} failed: {_ERR.get(rc, rc)}")

@@ -28,12 +28,12 @@ struct FlSample {
 };
 
 __global__ __launch_bounds__(64) void flanger_kernel(
-    const float *__restrict__ x, const float *__restrict__ mod, int n_mod, float mod_scale,
+    const float *__restrict__ x, long long x_stride, const float *__restrict__ mod, int n_mod, float mod_scale,
     const float *__restrict__ lfo_scale, const float *__restrict__ min_delay,
     const float *__restrict__ feedback, const float *__restrict__ depth,
     const float *__restrict__ mix, const float *__restrict__ one_minus_mix,
     const int *__restrict__ max_delay, const int *__restrict__ rows, int N,
-    float *__restrict__ y, float *__restrict__ mod_up, long long *__restrict__ dbg_prev,
+    float *__restrict__ y, long long y_stride, float *__restrict__ mod_up, long long *__restrict__ dbg_prev,
     float *__restrict__ dbg_frac)
 {
     extern __shared__ float buf[];
@@ -43,9 +43,9 @@ __global__ __launch_bounds__(64) void flanger_kernel(
     const float Mf = (float)M;
     const float ls = lfo_scale[b], md = min_delay[b], fb = feedback[b], dp = depth[b];
     const float mx = mix[b], omm = one_minus_mix[b];
-    const float *xb = x + (size_t)b * N;
+    const float *xb = x + (size_t)b * x_stride;
     const float *mb = mod + (size_t)b * n_mod;
-    float *yb = y + (size_t)b * N;
+    float *yb = y + (size_t)b * y_stride;
 
     for (int i = lane; i < M; i += 64) buf[i] = 0.0f;  // fx.py:92 (LDS ops of one wave are in order)
 
@@ -151,24 +151,24 @@ __global__ __launch_bounds__(64) void flanger_kernel(
 }
 
 // C ABI ---------------------------------------------------------------------------------------
-// x (B,N); mod (B,n_mod) with n_mod == N or any shorter length (resampled in-kernel,
+// x: row b at x + b*x_stride (N samples); y likewise with y_stride; mod (B,n_mod) with n_mod == N or any shorter length (resampled in-kernel,
 // align_corners=True); per-clip fp32 constants lfo_scale = max_lfo_delay_samples*width,
 // min_delay = min_delay_width*max_min_delay_samples, feedback, depth, mix, one_minus_mix;
 // max_delay (B,) int32 = delay-line length M per clip (flanger and chorus clips may be mixed in
 // one batch); rows: optional list of n_rows clip indices to process (others untouched).
 // Optional outputs: mod_up (B,N) resampled LFO; dbg_prev (B,N) int64 / dbg_frac (B,N) for the
 // index-parity tests.
-MX_EXPORT int mx_flanger_fwd(const float *x, const float *mod, int64_t n_mod, const float *lfo_scale,
+MX_EXPORT int mx_flanger_fwd(const float *x, int64_t x_stride, const float *mod, int64_t n_mod, const float *lfo_scale,
                              const float *min_delay, const float *feedback, const float *depth,
                              const float *mix, const float *one_minus_mix, const int32_t *max_delay,
                              int32_t max_delay_max, const int32_t *rows, int64_t n_rows, int64_t B,
-                             int64_t N, float *y, float *mod_up, int64_t *dbg_prev, float *dbg_frac,
+                             int64_t N, float *y, int64_t y_stride, float *mod_up, int64_t *dbg_prev, float *dbg_frac,
                              void *stream)
 {
     if (!x || !mod || !lfo_scale || !min_delay || !feedback || !depth || !mix || !one_minus_mix ||
         !max_delay || !y || B <= 0 || N <= 0 || n_mod <= 0)
         return MX_ERR_ARG;
-    if (max_delay_max < 2) return MX_ERR_ARG;
+    if (max_delay_max < 2 || x_stride < N || y_stride < N) return MX_ERR_ARG;
     if (max_delay_max > FL_MAX_M || N >= (1ll << 30)) return MX_ERR_UNSUPPORTED;
     const int64_t items = rows ? n_rows : B;
     if (items <= 0) return MX_OK;
@@ -179,9 +179,9 @@ MX_EXPORT int mx_flanger_fwd(const float *x, const float *mod, int64_t n_mod, co
         attr_set = true;
     }
     const size_t lds = (size_t)max_delay_max * sizeof(float);
-    hipLaunchKernelGGL(flanger_kernel, dim3((unsigned)items), dim3(64), lds, (hipStream_t)stream, x, mod,
+    hipLaunchKernelGGL(flanger_kernel, dim3((unsigned)items), dim3(64), lds, (hipStream_t)stream, x, (long long)x_stride, mod,
                        (int)n_mod, interp_scale_host(n_mod, N), lfo_scale, min_delay, feedback, depth,
-                       mix, one_minus_mix, max_delay, rows, (int)N, y, mod_up, (long long *)dbg_prev,
+                       mix, one_minus_mix, max_delay, rows, (int)N, y, (long long)y_stride, mod_up, (long long *)dbg_prev,
                        dbg_frac);
     return mx_launch_status();
 }

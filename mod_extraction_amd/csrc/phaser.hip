@@ -1,0 +1,126 @@
+// phaser.hip -- K3: 6-stage all-pass phaser with feedback (reference call site:
+// mod_extraction/datasets.py:455-482 -> pedalboard==0.7.3 Phaser == JUCE dsp::Phaser<float>;
+// third-party source absent from the reference tree: PARITY UNPINNED, checked against
+// oracle/csrc/oracle_ref.c:orc_phaser, which restates the published JUCE algorithm).
+//
+// One wavefront per clip.  The recurrence (in - lastOut -> 6 first-order TPT all-pass stages ->
+// out; lastOut = out * feedback) is strictly serial per sample, so the wave splits the work by
+// kind: per block of 256 samples the 64 lanes evaluate the 64 LFO / cut-off updates in parallel
+// (sin, pow, fp64 tan -> G = g / (1 + g), one per lane), samples are loaded/stored 4 per lane
+// coalesced through LDS, and only the 256-sample dependent chain runs wave-uniformly.
+// sin / pow / log10 are evaluated in fp64 and rounded once, which reproduces the host libm's (correctly
+// rounded) float results; the LFO phase accumulator is advanced sequentially in fp32 (as JUCE does) to stay bit-faithful.
+// `lead` samples are processed (filter warm-up, LFO phase) before the N output samples: the
+// reference renders n + sr/rate samples and crops at a random offset (datasets.py:428-449).
+// Algorithmic HBM traffic: 8 B/sample (+4 B/sample when the cropped dry clip is also written).
+#include "common.h"
+
+#define PH_BLOCK 256
+
+__global__ __launch_bounds__(64) void phaser_kernel(const float *__restrict__ x, long long x_stride,
+                                                    const float *__restrict__ rate,
+                                                    const float *__restrict__ depth,
+                                                    const float *__restrict__ centre,
+                                                    const float *__restrict__ feedback,
+                                                    const float *__restrict__ mix,
+                                                    const int *__restrict__ lead_arr,
+                                                    const int *__restrict__ rows, int N, float sr_f,
+                                                    double sr, float *__restrict__ y, long long y_stride,
+                                                    float *__restrict__ dry_out)
+{
+    __shared__ float xs[PH_BLOCK], ys[PH_BLOCK], Gs[PH_BLOCK / 4];
+    const int lane = threadIdx.x;
+    const int b = rows ? rows[blockIdx.x] : (int)blockIdx.x;
+    const int lead = lead_arr ? lead_arr[b] : 0;
+    const int total = lead + N;
+    const float *xb = x + (size_t)b * x_stride;
+    float *yb = y + (size_t)b * y_stride;
+    float *db = dry_out ? dry_out + (size_t)b * y_stride : nullptr;
+
+    const float two_pi = 6.283185307179586476925286766559f;
+    const float pi_f = 3.14159265358979323846f;
+    const float fmax_hz = (float)fmin(20000.0, 0.49 * sr);
+    const float log_min = (float)log10(20.0), log_max = (float)log10((double)fmax_hz);
+    const float inc = __fmul_rn(__fdiv_rn(two_pi, (float)(sr / 4.0)), rate[b]);
+    const float norm_centre = __fdiv_rn(__fsub_rn((float)log10((double)centre[b]), log_min), __fsub_rn(log_max, log_min));
+    const float osc_vol = __fmul_rn(depth[b], 0.5f);
+    const float fb = feedback[b];
+    const float wet_g = mix[b], dry_g = __fsub_rn(1.0f, mix[b]);
+    (void)sr_f;
+
+    float phase = 0.0f;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f, s5 = 0.f, last = 0.f;
+
+    for (int n0 = 0; n0 < total; n0 += PH_BLOCK) {
+        // (1) coalesced load of 256 input samples
+#pragma unroll
+        for (int j = 0; j < PH_BLOCK / 64; ++j) {
+            const int n = n0 + j * 64 + lane;
+            xs[j * 64 + lane] = n < total ? xb[n] : 0.0f;
+        }
+        // (2) sequential fp32 phase accumulation; lane k keeps the phase of update k
+        float my_phase = 0.0f;
+        for (int k = 0; k < PH_BLOCK / 4; ++k) {
+            if (lane == k) my_phase = phase;
+            phase = __fadd_rn(phase, inc);
+            while (phase >= two_pi) phase = __fsub_rn(phase, two_pi);
+        }
+        // (3) one cut-off update per lane
+        {
+            float osc = (float)sin((double)__fsub_rn(my_phase, pi_f));
+            float lfo = __fadd_rn(__fmul_rn(osc, osc_vol), norm_centre);
+            lfo = lfo < 0.0f ? 0.0f : (lfo > 1.0f ? 1.0f : lfo);
+            float fc = (float)pow(10.0, (double)__fadd_rn(__fmul_rn(lfo, __fsub_rn(log_max, log_min)), log_min));
+            float g = (float)tan(3.14159265358979323846 * (double)fc / sr);
+            Gs[lane] = __fdiv_rn(g, __fadd_rn(1.0f, g));
+        }
+        __builtin_amdgcn_s_waitcnt(0);      // LDS writes of this wave are visible to its own reads in order
+        // (4) the dependent chain, wave-uniform
+        const int cnt = min(PH_BLOCK, total - n0);
+        for (int i = 0; i < cnt; ++i) {
+            const float G = Gs[i >> 2];
+            const float in = xs[i];
+            float out = __fsub_rn(in, last);
+            float v, yk;
+#define PH_STAGE(S)                                   \
+    v = __fmul_rn(G, __fsub_rn(out, S));             \
+    yk = __fadd_rn(v, S);                            \
+    S = __fadd_rn(v, yk);                            \
+    out = __fsub_rn(__fmul_rn(2.0f, yk), out);
+            PH_STAGE(s0) PH_STAGE(s1) PH_STAGE(s2) PH_STAGE(s3) PH_STAGE(s4) PH_STAGE(s5)
+#undef PH_STAGE
+            last = __fmul_rn(out, fb);
+            float m = __fadd_rn(__fmul_rn(out, wet_g), __fmul_rn(in, dry_g));
+            m = m < -1.0f ? -1.0f : (m > 1.0f ? 1.0f : m);
+            if (lane == 0) ys[i] = m;
+        }
+        // (5) coalesced store of the samples that fall inside the output window
+#pragma unroll
+        for (int j = 0; j < PH_BLOCK / 64; ++j) {
+            const int n = n0 + j * 64 + lane;
+            if (n >= lead && n < total) {
+                yb[n - lead] = ys[j * 64 + lane];
+                if (db) db[n - lead] = xs[j * 64 + lane];
+            }
+        }
+    }
+}
+
+// x: source audio, row b at x + b*x_stride, at least lead[b] + N samples; rate, depth, centre,
+// feedback, mix: (B,) fp32; lead: (B,) int32 warm-up samples (NULL = 0); rows/n_rows: optional
+// subset of clip indices.  y: row b at y + b*y_stride, N samples = processed[lead : lead+N];
+// dry_out (optional, same stride as y): the matching crop of the source.
+MX_EXPORT int mx_phaser_fwd(const float *x, int64_t x_stride, const float *rate, const float *depth,
+                            const float *centre, const float *feedback, const float *mix, const int32_t *lead,
+                            const int32_t *rows, int64_t n_rows, int64_t B, int64_t N, double sr, float *y,
+                            int64_t y_stride, float *dry_out, void *stream)
+{
+    if (!x || !rate || !depth || !centre || !feedback || !mix || !y || B <= 0 || N <= 0 || sr <= 0.0) return MX_ERR_ARG;
+    if (N >= (1ll << 30)) return MX_ERR_UNSUPPORTED;
+    const int64_t items = rows ? n_rows : B;
+    if (items <= 0) return MX_OK;
+    hipLaunchKernelGGL(phaser_kernel, dim3((unsigned)items), dim3(64), 0, (hipStream_t)stream, x, (long long)x_stride,
+                       rate, depth, centre, feedback, mix, lead, rows, (int)N, (float)sr, sr, y, (long long)y_stride,
+                       dry_out);
+    return mx_launch_status();
+}

@@ -1,0 +1,260 @@
+"""Host mirror of the hot-path part of mod_extraction/data_modules.py + datasets.py: the batch
+contract ``(dry, wet, mod_sig, fx_params)`` (lightning.py:100,310) and the effect-parameter /
+LFO sampling recipes (datasets.py:365-398, 428-482; data_modules.py:419-458), with the effect
+rendering moved onto the device:
+
+* flanger / chorus  -> ``mx_flanger_fwd`` (the reference runs fx.py on the CPU in
+  ``on_before_batch_transfer`` or pre-renders to disk)
+* phaser            -> ``mx_phaser_fwd`` (the reference calls pedalboard in DataLoader workers)
+* LFO labels        -> ``mx_lfo_synth``
+
+Audio comes from a synthetic clip source (peak-normalised uniform noise, seeded per rank): the
+IDMT / EGFx datasets are not available, so the file-backed dataset classes (random non-silent
+chunk search, pairing, peak normalisation) are out of scope of this path.
+Data-module classes keep the reference names and accept the reference ``init_args`` so the shipped
+YAML configs instantiate; directory arguments are accepted and ignored.
+"""
+import math
+from typing import Any, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+from torch import Tensor as T
+
+from . import fx, util
+from .modulations import SHAPE_IDS, make_mod_signals
+
+LFO_SHAPES = ["cos", "rect_cos", "inv_rect_cos", "tri", "saw", "rsaw"]
+
+# parameter ranges of the shipped configs
+FLANGER_FX = {"max_min_delay_ms": 1.0, "max_lfo_delay_ms": 10.0, "feedback": (0.0, 0.7),
+              "min_delay_width": (0.0, 1.0), "width": (0.25, 1.0), "depth": (0.25, 1.0),
+              "mix": (0.25, 1.0)}                               # configs/train_lfo_flanger.yml:52-71
+CHORUS_FX = dict(FLANGER_FX, max_min_delay_ms=30.0, min_delay_width=(0.367, 1.0))   # configs/data/gen_idmt_ch.yml:34-51
+PHASER_FX = {"rate_hz": (0.5, 3.0), "depth": (0.2, 1.0), "centre_frequency_hz": (70.0, 18000.0),
+             "feedback": (0.0, 0.7), "mix": (0.2, 1.0)}        # configs/train_lfo_phaser.yml:33-48
+MOD_SIG = {"rate_hz": (0.5, 3.0), "phase": (0.0, 2 * math.pi), "shapes": LFO_SHAPES, "exp": 1.0}
+
+
+def _rng(v: Any) -> Tuple[float, float]:
+    if isinstance(v, dict):
+        return float(v["min"]), float(v["max"])
+    return float(v[0]), float(v[1])
+
+
+def _fx_from_config(cfg: Optional[Dict[str, Any]], default: Dict[str, Any]) -> Dict[str, Any]:
+    out = dict(default)
+    if cfg:
+        for k, v in cfg.items():
+            out[k] = _rng(v) if isinstance(v, (dict, list, tuple)) else v
+    return out
+
+
+class SyntheticFxBatcher:
+    """Builds one training batch entirely on the device.
+
+    ``kinds`` lists the effect of each slot of the interleave, clip ``i`` gets ``kinds[i % len(kinds)]``
+    (datasets.py:79-83): "flanger", "chorus" (fx.py with 1 ms / 30 ms base delay) or "phaser".
+    Host RNG: ``torch`` global generator and numpy global RNG (scipy ``loguniform``), as in the
+    reference; draws are vectorised per batch (one call per parameter).
+    """
+
+    def __init__(self, batch_size: int, n_samples: int, sr: float, kinds: Sequence[str], device: torch.device,
+                 flanger_fx: Optional[Dict] = None, chorus_fx: Optional[Dict] = None,
+                 phaser_fx: Optional[Dict] = None, mod_sig: Optional[Dict] = None, audio_seed: int = 43,
+                 peak_db: float = -1.0, fixed_lead: Optional[int] = None) -> None:
+        self.B, self.N, self.sr, self.device = batch_size, n_samples, float(sr), device
+        self.kinds = [kinds[i % len(kinds)] for i in range(batch_size)]
+        self.fl = _fx_from_config(flanger_fx, FLANGER_FX)
+        self.ch = _fx_from_config(chorus_fx, CHORUS_FX)
+        self.ph = _fx_from_config(phaser_fx, PHASER_FX)
+        self.ms = dict(MOD_SIG)
+        if mod_sig:
+            for k, v in mod_sig.items():
+                self.ms[k] = _rng(v) if isinstance(v, dict) else v
+        self.n_lfo = n_samples // 100                               # datasets.py:382
+        self.lfo_sr = self.sr // 100
+        self.kind_id = torch.tensor([{"flanger": 0, "chorus": 1, "phaser": 2}[k] for k in self.kinds])
+        self.rows_fx = torch.nonzero(self.kind_id != 2).view(-1).to(torch.int32).to(device)
+        self.rows_ph = torch.nonzero(self.kind_id == 2).view(-1).to(torch.int32).to(device)
+        self.has_ph = bool((self.kind_id == 2).any())
+        self.has_fx = bool((self.kind_id != 2).any())
+        self.fixed_lead = fixed_lead
+        # phaser: the reference renders n + sr/rate samples and crops (datasets.py:428-449)
+        self.max_lead = int(self.sr / self.ph["rate_hz"][0] + 0.5) if self.has_ph else 0
+        self.gen = torch.Generator(device=device)
+        self.gen.manual_seed(audio_seed)
+        self.peak = 10.0 ** (peak_db / 20.0)
+        mm = torch.tensor([fx.delay_samples((self.ch if k == "chorus" else self.fl)["max_min_delay_ms"], self.sr)
+                           for k in self.kinds], dtype=torch.float32)
+        ml = torch.tensor([fx.delay_samples((self.ch if k == "chorus" else self.fl)["max_lfo_delay_ms"], self.sr)
+                           for k in self.kinds], dtype=torch.float32)
+        self.max_min_delay = mm.to(device)
+        self.max_lfo_delay = ml.to(device)
+        self.max_delay = (mm + ml).to(torch.int32).to(device)
+        self.max_delay_max = int((mm + ml).max())
+        self.src = torch.empty((batch_size, n_samples + self.max_lead), device=device, dtype=torch.float32)
+        self.audio = torch.empty((batch_size, 2, n_samples), device=device, dtype=torch.float32)
+
+    # ---- host-side parameter draws -------------------------------------------------------------
+    def _uniform(self, lo: float, hi: float) -> T:
+        return util.sample_uniform(lo, hi, n=self.B).float()
+
+    def _choose(self, per_kind: Dict[str, Tuple[float, float]]) -> T:
+        """one vectorised draw per effect kind, merged by slot"""
+        out = torch.zeros(self.B)
+        for kid, name in enumerate(("flanger", "chorus")):
+            if name in per_kind:
+                lo, hi = per_kind[name]
+                v = self._uniform(lo, hi)
+                out = torch.where(self.kind_id == kid, v, out)
+        return out
+
+    def sample_params(self) -> Dict[str, Any]:
+        B = self.B
+        rate = util.sample_log_uniform(*self.ms["rate_hz"], n=B).float()
+        phase = self._uniform(*self.ms["phase"])
+        shape_idx = util.randint(0, len(self.ms["shapes"]), n=B)
+        shapes = [self.ms["shapes"][int(i)] for i in shape_idx]
+        is_ph = self.kind_id == 2
+        p: Dict[str, Any] = {}
+        if self.has_fx:
+            for name in ("feedback", "min_delay_width", "width", "depth", "mix"):   # data_modules.py:421-445 order
+                p[name] = self._choose({"flanger": self.fl[name], "chorus": self.ch[name]})
+        else:
+            for name in ("feedback", "min_delay_width", "width", "depth", "mix"):
+                p[name] = torch.zeros(B)
+        lead = torch.zeros(B, dtype=torch.int32)
+        centre = torch.full((B,), 440.0)
+        if self.has_ph:
+            ph_rate = util.sample_log_uniform(*self.ph["rate_hz"], n=B).float()   # datasets.py:429-432
+            ph_depth = self._uniform(*self.ph["depth"])                           # datasets.py:460-465 order
+            centre = util.sample_log_uniform(*self.ph["centre_frequency_hz"], n=B).float()
+            ph_fb = self._uniform(*self.ph["feedback"])
+            ph_mix = self._uniform(*self.ph["mix"])
+            rate = torch.where(is_ph, ph_rate, rate)
+            phase = torch.where(is_ph, torch.full((B,), math.pi / 2), phase)      # datasets.py:442
+            shapes = ["cos" if is_ph[i] else s for i, s in enumerate(shapes)]
+            p["depth"] = torch.where(is_ph, ph_depth, p["depth"])
+            p["feedback"] = torch.where(is_ph, ph_fb, p["feedback"])
+            p["mix"] = torch.where(is_ph, ph_mix, p["mix"])
+            rate_n = (self.sr / rate.double() + 0.5).to(torch.int64)              # datasets.py:433
+            if self.fixed_lead is None:
+                u = torch.rand(B, dtype=torch.float64)
+                lead = torch.minimum((u * (rate_n + 1).double()).to(torch.int64), rate_n)   # randint(0, rate_n + 1)
+            else:
+                lead = torch.full((B,), int(self.fixed_lead), dtype=torch.int64)
+            lead = torch.where(is_ph, lead, torch.zeros_like(lead)).to(torch.int32)
+        p.update(rate_hz=rate, phase=phase, shape=shapes, exp=torch.full((B,), float(self.ms["exp"])),
+                 centre_frequency_hz=centre, lead=lead)
+        return p
+
+    # ---- device-side rendering -------------------------------------------------------------------
+    def render(self, p: Dict[str, Any]) -> Tuple[T, T, T, Dict[str, Any]]:
+        dev, B, N = self.device, self.B, self.N
+        d = {k: v.to(dev) for k, v in p.items() if isinstance(v, torch.Tensor)}
+        shape_id = torch.tensor([SHAPE_IDS[s] for s in p["shape"]], dtype=torch.int32, device=dev)
+        # synthetic dry audio: uniform noise at `peak`
+        self.src.uniform_(-self.peak, self.peak, generator=self.gen)
+        self.audio[:, 0, :].copy_(self.src[:, :N])
+        # LFO labels at n_samples // 100 points
+        mod = make_mod_signals(self.n_lfo, self.lfo_sr, d["rate_hz"], d["phase"], shape_id, d["exp"])
+        if self.has_ph:
+            half_pi = torch.full((B,), math.pi / 2, device=dev)
+            mod_ph = make_mod_signals(N, self.sr, d["rate_hz"], half_pi, None, None, d["lead"], n_out=self.n_lfo)
+            mod = torch.where((self.kind_id == 2).to(dev).unsqueeze(1), mod_ph, mod)
+        dry, wet = self.audio[:, 0, :], self.audio[:, 1, :]
+        if self.has_fx:
+            consts = {"lfo_scale": (d["width"] * self.max_lfo_delay).contiguous(),
+                      "min_delay": (d["min_delay_width"] * self.max_min_delay).contiguous(),
+                      "feedback": d["feedback"], "depth": d["depth"], "mix": d["mix"],
+                      "one_minus_mix": (1.0 - d["mix"]).contiguous()}
+            fx.flanger_forward(dry, mod, consts, self.max_delay, self.max_delay_max, rows=self.rows_fx, out=wet)
+        if self.has_ph:
+            fx.phaser_forward(self.src, d, d["lead"], self.sr, N, rows=self.rows_ph, out=wet, dry_out=dry)
+        fx_params = dict(d)
+        fx_params["shape"] = p["shape"]
+        return self.audio[:, 0:1, :], self.audio[:, 1:2, :], mod, fx_params
+
+    def next_batch(self) -> Tuple[T, T, T, Dict[str, Any]]:
+        with torch.no_grad():
+            return self.render(self.sample_params())
+
+
+# ---- data modules with the reference's class names ---------------------------------------------
+class _SyntheticDataModule:
+    """Common part: per-rank batch size (``batch_size`` is per process, as under Lightning DDP),
+    ``train_batch()`` / ``val_batch()`` producing the 4-tuple on the device."""
+
+    kinds: Sequence[str] = ("flanger",)
+
+    def __init__(self, batch_size: int, n_samples: int = 88200, sr: float = 44100,
+                 train_num_examples_per_epoch: int = 8000, val_num_examples_per_epoch: int = 2000,
+                 fx_config: Optional[Dict[str, Any]] = None, **ignored: Any) -> None:
+        self.batch_size, self.n_samples, self.sr = batch_size, n_samples, sr
+        self.train_num_examples_per_epoch = train_num_examples_per_epoch
+        self.val_num_examples_per_epoch = val_num_examples_per_epoch
+        self.fx_config = fx_config or {}
+        self.ignored_args = ignored          # dataset directories, num_workers, silence thresholds, ...
+        self._batcher: Optional[SyntheticFxBatcher] = None
+
+    def setup(self, device: torch.device, rank: int = 0, seed: int = 43) -> None:
+        fl = self.fx_config.get("flanger")
+        self._batcher = SyntheticFxBatcher(self.batch_size, self.n_samples, self.sr, self.kinds, device,
+                                           flanger_fx=fl, chorus_fx=fl if "chorus" in self.kinds and fl else None,
+                                           phaser_fx=self.fx_config.get("pedalboard_phaser"),
+                                           mod_sig=self.fx_config.get("mod_sig"), audio_seed=seed + rank)
+
+    def train_steps_per_epoch(self) -> int:
+        return max(1, self.train_num_examples_per_epoch // self.batch_size)
+
+    def val_steps_per_epoch(self) -> int:
+        return max(1, self.val_num_examples_per_epoch // self.batch_size)
+
+    def train_batch(self):
+        return self._batcher.next_batch()
+
+    val_batch = train_batch
+
+
+class FlangerCPUDataModule(_SyntheticDataModule):
+    """data_modules.py:374-458 -- the flanger is rendered on the device, not on the CPU."""
+    kinds = ("flanger",)
+
+
+class PedalboardPhaserDataModule(_SyntheticDataModule):
+    """data_modules.py:259-328."""
+    kinds = ("phaser",)
+
+
+class InterwovenDataModule(_SyntheticDataModule):
+    """data_modules.py:20-83 with configs/data/interwoven_idmt_all.yml: flanger, chorus, phaser
+    interleaved by ``idx % 3`` (the reference pre-renders flanger/chorus to disk)."""
+    kinds = ("flanger", "chorus", "phaser")
+
+    def __init__(self, batch_size: int, num_workers: int = 0, shared_args: Optional[Dict[str, Any]] = None,
+                 shared_train_args: Optional[Dict[str, Any]] = None, shared_val_args: Optional[Dict[str, Any]] = None,
+                 train_dataset_args: Optional[List[Dict[str, Any]]] = None,
+                 val_dataset_args: Optional[List[Dict[str, Any]]] = None, **ignored: Any) -> None:
+        shared_args = shared_args or {}
+        fx_config: Dict[str, Any] = {}
+        for ds in (train_dataset_args or []):
+            if "fx_config" in ds:
+                fx_config.update(ds["fx_config"])
+        super().__init__(batch_size, n_samples=shared_args.get("n_samples", 88200), sr=shared_args.get("sr", 44100),
+                         train_num_examples_per_epoch=(shared_train_args or {}).get("num_examples_per_epoch", 8000),
+                         val_num_examples_per_epoch=(shared_val_args or {}).get("num_examples_per_epoch", 2000),
+                         fx_config=fx_config, num_workers=num_workers, **ignored)
+        self.shared_args = shared_args
+
+
+class RandomAudioChunkDryWetDataModule(_SyntheticDataModule):
+    """data_modules.py:177-256 (dry/wet pairs of an unseen effect, configs/train_em_dry_wet.yml):
+    the EGFx recordings are replaced by synthetic dry clips and this package's phaser render."""
+    kinds = ("phaser",)
+
+    def train_batch(self):
+        dry, wet, _, _ = self._batcher.next_batch()
+        return dry, wet, None, None
+
+    val_batch = train_batch

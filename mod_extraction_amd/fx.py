@@ -2,7 +2,7 @@
 (fx.py:25-44,121-130); the per-sample delay-line recurrence runs in the ``mx_flanger_fwd`` HIP
 kernel (one wavefront per clip, delay line in LDS) instead of 88 200 python iterations.
 """
-from typing import Dict, Optional, Union
+from typing import Dict, Optional, Tuple, Union
 
 import torch
 from torch import Tensor as T, nn
@@ -69,17 +69,28 @@ def derive_clip_constants(bs: int, device: torch.device, max_min_delay_samples: 
             "feedback": vec(feedback), "depth": vec(depth), "mix": mix_v, "one_minus_mix": omm.contiguous()}
 
 
+def _rows_view(t: T) -> Tuple[int, int]:
+    """(data_ptr, row stride in floats) of a (B, N) view whose rows are contiguous."""
+    if not t.is_cuda:
+        raise _hip.HipLibraryError("mod_extraction_amd ops need tensors on a HIP device (no CPU fallback)")
+    assert t.dtype == torch.float32 and t.ndim == 2 and t.stride(1) == 1
+    return t.data_ptr(), t.stride(0)
+
+
 def flanger_forward(x: T, mod_sig: T, consts: Dict[str, T], max_delay: T, max_delay_max: int,
                     rows: Optional[T] = None, out: Optional[T] = None, mod_up: Optional[T] = None,
                     dbg_prev: Optional[T] = None, dbg_frac: Optional[T] = None) -> T:
-    """Launch mx_flanger_fwd.  x (B,N) fp32, mod_sig (B,n_mod) fp32, max_delay (B,) int32."""
+    """Launch mx_flanger_fwd.  x, out: (B,N) fp32 views with contiguous rows (any row stride, e.g. one
+    channel of a (B,2,N) tensor); mod_sig (B,n_mod) fp32; max_delay (B,) int32."""
     B, N = x.shape
     y = out if out is not None else torch.empty_like(x)
-    _hip.call("mx_flanger_fwd", _hip.ptr(x), _hip.ptr(mod_sig), mod_sig.size(-1),
+    xp, xs = _rows_view(x)
+    yp, ys = _rows_view(y)
+    _hip.call("mx_flanger_fwd", xp, xs, _hip.ptr(mod_sig), mod_sig.size(-1),
               _hip.ptr(consts["lfo_scale"]), _hip.ptr(consts["min_delay"]), _hip.ptr(consts["feedback"]),
               _hip.ptr(consts["depth"]), _hip.ptr(consts["mix"]), _hip.ptr(consts["one_minus_mix"]),
               _hip.ptr(max_delay), int(max_delay_max), _hip.ptr(rows), 0 if rows is None else rows.numel(),
-              B, N, _hip.ptr(y), _hip.ptr(mod_up), _hip.ptr(dbg_prev), _hip.ptr(dbg_frac), _hip.stream())
+              B, N, yp, ys, _hip.ptr(mod_up), _hip.ptr(dbg_prev), _hip.ptr(dbg_frac), _hip.stream())
     return y
 
 
@@ -118,3 +129,24 @@ class MonoFlangerChorusModule(nn.Module):
             mc = mod_sig.reshape(bs, -1).contiguous().float()
             y = flanger_forward(xc, mc, consts, md, self.max_delay_samples)
         return y.view(bs, 1, n)
+
+
+def phaser_forward(src: T, params: Dict[str, T], lead: Optional[T], sr: float, n_samples: int,
+                   rows: Optional[T] = None, out: Optional[T] = None, dry_out: Optional[T] = None) -> T:
+    """Launch mx_phaser_fwd (pedalboard.Phaser semantics, datasets.py:455-482).
+    src (B, >= lead+n_samples) source audio rows; params: rate_hz, depth, centre_frequency_hz,
+    feedback, mix -- each (B,) fp32 on the device; lead (B,) int32 warm-up samples or None;
+    out / dry_out: (B, n_samples) views with contiguous rows."""
+    B = src.size(0)
+    y = out if out is not None else torch.empty((B, n_samples), device=src.device, dtype=torch.float32)
+    sp, ss = _rows_view(src)
+    yp, ys = _rows_view(y)
+    dp = None
+    if dry_out is not None:
+        dp, ds = _rows_view(dry_out)
+        assert ds == ys
+    _hip.call("mx_phaser_fwd", sp, ss, _hip.ptr(params["rate_hz"]), _hip.ptr(params["depth"]),
+              _hip.ptr(params["centre_frequency_hz"]), _hip.ptr(params["feedback"]), _hip.ptr(params["mix"]),
+              _hip.ptr(lead), _hip.ptr(rows), 0 if rows is None else rows.numel(), B, n_samples, float(sr),
+              yp, ys, dp, _hip.stream())
+    return y

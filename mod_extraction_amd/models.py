@@ -311,3 +311,59 @@ class Spectral2DCNN(nn.Module):
         logmel = self.log_mel(x, masks)
         out, latent = _CNNStack.apply(logmel, self.n_frames, tuple(self.temp_dilations), *self._stack_params())
         return out, latent
+
+
+class RandomLFO(nn.Module):
+    """models.py:19-69: baseline 'extractor' that emits random / perturbed-ground-truth LFOs."""
+
+    def __init__(self,
+                 n_samples: int,
+                 sr: float,
+                 use_shape_gt: bool = False,
+                 use_phase_gt: bool = False,
+                 use_freq_gt: bool = False,
+                 shapes: Optional[List[str]] = None,
+                 freq_min: float = 0.5,
+                 freq_max: float = 3.0,
+                 phase_error: float = 0.0,
+                 freq_error: float = 0.0) -> None:
+        super().__init__()
+        self.n_samples, self.sr = n_samples, sr
+        self.use_shape_gt, self.use_phase_gt, self.use_freq_gt = use_shape_gt, use_phase_gt, use_freq_gt
+        self.shapes, self.freq_min, self.freq_max = shapes, freq_min, freq_max
+        self.phase_error, self.freq_error = phase_error, freq_error
+
+    def forward(self, batch_size: int, fx_params: Optional[Dict[str, T]] = None) -> T:
+        from .modulations import make_rand_mod_signal
+        shapes_gt = phase_gt = freq_gt = None
+        if self.use_shape_gt:
+            assert fx_params is not None and "shape" in fx_params
+            shapes_gt = fx_params["shape"]
+        if self.use_phase_gt:
+            assert fx_params is not None and "phase" in fx_params
+            phase_gt = fx_params["phase"]
+        if self.use_freq_gt:
+            assert fx_params is not None and "rate_hz" in fx_params
+            freq_gt = fx_params["rate_hz"]
+        return make_rand_mod_signal(batch_size, self.n_samples, self.sr, self.freq_min, self.freq_max, shapes_gt,
+                                    self.shapes, phase_gt, self.phase_error, freq_gt, self.freq_error).unsqueeze(1)
+
+
+class HiddenStateModel(nn.Module):
+    """models.py:292-308."""
+
+    def __init__(self) -> None:
+        super().__init__()
+        self.hidden: Tuple[T, T] = (torch.zeros((1,)), torch.zeros((1,)))
+        self.is_hidden_init = False
+
+    def update_hidden(self, hidden: Tuple[T, T]) -> None:
+        self.hidden = hidden
+        self.is_hidden_init = True
+
+    def detach_hidden(self) -> None:
+        if self.is_hidden_init:
+            self.hidden = tuple((h.detach().clone() for h in self.hidden))
+
+    def clear_hidden(self) -> None:
+        self.is_hidden_init = False

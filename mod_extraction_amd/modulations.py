@@ -45,3 +45,90 @@ def make_mod_signal(n_samples: int, sr: float, freq: float, phase: float = 0.0, 
     s = torch.tensor([SHAPE_IDS[shape]], device=dev, dtype=torch.int32)
     e = torch.tensor([float(exp)], device=dev, dtype=torch.float32)
     return make_mod_signals(n_samples, sr, f, p, s, e).view(-1)
+
+
+# ---- K9: corner bookkeeping (modulations.py:219-363), bit-exact on the device ------------------
+def _rows2d(x: T):
+    assert x.ndim == 2
+    return x.contiguous().float()
+
+
+def smoothen(x: T, smooth_n_frames: int) -> T:
+    """modulations.py:359-363."""
+    if smooth_n_frames <= 1:
+        return x
+    lead = x.shape[:-1]
+    xc = x.reshape(-1, x.size(-1)).contiguous().float()
+    n_out = xc.size(-1) - smooth_n_frames + 1
+    out = torch.empty((xc.size(0), n_out), device=xc.device, dtype=torch.float32)
+    _hip.call("mx_smoothen", _hip.ptr(xc), xc.size(0), xc.size(-1), smooth_n_frames, _hip.ptr(out), _hip.stream())
+    return out.view(lead + (n_out,))
+
+
+def find_corners(mod_sig: T) -> (T, T):
+    """modulations.py:219-238: float 0/1 maps of top and bottom corners."""
+    m = _rows2d(mod_sig)
+    top, bot = torch.empty_like(m), torch.empty_like(m)
+    _hip.call("mx_find_corners", _hip.ptr(m), m.size(0), m.size(1), _hip.ptr(top), _hip.ptr(bot), _hip.stream())
+    return top, bot
+
+
+def stretch_corners(mod_sig: T, max_n_corners: int = 10, smooth_n_frames: int = 32) -> T:
+    """modulations.py:294-307."""
+    m = _rows2d(smoothen(mod_sig, smooth_n_frames))
+    out = torch.empty_like(m)
+    _hip.call("mx_stretch_corners", _hip.ptr(m), m.size(0), m.size(1), int(max_n_corners), _hip.ptr(out),
+              _hip.stream())
+    return out
+
+
+def valid_mod_sig_mask(mod_sig: T, min_top_corners: int = 1, max_top_corners: int = 6,
+                       min_bottom_corners: int = 1, max_bottom_corners: int = 6,
+                       min_fraction_between_corners: float = 0.10) -> T:
+    """check_mod_sig (modulations.py:311-343) for every row: (B,) int32 0/1 on the device."""
+    m = _rows2d(mod_sig)
+    valid = torch.empty(m.size(0), device=m.device, dtype=torch.int32)
+    _hip.call("mx_check_mod_sig", _hip.ptr(m), m.size(0), m.size(1), min_top_corners, max_top_corners,
+              min_bottom_corners, max_bottom_corners, int(min_fraction_between_corners * m.size(1)),
+              _hip.ptr(valid), _hip.stream())
+    return valid
+
+
+def find_valid_mod_sig_indices(mod_sig: T) -> List[int]:
+    """modulations.py:346-356 (host list, like the reference; one small D2H copy)."""
+    return torch.nonzero(valid_mod_sig_mask(mod_sig)).view(-1).tolist()
+
+
+def make_rand_mod_signal(batch_size: int, n_samples: int, sr: float, freq_min: float, freq_max: float,
+                         shapes_gt: Optional[Sequence[str]] = None, shapes: Optional[List[str]] = None,
+                         phase_gt: Optional[T] = None, phase_error: float = 0.5,
+                         freq_gt: Optional[T] = None, freq_error: float = 0.25, device=None) -> T:
+    """modulations.py:60-101: the per-item host RNG draws are kept in the reference's order; the
+    batch of LFOs is then synthesised by one ``mx_lfo_synth`` launch."""
+    from . import util
+    if shapes is None:
+        shapes = ["cos", "tri", "rect_cos", "inv_rect_cos", "saw", "rsaw"]
+    freqs, phases, shape_ids = [], [], []
+    for idx in range(batch_size):
+        if phase_gt is not None:
+            assert phase_gt.size(0) == batch_size
+            phase = float(phase_gt[idx])
+            if phase_error > 0:
+                phase += util.sample_uniform(-1.0, 1.0) * math.pi * phase_error
+                phase = (phase + (2 * math.pi)) % (2 * math.pi)
+        else:
+            phase = util.sample_uniform(0.0, 2 * math.pi)
+        if freq_gt is not None:
+            assert freq_gt.size(0) == batch_size
+            freq = float(freq_gt[idx])
+            if freq_error > 0:
+                freq *= util.sample_uniform(1.0 - freq_error, 1.0 + freq_error)
+                freq = min(max(freq, freq_min), freq_max)
+        else:
+            freq = util.sample_uniform(freq_min, freq_max)
+        shape = shapes_gt[idx] if shapes_gt is not None else util.choice(shapes)
+        freqs.append(freq); phases.append(phase); shape_ids.append(SHAPE_IDS[shape])
+    dev = _device(device)
+    return make_mod_signals(n_samples, sr, torch.tensor(freqs, dtype=torch.float32, device=dev),
+                            torch.tensor(phases, dtype=torch.float32, device=dev),
+                            torch.tensor(shape_ids, dtype=torch.int32, device=dev))

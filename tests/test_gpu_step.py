@@ -1,0 +1,116 @@
+"""GPU: K3 phaser, K9 corner bookkeeping, K12 AdamW, the on-device batch synthesis and one full
+LFOExtraction train step against the CPU oracle."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import fx as ofx, lightning as ol, models as om, modulations as omod
+
+pytestmark = pytest.mark.gpu
+
+
+def test_phaser_vs_oracle(dev):
+    """K3 against oracle_ref.c:orc_phaser (pedalboard/JUCE restatement; parity with pedalboard itself is
+    unpinned).  Tolerance 1e-5 absolute on [-1,1] audio: device sin/pow/tan differ in the last ulp."""
+    from mod_extraction_amd import fx as afx
+    torch.manual_seed(2)
+    B, N = 5, 30000
+    lead = torch.tensor([0, 1000, 3, 14701, 257], dtype=torch.int32)
+    src = torch.rand(B, N + 14701) * 1.6 - 0.8
+    p = {"rate_hz": torch.tensor([0.5, 3.0, 1.3, 2.2, 0.9]), "depth": torch.tensor([1.0, 0.2, 0.6, 0.9, 0.5]),
+         "centre_frequency_hz": torch.tensor([70.0, 18000.0, 440.0, 1300.0, 5000.0]),
+         "feedback": torch.tensor([0.0, 0.7, 0.25, 0.5, 0.69]), "mix": torch.tensor([1.0, 0.2, 0.5, 0.8, 1.0])}
+    y = torch.empty(B, N, device=dev)
+    dry = torch.empty(B, N, device=dev)
+    afx.phaser_forward(src.to(dev), {k: v.to(dev) for k, v in p.items()}, lead.to(dev), 44100.0, N, out=y, dry_out=dry)
+    for b in range(B):
+        L = int(lead[b])
+        ref = ofx.phaser_np(src[b:b + 1, :L + N].numpy(), [float(p["rate_hz"][b])], [float(p["depth"][b])],
+                            [float(p["centre_frequency_hz"][b])], [float(p["feedback"][b])], [float(p["mix"][b])], 44100.0)
+        assert np.array_equal(dry[b].cpu().numpy(), src[b, L:L + N].numpy())
+        err = np.abs(y[b].cpu().numpy() - ref[0, L:]).max()
+        assert err < 1e-5, (b, err)
+
+
+@pytest.mark.parametrize("k", [0, 4, 8])
+def test_corner_bookkeeping_bit_exact(golden_dir, dev, k):
+    """K9 vs the golden vectors captured from the reference's modulations.py: ==, not allclose."""
+    from mod_extraction_amd import modulations as amod
+    g = np.load(os.path.join(golden_dir, "corners.npz"))
+    m = torch.from_numpy(g["mod_sig"]).to(dev)
+    ms = amod.smoothen(m, k)
+    assert np.array_equal(ms.cpu().numpy(), g[f"smooth_{k}"])
+    top, bot = amod.find_corners(ms)
+    assert np.array_equal(top.cpu().numpy().astype(np.int8), g[f"top_{k}"])
+    assert np.array_equal(bot.cpu().numpy().astype(np.int8), g[f"bot_{k}"])
+    for mx in (16, 4):
+        s = amod.stretch_corners(ms.clone(), mx, 0).cpu().numpy()
+        assert np.array_equal(s, g[f"stretch_{k}_{mx}"], equal_nan=True), (k, mx)
+    assert amod.find_valid_mod_sig_indices(ms) == g[f"valid_{k}"].tolist()
+    # smoothing inside stretch_corners (smooth_n_frames > 1) goes through the same kernels
+    if k == 0:
+        s2 = amod.stretch_corners(m, 16, 4).cpu().numpy()
+        assert np.array_equal(s2, g["stretch_4_16"], equal_nan=True)
+
+
+def test_adamw_kernel_vs_torch(dev):
+    from mod_extraction_amd import optim
+    torch.manual_seed(0)
+    ps = [torch.nn.Parameter(torch.randn(64, 2, 5, 13)), torch.nn.Parameter(torch.randn(64)),
+          torch.nn.Parameter(torch.randn(1, 64, 1))]
+    ref = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    mine = [torch.nn.Parameter(p.detach().clone().to(dev)) for p in ps]
+    o_ref = torch.optim.AdamW(ref, lr=1e-4, betas=(0.8, 0.99))
+    o_mine = optim.FlatAdamW(mine, lr=1e-4, betas=(0.8, 0.99))
+    for step in range(5):
+        grads = [torch.randn_like(p) * (10.0 ** -step) for p in ps]
+        for p, g in zip(ref, grads):
+            p.grad = g.clone()
+        o_mine.zero_grad()
+        for p, g in zip(mine, grads):
+            p.grad.copy_(g.to(dev) * 2.0)          # grad_scale 0.5 undoes this (the DDP 1/world path)
+        o_ref.step()
+        o_mine.step(grad_scale=0.5)
+        for p, q in zip(mine, ref):
+            assert float((p.detach().cpu() - q.detach()).abs().max()) < 3e-7, step
+
+
+def test_batch_synthesis_and_train_step(dev):
+    from mod_extraction_amd import data_modules, lightning, models, optim, trainer
+    n, sr, B = 22272, 44100, 6
+    cfg = dict(in_ch=2, n_samples=n, sr=sr, n_fft=1024, hop_len=256, n_mels=64, kernel_size=(5, 13),
+               out_channels=[64] * 6, temp_dilations=[1, 1, 2, 4, 8, 16], pool_size=(2, 1), latent_dim=1,
+               freq_mask_amount=0.25, time_mask_amount=0.25, use_ln=True)
+    loss_dict = {"l1": 1.0, "fdl1": 5.0, "sdl1": 10.0, "mse": 0.0}
+    torch.manual_seed(0); np.random.seed(0)
+    ref = om.Spectral2DCNN(**cfg)
+    mine = models.Spectral2DCNN(**cfg)
+    mine.load_state_dict(ref.state_dict())
+    module = lightning.LFOExtraction(mine, sr=sr, model_smooth_n_frames=0, loss_dict=loss_dict).to(dev).train()
+    opt = optim.FlatAdamW(module.parameters(), lr=1e-4, betas=(0.8, 0.99))
+    batcher = data_modules.SyntheticFxBatcher(B, n, sr, ("flanger", "chorus", "phaser"), dev, audio_seed=1)
+    params = batcher.sample_params()
+    dry, wet, mod, fxp = batcher.render(params)
+    assert set(("depth", "feedback", "min_delay_width", "mix", "width", "rate_hz", "phase", "shape", "exp")) <= set(fxp)
+    d_r, w_r, m_r = ol.synth_batch(params, batcher.kinds, batcher.src.cpu().numpy(), n, sr,
+                                   {"flanger": 1.0, "chorus": 30.0}, mod_override=mod.cpu().numpy())
+    assert torch.equal(dry.cpu(), d_r)
+    fx_rows = [i for i, k in enumerate(batcher.kinds) if k != "phaser"]
+    ph_rows = [i for i, k in enumerate(batcher.kinds) if k == "phaser"]
+    assert torch.equal(wet.cpu()[fx_rows], w_r[fx_rows])          # flanger / chorus: bit-exact
+    assert float((wet.cpu()[ph_rows] - w_r[ph_rows]).abs().max()) < 1e-5
+    assert float((mod.cpu() - m_r).abs().max()) < 2e-6
+    # the SpecAugment draw comes from the host generator: same seed on both sides -> same masks
+    torch.manual_seed(123)
+    ref.train()
+    masks = None
+    loss_r, terms_r, _ = ol.lfo_common_step(ref, d_r, wet.cpu(), m_r, loss_dict)
+    torch.manual_seed(123)
+    loss = trainer.Trainer(log_fn=None).train_step(module, opt, (dry, wet, mod, None))
+    assert abs(float(loss) - float(loss_r)) < 1e-5 * max(1.0, abs(float(loss_r)))
+    for k in loss_dict:
+        assert abs(float(module.logged[f"train/{k}"][-1]) - float(terms_r[k])) < 2e-6
+    assert opt.step_count == 1
