@@ -161,6 +161,30 @@ int mx_stretch_corners(const float *x, int64_t rows, int64_t n, int64_t max_n_co
 int mx_check_mod_sig(const float *x, int64_t rows, int64_t n, int32_t min_top, int32_t max_top,
                      int32_t min_bot, int32_t max_bot, int32_t min_gap, int32_t *valid, void *stream);
 
+/* ---- K10: LSTM-64 effect model -- mod_extraction/models.py:311-339 (nn.LSTM(2,64) -> Linear(64,1) ->
+ * + x -> tanh, input order (lfo, audio)) and its truncated BPTT, lightning.py:355-384.
+ * x, lfo, y: B rows of T samples with row strides (chunks are views into (B,1,n) tensors).
+ * Parameters in torch layout: w_ih (256,2), w_hh (256,64), b_ih (256), b_hh (256), fc_w (64), fc_b (1).
+ * h_io, c_io (B,64): initial state in, final state out.  stash (B,T,384) = per-step (i,f,g,o,c,h) for
+ * the backward, or NULL. */
+int mx_lstm_fwd(const float *x, int64_t x_stride, const float *lfo, int64_t lfo_stride, const float *w_ih,
+                const float *w_hh, const float *b_ih, const float *b_hh, const float *fc_w, const float *fc_b,
+                float *h_io, float *c_io, float *y, int64_t y_stride, float *stash, int64_t B, int64_t T,
+                void *stream);
+/* BPTT of one chunk with nn.L1Loss fused: loss = loss_scale * sum |y - wet| (loss_scale = w/(B*T)).
+ * h_init, c_init (B,64): state at the chunk start (detached, lightning.py:383).  part (B,17473):
+ * per-clip gradient rows in state-dict order [weight_ih | weight_hh | bias_ih | bias_hh | fc.weight |
+ * fc.bias]; sum them with mx_reduce_rows. */
+int mx_lstm_bwd_l1(const float *x, int64_t x_stride, const float *lfo, int64_t lfo_stride, const float *y,
+                   int64_t y_stride, const float *wet, int64_t wet_stride, const float *stash,
+                   const float *w_hh, const float *fc_w, const float *h_init, const float *c_init,
+                   float loss_scale, float *part, int64_t B, int64_t T, void *stream);
+
+/* ---- effect-model losses -- mod_extraction/losses.py:14-67 (ESR, DC) and nn.L1Loss:
+ * part (B,4) = per-clip sums of |y - y_hat|, (y - y_hat)^2, y^2, (y - y_hat). */
+int mx_effect_loss_sums(const float *y_hat, int64_t y_hat_stride, const float *y, int64_t y_stride, int64_t B,
+                        int64_t T, float *part, void *stream);
+
 /* ---- K12: AdamW -- torch.optim.AdamW (configs/opt/adam_w.yml), flat fp32 buffers of n elements;
  * step = 1-based step index; grad_scale multiplies the gradient first (1/world after a sum
  * all-reduce). */

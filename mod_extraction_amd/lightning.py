@@ -147,3 +147,193 @@ class LFOExtraction(BaseLightingModule):
         step = self.common_step if self.sub_batch_size is None else self.sub_batch_size_common_step
         with torch.no_grad():
             return step(batch, is_training=False)
+
+
+class TBPTTLFOEffectModeling(BaseLightingModule):
+    """lightning.py:202-431: frozen LFO-net -> smooth / stretch / crop -> discard invalid LFOs -> LSTM
+    effect model trained with truncated BPTT (1024-sample warm-up, then one optimizer step per
+    1024-sample chunk).  ``automatic_optimization`` is False like in the reference: ``training_step``
+    receives the optimizer and runs the 83 inner steps itself; under DDP every inner step is one
+    all-reduce of the 70 KB flat gradient, and a rank without any valid LFO still takes part with
+    zero gradients (the reference would return None there and dead-lock DDP)."""
+    default_loss_dict = {"l1": 1.0, "esr": 0.0, "dc": 0.0}
+
+    def __init__(self,
+                 warmup_n_samples: int,
+                 step_n_samples: int,
+                 effect_model: HiddenStateModel,
+                 lfo_model: Optional[nn.Module] = None,
+                 lfo_model_weights_path: Optional[str] = None,
+                 freeze_lfo_model: bool = True,
+                 param_model: Optional[nn.Module] = None,
+                 sr: float = 44100,
+                 use_dry: bool = True,
+                 model_smooth_n_frames: int = 8,
+                 should_stretch: bool = True,
+                 max_n_corners: int = 16,
+                 stretch_smooth_n_frames: int = 0,
+                 discard_invalid_lfos: bool = True,
+                 loss_dict: Optional[Dict[str, float]] = None) -> None:
+        super().__init__(loss_dict)
+        assert warmup_n_samples > 0
+        if param_model is not None:
+            raise NotImplementedError("param_model is not used by any shipped config")
+        if lfo_model is not None and not freeze_lfo_model:
+            raise NotImplementedError("the LSTM kernels do not propagate gradients into the LFO model; every "
+                                      "shipped config trains with freeze_lfo_model: true")
+        for name, w in self.loss_dict.items():
+            if w > 0 and name != "l1":
+                raise NotImplementedError("the fused BPTT kernel back-propagates nn.L1Loss only (the shipped "
+                                          "configs use l1: 1.0, esr: 0.0, dc: 0.0)")
+        self.warmup_n_samples, self.step_n_samples = warmup_n_samples, step_n_samples
+        self.effect_model = effect_model
+        self.lfo_model_weights_path = lfo_model_weights_path
+        self.freeze_lfo_model = freeze_lfo_model
+        self.param_model = param_model
+        self.sr, self.use_dry = sr, use_dry
+        self.model_smooth_n_frames = model_smooth_n_frames
+        self.should_stretch, self.max_n_corners = should_stretch, max_n_corners
+        self.stretch_smooth_n_frames = stretch_smooth_n_frames
+        self.discard_invalid_lfos = discard_invalid_lfos
+        if lfo_model is not None:
+            if lfo_model_weights_path is not None:
+                log.info("Loading LFO model weights")
+                assert os.path.isfile(lfo_model_weights_path)
+                lfo_model.load_state_dict(torch.load(lfo_model_weights_path, map_location="cpu"))
+            log.info("Freezing LFO model")
+            lfo_model.eval()
+            for p in lfo_model.parameters():
+                p.requires_grad = False
+        else:
+            log.info("Using ground truth mod_sig")
+        self.lfo_model = lfo_model
+        self.automatic_optimization = False
+        self.use_gt_mod_sig = lfo_model is None
+
+    def train(self, mode: bool = True):
+        super().train(mode)
+        if self.lfo_model is not None:
+            self.lfo_model.eval()               # frozen extractor stays in eval mode (lightning.py:243-244)
+        return self
+
+    center_crop_mod_sig = staticmethod(LFOExtraction.center_crop_mod_sig)
+
+    def extract_mod_sig(self, wet: T, mod_sig: Optional[T] = None, fx_params=None):
+        """lightning.py:254-272."""
+        with torch.no_grad():
+            if self.lfo_model is None:
+                assert mod_sig is not None and mod_sig.ndim == 2
+                mod_sig_hat = mod_sig
+            elif isinstance(self.lfo_model, RandomLFO):
+                mod_sig_hat = self.lfo_model(wet.size(0), fx_params).squeeze(1).to(wet.device)
+            else:
+                mod_sig_hat, _ = self.lfo_model(wet)
+                mod_sig_hat = mod_sig_hat.squeeze(1)
+            if mod_sig is not None and mod_sig.size(-1) != mod_sig_hat.size(-1):
+                mod_sig = linear_interpolate_last_dim(mod_sig, mod_sig_hat.size(-1), align_corners=True)
+            return mod_sig_hat, mod_sig
+
+    def smooth_stretch_crop_mod_sig(self, mod_sig_hat: T, mod_sig: Optional[T] = None):
+        """lightning.py:284-300."""
+        orig = mod_sig_hat.size(-1)
+        if self.model_smooth_n_frames > 1:
+            mod_sig_hat = smoothen(mod_sig_hat, self.model_smooth_n_frames)
+            if mod_sig is not None:
+                mod_sig = self.center_crop_mod_sig(mod_sig, mod_sig_hat.size(-1))
+        if self.should_stretch:
+            mod_sig_hat = stretch_corners(mod_sig_hat, max_n_corners=self.max_n_corners,
+                                          smooth_n_frames=self.stretch_smooth_n_frames)
+            if self.stretch_smooth_n_frames > 1 and mod_sig is not None:
+                mod_sig = self.center_crop_mod_sig(mod_sig, mod_sig_hat.size(-1))
+        return mod_sig_hat, mod_sig, orig - mod_sig_hat.size(-1)
+
+    def prepare(self, batch):
+        """lightning.py:310-337: everything before the LSTM loop.  Returns None if no clip has a valid
+        LFO, else (dry, wet, mod_sig_hat, mod_sig, lfo_at_sample_rate (B',1,n'))."""
+        dry, wet, mod_sig, fx_params = batch
+        assert dry.size(-1) == wet.size(-1) >= self.warmup_n_samples + self.step_n_samples
+        lfo_in = torch.cat([dry, wet], dim=1) if self.use_dry else wet
+        mod_sig_hat, mod_sig = self.extract_mod_sig(lfo_in, mod_sig, fx_params)
+        mod_sig_hat, mod_sig, removed = self.smooth_stretch_crop_mod_sig(mod_sig_hat, mod_sig)
+        n_frames = mod_sig_hat.size(-1)
+        n_samples = int((n_frames / (n_frames + removed)) * dry.size(-1))
+        dry = self.center_crop_mod_sig(dry, n_samples)
+        wet = self.center_crop_mod_sig(wet, n_samples)
+        if self.discard_invalid_lfos:
+            keep = torch.nonzero(valid_mod_sig_mask(mod_sig_hat)).view(-1)
+            if keep.numel() == 0:
+                log.info("No valid LFO signals found")
+                return None
+            dry, wet, mod_sig_hat = dry[keep], wet[keep], mod_sig_hat[keep]
+            if mod_sig is not None:
+                mod_sig = mod_sig[keep]
+        dry, wet = dry.contiguous(), wet.contiguous()
+        lfo_sr = linear_interpolate_last_dim(mod_sig_hat, dry.size(-1), align_corners=True).unsqueeze(1)
+        return dry, wet, mod_sig_hat, mod_sig, lfo_sr
+
+    def common_step(self, batch, is_training: bool, optimizer=None, world_size: int = 1):
+        """lightning.py:302-419."""
+        from .effect_losses import effect_loss_terms
+        from .trainer import allreduce_flat_grad
+        prefix = "train" if is_training else "val"
+        prep = self.prepare(batch)
+        n_chunks_max = (batch[0].size(-1) - self.warmup_n_samples) // self.step_n_samples
+        if prep is None:
+            if is_training and world_size > 1:          # stay in lock-step with the other ranks
+                for _ in range(n_chunks_max):
+                    optimizer.zero_grad()
+                    optimizer.step(grad_scale=allreduce_flat_grad(optimizer.flat_grad, world_size))
+            return None
+        dry, wet, mod_sig_hat, mod_sig, lfo_sr = prep
+        em, W, S = self.effect_model, self.warmup_n_samples, self.step_n_samples
+        n = dry.size(-1)
+        B = dry.size(0)
+        em.clear_hidden()
+        with torch.no_grad():
+            chunks = [em.run_chunk(dry[:, :, :W], lfo_sr[:, :, :W])[0]]          # warm-up, no loss
+            if is_training:
+                em.detach_hidden()
+                stash = torch.empty((B, S, 384), device=dry.device, dtype=torch.float32)
+                w_l1 = float(self.loss_dict.get("l1", 0.0))
+            done = 0
+            for start in range(W, n, S):
+                end = start + S
+                if end > n:
+                    break
+                x, lat, tgt = dry[:, :, start:end], lfo_sr[:, :, start:end], wet[:, :, start:end]
+                if is_training:
+                    y, h0, c0 = em.run_chunk(x, lat, stash)
+                    optimizer.zero_grad()
+                    em.bptt_l1_chunk(x, lat, y, tgt, stash, h0, c0, w_l1 / (B * S), optimizer.flat_grad)
+                    optimizer.step(grad_scale=allreduce_flat_grad(optimizer.flat_grad, world_size))
+                    em.detach_hidden()
+                    done += 1
+                else:
+                    y = em.run_chunk(x, lat)[0]
+                chunks.append(y)
+            if is_training and world_size > 1:          # ranks may have cropped differently: pad the step count
+                for _ in range(n_chunks_max - done):
+                    optimizer.zero_grad()
+                    optimizer.step(grad_scale=allreduce_flat_grad(optimizer.flat_grad, world_size))
+            wet_hat = torch.cat(chunks, dim=-1)
+            m = wet_hat.size(-1)
+            dry_c, wet_c, wet_hat = dry[:, :, W:m], wet[:, :, W:m].contiguous(), wet_hat[:, :, W:m].contiguous()
+            terms = effect_loss_terms(wet_hat, wet_c)
+            loss = None
+            for name, w in self.loss_dict.items():
+                self.log(f"{prefix}/{name}", terms[name])
+                if w > 0:
+                    loss = w * terms[name] if loss is None else loss + w * terms[name]
+            self.log(f"{prefix}/loss", loss)
+        data_dict = {"dry": dry_c, "wet": wet_c, "wet_hat": wet_hat, "mod_sig_hat": mod_sig_hat}
+        if mod_sig is not None:
+            data_dict["mod_sig"] = mod_sig
+        return loss, data_dict, batch[3]
+
+    def training_step(self, batch, batch_idx: int = 0, optimizer=None, world_size: int = 1):
+        assert optimizer is not None, "manual optimisation: pass the FlatAdamW optimizer"
+        result = self.common_step(batch, is_training=True, optimizer=optimizer, world_size=world_size)
+        return None if result is None else result[0]
+
+    def validation_step(self, batch, batch_idx: int = 0):
+        return self.common_step(batch, is_training=False)

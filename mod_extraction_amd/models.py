@@ -367,3 +367,82 @@ class HiddenStateModel(nn.Module):
 
     def clear_hidden(self) -> None:
         self.is_hidden_init = False
+
+
+LSTM_NPARAM = 17473        # 256*2 + 256*64 + 256 + 256 + 64 + 1 (csrc/lstm.hip)
+
+
+def _rows(t: T) -> Tuple[int, int]:
+    """(device pointer, row stride) of a (B,1,T)/(B,T) fp32 view whose rows are contiguous."""
+    if not t.is_cuda:
+        raise _hip.HipLibraryError("mod_extraction_amd ops need tensors on a HIP device (no CPU fallback)")
+    if t.ndim == 3:
+        assert t.size(1) == 1
+        t = t[:, 0, :]
+    assert t.dtype == torch.float32 and t.ndim == 2 and t.stride(1) == 1
+    return t.data_ptr(), t.stride(0)
+
+
+class LSTMEffectModel(HiddenStateModel):
+    """models.py:311-339.  ``self.lstm`` / ``self.fc`` hold the parameters under the reference's
+    state-dict keys (the 7 shipped ``models/lstm_64__*.pt`` files load with strict=True); the recurrence
+    runs in ``mx_lstm_fwd`` (one workgroup per clip, weights in registers, state in LDS)."""
+
+    def __init__(self, in_ch: int = 1, out_ch: int = 1, n_hidden: int = 64, latent_dim: int = 1) -> None:
+        super().__init__()
+        if (in_ch, out_ch, n_hidden, latent_dim) != (1, 1, 64, 1):
+            raise NotImplementedError("the LSTM kernels are built for the shipped LSTM-64 (in 1 + latent 1, out 1)")
+        self.in_ch, self.out_ch, self.n_hidden, self.latent_dim = in_ch, out_ch, n_hidden, latent_dim
+        self.lstm = nn.LSTM(in_ch + latent_dim, n_hidden, batch_first=True)     # parameter holder
+        self.fc = nn.Linear(n_hidden, out_ch)                                    # parameter holder
+
+    def _params(self) -> List[T]:
+        return [self.lstm.weight_ih_l0, self.lstm.weight_hh_l0, self.lstm.bias_ih_l0, self.lstm.bias_hh_l0,
+                self.fc.weight, self.fc.bias]
+
+    def _state(self, B: int, device) -> Tuple[T, T]:
+        if self.is_hidden_init:
+            h, c = self.hidden
+            return h.reshape(B, 64).clone(), c.reshape(B, 64).clone()
+        return (torch.zeros((B, 64), device=device, dtype=torch.float32),
+                torch.zeros((B, 64), device=device, dtype=torch.float32))
+
+    def run_chunk(self, x: T, latent: T, stash: Optional[T] = None) -> Tuple[T, T, T]:
+        """Forward one chunk without autograd.  Returns (y (B,1,T), h_start, c_start); updates the hidden
+        state.  ``stash`` (B,T,384) receives the per-step activations when a BPTT step follows."""
+        assert x.ndim == 3 and latent.shape == (x.size(0), self.latent_dim, x.size(-1))
+        B, _, Tn = x.shape
+        h, c = self._state(B, x.device)
+        h0, c0 = h.clone(), c.clone()
+        y = torch.empty((B, 1, Tn), device=x.device, dtype=torch.float32)
+        xp, xs = _rows(x)
+        lp, ls = _rows(latent)
+        yp, ys = _rows(y)
+        w = [p.detach().contiguous() for p in self._params()]
+        _hip.call("mx_lstm_fwd", xp, xs, lp, ls, _hip.ptr(w[0]), _hip.ptr(w[1]), _hip.ptr(w[2]), _hip.ptr(w[3]),
+                  _hip.ptr(w[4]), _hip.ptr(w[5]), _hip.ptr(h), _hip.ptr(c), yp, ys, _hip.ptr(stash), B, Tn,
+                  _hip.stream())
+        self.update_hidden((h.view(1, B, 64), c.view(1, B, 64)))
+        return y, h0, c0
+
+    def bptt_l1_chunk(self, x: T, latent: T, y: T, wet: T, stash: T, h0: T, c0: T, loss_scale: float,
+                      grad_out: T) -> None:
+        """BPTT of one chunk with the L1 loss fused; the summed parameter gradient (17473,) in
+        state-dict order is written to ``grad_out``."""
+        B, _, Tn = x.shape
+        part = torch.empty((B, LSTM_NPARAM), device=x.device, dtype=torch.float32)
+        xp, xs = _rows(x)
+        lp, ls = _rows(latent)
+        yp, ys = _rows(y)
+        wp, ws = _rows(wet)
+        _hip.call("mx_lstm_bwd_l1", xp, xs, lp, ls, yp, ys, wp, ws, _hip.ptr(stash),
+                  _hip.ptr(self.lstm.weight_hh_l0.detach().contiguous()), _hip.ptr(self.fc.weight.detach().contiguous()),
+                  _hip.ptr(h0), _hip.ptr(c0), float(loss_scale), _hip.ptr(part), B, Tn, _hip.stream())
+        _hip.call("mx_reduce_rows", _hip.ptr(part), B, LSTM_NPARAM, 0, _hip.ptr(grad_out), _hip.stream())
+
+    def forward(self, x: T, latent: T) -> T:
+        """Inference / validation forward (no autograd graph; training goes through the fused TBPTT
+        step of ``lightning.TBPTTLFOEffectModeling``)."""
+        with torch.no_grad():
+            y, _, _ = self.run_chunk(x.contiguous().float(), latent.contiguous().float())
+        return y

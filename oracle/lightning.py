@@ -86,3 +86,60 @@ def lfo_train_step(model, opt: torch.optim.Optimizer, dry: T, wet: T, mod_sig: T
     loss.backward()
     opt.step()
     return float(loss), {k: float(v) for k, v in terms.items()}
+
+
+def tbptt_common_step(effect_model, opt: Optional[torch.optim.Optimizer], dry: T, wet: T, mod_sig_hat: T,
+                      warmup_n_samples: int, step_n_samples: int, loss_dict: Dict[str, float],
+                      is_training: bool = True, model_smooth_n_frames: int = 8, should_stretch: bool = True,
+                      max_n_corners: int = 16, stretch_smooth_n_frames: int = 0,
+                      discard_invalid_lfos: bool = True):
+    """lightning.py:302-419 (TBPTTLFOEffectModeling.common_step) given the extractor output
+    ``mod_sig_hat`` (B, frames) (lightning.py:318 -- the frozen LFO-net, or the ground truth when
+    lfo_model is None).  Returns None when no LFO is valid, else a dict with the batch loss terms,
+    wet_hat, the processed LFOs, the kept clip indices and the number of optimizer steps taken."""
+    n_frames_orig = mod_sig_hat.size(-1)
+    # smooth_stretch_crop_mod_sig (lightning.py:284-300)
+    if model_smooth_n_frames > 1:
+        mod_sig_hat = omod.smoothen(mod_sig_hat, model_smooth_n_frames)
+    if should_stretch:
+        mod_sig_hat = omod.stretch_corners(mod_sig_hat, max_n_corners, stretch_smooth_n_frames)
+    n_frames = mod_sig_hat.size(-1)
+    removed = n_frames_orig - n_frames
+    n_samples = int((n_frames / (n_frames + removed)) * dry.size(-1))                # lightning.py:321
+    dry, wet = center_crop(dry, n_samples), center_crop(wet, n_samples)
+    kept = list(range(dry.size(0)))
+    if discard_invalid_lfos:
+        kept = omod.find_valid_mod_sig_indices(mod_sig_hat)
+        if not kept:
+            return None
+        dry, wet, mod_sig_hat = dry[kept], wet[kept], mod_sig_hat[kept]
+    lfo_sr = outil.linear_interpolate_last_dim(mod_sig_hat, dry.size(-1)).unsqueeze(1)   # lightning.py:337
+    effect_model.clear_hidden()
+    W, S = warmup_n_samples, step_n_samples
+    chunks = [effect_model(dry[:, :, :W], lfo_sr[:, :, :W])]
+    steps = 0
+    if is_training:
+        effect_model.detach_hidden()
+        opt.zero_grad()
+    for start in range(W, dry.size(-1), S):
+        end = start + S
+        if end > dry.size(-1):
+            break
+        y = effect_model(dry[:, :, start:end], lfo_sr[:, :, start:end])
+        chunks.append(y)
+        if is_training:
+            tgt = wet[:, :, start:end]
+            terms = {k: olosses.get_loss_func_by_name(k)(y, tgt) for k in loss_dict}
+            loss = sum(w * terms[k] for k, w in loss_dict.items() if w > 0)
+            loss.backward()
+            opt.step()
+            effect_model.detach_hidden()
+            opt.zero_grad()
+            steps += 1
+    wet_hat = torch.cat(chunks, dim=-1).detach()
+    m = wet_hat.size(-1)
+    wet_c, wet_hat = wet[:, :, W:m], wet_hat[:, :, W:m]
+    terms = {k: olosses.get_loss_func_by_name(k)(wet_hat, wet_c) for k in loss_dict}
+    loss = sum(w * terms[k] for k, w in loss_dict.items() if w > 0)
+    return {"loss": loss, "terms": terms, "wet_hat": wet_hat, "wet": wet_c, "mod_sig_hat": mod_sig_hat,
+            "kept": kept, "steps": steps, "n_samples": n_samples}

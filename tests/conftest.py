@@ -9,6 +9,12 @@ if ROOT not in sys.path:
 
 
 def pytest_configure(config):
+    # the GPU box has 256 host cores: torch's CPU oracle is much faster with a bounded thread count
+    try:
+        import torch
+        torch.set_num_threads(min(16, os.cpu_count() or 1))
+    except Exception:
+        pass
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 

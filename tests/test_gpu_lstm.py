@@ -1,0 +1,141 @@
+"""GPU parity: K10 LSTM-64 effect model (forward with the 7 shipped weight files, BPTT gradients of a
+1024-sample chunk, the TBPTT step logic) and the effect-model losses, against the golden vectors of
+the reference's own classes and the CPU oracle.  Tolerances: audio in [-1,1], 1e-5 absolute;
+gradients 1e-4 relative to each tensor's max (fp32, ~1k-step recurrences, device tanh/exp)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import lightning as ol, losses as olosses, models as om
+
+pytestmark = pytest.mark.gpu
+
+
+def load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name), allow_pickle=False)
+
+
+def test_lstm_forward_with_shipped_weights(golden_dir, dev):
+    from mod_extraction_amd import models as am
+    g = load(golden_dir, "lstm.npz")
+    x, lat = torch.from_numpy(g["x"]).to(dev), torch.from_numpy(g["latent"]).to(dev)
+    T = x.size(-1) // 2
+    for i in range(int(g["n_files"])):
+        m = am.LSTMEffectModel(1, 1, 64, 1)
+        sd = {k[len(f"w_{i}_"):]: torch.from_numpy(g[k]) for k in g.files if k.startswith(f"w_{i}_")}
+        m.load_state_dict(sd, strict=True)            # the shipped state-dict keys load unchanged
+        m = m.to(dev)
+        m.clear_hidden()
+        y1 = m(x[..., :T].contiguous(), lat[..., :T].contiguous())
+        m.detach_hidden()
+        y2 = m(x[..., T:], lat[..., T:])              # strided chunk views are accepted
+        y = torch.cat([y1, y2], -1).cpu().numpy()
+        assert np.abs(y - g[f"y_{i}"]).max() < 1e-5, str(g[f"name_{i}"])
+        assert np.abs(m.hidden[0].cpu().numpy() - g[f"h_{i}"]).max() < 1e-5
+        assert np.abs(m.hidden[1].cpu().numpy() - g[f"c_{i}"]).max() < 2e-5
+
+
+def test_lstm_bptt_chunk_gradients(golden_dir, dev):
+    from mod_extraction_amd import models as am
+    g = load(golden_dir, "lstm.npz")
+    torch.manual_seed(4)
+    B, T = 3, 1024
+    x = torch.rand(B, 1, 2 * T) * 1.6 - 0.8
+    lat = torch.rand(B, 1, 2 * T)
+    wet = (0.6 * x + 0.3 * torch.roll(x, 2, -1)).clamp(-1, 1)
+    for i in (0, 3):
+        sd = {k[len(f"w_{i}_"):]: torch.from_numpy(g[k]) for k in g.files if k.startswith(f"w_{i}_")}
+        ref = om.LSTMEffectModel(1, 1, 64, 1); ref.load_state_dict(sd)
+        mine = am.LSTMEffectModel(1, 1, 64, 1); mine.load_state_dict(sd); mine = mine.to(dev)
+        # warm-up chunk, detach, then the chunk whose gradients are compared
+        ref.clear_hidden(); ref(x[..., :T], lat[..., :T]); ref.detach_hidden()
+        y_r = ref(x[..., T:], lat[..., T:])
+        torch.nn.functional.l1_loss(y_r, wet[..., T:]).backward()
+        xd, ld, wd = x.to(dev), lat.to(dev), wet.to(dev)
+        mine.clear_hidden(); mine.run_chunk(xd[..., :T], ld[..., :T]); mine.detach_hidden()
+        stash = torch.empty((B, T, 384), device=dev)
+        y_m, h0, c0 = mine.run_chunk(xd[..., T:], ld[..., T:], stash)
+        grad = torch.empty(am.LSTM_NPARAM, device=dev)
+        mine.bptt_l1_chunk(xd[..., T:], ld[..., T:], y_m, wd[..., T:], stash, h0, c0, 1.0 / (B * T), grad)
+        assert float((y_m.cpu() - y_r.detach()).abs().max()) < 1e-5
+        flat_r = torch.cat([p.grad.reshape(-1) for p in ref.parameters()])
+        assert [n for n, _ in ref.named_parameters()] == ["lstm.weight_ih_l0", "lstm.weight_hh_l0", "lstm.bias_ih_l0",
+                                                          "lstm.bias_hh_l0", "fc.weight", "fc.bias"]
+        off = 0
+        for n, p in ref.named_parameters():
+            k = p.numel()
+            a, r = grad[off:off + k].cpu(), p.grad.reshape(-1)
+            e = float((a - r).abs().max() / r.abs().max())
+            assert e < 1e-4, (n, e)
+            off += k
+        assert off == am.LSTM_NPARAM == flat_r.numel()
+
+
+def test_effect_losses(golden_dir, dev):
+    from mod_extraction_amd import losses as alosses
+    g = load(golden_dir, "losses.npz")
+    wa, wb = torch.from_numpy(g["wa"]).to(dev), torch.from_numpy(g["wb"]).to(dev)
+    for name in ("esr", "dc"):
+        v = float(alosses.get_loss_func_by_name(name)(wa, wb))
+        assert abs(v - float(g["w_" + name])) <= 1e-5 * abs(float(g["w_" + name])) + 1e-9, name
+    from mod_extraction_amd.effect_losses import effect_loss_terms
+    assert abs(float(effect_loss_terms(wa, wb)["l1"]) - float(g["w_l1"])) < 1e-6
+
+
+def test_tbptt_training_step_vs_reference_golden(golden_dir, dev):
+    """TBPTTLFOEffectModeling.common_step with ground-truth LFOs against the golden captured from the
+    reference's own class: kept clips, crop length, number of optimizer steps, processed LFOs (bit-exact),
+    wet_hat and the logged batch losses."""
+    from mod_extraction_amd import lightning as al, models as am, optim
+    g = load(golden_dir, "steps.npz")
+    em = am.LSTMEffectModel(1, 1, 64, 1)
+    em.load_state_dict({k[len("tb_init_"):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("tb_init_")})
+    mod = al.TBPTTLFOEffectModeling(256, 256, em, lfo_model=None, model_smooth_n_frames=8, should_stretch=True,
+                                    max_n_corners=16, stretch_smooth_n_frames=0, discard_invalid_lfos=True,
+                                    loss_dict={"l1": 1.0, "esr": 0.0, "dc": 0.0}).to(dev).train()
+    opt = optim.FlatAdamW(mod.parameters(), lr=1e-4, betas=(0.8, 0.99))
+    assert opt.numel == am.LSTM_NPARAM
+    batch = (torch.from_numpy(g["tb_dry"]).to(dev), torch.from_numpy(g["tb_wet"]).to(dev),
+             torch.from_numpy(g["tb_lfo"]).to(dev), None)
+    loss, dd, _ = mod.common_step(batch, is_training=True, optimizer=opt, world_size=1)
+    assert dd["dry"].shape[0] == int(g["tb_kept"])
+    assert opt.step_count == int(g["tb_steps"])
+    assert np.array_equal(dd["mod_sig_hat"].cpu().numpy(), g["tb_mod_sig_hat"])       # K9: bit-exact
+    assert dd["wet_hat"].shape == g["tb_wet_hat"].shape
+    assert np.abs(dd["wet_hat"].cpu().numpy() - g["tb_wet_hat"]).max() < 1e-4
+    assert abs(float(loss) - float(g["tb_loss"])) < 1e-5
+    names = [str(n) for n in g["tb_names"]]
+    for n, v in zip(names, g["tb_logged"]):
+        assert abs(float(mod.logged[n][-1]) - float(v)) < 1e-5 * max(1.0, abs(float(v))), n
+    # weights after the Adam steps: every weight moved by O(lr) per step; weights whose gradient is ~eps
+    # are ill-conditioned under Adam, so the bulk statistic is compared, not the max
+    for k, v in em.state_dict().items():
+        d = np.abs(v.cpu().numpy() - g[f"tb_final_{k}"])
+        moved = np.abs(g[f"tb_final_{k}"] - g[f"tb_init_{k}"])
+        assert np.median(d) < 0.02 * max(np.median(moved), 1e-9), k
+
+
+def test_tbptt_full_length_vs_oracle(dev):
+    """2 s clips, warm-up 1024 + 83 chunks of 1024 (configs/train_em_dry_wet.yml geometry), validation mode
+    (no optimizer), frozen random-init CNN replaced by ground-truth LFOs."""
+    from mod_extraction_amd import lightning as al, models as am
+    from oracle import modulations as omod
+    torch.manual_seed(6)
+    B, n = 3, 88200
+    dry = torch.rand(B, 1, n) * 1.6 - 0.8
+    wet = (0.7 * dry + 0.2 * torch.roll(dry, 5, -1)).clamp(-1, 1)
+    lfo = torch.stack([omod.make_mod_signal(345, 172.5, f, p, "cos") for f, p in ((1.0, 0.2), (2.2, 1.0), (1.5, 3.0))])
+    sd = om.LSTMEffectModel().state_dict()
+    ref = om.LSTMEffectModel(); ref.load_state_dict(sd)
+    em = am.LSTMEffectModel(); em.load_state_dict(sd)
+    mod = al.TBPTTLFOEffectModeling(1024, 1024, em, lfo_model=None, loss_dict={"l1": 1.0, "esr": 0.0, "dc": 0.0}).to(dev).eval()
+    loss, dd, _ = mod.validation_step((dry.to(dev), wet.to(dev), lfo.to(dev), None))
+    with torch.no_grad():
+        res = ol.tbptt_common_step(ref, None, dry, wet, lfo, 1024, 1024, {"l1": 1.0, "esr": 0.0, "dc": 0.0}, is_training=False)
+    assert res["n_samples"] == 86410 and dd["wet_hat"].shape[-1] == 84992 == res["wet_hat"].shape[-1]
+    assert float((dd["wet_hat"].cpu() - res["wet_hat"]).abs().max()) < 2e-5
+    assert abs(float(loss) - float(res["loss"])) < 1e-6
+    for k in ("l1", "esr", "dc"):
+        assert abs(float(mod.logged[f"val/{k}"][-1]) - float(res["terms"][k])) < 1e-5 * max(1.0, abs(float(res["terms"][k])))
