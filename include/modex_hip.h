@@ -185,6 +185,22 @@ int mx_lstm_bwd_l1(const float *x, int64_t x_stride, const float *lfo, int64_t l
 int mx_effect_loss_sums(const float *y_hat, int64_t y_hat_stride, const float *y, int64_t y_stride, int64_t B,
                         int64_t T, float *part, void *stream);
 
+/* ---- K11: multi-resolution STFT loss -- mod_extraction/losses.py:155-156 (auraloss==0.4.0
+ * MultiResolutionSTFTLoss(reduction="mean"), third-party: restated from its published defaults,
+ * parity unpinned): mean over resolutions of [ w_sc * ||Y-X||_F/||Y||_F + w_log * mean|log X - log Y| ],
+ * mag = sqrt(clamp(re^2+im^2, eps)).  y_hat, y: B rows of T samples (row strides).
+ * fft_sizes, hops: HOST int32 arrays of n_res entries (fft sizes in {512,1024,2048}) -- the only host
+ * pointers of this ABI.  windows (n_res, 2048) device: row r = n_fft_r-long analysis window (hann of
+ * win_length centred in the frame).  twiddle (2048,2) device = exp(-2 pi i m/2048).
+ * terms (2*n_res+1) device: [sc_0, logmag_0, ..., total].  dx: d total / d y_hat rows (stride dx_stride)
+ * or NULL.  Workspaces (device): part >= 3*B*max_r ceil(frames_r/8) doubles, coef 2 floats,
+ * scratch >= B*max_r(frames_r*n_fft_r) floats (needed only when dx != NULL); frames_r = 1 + T/hop_r. */
+int mx_mrstft_loss(const float *y_hat, int64_t y_hat_stride, const float *y, int64_t y_stride, int64_t B,
+                   int64_t T, int32_t n_res, const int32_t *fft_sizes, const int32_t *hops,
+                   const float *windows, const float *twiddle, float w_sc, float w_log, float eps,
+                   double *part, float *coef, float *scratch, float *terms, float *dx, int64_t dx_stride,
+                   void *stream);
+
 /* ---- K12: AdamW -- torch.optim.AdamW (configs/opt/adam_w.yml), flat fp32 buffers of n elements;
  * step = 1-based step index; grad_scale multiplies the gradient first (1/world after a sum
  * all-reduce). */

@@ -1,0 +1,79 @@
+"""``mrstft`` loss of mod_extraction/losses.py:155-156 (auraloss.freq.MultiResolutionSTFTLoss with its
+default arguments) as a ``torch.autograd.Function`` over the ``mx_mrstft_loss`` HIP kernels (forward
+value + gradient w.r.t. the prediction in one call; the target gets no gradient, as in training)."""
+import ctypes
+import math
+from typing import Sequence, Tuple
+
+import torch
+from torch import Tensor as T, nn
+
+from . import _hip
+
+MAXN = 2048
+
+
+def _windows(fft_sizes: Sequence[int], win_lengths: Sequence[int], device) -> T:
+    w = torch.zeros((len(fft_sizes), MAXN), dtype=torch.float32)
+    for r, (n, wl) in enumerate(zip(fft_sizes, win_lengths)):
+        left = (n - wl) // 2                               # torch.stft centres a short window in the frame
+        w[r, left:left + wl] = torch.hann_window(wl)
+    return w.to(device)
+
+
+class _MRSTFTFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y_hat: T, y: T, mod: "MultiResolutionSTFTLoss"):
+        assert y_hat.shape == y.shape
+        Tn = y_hat.size(-1)
+        a = y_hat.reshape(-1, Tn).contiguous().float()
+        t = y.reshape(-1, Tn).contiguous().float()
+        B = a.size(0)
+        dev = a.device
+        n_res = len(mod.fft_sizes)
+        frames = [1 + Tn // h for h in mod.hop_sizes]
+        part = torch.empty(3 * B * max(-(-f // 8) for f in frames), device=dev, dtype=torch.float64)
+        coef = torch.empty(2, device=dev, dtype=torch.float32)
+        terms = torch.empty(2 * n_res + 1, device=dev, dtype=torch.float32)
+        need_grad = y_hat.requires_grad
+        scratch = torch.empty(B * max(f * n for f, n in zip(frames, mod.fft_sizes)), device=dev,
+                              dtype=torch.float32) if need_grad else None
+        dx = torch.empty_like(a) if need_grad else None
+        ffts = (ctypes.c_int32 * n_res)(*mod.fft_sizes)
+        hops = (ctypes.c_int32 * n_res)(*mod.hop_sizes)
+        win, tw = mod.buffers_on(dev)
+        _hip.call("mx_mrstft_loss", _hip.ptr(a), a.stride(0), _hip.ptr(t), t.stride(0), B, Tn, n_res,
+                  ctypes.cast(ffts, ctypes.c_void_p), ctypes.cast(hops, ctypes.c_void_p), _hip.ptr(win), _hip.ptr(tw),
+                  float(mod.w_sc), float(mod.w_log_mag), float(mod.eps), _hip.ptr(part), _hip.ptr(coef),
+                  _hip.ptr(scratch), _hip.ptr(terms), _hip.ptr(dx), Tn, _hip.stream())
+        ctx.save_for_backward(dx if need_grad else torch.empty(0, device=dev))
+        ctx.shape = y_hat.shape
+        mod.last_terms = terms.detach()
+        return terms[2 * n_res]
+
+    @staticmethod
+    def backward(ctx, g: T):
+        (dx,) = ctx.saved_tensors
+        return (dx * g).view(ctx.shape), None, None
+
+
+class MultiResolutionSTFTLoss(nn.Module):
+    def __init__(self, fft_sizes: Sequence[int] = (1024, 2048, 512), hop_sizes: Sequence[int] = (120, 240, 50),
+                 win_lengths: Sequence[int] = (600, 1200, 240), w_sc: float = 1.0, w_log_mag: float = 1.0,
+                 eps: float = 1e-8) -> None:
+        super().__init__()
+        assert all(n in (512, 1024, 2048) for n in fft_sizes)
+        self.fft_sizes, self.hop_sizes, self.win_lengths = list(fft_sizes), list(hop_sizes), list(win_lengths)
+        self.w_sc, self.w_log_mag, self.eps = w_sc, w_log_mag, eps
+        self._cache = None
+        self.last_terms = None
+
+    def buffers_on(self, device) -> Tuple[T, T]:
+        if self._cache is None or self._cache[0].device != device:
+            k = torch.arange(MAXN, dtype=torch.float64) * (-2.0 * math.pi / MAXN)
+            tw = torch.stack([torch.cos(k), torch.sin(k)], dim=1).float().to(device)
+            self._cache = (_windows(self.fft_sizes, self.win_lengths, device), tw)
+        return self._cache
+
+    def forward(self, input: T, target: T) -> T:
+        return _MRSTFTFn.apply(input, target, self)
