@@ -1,0 +1,196 @@
+"""Drop-in for the reference's entry layer (mod_extraction/cli.py:21-167 ``CustomLightningCLI`` on top
+of jsonargparse / LightningCLI, neither of which is needed here): parses the same YAML schema and
+drives ``trainer.Trainer`` instead of ``pl.Trainer``.
+
+Supported schema (what the shipped configs use):
+  * ``class_path`` / ``init_args`` objects, nested arbitrarily; ``mod_extraction.*`` class paths resolve to
+    this package's mirrors (``mod_extraction_amd.*``), ``torch.optim.AdamW`` to the flat HIP AdamW
+  * a value may be a path to another YAML (``model: ../configs/models/spectral_2dcnn.yml``); paths are
+    tried relative to the current directory (the reference runs from ``scripts/``) and to the config file
+  * the "link if possible" rules of configs/cli_config.yml:21-45 (n_samples / sr from data to the models)
+  * ``seed_everything``, ``trainer.{max_epochs, num_sanity_val_steps, limit_*_batches}``, ``custom.*``,
+    ``ckpt_path`` (Lightning ``.ckpt`` or bare ``.pt`` state dict, prefixes stripped like
+    scripts/extract_model_weights.py:38-47)
+GPU-only: there is no CPU fallback, so the reference's CPU overrides (cli.py:128-143) do not apply.
+"""
+import copy
+import importlib
+import logging
+import os
+from typing import Any, Dict, List, Optional
+
+import torch
+import yaml
+
+log = logging.getLogger(__name__)
+
+CLASS_ALIASES = {"torch.optim.AdamW": "mod_extraction_amd.optim.FlatAdamW"}
+LINKS = [  # (source path, destination path) -- configs/cli_config.yml:21-45
+    ("data.init_args.n_samples", "model.init_args.model.init_args.n_samples"),
+    ("data.init_args.n_samples", "model.init_args.lfo_model.init_args.n_samples"),
+    ("data.init_args.shared_args.n_samples", "model.init_args.model.init_args.n_samples"),
+    ("data.init_args.shared_args.n_samples", "model.init_args.lfo_model.init_args.n_samples"),
+    ("data.init_args.sr", "model.init_args.sr"),
+    ("data.init_args.shared_args.sr", "model.init_args.sr"),
+    ("data.init_args.sr", "model.init_args.model.init_args.sr"),
+    ("data.init_args.shared_args.sr", "model.init_args.model.init_args.sr"),
+    ("data.init_args.sr", "model.init_args.lfo_model.init_args.sr"),
+    ("data.init_args.shared_args.sr", "model.init_args.lfo_model.init_args.sr"),
+]
+
+
+def _is_yaml_path(v: Any) -> bool:
+    return isinstance(v, str) and v.lower().endswith((".yml", ".yaml"))
+
+
+def _find(path: str, base_dirs: List[str]) -> Optional[str]:
+    for b in base_dirs:
+        p = os.path.normpath(os.path.join(b, path))
+        if os.path.isfile(p):
+            return p
+    return None
+
+
+def load_config(path: str) -> Dict[str, Any]:
+    """Load a YAML config and inline every value that is itself a path to a YAML file."""
+    path = os.path.abspath(path)
+    base_dirs = [os.getcwd(), os.path.dirname(path), os.path.join(os.path.dirname(path), "..", "scripts")]
+
+    def expand(node: Any) -> Any:
+        if _is_yaml_path(node):
+            found = _find(node, base_dirs)
+            if found is None:
+                raise FileNotFoundError(f"config indirection {node!r} not found relative to {base_dirs}")
+            with open(found) as f:
+                return expand(yaml.safe_load(f))
+        if isinstance(node, dict):
+            return {k: expand(v) for k, v in node.items()}
+        if isinstance(node, list):
+            return [expand(v) for v in node]
+        return node
+
+    with open(path) as f:
+        return expand(yaml.safe_load(f))
+
+
+def _get(cfg: Dict[str, Any], dotted: str) -> Any:
+    cur: Any = cfg
+    for k in dotted.split("."):
+        if not isinstance(cur, dict) or k not in cur:
+            return None
+        cur = cur[k]
+    return cur
+
+
+def _set_if_possible(cfg: Dict[str, Any], dotted: str, value: Any) -> bool:
+    keys = dotted.split(".")
+    cur: Any = cfg
+    for k in keys[:-1]:
+        if not isinstance(cur, dict) or k not in cur or not isinstance(cur[k], dict):
+            return False
+        cur = cur[k]
+    cur[keys[-1]] = value
+    return True
+
+
+def apply_links(cfg: Dict[str, Any]) -> Dict[str, Any]:
+    for src, dst in LINKS:
+        v = _get(cfg, src)
+        if v is not None:
+            _set_if_possible(cfg, dst, v)
+    return cfg
+
+
+def resolve_class(class_path: str):
+    class_path = CLASS_ALIASES.get(class_path, class_path)
+    if class_path.startswith("mod_extraction."):
+        class_path = "mod_extraction_amd." + class_path[len("mod_extraction."):]
+    mod, _, name = class_path.rpartition(".")
+    return getattr(importlib.import_module(mod), name)
+
+
+def instantiate(spec: Any, **extra: Any) -> Any:
+    """Build the object graph of a ``class_path`` / ``init_args`` spec (depth first)."""
+    if isinstance(spec, dict) and "class_path" in spec:
+        kwargs = {k: instantiate(v) for k, v in (spec.get("init_args") or {}).items()}
+        kwargs.update(extra)
+        return resolve_class(spec["class_path"])(**kwargs)
+    if isinstance(spec, dict):
+        return {k: instantiate(v) for k, v in spec.items()}
+    if isinstance(spec, list):
+        return [instantiate(v) for v in spec]
+    return spec
+
+
+def load_weights(module: torch.nn.Module, path: str) -> None:
+    """Lightning ``.ckpt`` (``state_dict`` with ``model.`` / ``effect_model.`` / ``lfo_model.`` prefixes) or a
+    bare ``.pt`` state dict."""
+    blob = torch.load(path, map_location="cpu")
+    sd = blob.get("state_dict", blob) if isinstance(blob, dict) else blob
+    own = module.state_dict()
+    if not set(sd).issubset(set(own)):          # bare sub-module weights: find the attribute they belong to
+        for prefix in ("model.", "effect_model.", "lfo_model."):
+            cand = {prefix + k: v for k, v in sd.items()}
+            if set(cand).issubset(set(own)):
+                sd = cand
+                break
+    missing, unexpected = module.load_state_dict(sd, strict=False)
+    if unexpected:
+        raise KeyError(f"unexpected keys in {path}: {unexpected[:5]}")
+    if missing:
+        log.warning("checkpoint %s leaves %d keys untouched", path, len(missing))
+
+
+class CustomLightningCLI:
+    """``CustomLightningCLI(args=["fit" | "validate", "-c", config.yml])`` as in scripts/train.py:30 and
+    scripts/validate.py:25.  With ``run=False`` only the object graph is built (``.model``,
+    ``.datamodule``, ``.optimizer_spec``, ``.trainer``)."""
+
+    def __init__(self, args: List[str], trainer_defaults: Optional[Dict[str, Any]] = None, run: bool = True,
+                 device: Optional[torch.device] = None) -> None:
+        assert args and args[0] in ("fit", "validate")
+        self.subcommand = args[0]
+        cfg_path = args[args.index("-c") + 1] if "-c" in args else args[args.index("--config") + 1]
+        self.config = apply_links(load_config(cfg_path))
+        seed = self.config.get("seed_everything")
+        if seed is not None:
+            import random
+            import numpy as np
+            random.seed(seed); np.random.seed(seed); torch.manual_seed(seed)
+        from . import trainer as tr
+        self.env = tr.init_distributed()
+        if device is None:
+            device = torch.device("cuda", self.env["local_rank"])
+        self.device = device
+        self.custom = self.config.get("custom", {}) or {}
+        tkw = dict(trainer_defaults or {})
+        tkw.update({k: v for k, v in (self.config.get("trainer") or {}).items()
+                    if k in ("max_epochs", "num_sanity_val_steps", "limit_train_batches", "limit_val_batches")})
+        tkw = {k: v for k, v in tkw.items() if k in ("max_epochs", "num_sanity_val_steps", "limit_train_batches",
+                                                      "limit_val_batches", "log_fn")}
+        self.trainer = tr.Trainer(**tkw)
+        self.datamodule = instantiate(self.config["data"])
+        self.model = instantiate(self.config["model"]).to(device)
+        self.optimizer_spec = self.config.get("optimizer")
+        self.optimizer = None
+        ckpt = self.config.get("ckpt_path")
+        if ckpt:
+            found = _find(ckpt, [os.getcwd(), os.path.dirname(os.path.abspath(cfg_path))])
+            if found:
+                load_weights(self.model, found)
+            else:
+                log.warning("ckpt_path %s not found (large blobs are not part of the repository)", ckpt)
+        if run:
+            self.run()
+
+    def run(self):
+        self.datamodule.setup(self.device, rank=self.env["rank"], seed=self.config.get("seed_everything") or 43)
+        if self.subcommand == "validate":
+            self.model.eval()
+            metrics = self.trainer.validate(self.model, self.datamodule)
+            if self.env["rank"] == 0:
+                print(metrics)
+            return metrics
+        params = [p for p in self.model.parameters() if p.requires_grad]
+        self.optimizer = instantiate(self.optimizer_spec, params=params)
+        return self.trainer.fit(self.model, self.datamodule, self.optimizer)
