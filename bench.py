@@ -47,7 +47,7 @@ def conv_flops(block: int, batch: int) -> float:
     return 2.0 * 64 * BLOCK_CIN[block] * 65 * BLOCK_H[block] * W_FRAMES * batch
 
 
-def build_job(device, rank, batch):
+def build_job(device, rank, batch, overlap=True):
     from mod_extraction_amd import data_modules, lightning, models, optim
     torch.manual_seed(43 + rank)
     import numpy as np
@@ -57,7 +57,8 @@ def build_job(device, rank, batch):
                                      loss_dict=LOSS).to(device)
     module.train()
     opt = optim.FlatAdamW(module.parameters(), lr=1e-4, betas=(0.8, 0.99))
-    batcher = data_modules.SyntheticFxBatcher(batch, N_SAMPLES, SR, KINDS, device, audio_seed=43 + rank)
+    batcher = data_modules.SyntheticFxBatcher(batch, N_SAMPLES, SR, KINDS, device, audio_seed=43 + rank,
+                                              overlap=overlap)
     return module, opt, batcher
 
 
@@ -97,6 +98,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=BATCH, help="clips per GPU (default: the BASELINE config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="render each batch on the main stream instead of one step ahead on a side stream")
     args = ap.parse_args()
 
     from mod_extraction_amd import _hip, trainer as tr
@@ -105,7 +108,7 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     device = torch.device("cuda", env["local_rank"])
     torch.cuda.set_device(device)
-    module, opt, batcher = build_job(device, rank, args.batch)
+    module, opt, batcher = build_job(device, rank, args.batch, overlap=not args.no_overlap)
     runner = tr.Trainer(log_fn=None)
 
     def step():

@@ -68,34 +68,68 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(ConvArgs a)
     for (int s = 0; s < n_stage; ++s) {
         __syncthreads();
         // ---- stage the weight slab of channels (2s, 2s+1): contiguous 33 KB ----
+        // All global loads of a batch are issued before the first LDS write (one memory round trip per
+        // batch instead of one per vector): 8+1 weight vectors, then NP patch vectors per thread.
         {
             const floatx4 *src = reinterpret_cast<const floatx4 *>(a.wt + (size_t)s * WSLAB);
             floatx4 *dst = reinterpret_cast<floatx4 *>(wl);
-            for (int i = tid; i < WSLAB / 4; i += 256) dst[i] = src[i];
+            constexpr int NWV = (WSLAB / 4) / 256;             // 8 full rounds, + 32 vectors
+            floatx4 wv[NWV], wtail = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int q = 0; q < NWV; ++q) wv[q] = src[tid + q * 256];
+            if (tid < WSLAB / 4 - NWV * 256) wtail = src[NWV * 256 + tid];
+#pragma unroll
+            for (int q = 0; q < NWV; ++q) dst[tid + q * 256] = wv[q];
+            if (tid < WSLAB / 4 - NWV * 256) dst[NWV * 256 + tid] = wtail;
         }
         // ---- stage the input patch with the fused transform ----
-        for (int i = tid; i < 2 * PROWS * PW4; i += 256) {
-            const int rowid = i / PW4, c4 = i - rowid * PW4;
-            const int cl = rowid / PROWS, r = rowid - cl * PROWS;
-            const int h = h0 - 2 + r;
-            const int w0 = c4 * 4 - HALO;
-            const int ci = 2 * s + cl;
-            floatx4 v = {0.0f, 0.0f, 0.0f, 0.0f};
-            if (h >= 0 && h < a.H && w0 >= 0 && w0 < CV_PITCH) {
-                const int hin = (INMODE == IN_ROUTE) ? (h >> 1) : h;
-                const size_t off = (((size_t)b * a.Cin + ci) * Hin + hin) * CV_PITCH + w0;
-                v = *reinterpret_cast<const floatx4 *>(a.in + off);
+        {
+            constexpr int NITEM = 2 * PROWS * PW4;
+            constexpr int NP = (NITEM + 255) / 256;
+            floatx4 pv[NP];
+            uchar4 pam[NP];
+            float st_mean[2], st_rstd[2], st_sl[2];
+            if (INMODE != IN_ROUTE) {
+#pragma unroll
+                for (int cl = 0; cl < 2; ++cl) {
+                    const int ci = 2 * s + cl;
+                    st_mean[cl] = a.stats[((size_t)b * a.Cin + ci) * 2];
+                    st_rstd[cl] = a.stats[((size_t)b * a.Cin + ci) * 2 + 1];
+                    st_sl[cl] = (INMODE == IN_PRELU) ? a.slope[ci] : 1.0f;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+                const int i = tid + q * 256;
+                const int rowid = i / PW4, c4 = i - rowid * PW4;
+                const int cl = rowid / PROWS, r = rowid - cl * PROWS;
+                const int h = h0 - 2 + r, w0 = c4 * 4 - HALO;
+                pv[q] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+                pam[q] = uchar4{2, 2, 2, 2};
+                if (i < NITEM && h >= 0 && h < a.H && w0 >= 0 && w0 < CV_PITCH) {
+                    const int hin = (INMODE == IN_ROUTE) ? (h >> 1) : h;
+                    const size_t off = (((size_t)b * a.Cin + 2 * s + cl) * Hin + hin) * CV_PITCH + w0;
+                    pv[q] = *reinterpret_cast<const floatx4 *>(a.in + off);
+                    if (INMODE == IN_ROUTE) pam[q] = *reinterpret_cast<const uchar4 *>(a.amax + off);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+                const int i = tid + q * 256;
+                const int rowid = i / PW4, c4 = i - rowid * PW4;
+                const int cl = rowid / PROWS, r = rowid - cl * PROWS;
+                const int h = h0 - 2 + r, w0 = c4 * 4 - HALO;
+                floatx4 v = pv[q];
+                const bool inside = h >= 0 && h < a.H && w0 >= 0 && w0 < CV_PITCH;
                 if (INMODE == IN_ROUTE) {
-                    const uchar4 am = *reinterpret_cast<const uchar4 *>(a.amax + off);
                     const unsigned want = (unsigned)(h & 1);
-                    v[0] = am.x == want ? v[0] : 0.0f;
-                    v[1] = am.y == want ? v[1] : 0.0f;
-                    v[2] = am.z == want ? v[2] : 0.0f;
-                    v[3] = am.w == want ? v[3] : 0.0f;
-                } else {
-                    const float mean = a.stats[((size_t)b * a.Cin + ci) * 2];
-                    const float rstd = a.stats[((size_t)b * a.Cin + ci) * 2 + 1];
-                    const float sl = (INMODE == IN_PRELU) ? a.slope[ci] : 1.0f;
+                    v[0] = pam[q].x == want ? v[0] : 0.0f;
+                    v[1] = pam[q].y == want ? v[1] : 0.0f;
+                    v[2] = pam[q].z == want ? v[2] : 0.0f;
+                    v[3] = pam[q].w == want ? v[3] : 0.0f;
+                } else if (inside) {
+                    const float mean = cl ? st_mean[1] : st_mean[0], rstd = cl ? st_rstd[1] : st_rstd[0];
+                    const float sl = cl ? st_sl[1] : st_sl[0];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         float x = v[e];
@@ -105,26 +139,47 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(ConvArgs a)
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    if (w0 + e >= a.Wv) v[e] = 0.0f;
+                    if (!inside || w0 + e >= a.Wv) v[e] = 0.0f;
+                if (i < NITEM) *reinterpret_cast<floatx4 *>(patch + rowid * PW + c4 * 4) = v;
             }
-            *reinterpret_cast<floatx4 *>(patch + rowid * PW + c4 * 4) = v;
         }
         __syncthreads();
         // ---- 65 k-steps (one tap each, both channels of the pair), 11 MFMAs per k-step ----
-        const float *wbase = wl + half * (CV_TAPS * CV_CO) + mt * 32 + l32;
-        const float *pbase = patch + half * (PROWS * PW) + row * PW + HALO + l32 - 6 * T;
+        // Software pipelined by hand with two fragment register sets (ping-pong, loop unrolled by 2): the
+        // 12 LDS fragment reads of tap k+1 are issued BEFORE the 11 MFMAs of tap k, and sched_barriers keep
+        // the compiler from rotating the loads back in front of their own MFMAs, so the matrix pipe never
+        // waits on an LDS round trip.
+        {
+            const float *wp = wl + half * (CV_TAPS * CV_CO) + mt * 32 + l32;
+            const float *pp = patch + half * (PROWS * PW) + row * PW + HALO + l32 - 6 * T;
+            int kw = 0;
+            float a0, a1, b0[CV_WT], b1[CV_WT];
+#define CV_ADVANCE()                                                                      \
+    wp += CV_CO;                                                                          \
+    pp += (kw == CV_KW - 1) ? (PW - (CV_KW - 1) * T) : T; /* kw+1, or first tap of next row */ \
+    kw = (kw == CV_KW - 1) ? 0 : kw + 1;
+#define CV_LOAD(A, B)                                                                     \
+    A = wp[0];                                                                            \
+    _Pragma("unroll") for (int i = 0; i < CV_WT; ++i) B[i] = pp[i * 32];
+#define CV_MMA(A, B) _Pragma("unroll") for (int i = 0; i < CV_WT; ++i) acc[i] = mfma32(A, B[i], acc[i]);
+            CV_LOAD(a0, b0)
 #pragma unroll 1
-        for (int kh = 0; kh < CV_KH; ++kh) {
-#pragma unroll 1
-            for (int kw = 0; kw < CV_KW; ++kw) {
-                const float av = wbase[(kh * CV_KW + kw) * CV_CO];
-                const float *pp = pbase + kh * PW + kw * T;
-                float bv[CV_WT];
-#pragma unroll
-                for (int i = 0; i < CV_WT; ++i) bv[i] = pp[i * 32];
-#pragma unroll
-                for (int i = 0; i < CV_WT; ++i) acc[i] = mfma32(av, bv[i], acc[i]);
+            for (int tap = 0; tap < CV_TAPS - 1; tap += 2) {
+                CV_ADVANCE()
+                CV_LOAD(a1, b1)
+                __builtin_amdgcn_sched_barrier(0);
+                CV_MMA(a0, b0)
+                __builtin_amdgcn_sched_barrier(0);
+                CV_ADVANCE()
+                CV_LOAD(a0, b0)
+                __builtin_amdgcn_sched_barrier(0);
+                CV_MMA(a1, b1)
+                __builtin_amdgcn_sched_barrier(0);
             }
+            CV_MMA(a0, b0)           // tap 64 (65 taps: 32 pairs + 1)
+#undef CV_ADVANCE
+#undef CV_LOAD
+#undef CV_MMA
         }
     }
 

@@ -7,7 +7,8 @@
 // out; lastOut = out * feedback) is strictly serial per sample, so the wave splits the work by
 // kind: per block of 256 samples the 64 lanes evaluate the 64 LFO / cut-off updates in parallel
 // (sin, pow, fp64 tan -> G = g / (1 + g), one per lane), samples are loaded/stored 4 per lane
-// coalesced through LDS, and only the 256-sample dependent chain runs wave-uniformly.
+// coalesced (lane registers, broadcast with v_readlane), and only the 256-sample dependent chain
+// runs wave-uniformly.
 // sin / pow / log10 are evaluated in fp64 and rounded once, which reproduces the host libm's (correctly
 // rounded) float results; the LFO phase accumulator is advanced sequentially in fp32 (as JUCE does) to stay bit-faithful.
 // `lead` samples are processed (filter warm-up, LFO phase) before the N output samples: the
@@ -28,7 +29,6 @@ __global__ __launch_bounds__(64) void phaser_kernel(const float *__restrict__ x,
                                                     double sr, float *__restrict__ y, long long y_stride,
                                                     float *__restrict__ dry_out)
 {
-    __shared__ float xs[PH_BLOCK], ys[PH_BLOCK], Gs[PH_BLOCK / 4];
     const int lane = threadIdx.x;
     const int b = rows ? rows[blockIdx.x] : (int)blockIdx.x;
     const int lead = lead_arr ? lead_arr[b] : 0;
@@ -52,11 +52,13 @@ __global__ __launch_bounds__(64) void phaser_kernel(const float *__restrict__ x,
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f, s5 = 0.f, last = 0.f;
 
     for (int n0 = 0; n0 < total; n0 += PH_BLOCK) {
-        // (1) coalesced load of 256 input samples
+        // (1) coalesced load of 256 input samples: lane l holds samples n0 + j*64 + l, j = 0..3
+        float xr[PH_BLOCK / 64], yr[PH_BLOCK / 64];
 #pragma unroll
         for (int j = 0; j < PH_BLOCK / 64; ++j) {
             const int n = n0 + j * 64 + lane;
-            xs[j * 64 + lane] = n < total ? xb[n] : 0.0f;
+            xr[j] = n < total ? xb[n] : 0.0f;
+            yr[j] = 0.0f;
         }
         // (2) sequential fp32 phase accumulation; lane k keeps the phase of update k
         float my_phase = 0.0f;
@@ -65,42 +67,47 @@ __global__ __launch_bounds__(64) void phaser_kernel(const float *__restrict__ x,
             phase = __fadd_rn(phase, inc);
             while (phase >= two_pi) phase = __fsub_rn(phase, two_pi);
         }
-        // (3) one cut-off update per lane
+        // (3) one cut-off update per lane: lane k holds G of samples 4k .. 4k+3 of this block
+        float Greg;
         {
             float osc = (float)sin((double)__fsub_rn(my_phase, pi_f));
             float lfo = __fadd_rn(__fmul_rn(osc, osc_vol), norm_centre);
             lfo = lfo < 0.0f ? 0.0f : (lfo > 1.0f ? 1.0f : lfo);
             float fc = (float)pow(10.0, (double)__fadd_rn(__fmul_rn(lfo, __fsub_rn(log_max, log_min)), log_min));
             float g = (float)tan(3.14159265358979323846 * (double)fc / sr);
-            Gs[lane] = __fdiv_rn(g, __fadd_rn(1.0f, g));
+            Greg = __fdiv_rn(g, __fadd_rn(1.0f, g));
         }
-        __builtin_amdgcn_s_waitcnt(0);      // LDS writes of this wave are visible to its own reads in order
-        // (4) the dependent chain, wave-uniform
+        // (4) the dependent chain, wave-uniform; inputs and coefficients are broadcast from lane
+        //     registers (v_readlane) so that no LDS round trip sits between two samples
         const int cnt = min(PH_BLOCK, total - n0);
-        for (int i = 0; i < cnt; ++i) {
-            const float G = Gs[i >> 2];
-            const float in = xs[i];
-            float out = __fsub_rn(in, last);
-            float v, yk;
+#pragma unroll
+        for (int j = 0; j < PH_BLOCK / 64; ++j) {
+            const int lim = min(64, cnt - j * 64);
+            for (int li = 0; li < lim; ++li) {
+                const float G = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Greg), (j * 64 + li) >> 2));
+                const float in = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xr[j]), li));
+                float out = __fsub_rn(in, last);
+                float v, yk;
 #define PH_STAGE(S)                                   \
     v = __fmul_rn(G, __fsub_rn(out, S));             \
     yk = __fadd_rn(v, S);                            \
     S = __fadd_rn(v, yk);                            \
     out = __fsub_rn(__fmul_rn(2.0f, yk), out);
-            PH_STAGE(s0) PH_STAGE(s1) PH_STAGE(s2) PH_STAGE(s3) PH_STAGE(s4) PH_STAGE(s5)
+                PH_STAGE(s0) PH_STAGE(s1) PH_STAGE(s2) PH_STAGE(s3) PH_STAGE(s4) PH_STAGE(s5)
 #undef PH_STAGE
-            last = __fmul_rn(out, fb);
-            float m = __fadd_rn(__fmul_rn(out, wet_g), __fmul_rn(in, dry_g));
-            m = m < -1.0f ? -1.0f : (m > 1.0f ? 1.0f : m);
-            if (lane == 0) ys[i] = m;
+                last = __fmul_rn(out, fb);
+                float m = __fadd_rn(__fmul_rn(out, wet_g), __fmul_rn(in, dry_g));
+                m = m < -1.0f ? -1.0f : (m > 1.0f ? 1.0f : m);
+                yr[j] = lane == li ? m : yr[j];
+            }
         }
         // (5) coalesced store of the samples that fall inside the output window
 #pragma unroll
         for (int j = 0; j < PH_BLOCK / 64; ++j) {
             const int n = n0 + j * 64 + lane;
             if (n >= lead && n < total) {
-                yb[n - lead] = ys[j * 64 + lane];
-                if (db) db[n - lead] = xs[j * 64 + lane];
+                yb[n - lead] = yr[j];
+                if (db) db[n - lead] = xr[j];
             }
         }
     }

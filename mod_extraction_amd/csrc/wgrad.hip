@@ -8,7 +8,7 @@
 // accumulates one slab for one (kh, kw-half) in registers (fp32 MFMA 32x32x2, 6-7 accumulators
 // per wave) and writes a partial [kh][kw][co][ci] tile set; a second kernel sums the slabs in
 // fp64 (deterministic, no atomics) and transposes to torch's (Cout, Cin, 5, 13) layout.
-// dz and xhat are built on the fly while staging 32-position chunks into LDS, transposed to
+// dz and xhat are built on the fly while staging 88-position chunks (32 for T = 16) into LDS, transposed to
 // [position][channel] (pitch 65 floats) so that both MFMA operand reads are 32 consecutive floats:
 //   dz   = max-pool routing of the pooled gradient G via the stored argmax
 //   xhat = (prelu(p_prev) - mean) * rstd  (or (logmel - mean) * rstd for the first block)
@@ -30,14 +30,24 @@ struct WgradArgs {
 
 // ---- blocks 2..6: Cin = 64 ---------------------------------------------------------------------
 // grid (10, n_slabs): blockIdx.x = kh * 2 + kw_half (kw 0..6 | 7..12); 4 waves = (co tile, ci tile).
+// Per 32-position chunk: global loads of the NEXT chunk are issued into registers before the MFMAs of
+// the current one (latency hidden behind ~7k cycles of matrix work), the LDS tiles are rewritten
+// between two barriers, and the MFMA loop is ping-pong pipelined like the forward kernel.
 template <int T>
 __global__ __launch_bounds__(256, 2) void wgrad64_kernel(WgradArgs a)
 {
     constexpr int HALO = cv_halo(T);
-    constexpr int WIN = WG_CHUNK + 2 * HALO;       // staged xhat positions per chunk
+    constexpr int CH = T <= 2 ? 88 : (T <= 8 ? 44 : 32);   // positions per chunk (352 = 4 x 88 = 8 x 44 = 11 x 32):
+                                                   // longer MFMA phases between barriers where registers / LDS allow
+    constexpr int WIN = CH + 2 * HALO;             // staged xhat positions per chunk
     constexpr int WIN4 = WIN / 4;
-    __shared__ float dzl[WG_CHUNK * WG_LP];
+    constexpr int NXV = (64 * WIN4 + 255) / 256;   // xhat float4 loads per thread per chunk
+    constexpr int NCH = CV_PITCH / CH;             // chunks per row
+    constexpr int NDZ = (64 * (CH / 4) + 255) / 256; // dz float4 loads per thread per chunk
+    constexpr bool PREF = T < 16;                  // T = 16 would need 14 prefetch vectors per thread (spills)
+    __shared__ float dzl[CH * WG_LP];
     __shared__ float xl[WIN * WG_LP];
+    __shared__ float st_l[3 * 64];                 // mean | rstd | slope of the clip being staged
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int mt = wave & 1, cb = wave >> 1, half = lane >> 5, l32 = lane & 31;
     const int kh = blockIdx.x >> 1, kwh = blockIdx.x & 1;
@@ -53,35 +63,66 @@ __global__ __launch_bounds__(256, 2) void wgrad64_kernel(WgradArgs a)
     const int row_begin = blockIdx.y * a.rows_per_slab;
     int row_end = row_begin + a.rows_per_slab;
     if (row_end > a.B * a.H) row_end = a.B * a.H;
-    for (int rid = row_begin; rid < row_end; ++rid) {
-        const int b = rid / a.H, h = rid - b * a.H;
-        const int hx = h + kh - 2;
-        if (hx < 0 || hx >= a.H) continue;                      // block-uniform: xhat row is padding
-        for (int w0 = 0; w0 < CV_PITCH; w0 += WG_CHUNK) {
-            __syncthreads();
-            // dz chunk: 64 channels x 8 float4, transposed into dzl[pos][co]
-            for (int i = tid; i < 64 * (WG_CHUNK / 4); i += 256) {
-                const int co = i / (WG_CHUNK / 4), c4 = i - co * (WG_CHUNK / 4);
+
+    // iteration = (row id, chunk); rows whose xhat row (h + kh - 2) is padding contribute nothing
+    auto row_valid = [&](int rid) {
+        const int h = rid % a.H, hx = h + kh - 2;
+        return hx >= 0 && hx < a.H;
+    };
+    auto next_iter = [&](int &rid, int &ch) {          // advance to the next valid (rid, chunk)
+        if (++ch < NCH) return;
+        ch = 0;
+        do { ++rid; } while (rid < row_end && !row_valid(rid));
+    };
+
+    floatx4 pg[NDZ], px[PREF ? NXV : 1];
+    uchar4 pa[NDZ];
+    auto issue = [&](int rid, int ch) {                 // global loads of one chunk into registers
+        if (!PREF) return;
+        const int b = rid / a.H, h = rid - b * a.H, hx = h + kh - 2, w0 = ch * CH;
+#pragma unroll
+        for (int q = 0; q < NDZ; ++q) {
+            const int i = tid + q * 256, co = i / (CH / 4), c4 = i - co * (CH / 4);
+            if (i < 64 * (CH / 4)) {
                 const size_t off = (((size_t)b * 64 + co) * Hp + (h >> 1)) * CV_PITCH + w0 + c4 * 4;
-                floatx4 g = *reinterpret_cast<const floatx4 *>(a.G + off);
-                const uchar4 am = *reinterpret_cast<const uchar4 *>(a.amax + off);
-                const unsigned want = (unsigned)(h & 1);
+                pg[q] = *reinterpret_cast<const floatx4 *>(a.G + off);
+                pa[q] = *reinterpret_cast<const uchar4 *>(a.amax + off);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < (PREF ? NXV : 0); ++q) {
+            const int i = tid + q * 256, ci = i / WIN4, c4 = i - ci * WIN4;
+            const int wq = w0 - HALO + c4 * 4;
+            floatx4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (i < 64 * WIN4 && wq >= 0 && wq < CV_PITCH)
+                v = *reinterpret_cast<const floatx4 *>(a.x + (((size_t)b * 64 + ci) * a.H + hx) * CV_PITCH + wq);
+            px[q] = v;
+        }
+    };
+    auto store = [&](int rid, int ch) {                 // transform + transposed LDS writes
+        if (!PREF) return;
+        const int b = rid / a.H, h = rid - b * a.H, w0 = ch * CH;
+        const unsigned want = (unsigned)(h & 1);
+#pragma unroll
+        for (int q = 0; q < NDZ; ++q) {
+            const int i = tid + q * 256, co = i / (CH / 4), c4 = i - co * (CH / 4);
+            if (i < 64 * (CH / 4)) {
                 const int wq = w0 + c4 * 4;
                 float *d = dzl + (c4 * 4) * WG_LP + co;
-                d[0] = (am.x == want && wq + 0 < a.Wv) ? g[0] : 0.0f;
-                d[WG_LP] = (am.y == want && wq + 1 < a.Wv) ? g[1] : 0.0f;
-                d[2 * WG_LP] = (am.z == want && wq + 2 < a.Wv) ? g[2] : 0.0f;
-                d[3 * WG_LP] = (am.w == want && wq + 3 < a.Wv) ? g[3] : 0.0f;
+                d[0] = (pa[q].x == want && wq + 0 < a.Wv) ? pg[q][0] : 0.0f;
+                d[WG_LP] = (pa[q].y == want && wq + 1 < a.Wv) ? pg[q][1] : 0.0f;
+                d[2 * WG_LP] = (pa[q].z == want && wq + 2 < a.Wv) ? pg[q][2] : 0.0f;
+                d[3 * WG_LP] = (pa[q].w == want && wq + 3 < a.Wv) ? pg[q][3] : 0.0f;
             }
-            // xhat window [w0 - HALO, w0 + 32 + HALO): 64 channels, transposed into xl[pos][ci]
-            for (int i = tid; i < 64 * WIN4; i += 256) {
-                const int ci = i / WIN4, c4 = i - ci * WIN4;
+        }
+#pragma unroll
+        for (int q = 0; q < (PREF ? NXV : 0); ++q) {
+            const int i = tid + q * 256, ci = i / WIN4, c4 = i - ci * WIN4;
+            if (i < 64 * WIN4) {
                 const int wq = w0 - HALO + c4 * 4;
-                floatx4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+                floatx4 v = px[q];
                 if (wq >= 0 && wq < CV_PITCH) {
-                    v = *reinterpret_cast<const floatx4 *>(a.x + (((size_t)b * 64 + ci) * a.H + hx) * CV_PITCH + wq);
-                    const float mean = a.stats[((size_t)b * 64 + ci) * 2], rstd = a.stats[((size_t)b * 64 + ci) * 2 + 1];
-                    const float sl = a.slope[ci];
+                    const float mean = st_l[ci], rstd = st_l[64 + ci], sl = st_l[128 + ci];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         float t = v[e] > 0.0f ? v[e] : sl * v[e];
@@ -91,20 +132,86 @@ __global__ __launch_bounds__(256, 2) void wgrad64_kernel(WgradArgs a)
                 float *d = xl + (c4 * 4) * WG_LP + ci;
                 d[0] = v[0]; d[WG_LP] = v[1]; d[2 * WG_LP] = v[2]; d[3 * WG_LP] = v[3];
             }
+        }
+    };
+
+    int rid = row_begin, ch = 0;
+    while (rid < row_end && !row_valid(rid)) ++rid;
+    if (PREF && rid < row_end) issue(rid, ch);
+    const float *ab = dzl + half * WG_LP + mt * 32 + l32;
+    const float *bb = xl + (HALO + half + (kw0 - 6) * T) * WG_LP + cb * 32 + l32;
+    int b_cached = -1;
+    while (rid < row_end) {
+        __syncthreads();                                // everyone is done reading the previous tiles
+        if (rid / a.H != b_cached) {                    // new clip: its LayerNorm statistics / slopes -> LDS
+            b_cached = rid / a.H;
+            if (tid < 64) {
+                st_l[tid] = a.stats[((size_t)b_cached * 64 + tid) * 2];
+                st_l[64 + tid] = a.stats[((size_t)b_cached * 64 + tid) * 2 + 1];
+                st_l[128 + tid] = a.slope[tid];
+            }
             __syncthreads();
-            const float *ab = dzl + half * WG_LP + mt * 32 + l32;
-            const float *bb = xl + (HALO + half + (kw0 - 6) * T) * WG_LP + cb * 32 + l32;
-#pragma unroll 2
-            for (int ks = 0; ks < WG_CHUNK / 2; ++ks) {
-                const float av = ab[2 * ks * WG_LP];
-                float bv[7];
+        }
+        if (PREF) {
+            store(rid, ch);
+        } else {
+            // large dilation: the staged window is 7x the chunk, keep the loads in a loop (no register arrays)
+            const int b = rid / a.H, h = rid - b * a.H, hx = h + kh - 2, w0 = ch * CH;
+            const unsigned want = (unsigned)(h & 1);
+            for (int i = tid; i < 64 * (CH / 4); i += 256) {
+                const int co = i / (CH / 4), c4 = i - co * (CH / 4);
+                const size_t off = (((size_t)b * 64 + co) * Hp + (h >> 1)) * CV_PITCH + w0 + c4 * 4;
+                const floatx4 g = *reinterpret_cast<const floatx4 *>(a.G + off);
+                const uchar4 am = *reinterpret_cast<const uchar4 *>(a.amax + off);
+                const int wq = w0 + c4 * 4;
+                float *d = dzl + (c4 * 4) * WG_LP + co;
+                d[0] = (am.x == want && wq + 0 < a.Wv) ? g[0] : 0.0f;
+                d[WG_LP] = (am.y == want && wq + 1 < a.Wv) ? g[1] : 0.0f;
+                d[2 * WG_LP] = (am.z == want && wq + 2 < a.Wv) ? g[2] : 0.0f;
+                d[3 * WG_LP] = (am.w == want && wq + 3 < a.Wv) ? g[3] : 0.0f;
+            }
+            for (int i = tid; i < 64 * WIN4; i += 256) {
+                const int ci = i / WIN4, c4 = i - ci * WIN4;
+                const int wq = w0 - HALO + c4 * 4;
+                floatx4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (wq >= 0 && wq < CV_PITCH) {
+                    v = *reinterpret_cast<const floatx4 *>(a.x + (((size_t)b * 64 + ci) * a.H + hx) * CV_PITCH + wq);
+                    const float mean = st_l[ci], rstd = st_l[64 + ci], sl = st_l[128 + ci];
 #pragma unroll
-                for (int i = 0; i < 7; ++i) bv[i] = i < nkw ? bb[(2 * ks + i * T) * WG_LP] : 0.0f;
-#pragma unroll
-                for (int i = 0; i < 7; ++i)
-                    if (i < nkw) acc[i] = mfma32(av, bv[i], acc[i]);
+                    for (int e = 0; e < 4; ++e) {
+                        float t = v[e] > 0.0f ? v[e] : sl * v[e];
+                        v[e] = wq + e < a.Wv ? (t - mean) * rstd : 0.0f;
+                    }
+                }
+                float *d = xl + (c4 * 4) * WG_LP + ci;
+                d[0] = v[0]; d[WG_LP] = v[1]; d[2 * WG_LP] = v[2]; d[3 * WG_LP] = v[3];
             }
         }
+        int nrid = rid, nch = ch;
+        next_iter(nrid, nch);
+        if (PREF && nrid < row_end) issue(nrid, nch);   // in flight during the MFMAs below
+        __syncthreads();
+        float a0, a1, b0[7], b1[7];
+#define WG_LOAD(A, B, KS)                                                                    \
+    A = ab[2 * (KS) * WG_LP];                                                                \
+    _Pragma("unroll") for (int i = 0; i < 7; ++i) B[i] = i < nkw ? bb[(2 * (KS) + i * T) * WG_LP] : 0.0f;
+#define WG_MMA(A, B) _Pragma("unroll") for (int i = 0; i < 7; ++i) if (i < nkw) acc[i] = mfma32(A, B[i], acc[i]);
+        WG_LOAD(a0, b0, 0)
+#pragma unroll 1
+        for (int ks = 0; ks < CH / 2; ks += 2) {
+            WG_LOAD(a1, b1, ks + 1)
+            __builtin_amdgcn_sched_barrier(0);
+            WG_MMA(a0, b0)
+            __builtin_amdgcn_sched_barrier(0);
+            if (ks + 2 < CH / 2) { WG_LOAD(a0, b0, ks + 2) }
+            __builtin_amdgcn_sched_barrier(0);
+            WG_MMA(a1, b1)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#undef WG_LOAD
+#undef WG_MMA
+        rid = nrid;
+        ch = nch;
     }
     // partial tiles: part[slab][kh][kw][co][ci]
 #pragma unroll

@@ -62,7 +62,7 @@ class SyntheticFxBatcher:
     def __init__(self, batch_size: int, n_samples: int, sr: float, kinds: Sequence[str], device: torch.device,
                  flanger_fx: Optional[Dict] = None, chorus_fx: Optional[Dict] = None,
                  phaser_fx: Optional[Dict] = None, mod_sig: Optional[Dict] = None, audio_seed: int = 43,
-                 peak_db: float = -1.0, fixed_lead: Optional[int] = None) -> None:
+                 peak_db: float = -1.0, fixed_lead: Optional[int] = None, overlap: bool = False) -> None:
         self.B, self.N, self.sr, self.device = batch_size, n_samples, float(sr), device
         self.kinds = [kinds[i % len(kinds)] for i in range(batch_size)]
         self.fl = _fx_from_config(flanger_fx, FLANGER_FX)
@@ -93,8 +93,18 @@ class SyntheticFxBatcher:
         self.max_lfo_delay = ml.to(device)
         self.max_delay = (mm + ml).to(torch.int32).to(device)
         self.max_delay_max = int((mm + ml).max())
-        self.src = torch.empty((batch_size, n_samples + self.max_lead), device=device, dtype=torch.float32)
-        self.audio = torch.empty((batch_size, 2, n_samples), device=device, dtype=torch.float32)
+        # overlap=True: batches are rendered one step ahead on a side HIP stream into two alternating
+        # buffer sets, so the (latency-bound) effect kernels run concurrently with the previous train step
+        self.overlap = bool(overlap) and device.type == "cuda"
+        n_sets = 2 if self.overlap else 1
+        self._src = [torch.empty((batch_size, n_samples + self.max_lead), device=device, dtype=torch.float32)
+                     for _ in range(n_sets)]
+        self._audio = [torch.empty((batch_size, 2, n_samples), device=device, dtype=torch.float32)
+                       for _ in range(n_sets)]
+        self.src, self.audio = self._src[0], self._audio[0]
+        self._side = torch.cuda.Stream(device=device) if self.overlap else None
+        self._pending = None
+        self._slot = 0
 
     # ---- host-side parameter draws -------------------------------------------------------------
     def _uniform(self, lo: float, hi: float) -> T:
@@ -176,9 +186,32 @@ class SyntheticFxBatcher:
         fx_params["shape"] = p["shape"]
         return self.audio[:, 0:1, :], self.audio[:, 1:2, :], mod, fx_params
 
+    def _launch_ahead(self) -> None:
+        """render the next batch on the side stream into the idle buffer set"""
+        main = torch.cuda.current_stream(self.device)
+        slot = self._slot
+        self._slot ^= 1
+        self.src, self.audio = self._src[slot], self._audio[slot]
+        self._side.wait_stream(main)            # the idle set was last read two steps ago; also orders the RNG state
+        with torch.cuda.stream(self._side), torch.no_grad():
+            batch = self.render(self.sample_params())
+            ev = torch.cuda.Event()
+            ev.record(self._side)
+        self._pending = (batch, ev)
+
     def next_batch(self) -> Tuple[T, T, T, Dict[str, Any]]:
-        with torch.no_grad():
-            return self.render(self.sample_params())
+        if not self.overlap:
+            with torch.no_grad():
+                return self.render(self.sample_params())
+        if self._pending is None:
+            self._launch_ahead()
+        batch, ev = self._pending
+        main = torch.cuda.current_stream(self.device)
+        main.wait_event(ev)
+        for t in (batch[2], *[v for v in batch[3].values() if isinstance(v, torch.Tensor)]):
+            t.record_stream(main)               # allocated on the side stream, consumed on the main stream
+        self._launch_ahead()                    # overlaps with the train step the caller is about to enqueue
+        return batch
 
 
 # ---- data modules with the reference's class names ---------------------------------------------
