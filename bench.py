@@ -43,6 +43,18 @@ BLOCK_H = [256, 128, 64, 32, 16, 8]
 BLOCK_CIN = [2, 64, 64, 64, 64, 64]
 
 
+def measured_traffic(batch: int):
+    """HBM bytes per launch of the roofline kernel from the latest committed PMC pass (profiles/rNN/
+    pmc_conv_block2_fwd.json; FETCH_SIZE / WRITE_SIZE collected in separate rocprofv3 --pmc runs and
+    corrected as MI355X_MICROARCH.md prescribes), scaled linearly to this batch; None if absent."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_conv_block2_fwd.json")))
+    if not files:
+        return None
+    d = json.load(open(files[-1]))
+    return d["hbm_bytes_per_launch_b64"] * batch / d["batch_measured"]
+
+
 def conv_flops(block: int, batch: int) -> float:
     return 2.0 * 64 * BLOCK_CIN[block] * 65 * BLOCK_H[block] * W_FRAMES * batch
 
@@ -62,11 +74,14 @@ def build_job(device, rank, batch, overlap=True):
     return module, opt, batcher
 
 
-def cpu_baseline(batch_cpu: int = 8, steps: int = 2):
-    """The CPU oracle's version of the same step, on all host cores, bounded sample."""
+def cpu_baseline(batch_cpu: int = 8, steps: int = 5):
+    """The CPU oracle's version of the same step on the host cores, bounded sample (~10 s).
+    Thread count: torch's CPU conv stops scaling at ~32 threads for this batch (measured on the 256-core
+    GPU host: 16 thr 14.5, 32 thr 16.2, 64 thr 9.4, 256 thr 0.5 audio-s/s), so min(32, cores) is used
+    and reported as `cores`."""
     import numpy as np
     from oracle import lightning as ol, models as om
-    cores = os.cpu_count() or 1
+    cores = min(32, os.cpu_count() or 1)
     torch.set_num_threads(cores)
     torch.manual_seed(43)
     np.random.seed(43)
@@ -88,7 +103,8 @@ def cpu_baseline(batch_cpu: int = 8, steps: int = 2):
     t = sum(times[1:]) / steps
     return {"value": batch_cpu * N_SAMPLES / SR / t, "unit": "audio-seconds/s", "cores": cores, "kind": "port",
             "sample": f"{steps} train steps (after 1 warm-up) of the CPU oracle on {batch_cpu} clips x 2 s, same "
-                      f"interwoven recipe; torch fp32 CNN on {cores} threads, C effects single-threaded"}
+                      f"interwoven recipe; torch fp32 CNN on {cores} threads (host has {os.cpu_count()} cores; more threads are slower), C effects "
+                      f"single-threaded"}
 
 
 def main():
@@ -167,7 +183,8 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "conv_kernel<1,1,0> (block-2 forward: LayerNorm+conv5x13+bias+maxpool)",
                          "achieved": dom["tflops"], "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": None if dom["tflops"] is None else round(dom["tflops"] / FP32_MFMA_PEAK_TFLOPS, 4),
-                         "avg_launch_ms": dom["avg_ms"], "flops_per_launch": conv_flops(1, args.batch), "traffic": None},
+                         "avg_launch_ms": dom["avg_ms"], "flops_per_launch": conv_flops(1, args.batch),
+                         "traffic": measured_traffic(args.batch), "traffic_unit": "bytes/launch (rocprofv3 PMC pass)"},
             "kernels": kernels,
             "conv_ms_per_step": round(mfma_ms, 2),
             "final_loss": None if loss is None else float(loss),

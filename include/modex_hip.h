@@ -72,11 +72,13 @@ int mx_flanger_fwd(const float *x, int64_t x_stride, const float *mod, int64_t n
  * feedback, mix (B,) fp32; lead (B,) int32 = samples rendered before the output window (the
  * reference renders n + sr/rate samples and crops at a random offset, datasets.py:428-449), NULL = 0;
  * rows/n_rows: optional subset of clips.  y: row b at y + b*y_stride = processed[lead:lead+N];
- * dry_out (optional, same stride): the matching crop of x. */
+ * dry_out (optional, same stride): the matching crop of x.  exact_order != 0 keeps JUCE's operation order
+ * inside each all-pass stage; 0 uses the algebraically identical FMA form (4-5x shorter dependency chain,
+ * results within 1e-6). */
 int mx_phaser_fwd(const float *x, int64_t x_stride, const float *rate, const float *depth,
                   const float *centre, const float *feedback, const float *mix, const int32_t *lead,
-                  const int32_t *rows, int64_t n_rows, int64_t B, int64_t N, double sr, float *y,
-                  int64_t y_stride, float *dry_out, void *stream);
+                  const int32_t *rows, int64_t n_rows, int64_t B, int64_t N, double sr, int32_t exact_order,
+                  float *y, int64_t y_stride, float *dry_out, void *stream);
 
 /* ---- K4: log-mel front end -- mod_extraction/models.py:170-181,199-208
  * (torchaudio MelSpectrogram: n_fft 1024, hann, centre/reflect, power 2, mel filter bank `fb`)

@@ -25,7 +25,7 @@ SIGNATURES = {
     "mx_interp_linear": [_P, _I64, _I64, _I64, _P, _P],
     "mx_flanger_fwd": [_P, _I64, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _I32, _P, _I64, _I64, _I64,
                        _P, _I64, _P, _P, _P, _P],
-    "mx_phaser_fwd": [_P, _I64, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _F64, _P, _I64, _P, _P],
+    "mx_phaser_fwd": [_P, _I64, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _F64, _I32, _P, _I64, _P, _P],
     "mx_logmel_fwd": [_P, _I64, _I64, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _F32, _I32, _I32,
                       _I32, _I32, _P, _P],
     "mx_conv_pack_weights": [_P, _I64, _I64, _I32, _P, _P],

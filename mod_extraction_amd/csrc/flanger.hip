@@ -32,11 +32,11 @@ __global__ __launch_bounds__(64) void flanger_kernel(
     const float *__restrict__ lfo_scale, const float *__restrict__ min_delay,
     const float *__restrict__ feedback, const float *__restrict__ depth,
     const float *__restrict__ mix, const float *__restrict__ one_minus_mix,
-    const int *__restrict__ max_delay, const int *__restrict__ rows, int N,
+    const int *__restrict__ max_delay, const int *__restrict__ rows, int N, int lfo_off,
     float *__restrict__ y, long long y_stride, float *__restrict__ mod_up, long long *__restrict__ dbg_prev,
     float *__restrict__ dbg_frac)
 {
-    extern __shared__ float buf[];
+    extern __shared__ float buf[];           // [M delay line | n_mod LFO row (when resampled in-kernel)]
     const int lane = threadIdx.x;
     const int b = rows ? rows[blockIdx.x] : (int)blockIdx.x;
     const int M = max_delay[b];
@@ -50,6 +50,10 @@ __global__ __launch_bounds__(64) void flanger_kernel(
     for (int i = lane; i < M; i += 64) buf[i] = 0.0f;  // fx.py:92 (LDS ops of one wave are in order)
 
     const bool resample = (n_mod != N);
+    float *lfo = buf + lfo_off;                        // the short LFO row lives in LDS: no gather latency per chunk
+    if (resample)
+        for (int i = lane; i < n_mod; i += 64) lfo[i] = mb[i];
+    int w_chunk = 0;                                   // c0 % M, carried instead of a per-sample integer modulo
     float xr[FL_V], mr[FL_V];
     // software prefetch of the first chunk
 #pragma unroll
@@ -69,12 +73,13 @@ __global__ __launch_bounds__(64) void flanger_kernel(
             float m;
             if (resample) {
                 InterpTap t = interp_tap(mod_scale, valid ? n : 0, n_mod);
-                m = interp_combine(t, mb[t.i0], mb[t.i1]);
+                m = interp_combine(t, lfo[t.i0], lfo[t.i1]);
                 if (mod_up && valid) mod_up[(size_t)b * N + n] = m;
             } else {
                 m = mr[j];
             }
-            const int w = n % M;                               // fx.py:95
+            int w = w_chunk + j * 64 + lane;                   // fx.py:95: n % M without a division
+            while (w >= M) w -= M;
             const float d = __fadd_rn(__fmul_rn(ls, m), md);   // fx.py:99
             const float r1 = __fadd_rn(__fsub_rn((float)w, d), Mf);  // fx.py:100
             float r;
@@ -147,6 +152,8 @@ __global__ __launch_bounds__(64) void flanger_kernel(
             xr[j] = xn[j];
             mr[j] = mn[j];
         }
+        w_chunk += FL_CHUNK;
+        while (w_chunk >= M) w_chunk -= M;
     }
 }
 
@@ -178,10 +185,14 @@ MX_EXPORT int mx_flanger_fwd(const float *x, int64_t x_stride, const float *mod,
                             FL_MAX_M * sizeof(float));
         attr_set = true;
     }
-    const size_t lds = (size_t)max_delay_max * sizeof(float);
+    // LDS: delay line (max over the batch) + the LFO row when it is resampled in-kernel (n_mod < N)
+    const int lfo_off = max_delay_max;
+    const size_t lds_floats = (size_t)max_delay_max + (n_mod != N ? (size_t)n_mod : 0);
+    if (lds_floats > FL_MAX_M) return MX_ERR_UNSUPPORTED;
+    const size_t lds = lds_floats * sizeof(float);
     hipLaunchKernelGGL(flanger_kernel, dim3((unsigned)items), dim3(64), lds, (hipStream_t)stream, x, (long long)x_stride, mod,
                        (int)n_mod, interp_scale_host(n_mod, N), lfo_scale, min_delay, feedback, depth,
-                       mix, one_minus_mix, max_delay, rows, (int)N, y, (long long)y_stride, mod_up, (long long *)dbg_prev,
+                       mix, one_minus_mix, max_delay, rows, (int)N, lfo_off, y, (long long)y_stride, mod_up, (long long *)dbg_prev,
                        dbg_frac);
     return mx_launch_status();
 }

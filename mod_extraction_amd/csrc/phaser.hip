@@ -18,6 +18,7 @@
 
 #define PH_BLOCK 256
 
+template <bool FAST>
 __global__ __launch_bounds__(64) void phaser_kernel(const float *__restrict__ x, long long x_stride,
                                                     const float *__restrict__ rate,
                                                     const float *__restrict__ depth,
@@ -80,6 +81,10 @@ __global__ __launch_bounds__(64) void phaser_kernel(const float *__restrict__ x,
         // (4) the dependent chain, wave-uniform; inputs and coefficients are broadcast from lane
         //     registers (v_readlane) so that no LDS round trip sits between two samples
         const int cnt = min(PH_BLOCK, total - n0);
+        // FAST: the same all-pass stage written as out = (2G-1) x + (2-2G) s, s' = 2G x + (1-2G) s: one FMA
+        // per stage on the sample-to-sample critical path instead of five dependent operations (4-5x
+        // shorter chain).  Algebraically identical to the JUCE order, rounding differs (<= 1e-6 on audio).
+        const float c1r = 2.0f * Greg - 1.0f, c2r = 2.0f - 2.0f * Greg, c3r = 2.0f * Greg, c4r = 1.0f - 2.0f * Greg;
 #pragma unroll
         for (int j = 0; j < PH_BLOCK / 64; ++j) {
             const int lim = min(64, cnt - j * 64);
@@ -87,6 +92,26 @@ __global__ __launch_bounds__(64) void phaser_kernel(const float *__restrict__ x,
                 const float G = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Greg), (j * 64 + li) >> 2));
                 const float in = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xr[j]), li));
                 float out = __fsub_rn(in, last);
+                if (FAST) {
+                    const int src = (j * 64 + li) >> 2;
+                    const float c1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c1r), src));
+                    const float c2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c2r), src));
+                    const float c3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c3r), src));
+                    const float c4 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c4r), src));
+#define PH_FSTAGE(S)                              \
+    {                                             \
+        const float xin = out;                    \
+        out = fmaf(c1, xin, c2 * S);              \
+        S = fmaf(c3, xin, c4 * S);                \
+    }
+                    PH_FSTAGE(s0) PH_FSTAGE(s1) PH_FSTAGE(s2) PH_FSTAGE(s3) PH_FSTAGE(s4) PH_FSTAGE(s5)
+#undef PH_FSTAGE
+                    last = __fmul_rn(out, fb);
+                    float m = __fadd_rn(__fmul_rn(out, wet_g), __fmul_rn(in, dry_g));
+                    m = m < -1.0f ? -1.0f : (m > 1.0f ? 1.0f : m);
+                    yr[j] = lane == li ? m : yr[j];
+                    continue;
+                }
                 float v, yk;
 #define PH_STAGE(S)                                   \
     v = __fmul_rn(G, __fsub_rn(out, S));             \
@@ -117,17 +142,24 @@ __global__ __launch_bounds__(64) void phaser_kernel(const float *__restrict__ x,
 // feedback, mix: (B,) fp32; lead: (B,) int32 warm-up samples (NULL = 0); rows/n_rows: optional
 // subset of clip indices.  y: row b at y + b*y_stride, N samples = processed[lead : lead+N];
 // dry_out (optional, same stride as y): the matching crop of the source.
+// exact_order != 0: evaluate every all-pass stage in JUCE's operation order (v = G (x - s); y = v + s;
+// s = v + y; out = 2 y - x); 0: the algebraically identical FMA form with a 4-5x shorter dependency chain.
 MX_EXPORT int mx_phaser_fwd(const float *x, int64_t x_stride, const float *rate, const float *depth,
                             const float *centre, const float *feedback, const float *mix, const int32_t *lead,
-                            const int32_t *rows, int64_t n_rows, int64_t B, int64_t N, double sr, float *y,
-                            int64_t y_stride, float *dry_out, void *stream)
+                            const int32_t *rows, int64_t n_rows, int64_t B, int64_t N, double sr, int32_t exact_order,
+                            float *y, int64_t y_stride, float *dry_out, void *stream)
 {
     if (!x || !rate || !depth || !centre || !feedback || !mix || !y || B <= 0 || N <= 0 || sr <= 0.0) return MX_ERR_ARG;
     if (N >= (1ll << 30)) return MX_ERR_UNSUPPORTED;
     const int64_t items = rows ? n_rows : B;
     if (items <= 0) return MX_OK;
-    hipLaunchKernelGGL(phaser_kernel, dim3((unsigned)items), dim3(64), 0, (hipStream_t)stream, x, (long long)x_stride,
-                       rate, depth, centre, feedback, mix, lead, rows, (int)N, (float)sr, sr, y, (long long)y_stride,
-                       dry_out);
+    if (exact_order)
+        hipLaunchKernelGGL((phaser_kernel<false>), dim3((unsigned)items), dim3(64), 0, (hipStream_t)stream, x,
+                           (long long)x_stride, rate, depth, centre, feedback, mix, lead, rows, (int)N, (float)sr, sr, y,
+                           (long long)y_stride, dry_out);
+    else
+        hipLaunchKernelGGL((phaser_kernel<true>), dim3((unsigned)items), dim3(64), 0, (hipStream_t)stream, x,
+                           (long long)x_stride, rate, depth, centre, feedback, mix, lead, rows, (int)N, (float)sr, sr, y,
+                           (long long)y_stride, dry_out);
     return mx_launch_status();
 }

@@ -17,6 +17,19 @@
 
 #define WG_CHUNK 32
 #define WG_LP 65          // LDS pitch (floats) of the [position][channel] tiles
+// -DWG_DIAG builds a diagnostic variant (tools/diag_wgrad.py) that stamps s_memtime around the phases of
+// wave 0 of every workgroup; the shipped library never defines it.
+#ifdef WG_DIAG
+#define WG_STAMP(slot)                                                                           \
+    do {                                                                                         \
+        unsigned long long t_;                                                                   \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");               \
+        if (tid == 0) { diag_acc[slot] += t_ - diag_last; }                                      \
+        diag_last = t_;                                                                          \
+    } while (0)
+#else
+#define WG_STAMP(slot)
+#endif
 
 struct WgradArgs {
     const float *G;             // (B, 64, H/2, PITCH) gradient w.r.t. pooled pre-activations
@@ -26,6 +39,9 @@ struct WgradArgs {
     const float *slope;         // (Cin,) or nullptr (first block)
     float *part;                // (n_slabs, 5, 13, 64, Cin_pad) partial sums
     int B, H, Wv, rows_per_slab;
+#ifdef WG_DIAG
+    unsigned long long *diag;   // (n_workgroups, 4) cycles: barrier-wait, store, issue+barrier, mfma
+#endif
 };
 
 // ---- blocks 2..6: Cin = 64 ---------------------------------------------------------------------
@@ -141,8 +157,14 @@ __global__ __launch_bounds__(256, 2) void wgrad64_kernel(WgradArgs a)
     const float *ab = dzl + half * WG_LP + mt * 32 + l32;
     const float *bb = xl + (HALO + half + (kw0 - 6) * T) * WG_LP + cb * 32 + l32;
     int b_cached = -1;
+#ifdef WG_DIAG
+    unsigned long long diag_acc[4] = {0, 0, 0, 0}, diag_last = 0;
+    WG_STAMP(3);
+    diag_acc[3] = 0;
+#endif
     while (rid < row_end) {
         __syncthreads();                                // everyone is done reading the previous tiles
+        WG_STAMP(0);
         if (rid / a.H != b_cached) {                    // new clip: its LayerNorm statistics / slopes -> LDS
             b_cached = rid / a.H;
             if (tid < 64) {
@@ -187,10 +209,12 @@ __global__ __launch_bounds__(256, 2) void wgrad64_kernel(WgradArgs a)
                 d[0] = v[0]; d[WG_LP] = v[1]; d[2 * WG_LP] = v[2]; d[3 * WG_LP] = v[3];
             }
         }
+        WG_STAMP(1);
         int nrid = rid, nch = ch;
         next_iter(nrid, nch);
         if (PREF && nrid < row_end) issue(nrid, nch);   // in flight during the MFMAs below
         __syncthreads();
+        WG_STAMP(2);
         float a0, a1, b0[7], b1[7];
 #define WG_LOAD(A, B, KS)                                                                    \
     A = ab[2 * (KS) * WG_LP];                                                                \
@@ -210,9 +234,16 @@ __global__ __launch_bounds__(256, 2) void wgrad64_kernel(WgradArgs a)
         }
 #undef WG_LOAD
 #undef WG_MMA
+        WG_STAMP(3);
         rid = nrid;
         ch = nch;
     }
+#ifdef WG_DIAG
+    if (tid == 0 && a.diag) {
+        unsigned long long *o = a.diag + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4;
+        o[0] = diag_acc[0]; o[1] = diag_acc[1]; o[2] = diag_acc[2]; o[3] = diag_acc[3];
+    }
+#endif
     // partial tiles: part[slab][kh][kw][co][ci]
 #pragma unroll
     for (int i = 0; i < 7; ++i) {
@@ -347,6 +378,10 @@ static int launch_wgrad(const WgradArgs &a, int Cin, int n_slabs, hipStream_t st
     return mx_launch_status();
 }
 
+#ifdef WG_DIAG
+static unsigned long long *g_wgrad_diag = nullptr;
+MX_EXPORT void mx_diag_set_buffer(unsigned long long *p) { g_wgrad_diag = p; }
+#endif
 // G, amax: (B,64,H/2,352); x: (B,Cin,H,352) block input (pre PReLU / LayerNorm); stats (B,Cin,2);
 // slope (Cin,) or NULL for the first block; part: workspace of n_slabs*65*64*Cin floats with
 // n_slabs = ceil(B*H / rows_per_slab); dW: (64, Cin, 5, 13) torch layout (overwritten).
@@ -359,7 +394,11 @@ MX_EXPORT int mx_conv_block_wgrad(const float *G, const uint8_t *amax, const flo
         return MX_ERR_UNSUPPORTED;
     const int64_t n_slabs = (B * H + rows_per_slab - 1) / rows_per_slab;
     if (n_slabs > 65535) return MX_ERR_UNSUPPORTED;
+#ifdef WG_DIAG
+    WgradArgs a{G, amax, x, stats, slope, part, (int)B, (int)H, (int)Wv, (int)rows_per_slab, g_wgrad_diag};
+#else
     WgradArgs a{G, amax, x, stats, slope, part, (int)B, (int)H, (int)Wv, (int)rows_per_slab};
+#endif
     hipStream_t st = (hipStream_t)stream;
     int rc;
     switch (dilation) {

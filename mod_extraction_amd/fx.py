@@ -132,11 +132,13 @@ class MonoFlangerChorusModule(nn.Module):
 
 
 def phaser_forward(src: T, params: Dict[str, T], lead: Optional[T], sr: float, n_samples: int,
-                   rows: Optional[T] = None, out: Optional[T] = None, dry_out: Optional[T] = None) -> T:
+                   rows: Optional[T] = None, out: Optional[T] = None, dry_out: Optional[T] = None,
+                   exact_order: bool = False) -> T:
     """Launch mx_phaser_fwd (pedalboard.Phaser semantics, datasets.py:455-482).
     src (B, >= lead+n_samples) source audio rows; params: rate_hz, depth, centre_frequency_hz,
     feedback, mix -- each (B,) fp32 on the device; lead (B,) int32 warm-up samples or None;
-    out / dry_out: (B, n_samples) views with contiguous rows."""
+    out / dry_out: (B, n_samples) views with contiguous rows.  exact_order=True keeps JUCE's operation
+    order inside each all-pass stage (slower: the sample-to-sample dependency chain is 4-5x longer)."""
     B = src.size(0)
     y = out if out is not None else torch.empty((B, n_samples), device=src.device, dtype=torch.float32)
     sp, ss = _rows_view(src)
@@ -148,5 +150,5 @@ def phaser_forward(src: T, params: Dict[str, T], lead: Optional[T], sr: float, n
     _hip.call("mx_phaser_fwd", sp, ss, _hip.ptr(params["rate_hz"]), _hip.ptr(params["depth"]),
               _hip.ptr(params["centre_frequency_hz"]), _hip.ptr(params["feedback"]), _hip.ptr(params["mix"]),
               _hip.ptr(lead), _hip.ptr(rows), 0 if rows is None else rows.numel(), B, n_samples, float(sr),
-              yp, ys, dp, _hip.stream())
+              1 if exact_order else 0, yp, ys, dp, _hip.stream())
     return y

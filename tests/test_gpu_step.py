@@ -24,15 +24,20 @@ def test_phaser_vs_oracle(dev):
          "centre_frequency_hz": torch.tensor([70.0, 18000.0, 440.0, 1300.0, 5000.0]),
          "feedback": torch.tensor([0.0, 0.7, 0.25, 0.5, 0.69]), "mix": torch.tensor([1.0, 0.2, 0.5, 0.8, 1.0])}
     y = torch.empty(B, N, device=dev)
+    y_exact = torch.empty(B, N, device=dev)
     dry = torch.empty(B, N, device=dev)
-    afx.phaser_forward(src.to(dev), {k: v.to(dev) for k, v in p.items()}, lead.to(dev), 44100.0, N, out=y, dry_out=dry)
+    pd = {k: v.to(dev) for k, v in p.items()}
+    afx.phaser_forward(src.to(dev), pd, lead.to(dev), 44100.0, N, out=y, dry_out=dry)                  # FMA form
+    afx.phaser_forward(src.to(dev), pd, lead.to(dev), 44100.0, N, out=y_exact, exact_order=True)       # JUCE order
+    assert float((y - y_exact).abs().max()) < 5e-6
     for b in range(B):
         L = int(lead[b])
         ref = ofx.phaser_np(src[b:b + 1, :L + N].numpy(), [float(p["rate_hz"][b])], [float(p["depth"][b])],
                             [float(p["centre_frequency_hz"][b])], [float(p["feedback"][b])], [float(p["mix"][b])], 44100.0)
         assert np.array_equal(dry[b].cpu().numpy(), src[b, L:L + N].numpy())
-        err = np.abs(y[b].cpu().numpy() - ref[0, L:]).max()
-        assert err < 1e-5, (b, err)
+        for name, out in (("fma", y), ("exact", y_exact)):
+            err = np.abs(out[b].cpu().numpy() - ref[0, L:]).max()
+            assert err < 1e-5, (name, b, err)
 
 
 @pytest.mark.parametrize("k", [0, 4, 8])
