@@ -162,6 +162,7 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(ConvArgs a)
     A = wp[0];                                                                            \
     _Pragma("unroll") for (int i = 0; i < CV_WT; ++i) B[i] = pp[i * 32];
 #define CV_MMA(A, B) _Pragma("unroll") for (int i = 0; i < CV_WT; ++i) acc[i] = mfma32(A, B[i], acc[i]);
+            __builtin_amdgcn_s_setprio(1);              // matrix phase outranks the partner workgroup's staging VALU
             CV_LOAD(a0, b0)
 #pragma unroll 1
             for (int tap = 0; tap < CV_TAPS - 1; tap += 2) {
@@ -177,6 +178,7 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(ConvArgs a)
                 __builtin_amdgcn_sched_barrier(0);
             }
             CV_MMA(a0, b0)           // tap 64 (65 taps: 32 pairs + 1)
+            __builtin_amdgcn_s_setprio(0);
 #undef CV_ADVANCE
 #undef CV_LOAD
 #undef CV_MMA

@@ -215,6 +215,7 @@ __global__ __launch_bounds__(256, 2) void wgrad64_kernel(WgradArgs a)
         if (PREF && nrid < row_end) issue(nrid, nch);   // in flight during the MFMAs below
         __syncthreads();
         WG_STAMP(2);
+        __builtin_amdgcn_s_setprio(1);                  // matrix phase outranks the partner workgroup's staging VALU
         float a0, a1, b0[7], b1[7];
 #define WG_LOAD(A, B, KS)                                                                    \
     A = ab[2 * (KS) * WG_LP];                                                                \
@@ -234,6 +235,7 @@ __global__ __launch_bounds__(256, 2) void wgrad64_kernel(WgradArgs a)
         }
 #undef WG_LOAD
 #undef WG_MMA
+        __builtin_amdgcn_s_setprio(0);
         WG_STAMP(3);
         rid = nrid;
         ch = nch;

@@ -132,3 +132,82 @@ def make_rand_mod_signal(batch_size: int, n_samples: int, sr: float, freq_min: f
     return make_mod_signals(n_samples, sr, torch.tensor(freqs, dtype=torch.float32, device=dev),
                             torch.tensor(phases, dtype=torch.float32, device=dev),
                             torch.tensor(shape_ids, dtype=torch.int32, device=dev))
+
+
+# ---- evaluation LFO variants (modulations.py:104-210) ------------------------------------------
+# Per-item data-generation helpers of the eval configs (eval_lfo_quasi / combined / distorted): host
+# control flow and host RNG draws in the reference's order; every array operation (LFO synthesis,
+# corner detection, resampling) runs in the device kernels above.
+def _time_stretch_section(section: T, l_min: float, l_max: float, r_min: float, r_max: float,
+                          lr_split: float = 0.5) -> T:
+    from . import util
+    size = section.size(0)
+    if util.sample_uniform(0.0, 1.0) < lr_split:
+        x = int((util.sample_uniform(l_min, l_max) * size) + 0.5)
+        new_size = max(2, size - x)
+    else:
+        x = int((util.sample_uniform(r_min, r_max) * size) + 0.5)
+        new_size = size + x
+    return util.linear_interpolate_last_dim(section.contiguous(), new_size, align_corners=True)
+
+
+def _corner_indices(corners: T) -> List[int]:
+    return [int(c) for c in (corners.view(-1) == 1).nonzero(as_tuple=True)[0].tolist()]
+
+
+def make_quasi_periodic(mod_sig: T, l_min: float = 0.2, l_max: float = 0.2, r_min: float = 0.2,
+                        r_max: float = 0.2, lr_split: float = 0.5) -> T:
+    """modulations.py:121-160: time-stretch every corner-to-corner section by a random amount."""
+    from . import util
+    assert mod_sig.ndim == 1
+    top, bot = find_corners(mod_sig.unsqueeze(0))
+    corners = top if float(top.sum()) > float(bot.sum()) else bot
+    idx = _corner_indices(corners)
+    if len(idx) < 2:
+        return mod_sig
+    sections, total, prev = [], 0, 0
+    for c in idx:
+        new_section = _time_stretch_section(mod_sig[prev:c + 1], l_min, l_max, r_min, r_max, lr_split)[:-1]
+        total += new_section.size(0)
+        sections.append(new_section)
+        prev = c
+    n = mod_sig.size(0)
+    tail = mod_sig[prev:n]
+    total += tail.size(0)
+    if total < n:
+        tail = util.linear_interpolate_last_dim(tail.contiguous(), tail.size(0) + (n - total), align_corners=True)
+    sections.append(tail)
+    return torch.cat(sections, dim=0)[:n]
+
+
+def make_combined_mod_sig(n_samples: int, sr: float, freq: float, phase: float, shapes: List[str],
+                          device=None) -> T:
+    """modulations.py:191-210: a new random shape between every pair of bottom corners."""
+    from . import util
+    mod_sig = make_mod_signal(n_samples, sr, freq, phase, shape=util.choice(shapes), device=device)
+    _, bot = find_corners(mod_sig.unsqueeze(0))
+    idx = _corner_indices(bot)
+    for a, b in zip(idx[:-1], idx[1:]):
+        n = b - a + 1
+        mod_sig[a:b + 1] = make_mod_signal(n, n, freq=1.0, phase=0.0, shape=util.choice(shapes), device=mod_sig.device)
+    return mod_sig
+
+
+def make_concave_convex_mod_sig(n_samples: int, sr: float, freq: float, phase: float = 0.0,
+                                concave_min: float = 0.2, concave_max: float = 1.0, convex_min: float = 1.0,
+                                convex_max: float = 3.0, concave_prob: float = 0.5, device=None) -> T:
+    """modulations.py:163-188: triangle LFO with a random exponent per monotone segment."""
+    from . import util
+    mod_sig = make_mod_signal(n_samples, sr, freq, phase, shape="tri", device=device)
+    top, bot = find_corners(mod_sig.unsqueeze(0))
+    idx = _corner_indices(top + bot) + [mod_sig.size(0)]
+    exp = torch.ones_like(mod_sig)
+    prev = 0
+    for c in idx:
+        if util.sample_uniform(0.0, 1.0) < concave_prob:
+            v = util.sample_uniform(concave_min, concave_max)
+        else:
+            v = util.sample_uniform(convex_min, convex_max)
+        exp[prev:c] = v
+        prev = c
+    return mod_sig ** exp

@@ -62,11 +62,13 @@ def reduce_metrics(logged: Dict[str, List[torch.Tensor]], world_size: int) -> Di
 class Trainer:
     def __init__(self, max_epochs: int = 1, limit_train_batches: Optional[int] = None,
                  limit_val_batches: Optional[int] = None, num_sanity_val_steps: int = 0,
-                 log_fn: Optional[Callable[[str], None]] = print, **ignored: Any) -> None:
+                 log_fn: Optional[Callable[[str], None]] = print, checkpoints: Optional["CheckpointKeeper"] = None,
+                 **ignored: Any) -> None:
         self.max_epochs = max_epochs
         self.limit_train_batches, self.limit_val_batches = limit_train_batches, limit_val_batches
         self.num_sanity_val_steps = num_sanity_val_steps
         self.log_fn = log_fn
+        self.checkpoints = checkpoints
         self.env = dist_env()
         self.history: List[Dict[str, float]] = []
 
@@ -118,5 +120,57 @@ class Trainer:
             metrics["epoch"] = epoch
             metrics["epoch_time_s"] = time.time() - t0
             self.history.append(metrics)
+            if self.checkpoints is not None:
+                step = getattr(optimizer, "step_count", 0)
+                self.checkpoints.update(module, optimizer, epoch, step, metrics, rank=self.env["rank"])
             self._say(" ".join(f"{k}={v:.5g}" for k, v in metrics.items()))
         return self.history
+
+
+# ---- checkpoints (reference: cli.py:29-37,145-150 ModelCheckpoint(monitor="val/loss", save_top_k=1,
+# save_last=True), filename "{model_name}__{dataset_name}__epoch_{e}_step_{s}"; lightning.py:237-241 and
+# scripts/extract_model_weights.py:38-47 for the consumers of the format) --------------------------------
+def save_checkpoint(path: str, module, optimizer: Optional[FlatAdamW], epoch: int, global_step: int,
+                    extra: Optional[Dict[str, Any]] = None) -> None:
+    """Lightning-compatible layout: ``state_dict`` keyed like the LightningModule (``model.`` /
+    ``effect_model.`` / ``lfo_model.`` prefixes come from the attribute names), ``epoch``,
+    ``global_step``; the flat AdamW state goes under ``optimizer_states``."""
+    blob = {"state_dict": {k: v.detach().cpu() for k, v in module.state_dict().items()}, "epoch": epoch,
+            "global_step": global_step, "pytorch-lightning_version": "mod_extraction_amd"}
+    if optimizer is not None:
+        blob["optimizer_states"] = [{k: (v.cpu() if isinstance(v, torch.Tensor) else v)
+                                     for k, v in optimizer.state_dict().items()}]
+    if extra:
+        blob.update(extra)
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    torch.save(blob, path)
+
+
+def extract_model_weights(ckpt_path: str, out_path: str, prefix: str = "model.") -> Dict[str, torch.Tensor]:
+    """scripts/extract_model_weights.py:38-47: bare state dict of one sub-module (prefix stripped)."""
+    sd = torch.load(ckpt_path, map_location="cpu")["state_dict"]
+    bare = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
+    torch.save(bare, out_path)
+    return bare
+
+
+class CheckpointKeeper:
+    """save_top_k=1 on ``val/loss`` (mode min) + save_last, with the reference's file-name rule."""
+
+    def __init__(self, dirpath: str, model_name: str = "local_model", dataset_name: str = "local_dataset") -> None:
+        self.dirpath, self.model_name, self.dataset_name = dirpath, model_name, dataset_name
+        self.best, self.best_path = float("inf"), None
+
+    def name(self, epoch: int, step: int) -> str:
+        return f"{self.model_name}__{self.dataset_name}__epoch_{epoch}_step_{step}.ckpt"
+
+    def update(self, module, optimizer, epoch: int, step: int, metrics: Dict[str, float], rank: int = 0) -> None:
+        if rank != 0:
+            return
+        save_checkpoint(os.path.join(self.dirpath, "last.ckpt"), module, optimizer, epoch, step)
+        v = metrics.get("val/loss")
+        if v is not None and v < self.best:
+            if self.best_path and os.path.exists(self.best_path):
+                os.remove(self.best_path)
+            self.best, self.best_path = v, os.path.join(self.dirpath, self.name(epoch, step))
+            save_checkpoint(self.best_path, module, optimizer, epoch, step)

@@ -119,3 +119,21 @@ def test_batch_synthesis_and_train_step(dev):
     for k in loss_dict:
         assert abs(float(module.logged[f"train/{k}"][-1]) - float(terms_r[k])) < 2e-6
     assert opt.step_count == 1
+
+
+def test_eval_lfo_variants_vs_oracle(dev):
+    """(f) rank 2: quasi-periodic / combined / concave-convex LFOs -- same host RNG stream as the oracle
+    (which is pinned bit-exactly to the reference), device kernels for synthesis / corners / resampling."""
+    from mod_extraction_amd import modulations as amod
+    for seed in range(4):
+        base_o = omod.make_mod_signal(882, 441.0, 2.3, 0.4, "cos")
+        base_g = amod.make_mod_signal(882, 441.0, 2.3, 0.4, "cos", device=dev)
+        torch.manual_seed(seed); q_o = omod.make_quasi_periodic(base_o.clone(), 0.1, 0.3, 0.1, 0.3)
+        torch.manual_seed(seed); q_g = amod.make_quasi_periodic(base_g.clone(), 0.1, 0.3, 0.1, 0.3)
+        assert q_g.shape == q_o.shape and float((q_g.cpu() - q_o).abs().max()) < 1e-5
+        torch.manual_seed(seed); c_o = omod.make_combined_mod_sig(882, 441.0, 2.3, 0.4, ["cos", "tri", "saw"])
+        torch.manual_seed(seed); c_g = amod.make_combined_mod_sig(882, 441.0, 2.3, 0.4, ["cos", "tri", "saw"], device=dev)
+        assert c_g.shape == c_o.shape and float((c_g.cpu() - c_o).abs().max()) < 1e-5
+    torch.manual_seed(7)
+    cc = amod.make_concave_convex_mod_sig(882, 441.0, 1.7, 0.2, device=dev)
+    assert cc.shape == (882,) and float(cc.min()) >= 0.0 and float(cc.max()) <= 1.0
