@@ -140,16 +140,19 @@ def main():
     module.logged.clear()
 
     def key(name, a):
-        # (Cin, H) of the launch: positions of B, Cin, H in each entry point's argument list
+        # (Cin, H) of the launch: positions of Cin / H in each entry point's argument list
         if name == "mx_conv_block_fwd":
             return f"{a[6]}x{a[7]}"
         if name == "mx_conv_block_dgrad":
             return f"64x{a[4]}"
+        if name in ("mx_conv_block_fwd_f16", "mx_conv_block_dgrad_f16"):
+            return f"64x{a[6]}"
         return f"{a[6]}x{a[7]}"
 
     fence()
     t0 = time.perf_counter()
-    with _hip.KernelTimer({"mx_conv_block_fwd", "mx_conv_block_dgrad", "mx_conv_block_wgrad"}, key) as kt:
+    with _hip.KernelTimer({"mx_conv_block_fwd", "mx_conv_block_dgrad", "mx_conv_block_wgrad",
+                           "mx_conv_block_fwd_f16", "mx_conv_block_dgrad_f16"}, key) as kt:
         for _ in range(args.steps):
             loss = step()
     fence()
@@ -170,7 +173,8 @@ def main():
             avg = sum(ms) / len(ms)
             kernels[f"{name[3:]}[block{blk + 1}]"] = {"avg_ms": round(avg, 3),
                                                      "tflops": round(conv_flops(blk, args.batch) / (avg * 1e-3) / 1e12, 2)}
-        dom = kernels.get("conv_block_fwd[block2]", {"avg_ms": None, "tflops": None})
+        f16 = "conv_block_fwd_f16[block2]" in kernels
+        dom = kernels.get("conv_block_fwd_f16[block2]" if f16 else "conv_block_fwd[block2]", {"avg_ms": None, "tflops": None})
         mfma_ms = sum(sum(ms) for ms in timings.values()) / args.steps
         out = {
             "metric": "44.1 kHz audio-seconds/sec (train step), interwoven ph/fl/ch",

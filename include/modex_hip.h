@@ -115,6 +115,26 @@ int mx_conv_block_fwd(const float *in, const float *stats, const float *slope, c
 int mx_conv_block_dgrad(const float *G, const uint8_t *amax, const float *wt_flipped, int64_t B, int64_t H,
                         int64_t Wv, int32_t dilation, float *dxhat, void *stream);
 
+/* ---- K6 on the fp16 matrix cores with fp32-equivalent accuracy ("f16x3": every fp32 operand is split into
+ * an fp16 pair hi + lo, products are hi*hi + hi*lo + lo*hi accumulated in fp32; 3 MFMAs at 16x the fp32 MFMA
+ * rate).  Same reference semantics as mx_conv_block_fwd / mx_conv_block_dgrad (models.py:183-195) for the
+ * 64->64 channel blocks.  Operands are prepared once per layer as channels-last fp16 pairs:
+ *   w_hi, w_lo : 4*5*13*64*16 halfs each ([ci/16][kh][kw][co][16], weights * 256; flip = 1 for the data gradient)
+ *   x_hi, x_lo : (B, H, 352, 64) halfs: forward = split of (prelu(x) - mean) * rstd;
+ *                dgrad = split of the max-pool routed gradient * S_dz, S_dz = 2^k chosen from max|G|
+ *                (scale (2,) device floats receives {S_dz, 1/S_dz}; amax_ws = one uint32 workspace). */
+int mx_conv_pack_weights_f16(const float *W, int32_t flip, void *w_hi, void *w_lo, void *stream);
+int mx_conv_prep_fwd_f16(const float *x, const float *stats, const float *slope, int64_t B, int64_t H,
+                         int64_t Wv, void *x_hi, void *x_lo, void *stream);
+int mx_conv_prep_dgrad_f16(const float *G, const uint8_t *amax, int64_t B, int64_t H, int64_t Wv,
+                           uint32_t *amax_ws, float *scale, void *dz_hi, void *dz_lo, void *stream);
+int mx_conv_block_fwd_f16(const void *x_hi, const void *x_lo, const void *w_hi, const void *w_lo,
+                          const float *bias, int64_t B, int64_t H, int64_t Wv, int32_t dilation, float *out,
+                          uint8_t *out_amax, void *stream);
+int mx_conv_block_dgrad_f16(const void *dz_hi, const void *dz_lo, const void *w_hi, const void *w_lo,
+                            const float *scale, int64_t B, int64_t H, int64_t Wv, int32_t dilation,
+                            float *dxhat, void *stream);
+
 /* weight gradient: x (B,Cin,H,352) = block input before PReLU/LayerNorm (Cin = 64, or 2 for the
  * first block with slope = NULL); part = workspace of ceil(B*H/rows_per_slab)*65*64*Cin floats;
  * dW (64,Cin,5,13) torch layout, overwritten. */

@@ -17,6 +17,12 @@ from torch import Tensor as T, nn
 
 from . import _hip
 
+import os as _os
+
+# Arithmetic of the 64->64 channel convolutions (forward + data gradient):
+#   "f16x3"  fp16 matrix cores on split operands (hi + lo pairs, 3 MFMAs per product group) -- fp32-equivalent
+#            accuracy (csrc/conv_f16.hip), 5.3x the fp32 MFMA rate;   "f32"  exact fp32 MFMA (csrc/conv2d.hip).
+CONV_PRECISION = _os.environ.get("MODEX_CONV_PRECISION", "f16x3")
 DEBUG_TAP = None       # set to a dict to capture backward intermediates (tools/debug_cnn_bwd.py)
 PITCH = 352            # activation row pitch (floats); 345 frames + pad (csrc/conv_common.h)
 LN_EPS = 1e-5          # torch.nn.LayerNorm default
@@ -110,6 +116,18 @@ def _pack(w: T, flip: int) -> T:
     return out
 
 
+def _pack_f16(w: T, flip: int) -> Tuple[T, T]:
+    n = 4 * 5 * 13 * 64 * 16
+    hi = torch.empty(n, device=w.device, dtype=torch.float16)
+    lo = torch.empty(n, device=w.device, dtype=torch.float16)
+    _hip.call("mx_conv_pack_weights_f16", _hip.ptr(w.contiguous()), flip, _hip.ptr(hi), _hip.ptr(lo), _hip.stream())
+    return hi, lo
+
+
+def _use_f16(cin: int, precision: str) -> bool:
+    return precision == "f16x3" and cin == 64
+
+
 def _reduce_rows(part: T, rows: int, cols: int) -> T:
     out = torch.empty(cols, device=part.device, dtype=torch.float32)
     _hip.call("mx_reduce_rows", _hip.ptr(part), rows, cols, 0, _hip.ptr(out), _hip.stream())
@@ -121,7 +139,7 @@ class _CNNStack(torch.autograd.Function):
     params: [w1,b1,a1, ..., w6,b6,a6, wout, bout]."""
 
     @staticmethod
-    def forward(ctx, logmel: T, n_frames: int, dilations: Tuple[int, ...], *params: T):
+    def forward(ctx, logmel: T, n_frames: int, dilations: Tuple[int, ...], precision: str, *params: T):
         n_blocks = len(dilations)
         B, cin, H, _ = logmel.shape
         dev = logmel.device
@@ -133,12 +151,22 @@ class _CNNStack(torch.autograd.Function):
             stats = torch.empty((B, cin, 2), device=dev, dtype=torch.float32)
             _hip.call("mx_plane_stats", _hip.ptr(cur), _hip.ptr(slope), B, cin, H, n_frames, LN_EPS,
                       _hip.ptr(stats), st)
-            wt = _pack(w, 0)
             p = torch.empty((B, 64, H // 2, PITCH), device=dev, dtype=torch.float32)
             amax = torch.empty((B, 64, H // 2, PITCH), device=dev, dtype=torch.uint8)
-            _hip.call("mx_conv_block_fwd", _hip.ptr(cur), _hip.ptr(stats), _hip.ptr(slope), _hip.ptr(wt),
-                      _hip.ptr(b.contiguous()), B, cin, H, n_frames, int(dilations[l]), 1 if l == 0 else 0,
-                      _hip.ptr(p), _hip.ptr(amax), st)
+            if _use_f16(cin, precision):
+                x_hi = torch.empty((B, H, PITCH, 64), device=dev, dtype=torch.float16)
+                x_lo = torch.empty((B, H, PITCH, 64), device=dev, dtype=torch.float16)
+                _hip.call("mx_conv_prep_fwd_f16", _hip.ptr(cur), _hip.ptr(stats), _hip.ptr(slope), B, H, n_frames,
+                          _hip.ptr(x_hi), _hip.ptr(x_lo), st)
+                w_hi, w_lo = _pack_f16(w, 0)
+                _hip.call("mx_conv_block_fwd_f16", _hip.ptr(x_hi), _hip.ptr(x_lo), _hip.ptr(w_hi), _hip.ptr(w_lo),
+                          _hip.ptr(b.contiguous()), B, H, n_frames, int(dilations[l]), _hip.ptr(p), _hip.ptr(amax), st)
+                del x_hi, x_lo
+            else:
+                wt = _pack(w, 0)
+                _hip.call("mx_conv_block_fwd", _hip.ptr(cur), _hip.ptr(stats), _hip.ptr(slope), _hip.ptr(wt),
+                          _hip.ptr(b.contiguous()), B, cin, H, n_frames, int(dilations[l]), 1 if l == 0 else 0,
+                          _hip.ptr(p), _hip.ptr(amax), st)
             saved += [cur, stats, amax]
             cur, slope, cin, H = p, a.contiguous(), 64, H // 2
         wout, bout = params[3 * n_blocks], params[3 * n_blocks + 1]
@@ -148,12 +176,12 @@ class _CNNStack(torch.autograd.Function):
         _hip.call("mx_head_fwd", _hip.ptr(cur), _hip.ptr(slope), _hip.ptr(wout.contiguous()),
                   _hip.ptr(bout.contiguous()), B, 64, H, n_frames, L, _hip.ptr(latent), _hip.ptr(out), st)
         ctx.save_for_backward(*saved, cur, latent, out, *params)
-        ctx.meta = (n_frames, tuple(dilations), n_blocks)
+        ctx.meta = (n_frames, tuple(dilations), n_blocks, precision)
         return out, latent
 
     @staticmethod
     def backward(ctx, d_out: Optional[T], d_latent: Optional[T]):
-        n_frames, dilations, n_blocks = ctx.meta
+        n_frames, dilations, n_blocks, precision = ctx.meta
         tensors = ctx.saved_tensors
         saved, p_last, latent, out = tensors[:3 * n_blocks], tensors[3 * n_blocks], tensors[3 * n_blocks + 1], \
             tensors[3 * n_blocks + 2]
@@ -204,10 +232,22 @@ class _CNNStack(torch.autograd.Function):
             grads[3 * l] = dW
             del part
             if l > 0:
-                wt_f = _pack(w, 1)
                 dxhat = torch.empty((B, 64, H, PITCH), device=dev, dtype=torch.float32)
-                _hip.call("mx_conv_block_dgrad", _hip.ptr(G), _hip.ptr(amax), _hip.ptr(wt_f), B, H, n_frames,
-                          int(dilations[l]), _hip.ptr(dxhat), st)
+                if _use_f16(64, precision):
+                    dz_hi = torch.empty((B, H, PITCH, 64), device=dev, dtype=torch.float16)
+                    dz_lo = torch.empty((B, H, PITCH, 64), device=dev, dtype=torch.float16)
+                    ws = torch.empty(1, device=dev, dtype=torch.int32)
+                    scale = torch.empty(2, device=dev, dtype=torch.float32)
+                    _hip.call("mx_conv_prep_dgrad_f16", _hip.ptr(G), _hip.ptr(amax), B, H, n_frames, _hip.ptr(ws),
+                              _hip.ptr(scale), _hip.ptr(dz_hi), _hip.ptr(dz_lo), st)
+                    w_hi, w_lo = _pack_f16(w, 1)
+                    _hip.call("mx_conv_block_dgrad_f16", _hip.ptr(dz_hi), _hip.ptr(dz_lo), _hip.ptr(w_hi), _hip.ptr(w_lo),
+                              _hip.ptr(scale), B, H, n_frames, int(dilations[l]), _hip.ptr(dxhat), st)
+                    del dz_hi, dz_lo
+                else:
+                    wt_f = _pack(w, 1)
+                    _hip.call("mx_conv_block_dgrad", _hip.ptr(G), _hip.ptr(amax), _hip.ptr(wt_f), B, H, n_frames,
+                              int(dilations[l]), _hip.ptr(dxhat), st)
                 if DEBUG_TAP is not None:
                     DEBUG_TAP[f"dxhat{l}"] = dxhat.clone()
                 ds_part = torch.empty((B, 64), device=dev, dtype=torch.float32)
@@ -215,7 +255,7 @@ class _CNNStack(torch.autograd.Function):
                           B, 64, H, n_frames, _hip.ptr(ds_part), st)
                 grads[3 * (l - 1) + 2] = _reduce_rows(ds_part, B, 64)
                 G = dxhat
-        return (None, None, None, *grads)
+        return (None, None, None, None, *grads)
 
 
 class Spectral2DCNN(nn.Module):
@@ -262,6 +302,7 @@ class Spectral2DCNN(nn.Module):
             raise NotImplementedError("Spectral2DCNN HIP kernels support the shipped spectral_2dcnn.yml family: "
                                       "5x13 kernels, 64 channels, pool (2,1), LayerNorm, temp dilations in "
                                       "{1,2,4,8,16}, in_ch <= 2, <= 352 frames")
+        self.conv_precision = CONV_PRECISION        # "f16x3" (default) or "f32", see the module header
         self.spectrogram = MelSpectrogramHIP(int(sr), n_fft, hop_len, n_mels)
         self.freq_mask_param = int(freq_mask_amount * n_mels)
         self.time_mask_param = int(time_mask_amount * self.n_frames)
@@ -309,7 +350,8 @@ class Spectral2DCNN(nn.Module):
 
     def forward(self, x: T, masks: Optional[Sequence[int]] = None) -> (T, T):
         logmel = self.log_mel(x, masks)
-        out, latent = _CNNStack.apply(logmel, self.n_frames, tuple(self.temp_dilations), *self._stack_params())
+        out, latent = _CNNStack.apply(logmel, self.n_frames, tuple(self.temp_dilations), self.conv_precision,
+                                      *self._stack_params())
         return out, latent
 
 

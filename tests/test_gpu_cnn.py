@@ -135,9 +135,13 @@ def run_pair(dev, ref, mine, x, masks):
         assert e < 2e-5, (name, e)
 
 
+@pytest.mark.parametrize("precision", ["f16x3", "f32"])
 @pytest.mark.parametrize("n_samples,n_mels,B", [(22272, 64, 3), (88200, 256, 2)])
-def test_cnn_forward_backward(dev, n_samples, n_mels, B):
+def test_cnn_forward_backward(dev, n_samples, n_mels, B, precision):
+    """both conv arithmetic modes (split-fp16 matrix cores / exact fp32 MFMA) against the fp32 CPU oracle at
+    the same 1e-5 (outputs) / 2e-5 (gradients) tolerances"""
     ref, mine = make_pair(dev, n_samples=n_samples, n_mels=n_mels)
+    mine.conv_precision = precision
     ref.eval(); mine.eval()                        # no SpecAugment draw; masks injected explicitly
     run_pair(dev, ref, mine, audio(B, n_samples), (3, 11, 20, 41))
 

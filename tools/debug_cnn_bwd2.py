@@ -5,15 +5,16 @@ import torch, copy
 from mod_extraction_amd import models as am
 from tests.test_gpu_cnn import make_pair, audio, rel_err, _loss, oracle_forward_routed
 n_samples, n_mels, B, in_ch = (int(v) for v in sys.argv[1:5])
+precision = sys.argv[5] if len(sys.argv) > 5 else 'f16x3'
 dev = torch.device("cuda:0")
 ref, mine = make_pair(dev, n_samples=n_samples, n_mels=n_mels, in_ch=in_ch)
-ref.eval(); mine.eval()
+ref.eval(); mine.eval(); mine.conv_precision = precision
 x = audio(B, n_samples); masks = (3, 11, 20, 41)
 if in_ch == 1: x = x[:, 1:2]
 am.DEBUG_TAP = {}
 out_m, lat_m = mine(x.to(dev), masks); (_loss(out_m) + 0.1 * _loss(lat_m)).backward()
 amax = [am.DEBUG_TAP[f"amax{l}"] for l in range(6)]
-out_r, lat_r, n_ties = oracle_forward_routed(ref, x, masks, amax, mine.n_frames)
+out_r, lat_r, n_ties = oracle_forward_routed(ref, x, masks, am.DEBUG_TAP, mine.n_frames)
 (_loss(out_r) + 0.1 * _loss(lat_r)).backward()
 ref64 = copy.deepcopy(ref).double()
 for p in ref64.parameters(): p.grad = None
@@ -22,6 +23,8 @@ h = lm
 for i, m in enumerate(ref64.cnn):
     if isinstance(m, torch.nn.MaxPool2d):
         pick = amax[i // 4].cpu()[..., :mine.n_frames].bool(); h = torch.where(pick, h[:, :, 1::2], h[:, :, 0::2])
+    elif isinstance(m, torch.nn.PReLU):
+        pos = am.DEBUG_TAP[f'p{i // 4}'].cpu()[..., :mine.n_frames] > 0; h = torch.where(pos, h, m.weight.view(1, -1, 1, 1) * h)
     else:
         h = m(h)
 lat64 = h.mean(dim=-2); out64 = torch.sigmoid(ref64.output(lat64))
