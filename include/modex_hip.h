@@ -134,6 +134,11 @@ int mx_conv_block_fwd_f16(const void *x_hi, const void *x_lo, const void *w_hi, 
 int mx_conv_block_dgrad_f16(const void *dz_hi, const void *dz_lo, const void *w_hi, const void *w_lo,
                             const float *scale, int64_t B, int64_t H, int64_t Wv, int32_t dilation,
                             float *dxhat, void *stream);
+/* weight gradient from the same prepared operands (dz pair of mx_conv_prep_dgrad_f16, x pair of
+ * mx_conv_prep_fwd_f16); part = workspace of ceil(B*H/rows_per_slab)*65*64*64 floats; dW (64,64,5,13). */
+int mx_conv_block_wgrad_f16(const void *dz_hi, const void *dz_lo, const void *x_hi, const void *x_lo,
+                            const float *scale, int64_t B, int64_t H, int32_t dilation, int64_t rows_per_slab,
+                            float *part, float *dW, void *stream);
 
 /* weight gradient: x (B,Cin,H,352) = block input before PReLU/LayerNorm (Cin = 64, or 2 for the
  * first block with slope = NULL); part = workspace of ceil(B*H/rows_per_slab)*65*64*Cin floats;

@@ -220,26 +220,39 @@ class _CNNStack(torch.autograd.Function):
             bsum = torch.empty((B, 64), device=dev, dtype=torch.float32)
             _hip.call("mx_plane_sum", _hip.ptr(G), B * 64, H // 2, n_frames, _hip.ptr(bsum), st)
             grads[3 * l + 1] = _reduce_rows(bsum, B, 64)
-            # weight gradient
+            # weight gradient (+ data gradient below) -- f16x3 path: both share the prepared operand pairs
             rows = B * H
-            rps = max(1, -(-rows // (256 if cin == 64 else 1024)))
-            n_slabs = -(-rows // rps)
-            part = torch.empty(n_slabs * 65 * 64 * cin, device=dev, dtype=torch.float32)
+            f16 = _use_f16(cin, precision)
             dW = torch.empty_like(w)
-            _hip.call("mx_conv_block_wgrad", _hip.ptr(G), _hip.ptr(amax), _hip.ptr(x_in), _hip.ptr(stats),
-                      _hip.ptr(slope_prev), B, cin, H, n_frames, int(dilations[l]), rps, _hip.ptr(part),
-                      _hip.ptr(dW), st)
+            if f16:
+                dz_hi = torch.empty((B, H, PITCH, 64), device=dev, dtype=torch.float16)
+                dz_lo = torch.empty((B, H, PITCH, 64), device=dev, dtype=torch.float16)
+                ws = torch.empty(1, device=dev, dtype=torch.int32)
+                scale = torch.empty(2, device=dev, dtype=torch.float32)
+                _hip.call("mx_conv_prep_dgrad_f16", _hip.ptr(G), _hip.ptr(amax), B, H, n_frames, _hip.ptr(ws),
+                          _hip.ptr(scale), _hip.ptr(dz_hi), _hip.ptr(dz_lo), st)
+                x_hi = torch.empty((B, H, PITCH, 64), device=dev, dtype=torch.float16)
+                x_lo = torch.empty((B, H, PITCH, 64), device=dev, dtype=torch.float16)
+                _hip.call("mx_conv_prep_fwd_f16", _hip.ptr(x_in), _hip.ptr(stats), _hip.ptr(slope_prev), B, H, n_frames,
+                          _hip.ptr(x_hi), _hip.ptr(x_lo), st)
+                rps = max(1, -(-rows // 408))            # ~408 slabs x 5 kernel rows = 8 workgroups per CU
+                n_slabs = -(-rows // rps)
+                part = torch.empty(n_slabs * 65 * 64 * 64, device=dev, dtype=torch.float32)
+                _hip.call("mx_conv_block_wgrad_f16", _hip.ptr(dz_hi), _hip.ptr(dz_lo), _hip.ptr(x_hi), _hip.ptr(x_lo),
+                          _hip.ptr(scale), B, H, int(dilations[l]), rps, _hip.ptr(part), _hip.ptr(dW), st)
+                del part, x_hi, x_lo
+            else:
+                rps = max(1, -(-rows // (256 if cin == 64 else 1024)))
+                n_slabs = -(-rows // rps)
+                part = torch.empty(n_slabs * 65 * 64 * cin, device=dev, dtype=torch.float32)
+                _hip.call("mx_conv_block_wgrad", _hip.ptr(G), _hip.ptr(amax), _hip.ptr(x_in), _hip.ptr(stats),
+                          _hip.ptr(slope_prev), B, cin, H, n_frames, int(dilations[l]), rps, _hip.ptr(part),
+                          _hip.ptr(dW), st)
+                del part
             grads[3 * l] = dW
-            del part
             if l > 0:
                 dxhat = torch.empty((B, 64, H, PITCH), device=dev, dtype=torch.float32)
-                if _use_f16(64, precision):
-                    dz_hi = torch.empty((B, H, PITCH, 64), device=dev, dtype=torch.float16)
-                    dz_lo = torch.empty((B, H, PITCH, 64), device=dev, dtype=torch.float16)
-                    ws = torch.empty(1, device=dev, dtype=torch.int32)
-                    scale = torch.empty(2, device=dev, dtype=torch.float32)
-                    _hip.call("mx_conv_prep_dgrad_f16", _hip.ptr(G), _hip.ptr(amax), B, H, n_frames, _hip.ptr(ws),
-                              _hip.ptr(scale), _hip.ptr(dz_hi), _hip.ptr(dz_lo), st)
+                if f16:
                     w_hi, w_lo = _pack_f16(w, 1)
                     _hip.call("mx_conv_block_dgrad_f16", _hip.ptr(dz_hi), _hip.ptr(dz_lo), _hip.ptr(w_hi), _hip.ptr(w_lo),
                               _hip.ptr(scale), B, H, n_frames, int(dilations[l]), _hip.ptr(dxhat), st)
