@@ -3,7 +3,7 @@
 // third-party source absent from the reference tree: PARITY UNPINNED, checked against
 // oracle/csrc/oracle_ref.c:orc_phaser, which restates the published JUCE algorithm).
 //
-// One wavefront per clip.  The recurrence (in - lastOut -> 6 first-order TPT all-pass stages ->
+// One wavefront per clip (16 clips per workgroup).  The recurrence (in - lastOut -> 6 first-order TPT all-pass stages ->
 // out; lastOut = out * feedback) is strictly serial per sample, so the wave splits the work by
 // kind: per block of 256 samples the 64 lanes evaluate the 64 LFO / cut-off updates in parallel
 // (sin, pow, fp64 tan -> G = g / (1 + g), one per lane), samples are loaded/stored 4 per lane
@@ -17,21 +17,25 @@
 #include "common.h"
 
 #define PH_BLOCK 256
+#define PH_WPB 2          // clips (wavefronts) per workgroup: packs the long-running serial chains onto few CUs so
+                          // that the 1-workgroup-per-CU matrix kernels of the train step keep the other CUs
 
 template <bool FAST>
-__global__ __launch_bounds__(64) void phaser_kernel(const float *__restrict__ x, long long x_stride,
+__global__ __launch_bounds__(64 * PH_WPB) void phaser_kernel(const float *__restrict__ x, long long x_stride,
                                                     const float *__restrict__ rate,
                                                     const float *__restrict__ depth,
                                                     const float *__restrict__ centre,
                                                     const float *__restrict__ feedback,
                                                     const float *__restrict__ mix,
                                                     const int *__restrict__ lead_arr,
-                                                    const int *__restrict__ rows, int N, float sr_f,
+                                                    const int *__restrict__ rows, int n_items, int N, float sr_f,
                                                     double sr, float *__restrict__ y, long long y_stride,
                                                     float *__restrict__ dry_out)
 {
-    const int lane = threadIdx.x;
-    const int b = rows ? rows[blockIdx.x] : (int)blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int item = blockIdx.x * PH_WPB + (threadIdx.x >> 6);
+    if (item >= n_items) return;                        // whole wave exits; waves never synchronise with each other
+    const int b = rows ? rows[item] : item;
     const int lead = lead_arr ? lead_arr[b] : 0;
     const int total = lead + N;
     const float *xb = x + (size_t)b * x_stride;
@@ -85,24 +89,27 @@ __global__ __launch_bounds__(64) void phaser_kernel(const float *__restrict__ x,
         // per stage on the sample-to-sample critical path instead of five dependent operations (4-5x
         // shorter chain).  Algebraically identical to the JUCE order, rounding differs (<= 1e-6 on audio).
         const float c1r = 2.0f * Greg - 1.0f, c2r = 2.0f - 2.0f * Greg, c3r = 2.0f * Greg, c4r = 1.0f - 2.0f * Greg;
+        float fc1 = 0.f, fc2 = 0.f, fc3 = 0.f, fc4 = 0.f;
 #pragma unroll
         for (int j = 0; j < PH_BLOCK / 64; ++j) {
             const int lim = min(64, cnt - j * 64);
             for (int li = 0; li < lim; ++li) {
-                const float G = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Greg), (j * 64 + li) >> 2));
                 const float in = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xr[j]), li));
                 float out = __fsub_rn(in, last);
                 if (FAST) {
-                    const int src = (j * 64 + li) >> 2;
-                    const float c1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c1r), src));
-                    const float c2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c2r), src));
-                    const float c3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c3r), src));
-                    const float c4 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c4r), src));
+                    // coefficients change every 4 samples (one cut-off update): re-broadcast only then
+                    if ((li & 3) == 0) {
+                        const int src = (j * 64 + li) >> 2;
+                        fc1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c1r), src));
+                        fc2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c2r), src));
+                        fc3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c3r), src));
+                        fc4 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c4r), src));
+                    }
 #define PH_FSTAGE(S)                              \
     {                                             \
         const float xin = out;                    \
-        out = fmaf(c1, xin, c2 * S);              \
-        S = fmaf(c3, xin, c4 * S);                \
+        out = fmaf(fc1, xin, fc2 * S);            \
+        S = fmaf(fc3, xin, fc4 * S);              \
     }
                     PH_FSTAGE(s0) PH_FSTAGE(s1) PH_FSTAGE(s2) PH_FSTAGE(s3) PH_FSTAGE(s4) PH_FSTAGE(s5)
 #undef PH_FSTAGE
@@ -112,6 +119,7 @@ __global__ __launch_bounds__(64) void phaser_kernel(const float *__restrict__ x,
                     yr[j] = lane == li ? m : yr[j];
                     continue;
                 }
+                const float G = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Greg), (j * 64 + li) >> 2));
                 float v, yk;
 #define PH_STAGE(S)                                   \
     v = __fmul_rn(G, __fsub_rn(out, S));             \
@@ -154,12 +162,12 @@ MX_EXPORT int mx_phaser_fwd(const float *x, int64_t x_stride, const float *rate,
     const int64_t items = rows ? n_rows : B;
     if (items <= 0) return MX_OK;
     if (exact_order)
-        hipLaunchKernelGGL((phaser_kernel<false>), dim3((unsigned)items), dim3(64), 0, (hipStream_t)stream, x,
-                           (long long)x_stride, rate, depth, centre, feedback, mix, lead, rows, (int)N, (float)sr, sr, y,
-                           (long long)y_stride, dry_out);
+        hipLaunchKernelGGL((phaser_kernel<false>), dim3((unsigned)((items + PH_WPB - 1) / PH_WPB)), dim3(64 * PH_WPB), 0,
+                           (hipStream_t)stream, x, (long long)x_stride, rate, depth, centre, feedback, mix, lead, rows,
+                           (int)items, (int)N, (float)sr, sr, y, (long long)y_stride, dry_out);
     else
-        hipLaunchKernelGGL((phaser_kernel<true>), dim3((unsigned)items), dim3(64), 0, (hipStream_t)stream, x,
-                           (long long)x_stride, rate, depth, centre, feedback, mix, lead, rows, (int)N, (float)sr, sr, y,
-                           (long long)y_stride, dry_out);
+        hipLaunchKernelGGL((phaser_kernel<true>), dim3((unsigned)((items + PH_WPB - 1) / PH_WPB)), dim3(64 * PH_WPB), 0,
+                           (hipStream_t)stream, x, (long long)x_stride, rate, depth, centre, feedback, mix, lead, rows,
+                           (int)items, (int)N, (float)sr, sr, y, (long long)y_stride, dry_out);
     return mx_launch_status();
 }

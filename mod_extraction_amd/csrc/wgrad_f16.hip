@@ -38,17 +38,32 @@ struct WgradF16Args {
     int B, H, rows_per_slab, n_slabs;
 };
 
-// one transposed fragment: 8 consecutive rows (positions) r0 .. r0+7 of the 32-channel tile `tile`, for this
-// lane's channel; `img` = LDS image with 64 halfs per row and the 64-byte half swap described above
-__device__ __forceinline__ half8 tr_frag(const _Float16 *img, int r0, int tile, int lane)
+// One transposed fragment = 8 consecutive rows (positions) r0 .. r0+7 of a 32-channel tile, for this lane's
+// channel: two ds_read_b64_tr_b16 (rows +0..3 and +4..7 of the lane half's 8 rows).
+// Address of lane (q, p, g1, h2) for read t:  row = r0 + 8 h2 + 4 t + q,  byte = row*128 + (tile ^ swz)*64 +
+// 32 g1 + 8 p  with swz = (row >> 1) & 1.  r0 = 16 ks + kw T is wave-uniform, so swz = (((r0 & 3) + q) >> 1) & 1
+// takes one of 4 lane patterns selected by r0 & 3: the 4 lane offsets are computed once per kernel and every
+// read is `image + lane_off[r0 & 3] + r0*128 + t*512` (t*512 and the kw T part fold into the instruction's
+// immediate offset), leaving the VALU free for nothing but the MFMAs' neighbours.
+struct TrLane { int off[4]; };
+__device__ __forceinline__ TrLane tr_lane_offsets(int tile, int lane)
 {
     const int q = (lane & 15) >> 2, p = lane & 3, g1 = (lane >> 4) & 1, h2 = lane >> 5;
+    TrLane L;
+#pragma unroll
+    for (int ph = 0; ph < 4; ++ph) {
+        const int swz = ((ph + q) >> 1) & 1;
+        L.off[ph] = (8 * h2 + q) * 128 + ((tile ^ swz) * 64) + 32 * g1 + 8 * p;
+    }
+    return L;
+}
+// img_bytes: LDS byte address of the image; r0 = first row (wave-uniform); ph = r0 & 3 (compile-time where r0 is)
+__device__ __forceinline__ half8 tr_frag(const unsigned char *img_bytes, int lane_off, int r0)
+{
     half8 out;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-        const int row = r0 + 8 * h2 + 4 * t + q;
-        const int blk = tile ^ ((row >> 1) & 1);
-        const _Float16 *ptr = img + row * 64 + blk * 32 + 16 * g1 + 4 * p;
+        const unsigned char *ptr = img_bytes + lane_off + r0 * 128 + t * 512;
         short4v v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4v __attribute__((address_space(3))) *)ptr);
         union { short4v s; _Float16 h[4]; } u;
         u.s = v;
@@ -137,8 +152,11 @@ __global__ __launch_bounds__(256, 1) void wgrad_f16x3_kernel(WgradF16Args a)
 #pragma unroll
         for (int q = 0; q < NV; ++q) pv[q] = load_vec(tid + q * 256, rid, ch);
     }
-    const _Float16 *dz_h = dzl, *dz_l = dzl + WF_CH * 64;
-    const _Float16 *x_h = xl, *x_l = xl + WIN * 64;
+    const unsigned char *dz_h = reinterpret_cast<const unsigned char *>(dzl);
+    const unsigned char *dz_l = dz_h + WF_CH * 128;
+    const unsigned char *x_h = reinterpret_cast<const unsigned char *>(xl);
+    const unsigned char *x_l = x_h + WIN * 128;
+    const TrLane la = tr_lane_offsets(mt, lane), lb = tr_lane_offsets(nt, lane);
     while (rid < row_end) {
         __syncthreads();                                // everyone is done reading the previous tiles
         if (PREF) {
@@ -156,18 +174,19 @@ __global__ __launch_bounds__(256, 1) void wgrad_f16x3_kernel(WgradF16Args a)
         __syncthreads();
         // ---- 11 k-steps of 16 positions, 13 taps x 3 MFMAs each; fragments pipelined in two half-sets ----
         half8 ah, al, ah_n, al_n, bh0[7], bl0[7], bh1[6], bl1[6];
-#define WF_LOAD_A(AH, AL, KS)                 \
-    AH = tr_frag(dz_h, (KS) * 16, mt, lane);  \
-    AL = tr_frag(dz_l, (KS) * 16, mt, lane);
-#define WF_LOAD_S0(KS)                                                         \
-    _Pragma("unroll") for (int i = 0; i < 7; ++i) {                            \
-        bh0[i] = tr_frag(x_h, (KS) * 16 + i * T, nt, lane);                    \
-        bl0[i] = tr_frag(x_l, (KS) * 16 + i * T, nt, lane);                    \
+        // (KS)*16 is a multiple of 4, so the swizzle phase of a read is (kw T) & 3: a compile-time constant
+#define WF_LOAD_A(AH, AL, KS)                         \
+    AH = tr_frag(dz_h + (KS) * 2048, la.off[0], 0);   \
+    AL = tr_frag(dz_l + (KS) * 2048, la.off[0], 0);
+#define WF_LOAD_S0(KS)                                                                   \
+    _Pragma("unroll") for (int i = 0; i < 7; ++i) {                                      \
+        bh0[i] = tr_frag(x_h + (KS) * 2048, lb.off[(i * T) & 3], i * T);                 \
+        bl0[i] = tr_frag(x_l + (KS) * 2048, lb.off[(i * T) & 3], i * T);                 \
     }
-#define WF_LOAD_S1(KS)                                                         \
-    _Pragma("unroll") for (int i = 0; i < 6; ++i) {                            \
-        bh1[i] = tr_frag(x_h, (KS) * 16 + (i + 7) * T, nt, lane);              \
-        bl1[i] = tr_frag(x_l, (KS) * 16 + (i + 7) * T, nt, lane);              \
+#define WF_LOAD_S1(KS)                                                                   \
+    _Pragma("unroll") for (int i = 0; i < 6; ++i) {                                      \
+        bh1[i] = tr_frag(x_h + (KS) * 2048, lb.off[((i + 7) * T) & 3], (i + 7) * T);     \
+        bl1[i] = tr_frag(x_l + (KS) * 2048, lb.off[((i + 7) * T) & 3], (i + 7) * T);     \
     }
 #define WF_MMA(ACC, AH, AL, BH, BL)         \
     ACC = mfma16w(AL, BH, ACC);             \
