@@ -117,7 +117,8 @@ __global__ __launch_bounds__(256) void split_prep_kernel(const float *__restrict
     *reinterpret_cast<half8 *>(out_lo + o) = lo;
 }
 
-// torch (64, 64, 5, 13) fp32 -> [ci/16][kh][kw][co][16] fp16 pairs of W * 256
+// torch (64, 64, 5, 13) fp32 -> [ci/16][kh][kw][khalf][co][8] fp16 pairs of W * 256 (the LDS image of a stage, so
+// that staging is a linear copy: the two 8-channel halves of a 16-channel block are separate planes)
 //   flip = 0 (forward): in = ci, out = co;  flip = 1 (dgrad): in = co, out = ci, taps mirrored
 __global__ void pack_weights_f16_kernel(const float *__restrict__ W, int flip, _Float16 *__restrict__ w_hi,
                                         _Float16 *__restrict__ w_lo)
@@ -131,7 +132,7 @@ __global__ void pack_weights_f16_kernel(const float *__restrict__ W, int flip, _
         int cin, cout, kh2, kw2;
         if (!flip) { cin = ci; cout = co; kh2 = kh; kw2 = kw; }
         else { cin = co; cout = ci; kh2 = CV_KH - 1 - kh; kw2 = CV_KW - 1 - kw; }
-        const size_t o = ((((size_t)(cin >> 4) * CV_KH + kh2) * CV_KW + kw2) * 64 + cout) * 16 + (cin & 15);
+        const size_t o = (((((size_t)(cin >> 4) * CV_KH + kh2) * CV_KW + kw2) * 2 + ((cin & 15) >> 3)) * 64 + cout) * 8 + (cin & 7);
         w_hi[o] = hh;
         w_lo[o] = ll;
     }
@@ -140,13 +141,70 @@ __global__ void pack_weights_f16_kernel(const float *__restrict__ W, int flip, _
 // ---- the convolution ------------------------------------------------------------------------------------
 struct ConvF16Args {
     const _Float16 *x_hi, *x_lo;   // (B, H, 352, 64)
-    const _Float16 *w_hi, *w_lo;   // [4][5][13][64][16]
+    const _Float16 *w_hi, *w_lo;   // [4][5][13][2][64][8]
     const float *bias;             // forward: (64,)
     const float *scale;            // dgrad: {S_dz, 1/S_dz} on the device; forward: nullptr
     float *out;                    // forward: (B, 64, H/2, 352) pooled pre-activations; dgrad: (B, 64, H, 352)
     unsigned char *out_amax;       // forward
     int H, Wv;
 };
+
+// Epilogue shared by the conv kernels.  Wave = (output row, column half c); accumulator layout
+//   acc[2t + j], t < 5 : column tile c*6 + t, channel half j ^ c;      acc[10] : column tile 5, channel half c
+// OUTMODE 0: bias + max-pool over the row pair + argmax (rows exchanged through LDS), 1: plain rows * 1/S.
+template <int OUTMODE>
+__device__ __forceinline__ void conv_f16_epilogue(floatx16 (&acc)[CV_WT], const ConvF16Args &a, unsigned char *smem,
+                                                  int b, int h0, int row, int c, int lane)
+{
+    const int l32 = lane & 31;
+    // ---- epilogue (same data layout as the fp32 kernel) ----
+    const float inv = (OUTMODE == 1 ? a.scale[1] : 1.0f) * (1.0f / F16_WSCALE);
+    if (OUTMODE == 1) {
+        const int h = h0 + row;
+#pragma unroll
+        for (int i = 0; i < CV_WT; ++i) {
+            const int w = (i == 10 ? 5 : c * 6 + (i >> 1)) * 32 + l32;
+            const int cb0 = (i == 10 ? c : (i & 1) ^ c) * 32;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = cb0 + mfma_row(r, lane);
+                a.out[(((size_t)b * CV_CO + co) * a.H + h) * CV_PITCH + w] = w < a.Wv ? acc[i][r] * inv : 0.0f;
+            }
+        }
+    } else {
+        float *xch = reinterpret_cast<float *>(smem);
+        const int hp = h0 >> 1, Hp = a.H >> 1;
+#pragma unroll
+        for (int c0 = 0; c0 < CV_WT; c0 += 4) {
+            __syncthreads();
+            if (row == 1) {
+#pragma unroll
+                for (int i = c0; i < c0 + 4 && i < CV_WT; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) xch[((c * 4 + (i - c0)) * 16 + r) * 64 + lane] = acc[i][r];
+            }
+            __syncthreads();
+            if (row == 0) {
+#pragma unroll
+                for (int i = c0; i < c0 + 4 && i < CV_WT; ++i) {
+                    const int w = (i == 10 ? 5 : c * 6 + (i >> 1)) * 32 + l32;
+                    const int cb0 = (i == 10 ? c : (i & 1) ^ c) * 32;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int co = cb0 + mfma_row(r, lane);
+                        const float top = acc[i][r];
+                        const float bot = xch[((c * 4 + (i - c0)) * 16 + r) * 64 + lane];
+                        const bool take_bot = bot > top;                 // ties keep the first row (torch)
+                        const float m = (take_bot ? bot : top) * inv + a.bias[co];
+                        const size_t off = (((size_t)b * CV_CO + co) * Hp + hp) * CV_PITCH + w;
+                        a.out[off] = w < a.Wv ? m : 0.0f;
+                        a.out_amax[off] = take_bot ? 1 : 0;
+                    }
+                }
+            }
+        }
+    }
+}
 
 template <int T, int OUTMODE>      // OUTMODE 0: bias + maxpool + argmax, 1: plain rows
 __global__ __launch_bounds__(256, 1) void conv_f16x3_kernel(ConvF16Args a)
@@ -158,11 +216,19 @@ __global__ __launch_bounds__(256, 1) void conv_f16x3_kernel(ConvF16Args a)
     constexpr int NPI = 2 * 2 * PWP * 2;              // patch vectors: split x row x position x 2 halves
     constexpr int NPV = (NPI + 255) / 256;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    _Float16 *wl = reinterpret_cast<_Float16 *>(smem);            // [split][kw][co][16]
-    _Float16 *pl = wl + 2 * WSL;                                   // [split][row][q][16]
+    // LDS images keep the two 8-channel halves of a 16-channel block in separate planes, so that the 32 lanes of
+    // a fragment read touch 32 CONSECUTIVE 16-byte chunks (conflict-free ds_read_b128; interleaving the halves
+    // would put lanes l and l+8 on the same banks)
+    _Float16 *wl = reinterpret_cast<_Float16 *>(smem);            // [split][kw][khalf][co][8]
+    _Float16 *pl = wl + 2 * WSL;                                   // [split][row][khalf][q][8]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int mt = wave & 1, row = wave >> 1, half = lane >> 5, l32 = lane & 31;
+    // wave = (output row, column half c).  Each wave owns all 64 output channels of 5 whole column tiles plus ONE
+    // channel half of the middle tile (tile 5): 11 accumulators like a (channel half x whole row) split, but every
+    // patch fragment feeds two channel tiles, so a tap needs 12 + 4 fragment reads instead of 22 + 2 -- the LDS
+    // read pipe, shared by the four waves, was the co-limiter of the first version.
+    //   acc[2t + j], t < 5 : column tile c*6 + t, channel half j ^ c;      acc[10] : column tile 5, channel half c
+    const int row = wave >> 1, c = wave & 1, half = lane >> 5, l32 = lane & 31;
     const int b = blockIdx.y, h0 = blockIdx.x * 2;
 
     floatx16 acc[CV_WT];
@@ -200,18 +266,22 @@ __global__ __launch_bounds__(256, 1) void conv_f16x3_kernel(ConvF16Args a)
             }
         }
     };
-    auto commit = [&]() {                                       // registers -> LDS (layouts are linear in i)
+    auto commit = [&]() {                                       // registers -> LDS
         floatx4 *wd = reinterpret_cast<floatx4 *>(wl);
 #pragma unroll
         for (int q = 0; q < NWV; ++q) {
             const int i = tid + q * 256;
-            if (i < 2 * (WSL / 8)) wd[i] = wv[q];
+            if (i < 2 * (WSL / 8)) wd[i] = wv[q];             // the packed weights are the LDS image
         }
         floatx4 *pd = reinterpret_cast<floatx4 *>(pl);
 #pragma unroll
         for (int q = 0; q < NPV; ++q) {
             const int i = tid + q * 256;
-            if (i < NPI) pd[i] = pv[q];
+            if (i < NPI) {
+                // item i = ((split*2 + row)*PWP + pos)*2 + part  ->  LDS [split][row][part][pos]
+                const int part = i & 1, pos = (i >> 1) % PWP, sr = (i >> 1) / PWP;
+                pd[(sr * 2 + part) * PWP + pos] = pv[q];
+            }
         }
     };
 
@@ -223,100 +293,279 @@ __global__ __launch_bounds__(256, 1) void conv_f16x3_kernel(ConvF16Args a)
         if (s + 1 < N_STAGE) issue(s + 1);                      // in flight during the MFMAs below
         __syncthreads();
         // fragment base addresses (halfs)
-        const _Float16 *a_hi_p = wl + (mt * 32 + l32) * 16 + half * 8;
-        const _Float16 *a_lo_p = a_hi_p + WSL;
-        const _Float16 *b_hi_p = pl + ((size_t)row * PWP + l32) * 16 + half * 8;
-        const _Float16 *b_lo_p = b_hi_p + PSL;
-        // two half-tap fragment sets: tiles 0..5 and 6..10
-        half8 ah, al, ah_n, al_n, bh0[6], bl0[6], bh1[5], bl1[5];
-#define F16_LOAD_A(AH, AL, KW)                                              \
-    AH = *reinterpret_cast<const half8 *>(a_hi_p + (KW) * (64 * 16));        \
-    AL = *reinterpret_cast<const half8 *>(a_lo_p + (KW) * (64 * 16));
+        const _Float16 *a0_hi_p = wl + (half * 64 + c * 32 + l32) * 8;                        // + kw * 1024
+        const _Float16 *a1_hi_p = wl + (half * 64 + (c ^ 1) * 32 + l32) * 8;
+        const _Float16 *b_hi_p = pl + ((size_t)(row * 2 + half) * PWP + c * 6 * 32 + l32) * 8;   // + (t*32 + kw*T) * 8
+        const _Float16 *bm_hi_p = pl + ((size_t)(row * 2 + half) * PWP + 5 * 32 + l32) * 8;      // middle tile
+        // two half-tap fragment sets: {tiles 0,1,2} and {tiles 3,4,middle}
+        half8 a0h, a0l, a1h, a1l, n0h, n0l, n1h, n1l, bh0[3], bl0[3], bh1[3], bl1[3];
+#define F16_LOAD_A(A0H, A0L, A1H, A1L, KW)                                        \
+    A0H = *reinterpret_cast<const half8 *>(a0_hi_p + (KW) * (2 * 64 * 8));         \
+    A0L = *reinterpret_cast<const half8 *>(a0_hi_p + WSL + (KW) * (2 * 64 * 8));   \
+    A1H = *reinterpret_cast<const half8 *>(a1_hi_p + (KW) * (2 * 64 * 8));         \
+    A1L = *reinterpret_cast<const half8 *>(a1_hi_p + WSL + (KW) * (2 * 64 * 8));
 #define F16_LOAD_S0(KW)                                                                          \
-    _Pragma("unroll") for (int i = 0; i < 6; ++i) {                                              \
-        bh0[i] = *reinterpret_cast<const half8 *>(b_hi_p + (i * 32 + (KW) * T) * 16);            \
-        bl0[i] = *reinterpret_cast<const half8 *>(b_lo_p + (i * 32 + (KW) * T) * 16);            \
+    _Pragma("unroll") for (int i = 0; i < 3; ++i) {                                              \
+        bh0[i] = *reinterpret_cast<const half8 *>(b_hi_p + (i * 32 + (KW) * T) * 8);             \
+        bl0[i] = *reinterpret_cast<const half8 *>(b_hi_p + PSL + (i * 32 + (KW) * T) * 8);       \
     }
 #define F16_LOAD_S1(KW)                                                                          \
-    _Pragma("unroll") for (int i = 0; i < 5; ++i) {                                              \
-        bh1[i] = *reinterpret_cast<const half8 *>(b_hi_p + ((i + 6) * 32 + (KW) * T) * 16);      \
-        bl1[i] = *reinterpret_cast<const half8 *>(b_lo_p + ((i + 6) * 32 + (KW) * T) * 16);      \
-    }
-#define F16_MMA(ACC, AH, AL, BH, BL)        \
-    ACC = mfma16(AL, BH, ACC);              \
-    ACC = mfma16(AH, BL, ACC);              \
-    ACC = mfma16(AH, BH, ACC);
-        F16_LOAD_A(ah, al, 0)
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                              \
+        bh1[i] = *reinterpret_cast<const half8 *>(b_hi_p + ((i + 3) * 32 + (KW) * T) * 8);       \
+        bl1[i] = *reinterpret_cast<const half8 *>(b_hi_p + PSL + ((i + 3) * 32 + (KW) * T) * 8); \
+    }                                                                                            \
+    bh1[2] = *reinterpret_cast<const half8 *>(bm_hi_p + (KW) * T * 8);                           \
+    bl1[2] = *reinterpret_cast<const half8 *>(bm_hi_p + PSL + (KW) * T * 8);
+        F16_LOAD_A(a0h, a0l, a1h, a1l, 0)
         F16_LOAD_S0(0)
         F16_LOAD_S1(0)
 #pragma unroll 1
         for (int kw = 0; kw < CV_KW; ++kw) {
             const int kn = kw + 1 < CV_KW ? kw + 1 : kw;         // last tap reloads itself (discarded)
             __builtin_amdgcn_sched_barrier(0);
+            // the three split products of one accumulator are issued six MFMAs apart
 #pragma unroll
-            for (int i = 0; i < 6; ++i) { F16_MMA(acc[i], ah, al, bh0[i], bl0[i]) }
+            for (int i = 0; i < 3; ++i) { acc[2 * i] = mfma16(a0l, bh0[i], acc[2 * i]); acc[2 * i + 1] = mfma16(a1l, bh0[i], acc[2 * i + 1]); }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { acc[2 * i] = mfma16(a0h, bl0[i], acc[2 * i]); acc[2 * i + 1] = mfma16(a1h, bl0[i], acc[2 * i + 1]); }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { acc[2 * i] = mfma16(a0h, bh0[i], acc[2 * i]); acc[2 * i + 1] = mfma16(a1h, bh0[i], acc[2 * i + 1]); }
             __builtin_amdgcn_sched_barrier(0);
-            F16_LOAD_A(ah_n, al_n, kn)
+            F16_LOAD_A(n0h, n0l, n1h, n1l, kn)
             F16_LOAD_S0(kn)
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < 5; ++i) { F16_MMA(acc[i + 6], ah, al, bh1[i], bl1[i]) }
+            for (int i = 0; i < 2; ++i) { acc[6 + 2 * i] = mfma16(a0l, bh1[i], acc[6 + 2 * i]); acc[7 + 2 * i] = mfma16(a1l, bh1[i], acc[7 + 2 * i]); }
+            acc[10] = mfma16(a0l, bh1[2], acc[10]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) { acc[6 + 2 * i] = mfma16(a0h, bl1[i], acc[6 + 2 * i]); acc[7 + 2 * i] = mfma16(a1h, bl1[i], acc[7 + 2 * i]); }
+            acc[10] = mfma16(a0h, bl1[2], acc[10]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) { acc[6 + 2 * i] = mfma16(a0h, bh1[i], acc[6 + 2 * i]); acc[7 + 2 * i] = mfma16(a1h, bh1[i], acc[7 + 2 * i]); }
+            acc[10] = mfma16(a0h, bh1[2], acc[10]);
             __builtin_amdgcn_sched_barrier(0);
             F16_LOAD_S1(kn)
-            ah = ah_n;
-            al = al_n;
+            a0h = n0h; a0l = n0l; a1h = n1h; a1l = n1l;
         }
 #undef F16_LOAD_A
 #undef F16_LOAD_S0
 #undef F16_LOAD_S1
-#undef F16_MMA
     }
 
-    // ---- epilogue (same data layout as the fp32 kernel) ----
-    const float inv = (OUTMODE == 1 ? a.scale[1] : 1.0f) * (1.0f / F16_WSCALE);
-    if (OUTMODE == 1) {
-        const int h = h0 + row;
+    conv_f16_epilogue<OUTMODE>(acc, a, smem, b, h0, row, c, lane);
+}
+
+// ---- LDS-DMA version (T <= 4) ---------------------------------------------------------------------------
+// Same tiling and arithmetic as conv_f16x3_kernel, but the operands travel global -> LDS by
+// global_load_lds_dwordx4 (1 KiB per wave-instruction, no staging registers, no ds_write pass) into DOUBLE
+// buffers, so that staging overlaps the MFMAs instead of sitting between two barriers:
+//   LDS = W[2] (7 taps x 2 splits = 28 KB each) | P[2] (patch images [split][row][khalf][pos], 46-50 KB each)
+// A stage (16 input channels x one kernel row) runs as two phases, taps 0..6 from W[0] and taps 7..12 from W[1]:
+//   phase A issues  W[1] <- taps 7..12 of this stage,  first 8 pieces/wave of P[next] <- next stage's patch
+//   phase B issues  W[0] <- taps 0..6 of the next stage, the remaining pieces of P[next]
+// one DMA after every half tap (18 / 15 MFMAs), each phase ends with vmcnt(0) + barrier.  A DMA piece is 64
+// consecutive 16-byte slots of the LDS image; every lane derives its own source address (halo / padding slots read
+// a zero slot), precomputed once per kernel as a 32-bit descriptor per piece.
+__device__ __attribute__((aligned(16))) unsigned k_zero_slot[4];
+
+// One DMA piece: lane l's 16 bytes at gsrc land at LDS byte address lds_wave_base + 16 l.  Issued as inline asm on
+// purpose: behind the __builtin the compiler books an LDS-DMA as a pending FLAT access and from then on turns every
+// counted s_waitcnt lgkmcnt(n) of the fragment pipeline into lgkmcnt(0) (an MFMA bubble per tap); asm loads are
+// invisible to its counters, so the waits for them are written by hand (DMA_WAIT before the phase barriers).
+__device__ __forceinline__ void glds16(unsigned long long gsrc, unsigned lds_wave_base)
+{
+    unsigned keep;
+    lds_wave_base = __builtin_amdgcn_readfirstlane(lds_wave_base);   // wave-uniform by construction; pin it to an SGPR
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_wave_base)
+                 : "memory");
+}
+#define DMA_WAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+
+template <int T, int OUTMODE>
+__global__ __launch_bounds__(256, 1) void conv_f16x3_dma_kernel(ConvF16Args a)
+{
+    constexpr int PWP = CV_PITCH + 12 * T;            // patch positions per row (w = q - 6T)
+    constexpr int WSL = CV_KW * 64 * 16;              // halfs per packed weight stage and split
+    constexpr int PLANE = PWP * 16;                   // bytes of one (split, row, khalf) plane
+    constexpr int P_SLOTS = 8 * PWP;
+    constexpr int P_PIECES = (P_SLOTS + 63) / 64;
+    constexpr int P_BYTES = P_PIECES * 1024;
+    constexpr int PPW = (P_PIECES + 3) / 4;           // patch pieces per wave (12..13)
+    constexpr int W_SPLIT = 7 * 2048;                 // bytes per split inside a weight buffer
+    constexpr int W_BYTES = 2 * W_SPLIT;
+    constexpr int ROWB = CV_PITCH * 128;              // bytes of one operand row (352 positions x 64 halfs)
+    constexpr int N_STAGE = 4 * CV_KH;
+    static_assert(PPW <= 13, "patch pieces per wave");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char *const W0 = smem, *const W1 = smem + W_BYTES, *const P0 = smem + 2 * W_BYTES;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;   // LDS byte address
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int row = wave >> 1, c = wave & 1, half = lane >> 5, l32 = lane & 31;
+    const int b = blockIdx.y, h0 = blockIdx.x * 2;
+
+    floatx16 acc[CV_WT];
 #pragma unroll
-        for (int i = 0; i < CV_WT; ++i) {
-            const int w = i * 32 + l32;
+    for (int i = 0; i < CV_WT; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = mt * 32 + mfma_row(r, lane);
-                a.out[(((size_t)b * CV_CO + co) * a.H + h) * CV_PITCH + w] = w < a.Wv ? acc[i][r] * inv : 0.0f;
-            }
-        }
-    } else {
-        float *xch = reinterpret_cast<float *>(smem);
-        const int hp = h0 >> 1, Hp = a.H >> 1;
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+
+    // patch piece descriptors: bit 31 = no source (halo column / padding slot), bit 30 = split, bit 29 = row,
+    // low bits = byte offset of the slot's 16 bytes from the stage's first row
+    int desc[PPW];
 #pragma unroll
-        for (int c0 = 0; c0 < CV_WT; c0 += 4) {
-            __syncthreads();
-            if (row == 1) {
-#pragma unroll
-                for (int i = c0; i < c0 + 4 && i < CV_WT; ++i)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) xch[((mt * 4 + (i - c0)) * 16 + r) * 64 + lane] = acc[i][r];
-            }
-            __syncthreads();
-            if (row == 0) {
-#pragma unroll
-                for (int i = c0; i < c0 + 4 && i < CV_WT; ++i) {
-                    const int w = i * 32 + l32;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int co = mt * 32 + mfma_row(r, lane);
-                        const float top = acc[i][r];
-                        const float bot = xch[((mt * 4 + (i - c0)) * 16 + r) * 64 + lane];
-                        const bool take_bot = bot > top;                 // ties keep the first row (torch)
-                        const float m = (take_bot ? bot : top) * inv + a.bias[co];
-                        const size_t off = (((size_t)b * CV_CO + co) * Hp + hp) * CV_PITCH + w;
-                        a.out[off] = w < a.Wv ? m : 0.0f;
-                        a.out_amax[off] = take_bot ? 1 : 0;
-                    }
-                }
-            }
-        }
+    for (int k = 0; k < PPW; ++k) {
+        const int i = (wave + 4 * k) * 64 + lane;
+        const int plane = i / PWP, pos = i - plane * PWP, w = pos - 6 * T;
+        const int split = plane >> 2, r = (plane >> 1) & 1, part = plane & 1;
+        desc[k] = (i < P_SLOTS && w >= 0 && w < CV_PITCH) ? ((split << 30) | (r << 29) | (r * ROWB + w * 128 + part * 16)) : -1;
     }
+    // plain integer addresses (selecting between kernel-argument FIELDS per lane would make the compiler load the
+    // pointer through memory and wait for it -- and with it for every DMA in flight)
+    const unsigned long long zero_src = (unsigned long long)k_zero_slot, xh = (unsigned long long)a.x_hi,
+                             xl = (unsigned long long)a.x_lo, wh = (unsigned long long)a.w_hi, wlo = (unsigned long long)a.w_lo;
+    const int H = a.H;
+
+    // weights of (stage, taps [t0, t0 + nt)) -> Wb; piece pw of the 2 * nt * 2 covers one (split, tap, khalf) plane
+    auto dma_w = [&](int st, int t0, int nt, unsigned char *Wb, int j) {
+        const int pw = wave + 4 * j, per = 2 * nt;
+        const int split = pw / per, rem = pw - split * per;
+        const unsigned long long src = (split ? wlo : wh) + ((unsigned long long)st * WSL + (t0 * 2 + rem) * 512 + lane * 8) * 2;
+        glds16(src, lds0 + (unsigned)(Wb - smem) + split * W_SPLIT + rem * 1024);
+    };
+    // patch piece k of stage st -> Pb
+    auto dma_p = [&](int st, unsigned char *Pb, int k) {
+        const int pp = wave + 4 * k;
+        if (pp < P_PIECES) {
+            const int cb = st / CV_KH, kh = st - cb * CV_KH, hx0 = h0 + kh - 2;
+            const bool v0 = hx0 >= 0 && hx0 < H, v1 = hx0 + 1 >= 0 && hx0 + 1 < H;
+            const long long st_off = (((long long)b * H + hx0) * CV_PITCH * 64 + cb * 16) * 2;
+            const unsigned long long base_h = xh + st_off, base_l = xl + st_off;
+            const int d = desc[k];
+            const bool ok = d >= 0 && ((d & (1 << 29)) ? v1 : v0);
+            unsigned long long src = ((d & (1 << 30)) ? base_l : base_h) + (unsigned)(d & 0xFFFFF);
+            src = ok ? src : zero_src;
+            glds16(src, lds0 + (unsigned)(Pb - smem) + pp * 1024);
+        }
+    };
+
+    // prologue: taps 0..6 of stage 0 and its patch
+#pragma unroll
+    for (int j = 0; j < 7; ++j) dma_w(0, 0, 7, W0, j);
+#pragma unroll
+    for (int k = 0; k < PPW; ++k) dma_p(0, P0, k);
+    DMA_WAIT();
+    __syncthreads();
+
+#pragma unroll 1
+    for (int s = 0; s < N_STAGE; ++s) {
+        unsigned char *const Pc = P0 + (s & 1) * P_BYTES, *const Pn = P0 + ((s + 1) & 1) * P_BYTES;
+        const bool more = s + 1 < N_STAGE;
+        const unsigned char *b_p = Pc + (row * 2 + half) * PLANE + (c * 6 * 32 + l32) * 16;      // + split*4*PLANE + (t*32 + kw*T)*16
+        const unsigned char *bm_p = Pc + (row * 2 + half) * PLANE + (5 * 32 + l32) * 16;         // middle tile
+        // fragments of one tap, double buffered (FA: a0h a0l a1h a1l; FBH/FBL: tiles 0..4 + the middle tile)
+        half8 FA[2][4], FBH[2][6], FBL[2][6];
+        // read r (0..15) of the tap (weights buffer Wb, local tap tl, kernel column kw) into fragment set f
+        auto rd = [&](int f, const unsigned char *Wb, int tl, int kw, int r) {
+            if (r < 4) {
+                const int ch = (r >> 1) ? (c ^ 1) : c;
+                FA[f][r] = *reinterpret_cast<const half8 *>(Wb + (r & 1) * W_SPLIT + (tl * 2 + half) * 1024 + (ch * 32 + l32) * 16);
+            } else {
+                const int tile = (r - 4) >> 1, lo = (r - 4) & 1;
+                const unsigned char *p = (tile < 5 ? b_p + tile * 32 * 16 : bm_p) + lo * 4 * PLANE + kw * T * 16;
+                if (lo) FBL[f][tile] = *reinterpret_cast<const half8 *>(p);
+                else FBH[f][tile] = *reinterpret_cast<const half8 *>(p);
+            }
+        };
+        // MFMA i (0..32) of the tap: term (lo*hi, hi*lo, hi*hi) x 11 accumulators, so that one accumulator is touched
+        // every 11th instruction
+        auto mma = [&](int f, int i) {
+            const int term = i / 11, u = i - term * 11;
+            const int tile = u < 10 ? (u >> 1) : 5, j = u < 10 ? (u & 1) : 0;
+            const half8 av = FA[f][2 * j + (term == 0 ? 1 : 0)];
+            const half8 bv = term == 1 ? FBL[f][tile] : FBH[f][tile];
+            acc[u] = mfma16(av, bv, acc[u]);
+        };
+        // One tap: 33 MFMAs on set f, the next tap's 16 fragment reads into set f^1 (r_lo..15; r_lo = 4 skips the
+        // weights, 16 skips everything), one read after every second MFMA, and two DMA slots.  The wave issues in
+        // order, so anything clustered between MFMA groups is a matrix-pipe bubble: the interleave is pinned.
+#define DMA_TAP(F, WB, TLN, KWN, R_LO, SLOT_A, SLOT_B)                                           \
+    {                                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        _Pragma("unroll") for (int i = 0; i < 16; ++i) mma(F, i);                                \
+        _Pragma("unroll") for (int r = 0; r < 8; ++r) if (r >= (R_LO)) rd((F) ^ 1, WB, TLN, KWN, r); \
+        _Pragma("unroll") for (int g = 0; g < 8; ++g) {                                          \
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                   \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                   \
+        }                                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        SLOT_A;                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        _Pragma("unroll") for (int i = 16; i < 33; ++i) mma(F, i);                               \
+        _Pragma("unroll") for (int r = 8; r < 16; ++r) if (r >= (R_LO)) rd((F) ^ 1, WB, TLN, KWN, r); \
+        _Pragma("unroll") for (int g = 0; g < 8; ++g) {                                          \
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                   \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                   \
+        }                                                                                        \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        SLOT_B;                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+    }
+#ifdef EXP_NO_DMA
+#define DMA_SLOT_A(J) (void)0
+#define DMA_SLOT_B(J) (void)0
+#else
+        // phase A slots: 6 weight pieces (this stage's taps 7..12 -> W1), then patch pieces 0..7 of the next stage
+#define DMA_SLOT_A(J) { if ((J) < 6) dma_w(s, 7, 6, W1, (J)); else if (more) dma_p(s + 1, Pn, (J) - 6); }
+        // phase B slots: 7 weight pieces (next stage's taps 0..6 -> W0), then the remaining patch pieces
+#define DMA_SLOT_B(J) { if (more) { if ((J) < 7) dma_w(s + 1, 0, 7, W0, (J)); else if ((J) + 1 < PPW) dma_p(s + 1, Pn, (J) + 1); } }
+#endif
+
+        // ---- phase A: taps 0..6 from W0
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rd(0, W0, 0, 0, r);
+#pragma unroll
+        for (int t = 0; t < 7; ++t) {
+            if (t < 6) DMA_TAP(t & 1, W0, t + 1, t + 1, 0, DMA_SLOT_A(2 * t), DMA_SLOT_A(2 * t + 1))
+            else DMA_TAP(t & 1, W0, 0, 7, 4, DMA_SLOT_A(2 * t), DMA_SLOT_A(2 * t + 1))     // tap 7's patch fragments only
+        }
+        DMA_WAIT();                            // this wave's pieces landed ...
+        __syncthreads();                       // ... and everyone's did
+        // ---- phase B: taps 7..12 from W1 (fragment set 1 holds tap 7's patch fragments)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rd(1, W1, 0, 7, r);
+#pragma unroll
+        for (int t = 0; t < 6; ++t) {
+            if (t < 5) DMA_TAP((t + 1) & 1, W1, t + 1, 8 + t, 0, DMA_SLOT_B(2 * t), DMA_SLOT_B(2 * t + 1))
+            else DMA_TAP((t + 1) & 1, W1, 0, 0, 16, DMA_SLOT_B(2 * t), DMA_SLOT_B(2 * t + 1))
+        }
+        DMA_WAIT();
+        __syncthreads();
+#undef DMA_TAP
+#undef DMA_SLOT_A
+#undef DMA_SLOT_B
+    }
+    conv_f16_epilogue<OUTMODE>(acc, a, smem, b, h0, row, c, lane);
+}
+
+template <int T, int OUTMODE>
+static int launch_f16_dma(const ConvF16Args &a, int B, hipStream_t st)
+{
+    constexpr int PWP = CV_PITCH + 12 * T;
+    constexpr size_t lds = 2 * (2 * 7 * 2048) + 2 * (size_t)((8 * PWP + 63) / 64) * 1024;
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void *)conv_f16x3_dma_kernel<T, OUTMODE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess)
+            return MX_ERR_LAUNCH;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((conv_f16x3_dma_kernel<T, OUTMODE>), dim3(a.H / 2, B), dim3(256), lds, st, a);
+    return mx_launch_status();
 }
 
 template <int T, int OUTMODE>
@@ -338,15 +587,15 @@ static int launch_f16(const ConvF16Args &a, int B, hipStream_t st)
 static int dispatch_f16(int T, int outmode, const ConvF16Args &a, int B, hipStream_t st)
 {
     if (outmode == 0) {
-        if (T == 1) return launch_f16<1, 0>(a, B, st);
-        if (T == 2) return launch_f16<2, 0>(a, B, st);
-        if (T == 4) return launch_f16<4, 0>(a, B, st);
+        if (T == 1) return launch_f16_dma<1, 0>(a, B, st);
+        if (T == 2) return launch_f16_dma<2, 0>(a, B, st);
+        if (T == 4) return launch_f16_dma<4, 0>(a, B, st);
         if (T == 8) return launch_f16<8, 0>(a, B, st);
         if (T == 16) return launch_f16<16, 0>(a, B, st);
     } else {
-        if (T == 1) return launch_f16<1, 1>(a, B, st);
-        if (T == 2) return launch_f16<2, 1>(a, B, st);
-        if (T == 4) return launch_f16<4, 1>(a, B, st);
+        if (T == 1) return launch_f16_dma<1, 1>(a, B, st);
+        if (T == 2) return launch_f16_dma<2, 1>(a, B, st);
+        if (T == 4) return launch_f16_dma<4, 1>(a, B, st);
         if (T == 8) return launch_f16<8, 1>(a, B, st);
         if (T == 16) return launch_f16<16, 1>(a, B, st);
     }
