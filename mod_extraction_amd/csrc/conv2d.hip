@@ -202,6 +202,11 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(ConvArgs a)
         // 4 w-tiles at a time (2 co tiles x 4 x 16 regs x 64 lanes x 4 B = 32 KB, fits the staging LDS)
         float *xch = lds;
         const int hp = h0 >> 1, Hp = a.H >> 1;
+        // this lane's 16 bias values, fetched before the store loop (a load between stores would make every
+        // iteration wait for the previous stores: vmcnt retires in order)
+        float bias_r[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bias_r[r] = a.bias[mt * 32 + mfma_row(r, lane)];
 #pragma unroll
         for (int c0 = 0; c0 < CV_WT; c0 += 4) {
             __syncthreads();
@@ -222,7 +227,7 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(ConvArgs a)
                         const float top = acc[i][r];
                         const float bot = xch[((mt * 4 + (i - c0)) * 16 + r) * 64 + lane];
                         const bool take_bot = bot > top;                 // ties keep the first row (torch)
-                        const float m = (take_bot ? bot : top) + a.bias[co];
+                        const float m = (take_bot ? bot : top) + bias_r[r];
                         const size_t off = (((size_t)b * CV_CO + co) * Hp + hp) * CV_PITCH + w;
                         a.out[off] = w < a.Wv ? m : 0.0f;
                         a.out_amax[off] = take_bot ? 1 : 0;

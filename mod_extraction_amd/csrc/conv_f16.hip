@@ -172,35 +172,48 @@ __device__ __forceinline__ void conv_f16_epilogue(floatx16 (&acc)[CV_WT], const 
             }
         }
     } else {
+        // The two waves of a column half hold the two rows of the pooling pair.  They swap halves of their
+        // accumulators through LDS (row 1 hands over tiles 0..5, row 0 tiles 6..10: one barrier) and each pools,
+        // adds the bias and stores its half -- both rows' waves share the store work.
         float *xch = reinterpret_cast<float *>(smem);
+        float *reg_a = xch + c * (6 * 16 * 64);                       // row 1 -> row 0: accumulators 0..5
+        float *reg_b = xch + 2 * (6 * 16 * 64) + c * (5 * 16 * 64);   // row 0 -> row 1: accumulators 6..10
         const int hp = h0 >> 1, Hp = a.H >> 1;
+        // bias of this lane's 2 x 16 output channels, fetched BEFORE the store loop: a load between stores makes
+        // every iteration wait (vmcnt is in order) for the previous iteration's stores to be acknowledged
+        float bias_r[2][16];
 #pragma unroll
-        for (int c0 = 0; c0 < CV_WT; c0 += 4) {
-            __syncthreads();
-            if (row == 1) {
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int i = c0; i < c0 + 4 && i < CV_WT; ++i)
+            for (int r = 0; r < 16; ++r) bias_r[j][r] = a.bias[j * 32 + mfma_row(r, lane)];
+        __syncthreads();                                              // the K loop's LDS images are dead
+        if (row == 1) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) xch[((c * 4 + (i - c0)) * 16 + r) * 64 + lane] = acc[i][r];
-            }
-            __syncthreads();
-            if (row == 0) {
+            for (int i = 0; i < 6; ++i)
 #pragma unroll
-                for (int i = c0; i < c0 + 4 && i < CV_WT; ++i) {
-                    const int w = (i == 10 ? 5 : c * 6 + (i >> 1)) * 32 + l32;
-                    const int cb0 = (i == 10 ? c : (i & 1) ^ c) * 32;
+                for (int r = 0; r < 16; ++r) reg_a[(i * 16 + r) * 64 + lane] = acc[i][r];
+        } else {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int co = cb0 + mfma_row(r, lane);
-                        const float top = acc[i][r];
-                        const float bot = xch[((c * 4 + (i - c0)) * 16 + r) * 64 + lane];
-                        const bool take_bot = bot > top;                 // ties keep the first row (torch)
-                        const float m = (take_bot ? bot : top) * inv + a.bias[co];
-                        const size_t off = (((size_t)b * CV_CO + co) * Hp + hp) * CV_PITCH + w;
-                        a.out[off] = w < a.Wv ? m : 0.0f;
-                        a.out_amax[off] = take_bot ? 1 : 0;
-                    }
-                }
+            for (int i = 6; i < CV_WT; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) reg_b[((i - 6) * 16 + r) * 64 + lane] = acc[i][r];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < CV_WT; ++i) {
+            if ((i < 6) != (row == 0)) continue;                      // row 0 finishes 0..5, row 1 finishes 6..10
+            const int w = (i == 10 ? 5 : c * 6 + (i >> 1)) * 32 + l32;
+            const int chh = i == 10 ? c : (i & 1) ^ c, cb0 = chh * 32;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = cb0 + mfma_row(r, lane);
+                const float other = i < 6 ? reg_a[(i * 16 + r) * 64 + lane] : reg_b[((i - 6) * 16 + r) * 64 + lane];
+                const float top = i < 6 ? acc[i][r] : other, bot = i < 6 ? other : acc[i][r];
+                const bool take_bot = bot > top;                      // ties keep the first row (torch)
+                const float m = (take_bot ? bot : top) * inv + (chh ? bias_r[1][r] : bias_r[0][r]);
+                const size_t off = (((size_t)b * CV_CO + co) * Hp + hp) * CV_PITCH + w;
+                a.out[off] = w < a.Wv ? m : 0.0f;
+                a.out_amax[off] = take_bot ? 1 : 0;
             }
         }
     }
