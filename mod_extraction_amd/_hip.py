@@ -10,7 +10,8 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "_lib", "libmodex_hip.so")
+# MODEX_HIP_LIB: load another build of the same library (kernel experiments); there is no non-HIP fallback
+SO_PATH = os.environ.get("MODEX_HIP_LIB") or os.path.join(_HERE, "_lib", "libmodex_hip.so")
 ABI_VERSION = 1
 
 _ERR = {-1: "MX_ERR_ARG (bad argument)", -2: "MX_ERR_UNSUPPORTED (size not supported)",

@@ -17,8 +17,10 @@
 #include "common.h"
 
 #define PH_BLOCK 256
-#define PH_WPB 2          // clips (wavefronts) per workgroup: packs the long-running serial chains onto few CUs so
+#ifndef PH_WPB
+#define PH_WPB 4          // clips (wavefronts) per workgroup: packs the long-running serial chains onto few CUs so
                           // that the 1-workgroup-per-CU matrix kernels of the train step keep the other CUs
+#endif
 
 template <bool FAST>
 __global__ __launch_bounds__(64 * PH_WPB) void phaser_kernel(const float *__restrict__ x, long long x_stride,

@@ -146,6 +146,10 @@ class _CNNStack(torch.autograd.Function):
         st = _hip.stream()
         cur, slope = logmel, None
         saved: List[T] = []
+        # the fp16 operand pairs of the 64-channel blocks are kept for the weight gradient when a backward pass
+        # will follow (5.9 GB at 256 clips x 2 s: cheaper than re-deriving them from the saved activations)
+        keep_splits = any(ctx.needs_input_grad)
+        ctx.splits = {}
         for l in range(n_blocks):
             w, b, a = params[3 * l], params[3 * l + 1], params[3 * l + 2]
             stats = torch.empty((B, cin, 2), device=dev, dtype=torch.float32)
@@ -161,6 +165,8 @@ class _CNNStack(torch.autograd.Function):
                 w_hi, w_lo = _pack_f16(w, 0)
                 _hip.call("mx_conv_block_fwd_f16", _hip.ptr(x_hi), _hip.ptr(x_lo), _hip.ptr(w_hi), _hip.ptr(w_lo),
                           _hip.ptr(b.contiguous()), B, H, n_frames, int(dilations[l]), _hip.ptr(p), _hip.ptr(amax), st)
+                if keep_splits:
+                    ctx.splits[l] = (x_hi, x_lo)
                 del x_hi, x_lo
             else:
                 wt = _pack(w, 0)
@@ -231,10 +237,13 @@ class _CNNStack(torch.autograd.Function):
                 scale = torch.empty(2, device=dev, dtype=torch.float32)
                 _hip.call("mx_conv_prep_dgrad_f16", _hip.ptr(G), _hip.ptr(amax), B, H, n_frames, _hip.ptr(ws),
                           _hip.ptr(scale), _hip.ptr(dz_hi), _hip.ptr(dz_lo), st)
-                x_hi = torch.empty((B, H, PITCH, 64), device=dev, dtype=torch.float16)
-                x_lo = torch.empty((B, H, PITCH, 64), device=dev, dtype=torch.float16)
-                _hip.call("mx_conv_prep_fwd_f16", _hip.ptr(x_in), _hip.ptr(stats), _hip.ptr(slope_prev), B, H, n_frames,
-                          _hip.ptr(x_hi), _hip.ptr(x_lo), st)
+                if l in ctx.splits:
+                    x_hi, x_lo = ctx.splits.pop(l)
+                else:
+                    x_hi = torch.empty((B, H, PITCH, 64), device=dev, dtype=torch.float16)
+                    x_lo = torch.empty((B, H, PITCH, 64), device=dev, dtype=torch.float16)
+                    _hip.call("mx_conv_prep_fwd_f16", _hip.ptr(x_in), _hip.ptr(stats), _hip.ptr(slope_prev), B, H,
+                              n_frames, _hip.ptr(x_hi), _hip.ptr(x_lo), st)
                 rps = max(1, -(-rows // 408))            # ~408 slabs x 5 kernel rows = 8 workgroups per CU
                 n_slabs = -(-rows // rps)
                 part = torch.empty(n_slabs * 65 * 64 * 64, device=dev, dtype=torch.float32)
