@@ -120,7 +120,7 @@ int mx_conv_block_dgrad(const float *G, const uint8_t *amax, const float *wt_fli
  * rate).  Same reference semantics as mx_conv_block_fwd / mx_conv_block_dgrad (models.py:183-195) for the
  * 64->64 channel blocks.  Operands are prepared once per layer as channels-last fp16 pairs:
  *   w_hi, w_lo : 4*5*13*64*16 halfs each ([ci/16][kh][kw][co][16], weights * 256; flip = 1 for the data gradient)
- *   x_hi, x_lo : (B, H, 352, 64) halfs: forward = split of (prelu(x) - mean) * rstd;
+ *   x_hi, x_lo : (B, H, 4, 352, 16) halfs (channel-block major): forward = split of (prelu(x) - mean) * rstd;
  *                dgrad = split of the max-pool routed gradient * S_dz, S_dz = 2^k chosen from max|G|
  *                (scale (2,) device floats receives {S_dz, 1/S_dz}; amax_ws = one uint32 workspace). */
 int mx_conv_pack_weights_f16(const float *W, int32_t flip, void *w_hi, void *w_lo, void *stream);

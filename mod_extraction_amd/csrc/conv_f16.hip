@@ -12,8 +12,12 @@
 // Three MFMAs per fp32 MAC group = 5.3x the fp32-MFMA rate.
 //
 // Operands are prepared once per layer by streaming kernels in channels-last fp16 pairs
-//   X_hi, X_lo : (B, H, 352, 64)   forward: (prelu(p_prev) - mean) * rstd        (S = 1)
-//                                  dgrad  : max-pool routed gradient * S_dz      (S_dz = 2^k from max|G|)
+//   X_hi, X_lo : (B, H, 4, 352, 16)  forward: (prelu(p_prev) - mean) * rstd        (S = 1)
+//                                    dgrad  : max-pool routed gradient * S_dz      (S_dz = 2^k from max|G|)
+//                channel-block major: a K stage consumes ONE 16-channel block of a row, which is then a contiguous
+//                11 KB run of full cache lines (with the 64 channels of a position adjacent, every stage would touch
+//                a quarter of each line of the row and the row would be pulled from HBM once per block: measured 16x
+//                the algorithmic traffic)
 //   W_hi, W_lo : [ci/16][kh][kw][co][16]  weights * 256
 // so that the conv kernel stages plain 16-byte vectors and every MFMA fragment (8 consecutive channels of
 // one position / one output channel) is ONE aligned ds_read_b128.
@@ -64,8 +68,8 @@ __global__ void pow2_scale_kernel(const unsigned *__restrict__ amax_bits, float 
 }
 
 // NCHW fp32 planes -> channels-last fp16 pairs.  One workgroup per (b, h, 32-column tile): 64 channels x
-// 32 columns are read along w (coalesced), transformed, transposed through LDS and written as 128-byte
-// channel vectors per position.  MODE 0: xhat = (prelu(x) - mean) * rstd.  MODE 1: dz = routed G * S.
+// 32 columns are read along w (coalesced), transformed, transposed through LDS and written as 16-byte
+// vectors of 8 channels into the (B, H, 4, 352, 16) operand (1 KB contiguous per channel block).  MODE 0: xhat = (prelu(x) - mean) * rstd.  MODE 1: dz = routed G * S.
 template <int MODE>
 __global__ __launch_bounds__(256) void split_prep_kernel(const float *__restrict__ x,
                                                          const unsigned char *__restrict__ amax,
@@ -112,7 +116,7 @@ __global__ __launch_bounds__(256) void split_prep_kernel(const float *__restrict
         hi[j] = hh;
         lo[j] = (_Float16)(v - (float)hh);
     }
-    const size_t o = ((((size_t)b * H + h) * CV_PITCH + wt * 32 + pos) * 64 + cg * 8);
+    const size_t o = ((((size_t)b * H + h) * 4 + (cg >> 1)) * CV_PITCH + wt * 32 + pos) * 16 + (cg & 1) * 8;
     *reinterpret_cast<half8 *>(out_hi + o) = hi;
     *reinterpret_cast<half8 *>(out_lo + o) = lo;
 }
@@ -140,7 +144,7 @@ __global__ void pack_weights_f16_kernel(const float *__restrict__ W, int flip, _
 
 // ---- the convolution ------------------------------------------------------------------------------------
 struct ConvF16Args {
-    const _Float16 *x_hi, *x_lo;   // (B, H, 352, 64)
+    const _Float16 *x_hi, *x_lo;   // (B, H, 4, 352, 16)
     const _Float16 *w_hi, *w_lo;   // [4][5][13][2][64][8]
     const float *bias;             // forward: (64,)
     const float *scale;            // dgrad: {S_dz, 1/S_dz} on the device; forward: nullptr
@@ -242,7 +246,15 @@ __global__ __launch_bounds__(256, 1) void conv_f16x3_kernel(ConvF16Args a)
     // read pipe, shared by the four waves, was the co-limiter of the first version.
     //   acc[2t + j], t < 5 : column tile c*6 + t, channel half j ^ c;      acc[10] : column tile 5, channel half c
     const int row = wave >> 1, c = wave & 1, half = lane >> 5, l32 = lane & 31;
-    const int b = blockIdx.y, h0 = blockIdx.x * 2;
+    // Workgroups go to the 8 XCDs round-robin in launch order: hand every XCD a CONTIGUOUS range of (clip, row pair)
+    // tiles, so that the workgroups running together on one XCD are neighbouring row pairs of the same clips and
+    // share their halo rows and weight stages in that XCD's L2 (speed only; any mapping is correct).
+    int tile_id = blockIdx.y * gridDim.x + blockIdx.x;
+    {
+        const int n_tiles = gridDim.x * gridDim.y;
+        if ((n_tiles & 7) == 0) tile_id = (tile_id & 7) * (n_tiles >> 3) + (tile_id >> 3);
+    }
+    const int b = tile_id / gridDim.x, h0 = (tile_id - b * gridDim.x) * 2;
 
     floatx16 acc[CV_WT];
 #pragma unroll
@@ -273,7 +285,7 @@ __global__ __launch_bounds__(256, 1) void conv_f16x3_kernel(ConvF16Args a)
                 const int hx = h0 + r + kh - 2, w = pos - 6 * T;
                 if (hx >= 0 && hx < a.H && w >= 0 && w < CV_PITCH) {
                     const _Float16 *src = (split ? a.x_lo : a.x_hi) +
-                                          ((((size_t)b * a.H + hx) * CV_PITCH + w) * 64 + cb * 16 + part * 8);
+                                          ((((size_t)b * a.H + hx) * 4 + cb) * CV_PITCH + w) * 16 + part * 8;
                     pv[q] = *reinterpret_cast<const floatx4 *>(src);
                 }
             }
@@ -408,7 +420,7 @@ __global__ __launch_bounds__(256, 1) void conv_f16x3_dma_kernel(ConvF16Args a)
     constexpr int PPW = (P_PIECES + 3) / 4;           // patch pieces per wave (12..13)
     constexpr int W_SPLIT = 7 * 2048;                 // bytes per split inside a weight buffer
     constexpr int W_BYTES = 2 * W_SPLIT;
-    constexpr int ROWB = CV_PITCH * 128;              // bytes of one operand row (352 positions x 64 halfs)
+    constexpr int ROWB = 4 * CV_PITCH * 32;           // bytes of one operand row (4 channel blocks x 352 positions x 16 halfs)
     constexpr int N_STAGE = 4 * CV_KH;
     static_assert(PPW <= 13, "patch pieces per wave");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -417,7 +429,15 @@ __global__ __launch_bounds__(256, 1) void conv_f16x3_dma_kernel(ConvF16Args a)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int row = wave >> 1, c = wave & 1, half = lane >> 5, l32 = lane & 31;
-    const int b = blockIdx.y, h0 = blockIdx.x * 2;
+    // Workgroups go to the 8 XCDs round-robin in launch order: hand every XCD a CONTIGUOUS range of (clip, row pair)
+    // tiles, so that the workgroups running together on one XCD are neighbouring row pairs of the same clips and
+    // share their halo rows and weight stages in that XCD's L2 (speed only; any mapping is correct).
+    int tile_id = blockIdx.y * gridDim.x + blockIdx.x;
+    {
+        const int n_tiles = gridDim.x * gridDim.y;
+        if ((n_tiles & 7) == 0) tile_id = (tile_id & 7) * (n_tiles >> 3) + (tile_id >> 3);
+    }
+    const int b = tile_id / gridDim.x, h0 = (tile_id - b * gridDim.x) * 2;
 
     floatx16 acc[CV_WT];
 #pragma unroll
@@ -433,7 +453,7 @@ __global__ __launch_bounds__(256, 1) void conv_f16x3_dma_kernel(ConvF16Args a)
         const int i = (wave + 4 * k) * 64 + lane;
         const int plane = i / PWP, pos = i - plane * PWP, w = pos - 6 * T;
         const int split = plane >> 2, r = (plane >> 1) & 1, part = plane & 1;
-        desc[k] = (i < P_SLOTS && w >= 0 && w < CV_PITCH) ? ((split << 30) | (r << 29) | (r * ROWB + w * 128 + part * 16)) : -1;
+        desc[k] = (i < P_SLOTS && w >= 0 && w < CV_PITCH) ? ((split << 30) | (r << 29) | (r * ROWB + w * 32 + part * 16)) : -1;
     }
     // plain integer addresses (selecting between kernel-argument FIELDS per lane would make the compiler load the
     // pointer through memory and wait for it -- and with it for every DMA in flight)
@@ -454,7 +474,7 @@ __global__ __launch_bounds__(256, 1) void conv_f16x3_dma_kernel(ConvF16Args a)
         if (pp < P_PIECES) {
             const int cb = st / CV_KH, kh = st - cb * CV_KH, hx0 = h0 + kh - 2;
             const bool v0 = hx0 >= 0 && hx0 < H, v1 = hx0 + 1 >= 0 && hx0 + 1 < H;
-            const long long st_off = (((long long)b * H + hx0) * CV_PITCH * 64 + cb * 16) * 2;
+            const long long st_off = (((long long)b * H + hx0) * 4 + cb) * (CV_PITCH * 32);
             const unsigned long long base_h = xh + st_off, base_l = xl + st_off;
             const int d = desc[k];
             const bool ok = d >= 0 && ((d & (1 << 29)) ? v1 : v0);
@@ -626,7 +646,7 @@ MX_EXPORT int mx_conv_pack_weights_f16(const float *W, int32_t flip, void *w_hi,
 }
 
 // forward operand: x (B,64,H,352) previous block's pooled pre-activations, stats (B,64,2), slope (64,)
-// -> x_hi, x_lo (B,H,352,64) fp16 = split of (prelu(x) - mean) * rstd
+// -> x_hi, x_lo (B,H,4,352,16) fp16 = split of (prelu(x) - mean) * rstd
 MX_EXPORT int mx_conv_prep_fwd_f16(const float *x, const float *stats, const float *slope, int64_t B, int64_t H,
                                    int64_t Wv, void *x_hi, void *x_lo, void *stream)
 {
@@ -638,7 +658,7 @@ MX_EXPORT int mx_conv_prep_fwd_f16(const float *x, const float *stats, const flo
     return mx_launch_status();
 }
 
-// dgrad operand: G, amax (B,64,H/2,352) -> dz_hi, dz_lo (B,H,352,64) fp16 = split of routed G * S_dz;
+// dgrad operand: G, amax (B,64,H/2,352) -> dz_hi, dz_lo (B,H,4,352,16) fp16 = split of routed G * S_dz;
 // scale (2,) device floats receives {S_dz, 1/S_dz} (S_dz = power of two from max|G|); amax_ws: 1 uint workspace
 MX_EXPORT int mx_conv_prep_dgrad_f16(const float *G, const uint8_t *amax, int64_t B, int64_t H, int64_t Wv,
                                      uint32_t *amax_ws, float *scale, void *dz_hi, void *dz_lo, void *stream)

@@ -5,7 +5,7 @@
 //
 // Operands are the channels-last fp16 pairs the f16x3 path prepares anyway: dz_hi/lo (the routed, scaled
 // gradient, shared with the data-gradient kernel) and x_hi/x_lo (the normalised block input), both
-// (B, H, 352, 64).  GEMM view per kernel row kh: D[co][ci] (13 taps) += A[co][k] * B[k][ci] with k = position.
+// (B, H, 4, 352, 16) -- channel-block major, see conv_f16.hip.  GEMM view per kernel row kh: D[co][ci] (13 taps) += A[co][k] * B[k][ci] with k = position.
 // The MFMA wants 8 consecutive k per lane, i.e. 8 consecutive POSITIONS of one channel, while memory and LDS
 // hold 64 consecutive CHANNELS per position: the fragments are fetched with ds_read_b64_tr_b16 (gfx950's
 // transposing LDS read: a 16-lane group reads 4 rows x 16 columns of halfs and each lane receives one column),
@@ -34,8 +34,8 @@ __device__ __forceinline__ floatx16 mfma16w(half8 a, half8 b, floatx16 c)
 #define WF_KS (WF_CH / 16)
 
 struct WgradF16Args {
-    const _Float16 *dz_hi, *dz_lo;     // (B, H, 352, 64)
-    const _Float16 *x_hi, *x_lo;       // (B, H, 352, 64)
+    const _Float16 *dz_hi, *dz_lo;     // (B, H, 4, 352, 16)
+    const _Float16 *x_hi, *x_lo;       // (B, H, 4, 352, 16)
     float *part;                       // (n_slabs, 5, 13, 64, 64)
     int B, H, rows_per_slab, n_slabs;
 };
@@ -122,14 +122,16 @@ __global__ __launch_bounds__(256, 1) void wgrad_f16x3_kernel(WgradF16Args a)
         floatx4 z = {0.f, 0.f, 0.f, 0.f};
         if (i < NDZ) {
             const int v = i & 7, pos = (i >> 3) % WF_CH, split = (i >> 3) / WF_CH;
-            const _Float16 *src = (split ? a.dz_lo : a.dz_hi) + ((((size_t)b * a.H + h) * CV_PITCH + w0 + pos) * 64 + v * 8);
+            const _Float16 *src = (split ? a.dz_lo : a.dz_hi) +
+                                  ((((size_t)b * a.H + h) * 4 + (v >> 1)) * CV_PITCH + w0 + pos) * 16 + (v & 1) * 8;
             return *reinterpret_cast<const floatx4 *>(src);
         } else if (i < NDZ + NX) {
             const int k = i - NDZ;
             const int v = k & 7, pos = (k >> 3) % WIN, split = (k >> 3) / WIN;
             const int w = w0 - 6 * T + pos, hx = h + kh - 2;
             if (w >= 0 && w < CV_PITCH) {
-                const _Float16 *src = (split ? a.x_lo : a.x_hi) + ((((size_t)b * a.H + hx) * CV_PITCH + w) * 64 + v * 8);
+                const _Float16 *src = (split ? a.x_lo : a.x_hi) +
+                                      ((((size_t)b * a.H + hx) * 4 + (v >> 1)) * CV_PITCH + w) * 16 + (v & 1) * 8;
                 return *reinterpret_cast<const floatx4 *>(src);
             }
         }
@@ -283,7 +285,7 @@ static int launch_wgrad_f16(const WgradF16Args &a, hipStream_t st)
     return mx_launch_status();
 }
 
-// dz_hi/lo, x_hi/lo: (B,H,352,64) fp16 pairs from mx_conv_prep_dgrad_f16 / mx_conv_prep_fwd_f16 of the same block;
+// dz_hi/lo, x_hi/lo: (B,H,4,352,16) fp16 pairs from mx_conv_prep_dgrad_f16 / mx_conv_prep_fwd_f16 of the same block;
 // scale: the {S_dz, 1/S_dz} pair; part: workspace of ceil(B*H/rows_per_slab)*65*64*64 floats; dW (64,64,5,13).
 MX_EXPORT int mx_conv_block_wgrad_f16(const void *dz_hi, const void *dz_lo, const void *x_hi, const void *x_lo,
                                       const float *scale, int64_t B, int64_t H, int32_t dilation,

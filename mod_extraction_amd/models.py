@@ -158,8 +158,8 @@ class _CNNStack(torch.autograd.Function):
             p = torch.empty((B, 64, H // 2, PITCH), device=dev, dtype=torch.float32)
             amax = torch.empty((B, 64, H // 2, PITCH), device=dev, dtype=torch.uint8)
             if _use_f16(cin, precision):
-                x_hi = torch.empty((B, H, PITCH, 64), device=dev, dtype=torch.float16)
-                x_lo = torch.empty((B, H, PITCH, 64), device=dev, dtype=torch.float16)
+                x_hi = torch.empty((B, H, 4, PITCH, 16), device=dev, dtype=torch.float16)
+                x_lo = torch.empty((B, H, 4, PITCH, 16), device=dev, dtype=torch.float16)
                 _hip.call("mx_conv_prep_fwd_f16", _hip.ptr(cur), _hip.ptr(stats), _hip.ptr(slope), B, H, n_frames,
                           _hip.ptr(x_hi), _hip.ptr(x_lo), st)
                 w_hi, w_lo = _pack_f16(w, 0)
@@ -231,8 +231,8 @@ class _CNNStack(torch.autograd.Function):
             f16 = _use_f16(cin, precision)
             dW = torch.empty_like(w)
             if f16:
-                dz_hi = torch.empty((B, H, PITCH, 64), device=dev, dtype=torch.float16)
-                dz_lo = torch.empty((B, H, PITCH, 64), device=dev, dtype=torch.float16)
+                dz_hi = torch.empty((B, H, 4, PITCH, 16), device=dev, dtype=torch.float16)
+                dz_lo = torch.empty((B, H, 4, PITCH, 16), device=dev, dtype=torch.float16)
                 ws = torch.empty(1, device=dev, dtype=torch.int32)
                 scale = torch.empty(2, device=dev, dtype=torch.float32)
                 _hip.call("mx_conv_prep_dgrad_f16", _hip.ptr(G), _hip.ptr(amax), B, H, n_frames, _hip.ptr(ws),
@@ -240,8 +240,8 @@ class _CNNStack(torch.autograd.Function):
                 if l in ctx.splits:
                     x_hi, x_lo = ctx.splits.pop(l)
                 else:
-                    x_hi = torch.empty((B, H, PITCH, 64), device=dev, dtype=torch.float16)
-                    x_lo = torch.empty((B, H, PITCH, 64), device=dev, dtype=torch.float16)
+                    x_hi = torch.empty((B, H, 4, PITCH, 16), device=dev, dtype=torch.float16)
+                    x_lo = torch.empty((B, H, 4, PITCH, 16), device=dev, dtype=torch.float16)
                     _hip.call("mx_conv_prep_fwd_f16", _hip.ptr(x_in), _hip.ptr(stats), _hip.ptr(slope_prev), B, H,
                               n_frames, _hip.ptr(x_hi), _hip.ptr(x_lo), st)
                 rps = max(1, -(-rows // 408))            # ~408 slabs x 5 kernel rows = 8 workgroups per CU

@@ -38,7 +38,7 @@ def run(B=64):
         name = os.path.basename(so)[4:-3]
         for (H, T) in ((128, 1), (64, 1), (32, 2)):
             g = torch.Generator(device="cpu").manual_seed(0)
-            x = torch.randn((B, H, 352, 64), generator=g).to(dev)
+            x = torch.randn((B, H, 4, 352, 16), generator=g).to(dev)
             x_hi = x.half()
             x_lo = (x - x_hi.float()).half()
             w = (torch.randn((4 * 5 * 13 * 64 * 16,), generator=g) * 8).to(dev)
