@@ -27,7 +27,12 @@ typedef short short4v __attribute__((__vector_size__(4 * sizeof(short))));
 
 __device__ __forceinline__ floatx16 mfma16w(half8 a, half8 b, floatx16 c)
 {
+#ifdef EXP_W_NOMMA
+    c[0] += (float)a[0] + (float)b[1];
+    return c;
+#else
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+#endif
 }
 
 #define WF_CH 176                      // positions per chunk (352 = 2 x 176, 11 k-steps of 16)
@@ -62,27 +67,24 @@ __device__ __forceinline__ TrLane tr_lane_offsets(int tile, int lane)
 // img_bytes: LDS byte address of the image; r0 = first row (wave-uniform); ph = r0 & 3 (compile-time where r0 is)
 __device__ __forceinline__ half8 tr_frag(const unsigned char *img_bytes, int lane_off, int r0)
 {
-    half8 out;
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const unsigned char *ptr = img_bytes + lane_off + r0 * 128 + t * 512;
-        short4v v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4v __attribute__((address_space(3))) *)ptr);
-        union { short4v s; _Float16 h[4]; } u;
-        u.s = v;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) out[4 * t + j] = u.h[j];
-    }
-    return out;
+    const unsigned char *ptr = img_bytes + lane_off + r0 * 128;
+    const short4v v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4v __attribute__((address_space(3))) *)ptr);
+    const short4v v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4v __attribute__((address_space(3))) *)(ptr + 512));
+    // pure register naming: the two 64-bit results are the low and high half of the fragment
+    typedef short short8v __attribute__((__vector_size__(8 * sizeof(short))));
+    const short8v both = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(half8, both);
 }
 
 template <int T>
 __global__ __launch_bounds__(256, 1) void wgrad_f16x3_kernel(WgradF16Args a)
 {
     constexpr int WIN = WF_CH + 12 * T;                 // staged x positions per chunk (origin at w0 - 6T)
-    constexpr int NDZ = 2 * WF_CH * 8;                  // 16-byte vectors: split x position x 8
-    constexpr int NX = 2 * WIN * 8;
-    constexpr bool PREF = T < 16;                       // T = 16 would need 34 prefetch vectors per thread
-    constexpr int NV = PREF ? (NDZ + NX + 255) / 256 : 1;
+    // staging map: thread = (position pos0 + 32 q, 16-byte vector v of the position's 8); every address below is a
+    // per-thread constant + a compile-time multiple of q, and the swizzle bit of a position is that of pos0
+    constexpr int QDZ = (WF_CH + 31) / 32, QX = (WIN + 31) / 32;       // iterations per split
+    constexpr bool PREF = T < 16;                       // T = 16 would need 36 prefetch vectors per thread
+    constexpr int NV = PREF ? 2 * (QDZ + QX) : 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     _Float16 *dzl = reinterpret_cast<_Float16 *>(smem);               // [split][WF_CH][64]
     _Float16 *xl = dzl + 2 * WF_CH * 64;                               // [split][WIN][64]
@@ -116,37 +118,39 @@ __global__ __launch_bounds__(256, 1) void wgrad_f16x3_kernel(WgradF16Args a)
     };
 
     floatx4 pv[NV];
-    // vector i of a chunk: i < NDZ -> dz (split, pos, v); else x window (split, pos, v)
-    auto load_vec = [&](int i, int rid, int ch) -> floatx4 {
+    const int sv = tid & 7, pos0 = tid >> 3;
+    const int g_thr = ((sv >> 1) * CV_PITCH + pos0) * 16 + (sv & 1) * 8;                 // halfs, within an operand row
+    const int l_thr = pos0 * 128 + ((sv ^ (((pos0 >> 1) & 1) << 2)) * 16);                 // bytes, within an LDS image
+    // vector k of a chunk, k = (kind * 2 + split) * Q + q with kind 0 = dz, 1 = x window
+    auto load_vec = [&](int k, int rid, int ch) -> floatx4 {
         const int b = rid / a.H, h = rid - b * a.H, w0 = ch * WF_CH;
         floatx4 z = {0.f, 0.f, 0.f, 0.f};
-        if (i < NDZ) {
-            const int v = i & 7, pos = (i >> 3) % WF_CH, split = (i >> 3) / WF_CH;
-            const _Float16 *src = (split ? a.dz_lo : a.dz_hi) +
-                                  ((((size_t)b * a.H + h) * 4 + (v >> 1)) * CV_PITCH + w0 + pos) * 16 + (v & 1) * 8;
-            return *reinterpret_cast<const floatx4 *>(src);
-        } else if (i < NDZ + NX) {
-            const int k = i - NDZ;
-            const int v = k & 7, pos = (k >> 3) % WIN, split = (k >> 3) / WIN;
-            const int w = w0 - 6 * T + pos, hx = h + kh - 2;
-            if (w >= 0 && w < CV_PITCH) {
-                const _Float16 *src = (split ? a.x_lo : a.x_hi) +
-                                      ((((size_t)b * a.H + hx) * 4 + (v >> 1)) * CV_PITCH + w) * 16 + (v & 1) * 8;
-                return *reinterpret_cast<const floatx4 *>(src);
+        if (k < 2 * QDZ) {
+            const int split = k / QDZ, q = k - split * QDZ;
+            if (pos0 + 32 * q < WF_CH) {
+                const _Float16 *row = (split ? a.dz_lo : a.dz_hi) + ((size_t)b * a.H + h) * (4 * CV_PITCH * 16) + w0 * 16;
+                return *reinterpret_cast<const floatx4 *>(row + g_thr + q * (32 * 16));
+            }
+        } else {
+            const int kk = k - 2 * QDZ, split = kk / QX, q = kk - split * QX;
+            const int w = w0 - 6 * T + pos0 + 32 * q;
+            if (pos0 + 32 * q < WIN && w >= 0 && w < CV_PITCH) {
+                const _Float16 *row = (split ? a.x_lo : a.x_hi) + ((size_t)b * a.H + (h + kh - 2)) * (4 * CV_PITCH * 16) +
+                                      (w0 - 6 * T) * 16;
+                return *reinterpret_cast<const floatx4 *>(row + g_thr + q * (32 * 16));
             }
         }
         return z;
     };
-    auto store_vec = [&](int i, floatx4 val) {
-        if (i < NDZ) {
-            const int v = i & 7, pos = (i >> 3) % WF_CH, split = (i >> 3) / WF_CH;
-            const int vs = v ^ (((pos >> 1) & 1) << 2);                 // swap the 64-byte halves on rows with bit 1 set
-            *reinterpret_cast<floatx4 *>(dzl + ((size_t)split * WF_CH + pos) * 64 + vs * 8) = val;
-        } else if (i < NDZ + NX) {
-            const int k = i - NDZ;
-            const int v = k & 7, pos = (k >> 3) % WIN, split = (k >> 3) / WIN;
-            const int vs = v ^ (((pos >> 1) & 1) << 2);
-            *reinterpret_cast<floatx4 *>(xl + ((size_t)split * WIN + pos) * 64 + vs * 8) = val;
+    auto store_vec = [&](int k, floatx4 val) {
+        if (k < 2 * QDZ) {
+            const int split = k / QDZ, q = k - split * QDZ;
+            if (pos0 + 32 * q < WF_CH)
+                *reinterpret_cast<floatx4 *>(reinterpret_cast<unsigned char *>(dzl) + split * (WF_CH * 128) + q * 4096 + l_thr) = val;
+        } else {
+            const int kk = k - 2 * QDZ, split = kk / QX, q = kk - split * QX;
+            if (pos0 + 32 * q < WIN)
+                *reinterpret_cast<floatx4 *>(reinterpret_cast<unsigned char *>(xl) + split * (WIN * 128) + q * 4096 + l_thr) = val;
         }
     };
 
@@ -154,7 +158,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_f16x3_kernel(WgradF16Args a)
     while (rid < row_end && !row_valid(rid)) ++rid;
     if (PREF && rid < row_end) {
 #pragma unroll
-        for (int q = 0; q < NV; ++q) pv[q] = load_vec(tid + q * 256, rid, ch);
+        for (int q = 0; q < NV; ++q) pv[q] = load_vec(q, rid, ch);
     }
     const unsigned char *dz_h = reinterpret_cast<const unsigned char *>(dzl);
     const unsigned char *dz_l = dz_h + WF_CH * 128;
@@ -168,79 +172,102 @@ __global__ __launch_bounds__(256, 1) void wgrad_f16x3_kernel(WgradF16Args a)
 #pragma unroll
     for (int j = 0; j < 4; ++j) lbg.off[j] = g ? lb.off[(j + 7 * T) & 3] : lb.off[j];
     const int xg_off = g * 7 * T * 128;
+    const int lag_off = g ? la1.off[0] : la0.off[0];
     while (rid < row_end) {
         __syncthreads();                                // everyone is done reading the previous tiles
+#ifdef EXP_W_NOCOMMIT
+        if (false) {
+#else
         if (PREF) {
+#endif
 #pragma unroll
-            for (int q = 0; q < NV; ++q) store_vec(tid + q * 256, pv[q]);
-        } else {
-            for (int i = tid; i < NDZ + NX; i += 256) store_vec(i, load_vec(i, rid, ch));
+            for (int q = 0; q < NV; ++q) store_vec(q, pv[q]);
+        } else if (!PREF) {
+#pragma unroll 4
+            for (int k = 0; k < 2 * (QDZ + QX); ++k) store_vec(k, load_vec(k, rid, ch));
         }
         int nrid = rid, nch = ch;
         next_iter(nrid, nch);
+#ifndef EXP_W_NOISSUE
         if (PREF && nrid < row_end) {
 #pragma unroll
-            for (int q = 0; q < NV; ++q) pv[q] = load_vec(tid + q * 256, nrid, nch);   // in flight during the MFMAs
+            for (int q = 0; q < NV; ++q) pv[q] = load_vec(q, nrid, nch);   // in flight during the MFMAs
         }
+#endif
         __syncthreads();
-        // ---- 11 k-steps of 16 positions, 39 MFMAs each; fragments pipelined in two half-sets:
-        //      S0 = taps k = 0..2, S1 = taps k = 3..5 + the middle tap
-        half8 a0h, a0l, a1h, a1l, n0h, n0l, n1h, n1l, bh0[3], bl0[3], bh1[4], bl1[4];
+        // ---- 11 k-steps of 16 positions, 39 MFMAs each, in three phases of 13 (one per split product, every
+        //      accumulator once per phase).  Fragment lifetimes are staggered so that ONE register set suffices and
+        //      every transposed read is issued a phase (>= 13 MFMAs) before its first use, one read per MFMA:
+        //        phase 1  lo(dz) * hi(x)   while lo(x) of this k-step arrives        (14 reads)
+        //        phase 2  hi(dz) * hi(x)   while the next k-step's dz arrives        (12 reads; hi(dz) double buffered)
+        //        phase 3  hi(dz) * lo(x)   while the next k-step's hi(x) arrives     (14 reads)
+        //      The wave issues in order and the LDS pipe serves four waves: reads clustered between MFMA groups
+        //      would idle the matrix pipe.
+        // A fragments: [co tile 0, co tile 1, co tile g (the middle tap's; fetched separately so that no register
+        // select -- which the optimizer would turn into a dynamically indexed private array -- is needed)]
+        half8 AL[3], AH[2][3], BH[7], BL[7];      // AH double buffered by k-step parity; B: taps 7g..7g+5 + the middle tap
         // (KS)*16 is a multiple of 4, so the swizzle phase of a read is its tap offset & 3: a compile-time constant
-#define WF_LOAD_A(A0H, A0L, A1H, A1L, KS)                \
-    A0H = tr_frag(dz_h + (KS) * 2048, la0.off[0], 0);    \
-    A0L = tr_frag(dz_l + (KS) * 2048, la0.off[0], 0);    \
-    A1H = tr_frag(dz_h + (KS) * 2048, la1.off[0], 0);    \
-    A1L = tr_frag(dz_l + (KS) * 2048, la1.off[0], 0);
-#define WF_LOAD_S0(KS)                                                                          \
-    _Pragma("unroll") for (int i = 0; i < 3; ++i) {                                             \
-        bh0[i] = tr_frag(x_h + xg_off + (KS) * 2048, lbg.off[(i * T) & 3], i * T);              \
-        bl0[i] = tr_frag(x_l + xg_off + (KS) * 2048, lbg.off[(i * T) & 3], i * T);              \
-    }
-#define WF_LOAD_S1(KS)                                                                          \
-    _Pragma("unroll") for (int i = 0; i < 3; ++i) {                                             \
-        bh1[i] = tr_frag(x_h + xg_off + (KS) * 2048, lbg.off[((i + 3) * T) & 3], (i + 3) * T);  \
-        bl1[i] = tr_frag(x_l + xg_off + (KS) * 2048, lbg.off[((i + 3) * T) & 3], (i + 3) * T);  \
-    }                                                                                           \
-    bh1[3] = tr_frag(x_h + (KS) * 2048, lb.off[(6 * T) & 3], 6 * T);                            \
-    bl1[3] = tr_frag(x_l + (KS) * 2048, lb.off[(6 * T) & 3], 6 * T);
-        WF_LOAD_A(a0h, a0l, a1h, a1l, 0)
-        WF_LOAD_S0(0)
-        WF_LOAD_S1(0)
-#pragma unroll 1
+        auto rd_a = [&](const unsigned char *img, int ks, int j) {
+            return tr_frag(img + ks * 2048, j == 0 ? la0.off[0] : (j == 1 ? la1.off[0] : lag_off), 0);
+        };
+        auto rd_b = [&](const unsigned char *img, int ks, int tap) {
+            return tap < 6 ? tr_frag(img + ks * 2048 + xg_off, lbg.off[(tap * T) & 3], tap * T)
+                           : tr_frag(img + ks * 2048, lb.off[(6 * T) & 3], 6 * T);
+        };
+#define WF_PIN(N_PAIR, N_MFMA_TAIL, N_DS_TAIL)                                                     \
+    _Pragma("unroll") for (int q_ = 0; q_ < (N_PAIR); ++q_) {                                      \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                         \
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                         \
+    }                                                                                              \
+    if ((N_MFMA_TAIL) > 0) __builtin_amdgcn_sched_group_barrier(0x008, (N_MFMA_TAIL), 0);          \
+    if ((N_DS_TAIL) > 0) __builtin_amdgcn_sched_group_barrier(0x100, (N_DS_TAIL), 0);
+#ifndef EXP_W_NOLDS
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { AL[j] = rd_a(dz_l, 0, j); AH[0][j] = rd_a(dz_h, 0, j); }
+#pragma unroll
+        for (int t = 0; t < 7; ++t) BH[t] = rd_b(x_h, 0, t);
+#endif
+#pragma unroll
         for (int ks = 0; ks < WF_KS; ++ks) {
-            const int kn = ks + 1 < WF_KS ? ks + 1 : ks;       // last step reloads itself (discarded)
+            const int p = ks & 1;
+            const bool last = ks + 1 == WF_KS;
             __builtin_amdgcn_sched_barrier(0);
-            // the three split products of one accumulator are issued six MFMAs apart
+            {   // phase 1
 #pragma unroll
-            for (int i = 0; i < 3; ++i) { acc[2 * i] = mfma16w(a0l, bh0[i], acc[2 * i]); acc[2 * i + 1] = mfma16w(a1l, bh0[i], acc[2 * i + 1]); }
+                for (int u = 0; u < 13; ++u) acc[u] = mfma16w(AL[u < 12 ? (u & 1) : 2], BH[u < 12 ? (u >> 1) : 6], acc[u]);
+#ifndef EXP_W_NOLDS
 #pragma unroll
-            for (int i = 0; i < 3; ++i) { acc[2 * i] = mfma16w(a0h, bl0[i], acc[2 * i]); acc[2 * i + 1] = mfma16w(a1h, bl0[i], acc[2 * i + 1]); }
-#pragma unroll
-            for (int i = 0; i < 3; ++i) { acc[2 * i] = mfma16w(a0h, bh0[i], acc[2 * i]); acc[2 * i + 1] = mfma16w(a1h, bh0[i], acc[2 * i + 1]); }
-            __builtin_amdgcn_sched_barrier(0);
-            WF_LOAD_A(n0h, n0l, n1h, n1l, kn)
-            WF_LOAD_S0(kn)
-            __builtin_amdgcn_sched_barrier(0);
-            {
-                const half8 amh = g ? a1h : a0h, aml = g ? a1l : a0l;      // middle tap: co tile g
-#pragma unroll
-                for (int i = 0; i < 3; ++i) { acc[6 + 2 * i] = mfma16w(a0l, bh1[i], acc[6 + 2 * i]); acc[7 + 2 * i] = mfma16w(a1l, bh1[i], acc[7 + 2 * i]); }
-                acc[12] = mfma16w(aml, bh1[3], acc[12]);
-#pragma unroll
-                for (int i = 0; i < 3; ++i) { acc[6 + 2 * i] = mfma16w(a0h, bl1[i], acc[6 + 2 * i]); acc[7 + 2 * i] = mfma16w(a1h, bl1[i], acc[7 + 2 * i]); }
-                acc[12] = mfma16w(amh, bl1[3], acc[12]);
-#pragma unroll
-                for (int i = 0; i < 3; ++i) { acc[6 + 2 * i] = mfma16w(a0h, bh1[i], acc[6 + 2 * i]); acc[7 + 2 * i] = mfma16w(a1h, bh1[i], acc[7 + 2 * i]); }
-                acc[12] = mfma16w(amh, bh1[3], acc[12]);
+                for (int t = 0; t < 7; ++t) BL[t] = rd_b(x_l, ks, t);
+                WF_PIN(13, 0, 1)
+#endif
             }
             __builtin_amdgcn_sched_barrier(0);
-            WF_LOAD_S1(kn)
-            a0h = n0h; a0l = n0l; a1h = n1h; a1l = n1l;
+            {   // phase 2
+#pragma unroll
+                for (int u = 0; u < 13; ++u) acc[u] = mfma16w(AH[p][u < 12 ? (u & 1) : 2], BH[u < 12 ? (u >> 1) : 6], acc[u]);
+#ifndef EXP_W_NOLDS
+                if (!last) {
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) { AL[j] = rd_a(dz_l, ks + 1, j); AH[p ^ 1][j] = rd_a(dz_h, ks + 1, j); }
+                    WF_PIN(12, 1, 0)
+                }
+#endif
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            {   // phase 3
+#pragma unroll
+                for (int u = 0; u < 13; ++u) acc[u] = mfma16w(AH[p][u < 12 ? (u & 1) : 2], BL[u < 12 ? (u >> 1) : 6], acc[u]);
+#ifndef EXP_W_NOLDS
+                if (!last) {
+#pragma unroll
+                    for (int t = 0; t < 7; ++t) BH[t] = rd_b(x_h, ks + 1, t);
+                    WF_PIN(13, 0, 1)
+                }
+#endif
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
-#undef WF_LOAD_A
-#undef WF_LOAD_S0
-#undef WF_LOAD_S1
+#undef WF_PIN
         rid = nrid;
         ch = nch;
     }

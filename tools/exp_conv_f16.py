@@ -61,7 +61,19 @@ def run(B=64):
                 return lib.mx_conv_block_dgrad_f16(vp(x_hi.data_ptr()), vp(x_lo.data_ptr()), vp(w_hi.data_ptr()),
                                                    vp(w_lo.data_ptr()), vp(scale.data_ptr()), i64(B), i64(H), i64(345), i32(T),
                                                    vp(out_d.data_ptr()), st)
-            for fn, tag in ((fwd, "fwd"), (dgr, "dgrad")):
+            rps = max(1, -(-(B * H) // 408))
+            n_slabs = -(-(B * H) // rps)
+            part = torch.empty(n_slabs * 65 * 64 * 64, device=dev)
+            dW = torch.empty(64 * 64 * 65, device=dev)
+
+            def wgr():
+                return lib.mx_conv_block_wgrad_f16(vp(x_hi.data_ptr()), vp(x_lo.data_ptr()), vp(x_hi.data_ptr()),
+                                                   vp(x_lo.data_ptr()), vp(scale.data_ptr()), i64(B), i64(H), i32(T), i64(rps),
+                                                   vp(part.data_ptr()), vp(dW.data_ptr()), st)
+            only = os.environ.get("EXP_ONLY", "fwd,dgrad,wgrad").split(",")
+            for fn, tag in ((fwd, "fwd"), (dgr, "dgrad"), (wgr, "wgrad")):
+                if tag not in only:
+                    continue
                 rc = fn()
                 assert rc == 0, (name, tag, rc)
                 torch.cuda.synchronize()
@@ -74,7 +86,7 @@ def run(B=64):
                 ms = e0.elapsed_time(e1) / 5
                 tf = 2.0 * 64 * 64 * 65 * B * H * 345 / ms / 1e9
                 res[(name, H, T, tag)] = ms
-                print(f"{name:24s} H={H:4d} T={T} {tag:6s} {ms:8.3f} ms  {tf:7.1f} TF(alg)  chk={float(out_d.flatten()[12345]) if tag == 'dgrad' else float(out_p.flatten()[12345]):.5g}",
+                print(f"{name:24s} H={H:4d} T={T} {tag:6s} {ms:8.3f} ms  {tf:7.1f} TF(alg)  chk={float(out_d.flatten()[12345]) if tag == 'dgrad' else (float(dW[1234]) if tag == 'wgrad' else float(out_p.flatten()[12345])):.5g}",
                       flush=True)
     return res
 
