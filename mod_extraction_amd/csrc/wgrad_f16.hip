@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_f16x3_kernel(WgradF16Args a)
     // staging map: thread = (position pos0 + 32 q, 16-byte vector v of the position's 8); every address below is a
     // per-thread constant + a compile-time multiple of q, and the swizzle bit of a position is that of pos0
     constexpr int QDZ = (WF_CH + 31) / 32, QX = (WIN + 31) / 32;       // iterations per split
-    constexpr bool PREF = T < 16;                       // T = 16 would need 36 prefetch vectors per thread
+    constexpr bool PREF = true;                         // the next chunk travels through registers during the MFMAs
     constexpr int NV = PREF ? 2 * (QDZ + QX) : 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     _Float16 *dzl = reinterpret_cast<_Float16 *>(smem);               // [split][WF_CH][64]
