@@ -122,12 +122,14 @@ int mx_conv_block_dgrad(const float *G, const uint8_t *amax, const float *wt_fli
  *   w_hi, w_lo : 4*5*13*64*16 halfs each ([ci/16][kh][kw][co][16], weights * 256; flip = 1 for the data gradient)
  *   x_hi, x_lo : (B, H, 4, 352, 16) halfs (channel-block major): forward = split of (prelu(x) - mean) * rstd;
  *                dgrad = split of the max-pool routed gradient * S_dz, S_dz = 2^k chosen from max|G|
- *                (scale (2,) device floats receives {S_dz, 1/S_dz}; amax_ws = one uint32 workspace). */
+ *                (scale (2,) device floats receives {S_dz, 1/S_dz}; amax_ws = one uint32 workspace, or with
+ *                amax_ready != 0 the bits of max|G| left there by mx_ln_prelu_bwd). */
 int mx_conv_pack_weights_f16(const float *W, int32_t flip, void *w_hi, void *w_lo, void *stream);
 int mx_conv_prep_fwd_f16(const float *x, const float *stats, const float *slope, int64_t B, int64_t H,
                          int64_t Wv, void *x_hi, void *x_lo, void *stream);
 int mx_conv_prep_dgrad_f16(const float *G, const uint8_t *amax, int64_t B, int64_t H, int64_t Wv,
-                           uint32_t *amax_ws, float *scale, void *dz_hi, void *dz_lo, void *stream);
+                           uint32_t *amax_ws, int32_t amax_ready, float *scale, void *dz_hi, void *dz_lo,
+                           void *stream);
 int mx_conv_block_fwd_f16(const void *x_hi, const void *x_lo, const void *w_hi, const void *w_lo,
                           const float *bias, int64_t B, int64_t H, int64_t Wv, int32_t dilation, float *out,
                           uint8_t *out_amax, void *stream);
@@ -149,9 +151,13 @@ int mx_conv_block_wgrad(const float *G, const uint8_t *amax, const float *x, con
 
 /* LayerNorm backward fused with the backward of the PReLU in front of it.  p (B,C,H,352): input of
  * that PReLU; dxhat_inout: in = grad w.r.t. the normalised tensor, out = G = dL/dp (in place);
- * dslope_part (B*C,) per-plane partial of dL/dslope. */
+ * dslope_part (B*C,) per-plane partial of dL/dslope.  Optional by-products of the same pass (NULL = skip):
+ * gsum_part (B*C,) = per-plane sum of G (the bias gradient partials mx_plane_sum would produce) and
+ * gmax_bits: atomicMax of the bit pattern of |G| into one zero-initialised uint32 (the amax_ready input of
+ * mx_conv_prep_dgrad_f16). */
 int mx_ln_prelu_bwd(const float *p, float *dxhat_inout, const float *stats, const float *slope, int64_t B,
-                    int64_t C, int64_t H, int64_t Wv, float *dslope_part, void *stream);
+                    int64_t C, int64_t H, int64_t Wv, float *dslope_part, float *gsum_part, uint32_t *gmax_bits,
+                    void *stream);
 
 /* out[c] (+)= sum_r part[r*C + c]  (fp64 accumulate; deterministic) */
 int mx_reduce_rows(const float *part, int64_t R, int64_t C, int32_t accumulate, float *out, void *stream);

@@ -659,17 +659,21 @@ MX_EXPORT int mx_conv_prep_fwd_f16(const float *x, const float *stats, const flo
 }
 
 // dgrad operand: G, amax (B,64,H/2,352) -> dz_hi, dz_lo (B,H,4,352,16) fp16 = split of routed G * S_dz;
-// scale (2,) device floats receives {S_dz, 1/S_dz} (S_dz = power of two from max|G|); amax_ws: 1 uint workspace
+// scale (2,) device floats receives {S_dz, 1/S_dz} (S_dz = power of two from max|G|); amax_ws: 1 uint workspace,
+// or -- amax_ready != 0 -- the bit pattern of max|G| that the producer of G already left there
 MX_EXPORT int mx_conv_prep_dgrad_f16(const float *G, const uint8_t *amax, int64_t B, int64_t H, int64_t Wv,
-                                     uint32_t *amax_ws, float *scale, void *dz_hi, void *dz_lo, void *stream)
+                                     uint32_t *amax_ws, int32_t amax_ready, float *scale, void *dz_hi, void *dz_lo,
+                                     void *stream)
 {
     if (!G || !amax || !amax_ws || !scale || !dz_hi || !dz_lo || B <= 0 || H < 2 || (H & 1) || Wv <= 0 || Wv > CV_PITCH)
         return MX_ERR_ARG;
     if (B > 65535 || H > 65535) return MX_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(amax_ws, 0, sizeof(uint32_t), st) != hipSuccess) return MX_ERR_LAUNCH;
-    const long long n4 = (long long)B * 64 * (H / 2) * CV_PITCH / 4;
-    hipLaunchKernelGGL(absmax_kernel, dim3(2048), dim3(256), 0, st, G, n4, amax_ws);
+    if (!amax_ready) {          // otherwise *amax_ws already holds the bits of max|G| (mx_ln_prelu_bwd's gmax_bits)
+        if (hipMemsetAsync(amax_ws, 0, sizeof(uint32_t), st) != hipSuccess) return MX_ERR_LAUNCH;
+        const long long n4 = (long long)B * 64 * (H / 2) * CV_PITCH / 4;
+        hipLaunchKernelGGL(absmax_kernel, dim3(2048), dim3(256), 0, st, G, n4, amax_ws);
+    }
     hipLaunchKernelGGL(pow2_scale_kernel, dim3(1), dim3(1), 0, st, amax_ws, scale);
     hipLaunchKernelGGL((split_prep_kernel<1>), dim3(CV_PITCH / 32, (unsigned)H, (unsigned)B), dim3(256), 0, st, G, amax,
                        nullptr, nullptr, scale, (int)H, (int)Wv, (_Float16 *)dz_hi, (_Float16 *)dz_lo);

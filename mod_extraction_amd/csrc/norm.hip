@@ -75,7 +75,8 @@ MX_EXPORT int mx_plane_stats(const float *x, const float *slope, int64_t B, int6
 __global__ __launch_bounds__(256) void ln_prelu_bwd_kernel(const float *__restrict__ p, float *__restrict__ dxhat,
                                                            const float *__restrict__ stats,
                                                            const float *__restrict__ slope, int C, int H, int Wv,
-                                                           float *__restrict__ dslope_part)
+                                                           float *__restrict__ dslope_part, float *__restrict__ gsum_part,
+                                                           unsigned *__restrict__ gmax_bits)
 {
     __shared__ double sh[8];
     const int plane = blockIdx.x;
@@ -101,7 +102,8 @@ __global__ __launch_bounds__(256) void ln_prelu_bwd_kernel(const float *__restri
     block_sum2(s1, s2, sh);
     const double n = (double)H * (double)Wv;
     const float m1 = (float)(s1 / n), m2 = (float)(s2 / n);
-    double ds = 0.0, dummy = 0.0;
+    double ds = 0.0, gs = 0.0;
+    float gmax = 0.0f;
     for (int i = threadIdx.x; i < n4; i += 256) {
         const int w0 = (i % (CV_PITCH / 4)) * 4;
         floatx4 pv = pp[i], gv = gp[i], o;
@@ -115,23 +117,33 @@ __global__ __launch_bounds__(256) void ln_prelu_bwd_kernel(const float *__restri
                 float dx = rstd * (gv[e] - m1 - xh * m2);
                 r = pos ? dx : sl * dx;
                 if (!pos) ds += (double)dx * (double)pv[e];
+                gs += (double)r;
+                gmax = fmaxf(gmax, fabsf(r));
             }
             o[e] = r;
         }
         gp[i] = o;
     }
-    block_sum2(ds, dummy, sh);
-    if (threadIdx.x == 0) dslope_part[plane] = (float)ds;
+    block_sum2(ds, gs, sh);
+    if (threadIdx.x == 0) {
+        dslope_part[plane] = (float)ds;
+        if (gsum_part) gsum_part[plane] = (float)gs;          // = mx_plane_sum of the G just written (bias gradient)
+    }
+    if (gmax_bits) {                                          // = max |G|, the input of the f16x3 gradient scale
+        gmax = wave_max_f32(gmax);
+        if ((threadIdx.x & 63) == 0) atomicMax(gmax_bits, __float_as_uint(gmax));
+    }
 }
 
 MX_EXPORT int mx_ln_prelu_bwd(const float *p, float *dxhat_inout, const float *stats, const float *slope,
-                              int64_t B, int64_t C, int64_t H, int64_t Wv, float *dslope_part, void *stream)
+                              int64_t B, int64_t C, int64_t H, int64_t Wv, float *dslope_part, float *gsum_part,
+                              uint32_t *gmax_bits, void *stream)
 {
     if (!p || !dxhat_inout || !stats || !slope || !dslope_part || B <= 0 || C <= 0 || H <= 0 || Wv <= 0 ||
         Wv > CV_PITCH)
         return MX_ERR_ARG;
     hipLaunchKernelGGL(ln_prelu_bwd_kernel, dim3((unsigned)(B * C)), dim3(256), 0, (hipStream_t)stream, p,
-                       dxhat_inout, stats, slope, (int)C, (int)H, (int)Wv, dslope_part);
+                       dxhat_inout, stats, slope, (int)C, (int)H, (int)Wv, dslope_part, gsum_part, gmax_bits);
     return mx_launch_status();
 }
 

@@ -213,6 +213,7 @@ class _CNNStack(torch.autograd.Function):
         grads[3 * n_blocks] = _reduce_rows(dw_part, B, L * 64).view_as(wout)
         grads[3 * n_blocks + 1] = _reduce_rows(db_part, B, L)
         grads[3 * (n_blocks - 1) + 2] = _reduce_rows(ds_part, B, 64)
+        bsum, gmax_ws = None, None       # by-products of mx_ln_prelu_bwd for the block below: bias partials, max|G| bits
         for l in range(n_blocks - 1, -1, -1):
             x_in, stats, amax = saved[3 * l], saved[3 * l + 1], saved[3 * l + 2]
             w = params[3 * l]
@@ -223,9 +224,11 @@ class _CNNStack(torch.autograd.Function):
                 DEBUG_TAP[f"G{l}"] = G.clone()
                 DEBUG_TAP[f"amax{l}"] = amax.clone()
                 DEBUG_TAP[f"p{l}"] = (p_last if l == n_blocks - 1 else saved[3 * (l + 1)]).clone()
-            bsum = torch.empty((B, 64), device=dev, dtype=torch.float32)
-            _hip.call("mx_plane_sum", _hip.ptr(G), B * 64, H // 2, n_frames, _hip.ptr(bsum), st)
+            if bsum is None:
+                bsum = torch.empty((B, 64), device=dev, dtype=torch.float32)
+                _hip.call("mx_plane_sum", _hip.ptr(G), B * 64, H // 2, n_frames, _hip.ptr(bsum), st)
             grads[3 * l + 1] = _reduce_rows(bsum, B, 64)
+            bsum = None
             # weight gradient (+ data gradient below) -- f16x3 path: both share the prepared operand pairs
             rows = B * H
             f16 = _use_f16(cin, precision)
@@ -233,10 +236,12 @@ class _CNNStack(torch.autograd.Function):
             if f16:
                 dz_hi = torch.empty((B, H, 4, PITCH, 16), device=dev, dtype=torch.float16)
                 dz_lo = torch.empty((B, H, 4, PITCH, 16), device=dev, dtype=torch.float16)
-                ws = torch.empty(1, device=dev, dtype=torch.int32)
+                ready = gmax_ws is not None
+                ws = gmax_ws if ready else torch.empty(1, device=dev, dtype=torch.int32)
+                gmax_ws = None
                 scale = torch.empty(2, device=dev, dtype=torch.float32)
                 _hip.call("mx_conv_prep_dgrad_f16", _hip.ptr(G), _hip.ptr(amax), B, H, n_frames, _hip.ptr(ws),
-                          _hip.ptr(scale), _hip.ptr(dz_hi), _hip.ptr(dz_lo), st)
+                          1 if ready else 0, _hip.ptr(scale), _hip.ptr(dz_hi), _hip.ptr(dz_lo), st)
                 if l in ctx.splits:
                     x_hi, x_lo = ctx.splits.pop(l)
                 else:
@@ -273,8 +278,11 @@ class _CNNStack(torch.autograd.Function):
                 if DEBUG_TAP is not None:
                     DEBUG_TAP[f"dxhat{l}"] = dxhat.clone()
                 ds_part = torch.empty((B, 64), device=dev, dtype=torch.float32)
+                bsum = torch.empty((B, 64), device=dev, dtype=torch.float32)
+                gmax_ws = torch.zeros(1, device=dev, dtype=torch.int32) if _use_f16(saved[3 * (l - 1)].size(1), precision) \
+                    else None
                 _hip.call("mx_ln_prelu_bwd", _hip.ptr(x_in), _hip.ptr(dxhat), _hip.ptr(stats), _hip.ptr(slope_prev),
-                          B, 64, H, n_frames, _hip.ptr(ds_part), st)
+                          B, 64, H, n_frames, _hip.ptr(ds_part), _hip.ptr(bsum), _hip.ptr(gmax_ws), st)
                 grads[3 * (l - 1) + 2] = _reduce_rows(ds_part, B, 64)
                 G = dxhat
         return (None, None, None, None, *grads)

@@ -85,6 +85,12 @@ def test_block_fwd_dgrad_wgrad(dev, T, W, H, cin):
         assert rel(dxhat.cpu()[..., :W], xhat_r.grad) < 1e-5, ("dgrad", rel(dxhat.cpu()[..., :W], xhat_r.grad))
         assert bool((dxhat[..., W:] == 0).all())
         ds_part = torch.empty(B * 64, device=dev)
+        gsum = torch.empty(B * 64, device=dev)
+        gmax = torch.zeros(1, device=dev, dtype=torch.int32)
         _hip.call("mx_ln_prelu_bwd", _hip.ptr(x_d), _hip.ptr(dxhat), _hip.ptr(stats), _hip.ptr(sl_d), B, 64, H, W,
-                  _hip.ptr(ds_part), st)
+                  _hip.ptr(ds_part), _hip.ptr(gsum), _hip.ptr(gmax), st)
         assert rel(dxhat.cpu()[..., :W], x_req.grad) < 1e-5, ("ln_prelu_bwd", rel(dxhat.cpu()[..., :W], x_req.grad))
+        # by-products of the same pass: per-plane sums and the bit pattern of max|G|
+        g_cpu = dxhat.cpu()[..., :W]
+        assert rel(gsum.view(B, 64).cpu(), g_cpu.sum(dim=(2, 3))) < 1e-5
+        assert float(gmax.view(torch.float32).cpu()) == float(g_cpu.abs().max())
