@@ -12,9 +12,11 @@ One step = on-device batch synthesis (LFO synth, flanger/chorus, phaser; inputs 
 (RCCL) -> AdamW.  Nothing is skipped or cached inside the timed region.  Rank 0 prints ONE JSON line.
 
 Extra objects in the JSON line:
-  roofline      the dominant kernel: conv_kernel<1,1,0> = block-2 forward (LayerNorm + 5x13 conv +
-                bias + max-pool on the fp32 matrix cores); algorithmic flops of that launch / its
-                HIP-event duration measured live on the launch stream, vs the 157.3 TFLOP/s fp32
+  roofline      the dominant kernel: conv_f16x3_dma_kernel<1,0> = block-2 forward (5x13 conv + bias +
+                max-pool on split-fp16 operands, fp32-equivalent); ALGORITHMIC flops of that launch / its
+                HIP-event duration measured live on the launch stream, vs the 2516.6 TFLOP/s dense fp16
+                MFMA peak (the pipes execute 3 MFMAs per algorithmic MAC group: achieved_executed /
+                frac_executed).  With --conv-precision f32: conv_kernel<1,1,0> vs the 157.3 TFLOP/s fp32
                 MFMA peak.  `kernels` lists the other conv launches the same way.
   cpu_baseline  the CPU oracle (oracle/: torch fp32 CNN step + C effects, "port") timed on this
                 host's cores on a bounded sample (rank 0, N = 1 only).
@@ -186,7 +188,7 @@ def main():
         if f16:
             dom = kernels["conv_block_fwd_f16[block2]"]
             roofline = {
-                "bound": "mfma", "kernel": "conv_f16x3_kernel<1,0> (block-2 forward: conv5x13+bias+maxpool on split-fp16 operands)",
+                "bound": "mfma", "kernel": "conv_f16x3_dma_kernel<1,0> (block-2 forward: conv5x13+bias+maxpool on split-fp16 operands)",
                 "achieved": dom["tflops"], "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(dom["tflops"] / F16_MFMA_PEAK_TFLOPS, 4),
                 "note": "achieved = ALGORITHMIC fp32-equivalent flops (2*64*64*65*128*345 per clip) / HIP-event launch time; "
