@@ -85,19 +85,24 @@ __global__ __launch_bounds__(256) void ln_prelu_bwd_kernel(const float *__restri
     const floatx4 *pp = reinterpret_cast<const floatx4 *>(p + (size_t)plane * H * CV_PITCH);
     floatx4 *gp = reinterpret_cast<floatx4 *>(dxhat + (size_t)plane * H * CV_PITCH);
     const int n4 = H * (CV_PITCH / 4);
+    // fp64 accumulators are fed once per 4-element vector (the 4 terms are summed in fp32): the pass is
+    // otherwise limited by the fp64 add rate, not by HBM
     double s1 = 0.0, s2 = 0.0;
     for (int i = threadIdx.x; i < n4; i += 256) {
         const int w0 = (i % (CV_PITCH / 4)) * 4;
         floatx4 pv = pp[i], gv = gp[i];
+        float t1 = 0.0f, t2 = 0.0f;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             if (w0 + e < Wv) {
                 float x = pv[e] > 0.0f ? pv[e] : sl * pv[e];
                 float xh = (x - mean) * rstd;
-                s1 += (double)gv[e];
-                s2 += (double)gv[e] * (double)xh;
+                t1 += gv[e];
+                t2 += gv[e] * xh;
             }
         }
+        s1 += (double)t1;
+        s2 += (double)t2;
     }
     block_sum2(s1, s2, sh);
     const double n = (double)H * (double)Wv;
@@ -107,6 +112,7 @@ __global__ __launch_bounds__(256) void ln_prelu_bwd_kernel(const float *__restri
     for (int i = threadIdx.x; i < n4; i += 256) {
         const int w0 = (i % (CV_PITCH / 4)) * 4;
         floatx4 pv = pp[i], gv = gp[i], o;
+        float tds = 0.0f, tgs = 0.0f;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             float r = 0.0f;
@@ -116,12 +122,14 @@ __global__ __launch_bounds__(256) void ln_prelu_bwd_kernel(const float *__restri
                 float xh = (x - mean) * rstd;
                 float dx = rstd * (gv[e] - m1 - xh * m2);
                 r = pos ? dx : sl * dx;
-                if (!pos) ds += (double)dx * (double)pv[e];
-                gs += (double)r;
+                if (!pos) tds += dx * pv[e];
+                tgs += r;
                 gmax = fmaxf(gmax, fabsf(r));
             }
             o[e] = r;
         }
+        ds += (double)tds;
+        gs += (double)tgs;
         gp[i] = o;
     }
     block_sum2(ds, gs, sh);
