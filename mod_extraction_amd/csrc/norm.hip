@@ -156,20 +156,32 @@ MX_EXPORT int mx_ln_prelu_bwd(const float *p, float *dxhat_inout, const float *s
 }
 
 // out[c] (+)= sum over r of part[r*C + c]   (deterministic column sum of a small (R, C) matrix)
+// 256 threads = 16 row lanes x 16 columns: a column is summed by 16 threads (rows r, r+16, ...) in fp64 and
+// combined in a fixed order through LDS, so that the few-column cases (C = 64 bias / slope gradients over R =
+// batch rows) are not one long dependent load chain per thread.
 __global__ __launch_bounds__(256) void reduce_rows_kernel(const float *__restrict__ part, int R, int C,
                                                           int accumulate, float *__restrict__ out)
 {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
+    __shared__ double sh[16][17];
+    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
     double s = 0.0;
-    for (int r = 0; r < R; ++r) s += (double)part[(size_t)r * C + c];
-    out[c] = accumulate ? out[c] + (float)s : (float)s;
+    if (c < C)
+        for (int r = rl; r < R; r += 16) s += (double)part[(size_t)r * C + c];
+    sh[rl][cl] = s;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += sh[k][cl];
+        out[c] = accumulate ? out[c] + (float)t : (float)t;
+    }
 }
 
 MX_EXPORT int mx_reduce_rows(const float *part, int64_t R, int64_t C, int32_t accumulate, float *out, void *stream)
 {
     if (!part || !out || R <= 0 || C <= 0) return MX_ERR_ARG;
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)((C + 15) / 16)), dim3(256), 0, (hipStream_t)stream,
                        part, (int)R, (int)C, (int)accumulate, out);
     return mx_launch_status();
 }
