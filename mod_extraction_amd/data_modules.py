@@ -8,13 +8,15 @@ rendering moved onto the device:
 * phaser            -> ``mx_phaser_fwd`` (the reference calls pedalboard in DataLoader workers)
 * LFO labels        -> ``mx_lfo_synth``
 
-Audio comes from a synthetic clip source (peak-normalised uniform noise, seeded per rank): the
-IDMT / EGFx datasets are not available, so the file-backed dataset classes (random non-silent
-chunk search, pairing, peak normalisation) are out of scope of this path.
+Audio comes from recorded files when the configured directories exist (``datasets.FileChunkSource``: the
+reference's random non-silent chunk search, datasets.py:151-213, feeding whole batches of chunks to the
+device renderer), otherwise from a synthetic clip source (peak-normalised uniform noise, seeded per
+rank -- the IDMT / EGFx datasets are not part of this repository, and the benchmark is synthetic).
 Data-module classes keep the reference names and accept the reference ``init_args`` so the shipped
-YAML configs instantiate; directory arguments are accepted and ignored.
+YAML configs instantiate.
 """
 import math
+import os
 from typing import Any, Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -62,8 +64,10 @@ class SyntheticFxBatcher:
     def __init__(self, batch_size: int, n_samples: int, sr: float, kinds: Sequence[str], device: torch.device,
                  flanger_fx: Optional[Dict] = None, chorus_fx: Optional[Dict] = None,
                  phaser_fx: Optional[Dict] = None, mod_sig: Optional[Dict] = None, audio_seed: int = 43,
-                 peak_db: float = -1.0, fixed_lead: Optional[int] = None, overlap: bool = False) -> None:
+                 peak_db: float = -1.0, fixed_lead: Optional[int] = None, overlap: bool = False,
+                 chunk_source: Optional[Any] = None) -> None:
         self.B, self.N, self.sr, self.device = batch_size, n_samples, float(sr), device
+        self.chunk_source = chunk_source                             # datasets.FileChunkSource or None (synthetic)
         self.kinds = [kinds[i % len(kinds)] for i in range(batch_size)]
         self.fl = _fx_from_config(flanger_fx, FLANGER_FX)
         self.ch = _fx_from_config(chorus_fx, CHORUS_FX)
@@ -102,6 +106,12 @@ class SyntheticFxBatcher:
         self._audio = [torch.empty((batch_size, 2, n_samples), device=device, dtype=torch.float32)
                        for _ in range(n_sets)]
         self.src, self.audio = self._src[0], self._audio[0]
+        # recorded audio is gathered on the host into a pinned staging buffer and copied over in one piece
+        self._host = None
+        if chunk_source is not None:
+            self._host = torch.empty((batch_size, n_samples + self.max_lead), dtype=torch.float32)
+            if device.type == "cuda":
+                self._host = self._host.pin_memory()
         self._side = torch.cuda.Stream(device=device) if self.overlap else None
         self._pending = None
         self._slot = 0
@@ -155,6 +165,7 @@ class SyntheticFxBatcher:
             else:
                 lead = torch.full((B,), int(self.fixed_lead), dtype=torch.int64)
             lead = torch.where(is_ph, lead, torch.zeros_like(lead)).to(torch.int32)
+            p["proc_extra"] = torch.where(is_ph, rate_n, torch.zeros_like(rate_n))   # the reference renders n + sr/rate
         p.update(rate_hz=rate, phase=phase, shape=shapes, exp=torch.full((B,), float(self.ms["exp"])),
                  centre_frequency_hz=centre, lead=lead)
         return p
@@ -164,8 +175,14 @@ class SyntheticFxBatcher:
         dev, B, N = self.device, self.B, self.N
         d = {k: v.to(dev) for k, v in p.items() if isinstance(v, torch.Tensor)}
         shape_id = torch.tensor([SHAPE_IDS[s] for s in p["shape"]], dtype=torch.int32, device=dev)
-        # synthetic dry audio: uniform noise at `peak`
-        self.src.uniform_(-self.peak, self.peak, generator=self.gen)
+        if self.chunk_source is not None:
+            # recorded audio: one non-silent chunk per clip (phaser clips: n + sr/rate samples, datasets.py:433-436)
+            extra = p.get("proc_extra", torch.zeros(B, dtype=torch.int64))
+            self.chunk_source.fill(self._host, (extra + N).clamp(max=self._host.size(1)))
+            self.src.copy_(self._host, non_blocking=True)
+        else:
+            # synthetic dry audio: uniform noise at `peak`
+            self.src.uniform_(-self.peak, self.peak, generator=self.gen)
         self.audio[:, 0, :].copy_(self.src[:, :N])
         # LFO labels at n_samples // 100 points
         mod = make_mod_signals(self.n_lfo, self.lfo_sr, d["rate_hz"], d["phase"], shape_id, d["exp"])
@@ -228,15 +245,36 @@ class _SyntheticDataModule:
         self.train_num_examples_per_epoch = train_num_examples_per_epoch
         self.val_num_examples_per_epoch = val_num_examples_per_epoch
         self.fx_config = fx_config or {}
-        self.ignored_args = ignored          # dataset directories, num_workers, silence thresholds, ...
-        self._batcher: Optional[SyntheticFxBatcher] = None
+        self.ignored_args = ignored          # num_workers, ... (dataset directories and chunk-search settings are used
+        self._batcher: Optional[SyntheticFxBatcher] = None      # when the directories exist, see _chunk_source)
+        self._val_batcher: Optional[SyntheticFxBatcher] = None
+
+    _DS_KEYS = ("ext", "silence_fraction_allowed", "silence_threshold_energy", "n_retries", "check_dataset",
+                "end_buffer_n_samples", "should_peak_norm", "peak_norm_db")
+
+    def _chunk_source(self, which: str) -> Optional[Any]:
+        """datasets.FileChunkSource over `<which>_dir` (train_dir / val_dir of the reference's init_args) if that
+        directory exists, else None (synthetic clips)."""
+        d = self.ignored_args.get(f"{which}_dir") or self.ignored_args.get(f"dry_{which}_dir")
+        if not d or not os.path.isdir(d):
+            return None
+        from . import datasets
+        kw = {k: self.ignored_args[k] for k in self._DS_KEYS if k in self.ignored_args}
+        n_ex = self.train_num_examples_per_epoch if which == "train" else self.val_num_examples_per_epoch
+        ds = datasets.RandomAudioChunkDataset(d, self.n_samples, self.sr, num_examples_per_epoch=n_ex, **kw)
+        return datasets.FileChunkSource(ds)
 
     def setup(self, device: torch.device, rank: int = 0, seed: int = 43) -> None:
         fl = self.fx_config.get("flanger")
+        common = dict(flanger_fx=fl, chorus_fx=fl if "chorus" in self.kinds and fl else None,
+                      phaser_fx=self.fx_config.get("pedalboard_phaser"), mod_sig=self.fx_config.get("mod_sig"),
+                      audio_seed=seed + rank)
         self._batcher = SyntheticFxBatcher(self.batch_size, self.n_samples, self.sr, self.kinds, device,
-                                           flanger_fx=fl, chorus_fx=fl if "chorus" in self.kinds and fl else None,
-                                           phaser_fx=self.fx_config.get("pedalboard_phaser"),
-                                           mod_sig=self.fx_config.get("mod_sig"), audio_seed=seed + rank)
+                                           chunk_source=self._chunk_source("train"), **common)
+        val_src = self._chunk_source("val")
+        if val_src is not None:
+            self._val_batcher = SyntheticFxBatcher(self.batch_size, self.n_samples, self.sr, self.kinds, device,
+                                                   chunk_source=val_src, **common)
 
     def train_steps_per_epoch(self) -> int:
         return max(1, self.train_num_examples_per_epoch // self.batch_size)
@@ -247,7 +285,8 @@ class _SyntheticDataModule:
     def train_batch(self):
         return self._batcher.next_batch()
 
-    val_batch = train_batch
+    def val_batch(self):
+        return (self._val_batcher or self._batcher).next_batch()
 
 
 class FlangerCPUDataModule(_SyntheticDataModule):
@@ -282,12 +321,42 @@ class InterwovenDataModule(_SyntheticDataModule):
 
 
 class RandomAudioChunkDryWetDataModule(_SyntheticDataModule):
-    """data_modules.py:177-256 (dry/wet pairs of an unseen effect, configs/train_em_dry_wet.yml):
-    the EGFx recordings are replaced by synthetic dry clips and this package's phaser render."""
+    """data_modules.py:177-256 (dry/wet pairs of an unseen effect, configs/train_em_dry_wet.yml).  With
+    ``dry_train_dir`` / ``wet_train_dir`` (and the ``_val_`` pair) present on disk the batches are recorded pairs
+    (``datasets.RandomAudioChunkDryWetDataset``); otherwise synthetic dry clips and this package's phaser render."""
     kinds = ("phaser",)
 
+    def _pair_dataset(self, which: str):
+        dry_d, wet_d = self.ignored_args.get(f"dry_{which}_dir"), self.ignored_args.get(f"wet_{which}_dir")
+        if not dry_d or not wet_d or not os.path.isdir(dry_d) or not os.path.isdir(wet_d):
+            return None
+        from . import datasets
+        kw = {k: self.ignored_args[k] for k in self._DS_KEYS if k in self.ignored_args}
+        n_ex = self.train_num_examples_per_epoch if which == "train" else self.val_num_examples_per_epoch
+        return datasets.RandomAudioChunkDryWetDataset(dry_d, wet_d, self.n_samples, self.sr, num_examples_per_epoch=n_ex, **kw)
+
+    def setup(self, device: torch.device, rank: int = 0, seed: int = 43) -> None:
+        self._pairs = {w: self._pair_dataset(w) for w in ("train", "val")}
+        self._device = device
+        if self._pairs["train"] is None:
+            super().setup(device, rank, seed)
+
+    def _pair_batch(self, ds):
+        dry = torch.empty((self.batch_size, 1, self.n_samples), dtype=torch.float32)
+        wet = torch.empty_like(dry)
+        for i in range(self.batch_size):
+            dry[i], wet[i] = ds[i]
+        return dry.to(self._device), wet.to(self._device), None, None
+
     def train_batch(self):
+        if self._pairs["train"] is not None:
+            return self._pair_batch(self._pairs["train"])
         dry, wet, _, _ = self._batcher.next_batch()
         return dry, wet, None, None
 
-    val_batch = train_batch
+    def val_batch(self):
+        ds = self._pairs["val"] or self._pairs["train"]
+        if ds is not None:
+            return self._pair_batch(ds)
+        dry, wet, _, _ = (self._val_batcher or self._batcher).next_batch()
+        return dry, wet, None, None
