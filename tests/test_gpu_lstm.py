@@ -139,3 +139,27 @@ def test_tbptt_full_length_vs_oracle(dev):
     assert abs(float(loss) - float(res["loss"])) < 1e-6
     for k in ("l1", "esr", "dc"):
         assert abs(float(mod.logged[f"val/{k}"][-1]) - float(res["terms"][k])) < 1e-5 * max(1.0, abs(float(res["terms"][k])))
+
+
+def test_streaming_effect_model_vs_reference_golden(golden_dir, dev):
+    """(f) rank 4: four consecutive stereo buffers through the streaming effect model (LFO phase and LSTM state
+    carried), against the real reference `EffectModel` / `do_forward_pass` (tests/golden/make_golden_streaming.py).
+    LFO phase bookkeeping: exact; waveforms: 1e-5 (fp32, north_star)."""
+    from mod_extraction_amd import streaming
+    g = load(golden_dir, "streaming.npz")
+    w = load(golden_dir, "lstm.npz")
+    i = int(g["weights_index"])
+    assert str(w[f"name_{i}"]) == str(g["weights_name"])
+    em = streaming.EffectModel()
+    em.model.load_state_dict({k[len(f"w_{i}_"):]: torch.from_numpy(w[k]) for k in w.files if k.startswith(f"w_{i}_")},
+                             strict=True)
+    em = em.to(dev)
+    wrap = streaming.EffectModelWrapper(em)
+    params = {k: torch.tensor(float(g[f"p_{k}"])) for k in ("lfo_rate", "lfo_depth", "lfo_stereo_phase_offset")}
+    em.model.clear_hidden()
+    for b, n in enumerate(g["sizes"]):
+        x = torch.from_numpy(g[f"x{b}"]).to(dev)
+        y = wrap.do_forward_pass(x, params)
+        assert y.shape == (2, int(n))
+        assert np.abs(y.cpu().numpy() - g[f"y{b}"]).max() < 1e-5, b
+        assert float(em.prev_phase) == float(g[f"phase{b}"]), b            # carried LFO phase: bit-exact
