@@ -136,6 +136,16 @@ int mx_conv_block_fwd_f16(const void *x_hi, const void *x_lo, const void *w_hi, 
 int mx_conv_block_dgrad_f16(const void *dz_hi, const void *dz_lo, const void *w_hi, const void *w_lo,
                             const float *scale, int64_t B, int64_t H, int64_t Wv, int32_t dilation,
                             float *dxhat, void *stream);
+/* First block (2 input channels) on the same matrix-core kernel: (kernel row, input channel) pairs become the 16
+ * "channels" of the operand (k = kh*2 + ci, 10 used), so that one 16-deep MFMA k-step covers a tap column and the
+ * K loop is a single stage.  Same reference semantics (models.py:183-195, first block: LayerNorm -> Conv2d(2,64,
+ * (5,13)) -> +bias -> MaxPool(2,1)).  w_hi, w_lo: 13*2*64*8 halfs each; xk_hi, xk_lo: (B, H, 352, 16) halfs. */
+int mx_conv_pack_weights_kvec_f16(const float *W, void *w_hi, void *w_lo, void *stream);
+int mx_conv_prep_fwd_kvec_f16(const float *x, const float *stats, int64_t B, int64_t H, int64_t Wv, void *xk_hi,
+                              void *xk_lo, void *stream);
+int mx_conv_block1_fwd_f16(const void *xk_hi, const void *xk_lo, const void *w_hi, const void *w_lo, const float *bias,
+                           int64_t B, int64_t H, int64_t Wv, float *out, uint8_t *out_amax, void *stream);
+
 /* weight gradient from the same prepared operands (dz pair of mx_conv_prep_dgrad_f16, x pair of
  * mx_conv_prep_fwd_f16); part = workspace of ceil(B*H/rows_per_slab)*65*64*64 floats; dW (64,64,5,13). */
 int mx_conv_block_wgrad_f16(const void *dz_hi, const void *dz_lo, const void *x_hi, const void *x_lo,

@@ -142,6 +142,62 @@ __global__ void pack_weights_f16_kernel(const float *__restrict__ W, int flip, _
     }
 }
 
+// ---- first block (2 input channels): the operand carries (kernel row, channel) as its 16 "channels" ---------------
+// x (B, 2, H, 352) fp32 log-mel, stats (B, 2, 2) -> xk_hi, xk_lo (B, H, 1, 352, 16): channel k = kh * 2 + ci (k < 10)
+// holds xhat[ci][h + kh - 2][w] = (x - mean) * rstd (0 outside the image), k >= 10 is 0.  One 16-deep MFMA k-step then
+// covers a whole tap COLUMN of the 5x13 kernel for both channels, and the K loop of the conv kernel is a single stage.
+__global__ __launch_bounds__(256) void split_prep_kvec_kernel(const float *__restrict__ x, const float *__restrict__ stats,
+                                                              int H, int Wv, _Float16 *__restrict__ out_hi,
+                                                              _Float16 *__restrict__ out_lo)
+{
+    __shared__ float tile[16][33];
+    const int wt = blockIdx.x, h = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
+    for (int i = tid; i < 16 * 8; i += 256) {
+        const int k = i >> 3, c4 = i & 7, kh = k >> 1, ci = k & 1;
+        const int hx = h + kh - 2, w0 = wt * 32 + c4 * 4;
+        floatx4 v = {0.f, 0.f, 0.f, 0.f};
+        if (k < 2 * CV_KH && hx >= 0 && hx < H) {
+            v = *reinterpret_cast<const floatx4 *>(x + (((size_t)b * 2 + ci) * H + hx) * CV_PITCH + w0);
+            const float mean = stats[((size_t)b * 2 + ci) * 2], rstd = stats[((size_t)b * 2 + ci) * 2 + 1];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (w0 + e < Wv) ? (v[e] - mean) * rstd : 0.0f;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) tile[k][c4 * 4 + e] = v[e];
+    }
+    __syncthreads();
+    if (tid < 64) {                                       // 32 positions x 2 groups of 8 channels
+        const int pos = tid >> 1, cg = tid & 1;
+        half8 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float v = tile[cg * 8 + j][pos];
+            const _Float16 hh = (_Float16)v;
+            hi[j] = hh;
+            lo[j] = (_Float16)(v - (float)hh);
+        }
+        const size_t o = (((size_t)b * H + h) * CV_PITCH + wt * 32 + pos) * 16 + cg * 8;
+        *reinterpret_cast<half8 *>(out_hi + o) = hi;
+        *reinterpret_cast<half8 *>(out_lo + o) = lo;
+    }
+}
+
+// torch (64, 2, 5, 13) fp32 -> [kw][khalf][co][8] fp16 pairs of W * 256 with k = kh * 2 + ci (zeros for k >= 10)
+__global__ void pack_weights_kvec_f16_kernel(const float *__restrict__ W, _Float16 *__restrict__ w_hi,
+                                             _Float16 *__restrict__ w_lo)
+{
+    const int total = CV_KW * 2 * 64 * 8;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int j = i & 7, co = (i >> 3) & 63, khalf = (i >> 9) & 1, kw = i >> 10;
+        const int k = khalf * 8 + j, kh = k >> 1, ci = k & 1;
+        float v = 0.0f;
+        if (k < 2 * CV_KH) v = W[(((size_t)co * 2 + ci) * CV_KH + kh) * CV_KW + kw] * F16_WSCALE;
+        const _Float16 hh = (_Float16)v;
+        w_hi[i] = hh;
+        w_lo[i] = (_Float16)(v - (float)hh);
+    }
+}
+
 // ---- the convolution ------------------------------------------------------------------------------------
 struct ConvF16Args {
     const _Float16 *x_hi, *x_lo;   // (B, H, 4, 352, 16)
@@ -408,7 +464,9 @@ __device__ __forceinline__ void glds16(unsigned long long gsrc, unsigned lds_wav
 }
 #define DMA_WAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 
-template <int T, int OUTMODE>
+// NCB x NKH = K stages: 4 channel blocks x 5 kernel rows for the 64-channel blocks; 1 x 1 for the first block, whose
+// operand already carries (kernel row, input channel) as its 16 "channels" (mx_conv_prep_fwd_kvec_f16).
+template <int T, int OUTMODE, int NCB = 4, int NKH = CV_KH>
 __global__ __launch_bounds__(256, 1) void conv_f16x3_dma_kernel(ConvF16Args a)
 {
     constexpr int PWP = CV_PITCH + 12 * T;            // patch positions per row (w = q - 6T)
@@ -420,8 +478,8 @@ __global__ __launch_bounds__(256, 1) void conv_f16x3_dma_kernel(ConvF16Args a)
     constexpr int PPW = (P_PIECES + 3) / 4;           // patch pieces per wave (12..13)
     constexpr int W_SPLIT = 7 * 2048;                 // bytes per split inside a weight buffer
     constexpr int W_BYTES = 2 * W_SPLIT;
-    constexpr int ROWB = 4 * CV_PITCH * 32;           // bytes of one operand row (4 channel blocks x 352 positions x 16 halfs)
-    constexpr int N_STAGE = 4 * CV_KH;
+    constexpr int ROWB = NCB * CV_PITCH * 32;         // bytes of one operand row (channel blocks x 352 positions x 16 halfs)
+    constexpr int N_STAGE = NCB * NKH;
     static_assert(PPW <= 13, "patch pieces per wave");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *const W0 = smem, *const W1 = smem + W_BYTES, *const P0 = smem + 2 * W_BYTES;
@@ -472,9 +530,9 @@ __global__ __launch_bounds__(256, 1) void conv_f16x3_dma_kernel(ConvF16Args a)
     auto dma_p = [&](int st, unsigned char *Pb, int k) {
         const int pp = wave + 4 * k;
         if (pp < P_PIECES) {
-            const int cb = st / CV_KH, kh = st - cb * CV_KH, hx0 = h0 + kh - 2;
+            const int cb = st / NKH, kh = st - cb * NKH, hx0 = h0 + kh - NKH / 2;
             const bool v0 = hx0 >= 0 && hx0 < H, v1 = hx0 + 1 >= 0 && hx0 + 1 < H;
-            const long long st_off = (((long long)b * H + hx0) * 4 + cb) * (CV_PITCH * 32);
+            const long long st_off = (((long long)b * H + hx0) * NCB + cb) * (CV_PITCH * 32);
             const unsigned long long base_h = xh + st_off, base_l = xl + st_off;
             const int d = desc[k];
             const bool ok = d >= 0 && ((d & (1 << 29)) ? v1 : v0);
@@ -584,7 +642,7 @@ __global__ __launch_bounds__(256, 1) void conv_f16x3_dma_kernel(ConvF16Args a)
     conv_f16_epilogue<OUTMODE>(acc, a, smem, b, h0, row, c, lane);
 }
 
-template <int T, int OUTMODE>
+template <int T, int OUTMODE, int NCB = 4, int NKH = CV_KH>
 static int launch_f16_dma(const ConvF16Args &a, int B, hipStream_t st)
 {
     constexpr int PWP = CV_PITCH + 12 * T;
@@ -592,12 +650,12 @@ static int launch_f16_dma(const ConvF16Args &a, int B, hipStream_t st)
     static_assert(lds <= 160 * 1024, "LDS budget");
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute((const void *)conv_f16x3_dma_kernel<T, OUTMODE>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds) != hipSuccess)
+        if (hipFuncSetAttribute((const void *)conv_f16x3_dma_kernel<T, OUTMODE, NCB, NKH>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return MX_ERR_LAUNCH;
         attr_done = true;
     }
-    hipLaunchKernelGGL((conv_f16x3_dma_kernel<T, OUTMODE>), dim3(a.H / 2, B), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((conv_f16x3_dma_kernel<T, OUTMODE, NCB, NKH>), dim3(a.H / 2, B), dim3(256), lds, st, a);
     return mx_launch_status();
 }
 
@@ -702,4 +760,38 @@ MX_EXPORT int mx_conv_block_dgrad_f16(const void *dz_hi, const void *dz_lo, cons
     ConvF16Args a{(const _Float16 *)dz_hi, (const _Float16 *)dz_lo, (const _Float16 *)w_hi, (const _Float16 *)w_lo,
                   nullptr, scale, dxhat, nullptr, (int)H, (int)Wv};
     return dispatch_f16(dilation, 1, a, (int)B, (hipStream_t)stream);
+}
+
+// ---- first block (2 input channels) on the same kernel: one K stage -------------------------------------------
+// W (64,2,5,13) -> w_hi, w_lo: 13*2*64*8 halfs each
+MX_EXPORT int mx_conv_pack_weights_kvec_f16(const float *W, void *w_hi, void *w_lo, void *stream)
+{
+    if (!W || !w_hi || !w_lo) return MX_ERR_ARG;
+    hipLaunchKernelGGL(pack_weights_kvec_f16_kernel, dim3(16), dim3(256), 0, (hipStream_t)stream, W, (_Float16 *)w_hi,
+                       (_Float16 *)w_lo);
+    return mx_launch_status();
+}
+
+// x (B,2,H,352) fp32 (log-mel), stats (B,2,2) -> xk_hi, xk_lo (B,H,352,16) fp16 = split of the LayerNorm-ed input,
+// channel k = kh*2 + ci holding row h + kh - 2
+MX_EXPORT int mx_conv_prep_fwd_kvec_f16(const float *x, const float *stats, int64_t B, int64_t H, int64_t Wv, void *xk_hi,
+                                        void *xk_lo, void *stream)
+{
+    if (!x || !stats || !xk_hi || !xk_lo || B <= 0 || H <= 0 || Wv <= 0 || Wv > CV_PITCH) return MX_ERR_ARG;
+    if (B > 65535 || H > 65535) return MX_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(split_prep_kvec_kernel, dim3(CV_PITCH / 32, (unsigned)H, (unsigned)B), dim3(256), 0,
+                       (hipStream_t)stream, x, stats, (int)H, (int)Wv, (_Float16 *)xk_hi, (_Float16 *)xk_lo);
+    return mx_launch_status();
+}
+
+// forward conv of the first block (2 -> 64 channels, dilation 1) + bias + max-pool from the k-vector operand
+MX_EXPORT int mx_conv_block1_fwd_f16(const void *xk_hi, const void *xk_lo, const void *w_hi, const void *w_lo,
+                                     const float *bias, int64_t B, int64_t H, int64_t Wv, float *out, uint8_t *out_amax,
+                                     void *stream)
+{
+    if (!xk_hi || !xk_lo || !w_hi || !w_lo || !bias || !out || !out_amax) return MX_ERR_ARG;
+    if (B <= 0 || B > 65535 || H < 2 || (H & 1) || Wv <= 0 || Wv > CV_PITCH) return MX_ERR_UNSUPPORTED;
+    ConvF16Args a{(const _Float16 *)xk_hi, (const _Float16 *)xk_lo, (const _Float16 *)w_hi, (const _Float16 *)w_lo, bias,
+                  nullptr, out, out_amax, (int)H, (int)Wv};
+    return launch_f16_dma<1, 0, 1, 1>(a, (int)B, (hipStream_t)stream);
 }

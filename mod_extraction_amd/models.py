@@ -10,6 +10,7 @@ and state-dict keys; every forward/backward runs hand-written HIP kernels throug
 * ``LSTMEffectModel`` / ``HiddenStateModel`` (models.py:292-339) and ``RandomLFO`` (models.py:19-69).
 """
 import math
+import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -124,6 +125,10 @@ def _pack_f16(w: T, flip: int) -> Tuple[T, T]:
     return hi, lo
 
 
+# first block on the fp16 pipes too (MODEX_BLOCK1=f32 keeps it on the exact-fp32 MFMA kernel; A/B knob)
+BLOCK1_F16 = os.environ.get("MODEX_BLOCK1", "f16x3") != "f32"
+
+
 def _use_f16(cin: int, precision: str) -> bool:
     return precision == "f16x3" and cin == 64
 
@@ -168,6 +173,19 @@ class _CNNStack(torch.autograd.Function):
                 if keep_splits:
                     ctx.splits[l] = (x_hi, x_lo)
                 del x_hi, x_lo
+            elif precision == "f16x3" and l == 0 and cin == 2 and BLOCK1_F16:
+                # first block: (kernel row, channel) pairs are the operand's 16 channels; one K stage
+                xk_hi = torch.empty((B, H, 1, PITCH, 16), device=dev, dtype=torch.float16)
+                xk_lo = torch.empty((B, H, 1, PITCH, 16), device=dev, dtype=torch.float16)
+                _hip.call("mx_conv_prep_fwd_kvec_f16", _hip.ptr(cur), _hip.ptr(stats), B, H, n_frames, _hip.ptr(xk_hi),
+                          _hip.ptr(xk_lo), st)
+                wk_hi = torch.empty(13 * 2 * 64 * 8, device=dev, dtype=torch.float16)
+                wk_lo = torch.empty(13 * 2 * 64 * 8, device=dev, dtype=torch.float16)
+                _hip.call("mx_conv_pack_weights_kvec_f16", _hip.ptr(w.detach().contiguous()), _hip.ptr(wk_hi),
+                          _hip.ptr(wk_lo), st)
+                _hip.call("mx_conv_block1_fwd_f16", _hip.ptr(xk_hi), _hip.ptr(xk_lo), _hip.ptr(wk_hi), _hip.ptr(wk_lo),
+                          _hip.ptr(b.contiguous()), B, H, n_frames, _hip.ptr(p), _hip.ptr(amax), st)
+                del xk_hi, xk_lo
             else:
                 wt = _pack(w, 0)
                 _hip.call("mx_conv_block_fwd", _hip.ptr(cur), _hip.ptr(stats), _hip.ptr(slope), _hip.ptr(wt),
