@@ -140,3 +140,37 @@ class LSTMEffectModel(nn.Module):
         seq = torch.cat([latent, x], dim=1).swapaxes(1, 2)               # LFO first, audio second
         out, self.hidden = self.lstm(seq, self.hidden)
         return torch.tanh(self.fc(out).swapaxes(1, 2) + x)
+
+
+def forward_routed(ref: "Spectral2DCNN", x: T, masks, tap: dict, W: int, tie_tol: float = 2e-6):
+    """Oracle forward that takes the device's decisions at the two non-differentiable points of a block: the
+    MaxPool2d((2,1)) argmax (``tap["amax<l>"]``) and the PReLU branch (sign of ``tap["p<l>"]``).  Wherever a
+    decision differs from torch's own, the oracle's values must sit on the kink to fp32 rounding (the two pooled
+    rows equal, or the pre-activation ~0; ``tie_tol`` relative to the tensor's max): either side is a valid
+    sub-gradient there.  Sharing the decisions lets every downstream gradient be compared at fp32 tolerance.
+    Returns (sigmoid output, latent, number of shared kink decisions)."""
+    h = ref.log_mel(x, masks)
+    n_kinks = 0
+    for i, m in enumerate(ref.cnn):
+        blk = i // 4
+        if isinstance(m, nn.MaxPool2d):
+            top, bot = h[:, :, 0::2], h[:, :, 1::2]
+            pick = tap[f"amax{blk}"].cpu()[..., :W].bool()
+            diff = pick != (bot > top)
+            if diff.any():
+                assert float((top - bot).abs()[diff].max()) <= tie_tol * float(h.detach().abs().max()), \
+                    "argmax differs away from a tie"
+                n_kinks += int(diff.sum())
+            h = torch.where(pick, bot, top)
+        elif isinstance(m, nn.PReLU):
+            pos = tap[f"p{blk}"].cpu()[..., :W] > 0
+            diff = pos != (h > 0)
+            if diff.any():
+                assert float(h.detach().abs()[diff].max()) <= tie_tol * float(h.detach().abs().max()), \
+                    "PReLU branch differs away from zero"
+                n_kinks += int(diff.sum())
+            h = torch.where(pos, h, m.weight.view(1, -1, 1, 1) * h)
+        else:
+            h = m(h)
+    latent = h.mean(dim=-2)
+    return torch.sigmoid(ref.output(latent)), latent, n_kinks

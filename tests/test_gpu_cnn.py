@@ -81,37 +81,7 @@ def _loss(out):
     return (out * w).sum() / out.numel()
 
 
-def oracle_forward_routed(ref, x, masks, tap, W):
-    """Oracle forward that takes the GPU's decisions at the two non-differentiable points of a block:
-    the MaxPool2d((2,1)) argmax and the PReLU branch.  Wherever the GPU's decision differs from
-    torch's own, the oracle's values must sit on the kink to fp32 rounding (the two pooled rows equal,
-    or the pre-activation ~0): either side is a valid sub-gradient there.  The check makes that
-    explicit, and the shared decisions let every downstream gradient be compared at 1e-5."""
-    h = ref.log_mel(x, masks)
-    n_kinks = 0
-    for i, m in enumerate(ref.cnn):
-        blk = i // 4
-        if isinstance(m, torch.nn.MaxPool2d):
-            top, bot = h[:, :, 0::2], h[:, :, 1::2]
-            pick = tap[f"amax{blk}"].cpu()[..., :W].bool()
-            diff = pick != (bot > top)
-            if diff.any():
-                assert float((top - bot).abs()[diff].max()) <= 2e-6 * float(h.detach().abs().max()), \
-                    "argmax differs away from a tie"
-                n_kinks += int(diff.sum())
-            h = torch.where(pick, bot, top)
-        elif isinstance(m, torch.nn.PReLU):
-            pos = tap[f"p{blk}"].cpu()[..., :W] > 0
-            diff = pos != (h > 0)
-            if diff.any():
-                assert float(h.detach().abs()[diff].max()) <= 2e-6 * float(h.detach().abs().max()), \
-                    "PReLU branch differs away from zero"
-                n_kinks += int(diff.sum())
-            h = torch.where(pos, h, m.weight.view(1, -1, 1, 1) * h)
-        else:
-            h = m(h)
-    latent = h.mean(dim=-2)
-    return torch.sigmoid(ref.output(latent)), latent, n_kinks
+oracle_forward_routed = omodels.forward_routed        # shared with __graft_entry__.smoke()
 
 
 def run_pair(dev, ref, mine, x, masks):
