@@ -145,6 +145,13 @@ int mx_conv_prep_fwd_kvec_f16(const float *x, const float *stats, int64_t B, int
                               void *xk_lo, void *stream);
 int mx_conv_block1_fwd_f16(const void *xk_hi, const void *xk_lo, const void *w_hi, const void *w_lo, const float *bias,
                            int64_t B, int64_t H, int64_t Wv, float *out, uint8_t *out_amax, void *stream);
+/* weight gradient of the first block from the same k-vector operand (torch Conv2d backward w.r.t. weight,
+ * models.py:187).  G, amax (B,64,H/2,352): gradient w.r.t. the pooled output and the pooling argmax; amax_bits: bit
+ * pattern of max|G| (mx_ln_prelu_bwd's gmax_bits); scale (2,) receives {S, 1/S}; part: workspace of
+ * ceil(B*H/rows_per_slab)*13*64*16 floats; dW (64,2,5,13). */
+int mx_conv_block1_wgrad_f16(const float *G, const uint8_t *amax, const uint32_t *amax_bits, const void *xk_hi,
+                             const void *xk_lo, int64_t B, int64_t H, int64_t Wv, int64_t rows_per_slab, float *scale,
+                             float *part, float *dW, void *stream);
 
 /* weight gradient from the same prepared operands (dz pair of mx_conv_prep_dgrad_f16, x pair of
  * mx_conv_prep_fwd_f16); part = workspace of ceil(B*H/rows_per_slab)*65*64*64 floats; dW (64,64,5,13). */

@@ -1,0 +1,206 @@
+// wgrad_kvec_f16.hip -- weight gradient of the FIRST Spectral2DCNN block (2 -> 64 channels, 5x13 taps, dilation 1) on
+// the fp16 matrix cores with fp32-equivalent accuracy ("f16x3", see conv_f16.hip).
+// Reference semantics: torch.nn.Conv2d backward w.r.t. weight (mod_extraction/models.py:187):
+//   dW[co][ci][kh][kw] = sum over (b, h, w) of  dz[b][co][h][w] * xhat[b][ci][h + kh - 2][w + kw - 6]
+//
+// The x operand is the "k-vector" tensor the forward pass of this block prepares and keeps
+// (mx_conv_prep_fwd_kvec_f16): xk[b][h][w][k = kh*2 + ci] = xhat[ci][h + kh - 2][w] as fp16 pairs, 16 "channels" per
+// position (10 used).  With it the kernel-row loop disappears:  D[co][k] (13 taps) += A[co][pos] * B[pos + kw - 6][k],
+// a GEMM with M = 64, N = 16, K = positions, evaluated with v_mfma_f32_16x16x32_f16 (16 x 16 tile, 32 positions deep).
+//   A = dz: the max-pool routed, scaled gradient, built on the fly from G / argmax while staging (fp32 -> route ->
+//       * S -> fp16 pair) into a [co][position] LDS image: a lane's 8 consecutive positions are one ds_read_b128.
+//   B = xk rows in a [position][16] image (32-byte rows): fragments by ds_read_b64_tr_b16 at row offset kw.
+// Workgroup = slab of (b, h) rows, 2 per CU (64 KB LDS each) so that one stages while the other multiplies; 4 waves =
+// (co half, tap group g): both 16-row co tiles of 6 taps 7g .. 7g+5 plus co tile g of the middle tap = 13 accumulators,
+// 39 MFMAs per 32 positions.  Partial results per slab, deterministic fp64 slab reduction (as the other wgrad kernels).
+#include "conv_common.h"
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef short short4v __attribute__((__vector_size__(4 * sizeof(short))));
+
+#define WK_KS_MAX 6                     // k-steps (of 32 positions) per chunk: a row = chunks of 6 + 5
+#define WK_CH (WK_KS_MAX * 32)          // 192 positions
+#define WK_AP (WK_CH + 8)               // A image pitch in halfs (400 B rows: 16-byte aligned, bank-spreading)
+#define WK_BR (WK_CH + 12)              // B image rows: positions w0 - 6 .. w0 + 191 + 6
+
+struct WgradKvecArgs {
+    const float *G;                     // (B, 64, H/2, 352) gradient w.r.t. the pooled output
+    const unsigned char *amax;          // (B, 64, H/2, 352) argmax of the pooling pair
+    const float *scale;                 // {S, 1/S}
+    const _Float16 *xk_hi, *xk_lo;      // (B, H, 352, 16)
+    float *part;                        // (n_slabs, 13, 64, 16)
+    int B, H, Wv, rows_per_slab, n_slabs;
+};
+
+__device__ __forceinline__ floatx4 mfma_16x16x32(half8 a, half8 b, floatx4 c)
+{
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+
+// B fragment: 8 consecutive rows (positions) r0 + 8 kg .. + 7 of this lane's column (k-channel) of a [row][16] image
+__device__ __forceinline__ half8 tr_frag16(const unsigned char *img, int lane_off, int r0)
+{
+    const unsigned char *ptr = img + lane_off + r0 * 32;
+    const short4v v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4v __attribute__((address_space(3))) *)ptr);
+    const short4v v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4v __attribute__((address_space(3))) *)(ptr + 4 * 32));
+    typedef short short8v __attribute__((__vector_size__(8 * sizeof(short))));
+    const short8v both = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(half8, both);
+}
+
+__global__ __launch_bounds__(256, 2) void wgrad_kvec_f16_kernel(WgradKvecArgs a)
+{
+    __shared__ __attribute__((aligned(16))) _Float16 dzA[2 * 64 * WK_AP];      // [split][co][position]   51,200 B
+    __shared__ __attribute__((aligned(16))) _Float16 xB[2 * WK_BR * 16];       // [split][position][16]   13,056 B
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int mh = wave & 1, g = wave >> 1;
+    const int m16 = lane & 15, kg = lane >> 4;
+    const int slab = blockIdx.x;
+    const int Hp = a.H >> 1;
+    const float S = a.scale[0];
+
+    floatx4 acc[CV_KW];
+#pragma unroll
+    for (int i = 0; i < CV_KW; ++i) acc[i] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    // fragment addressing (bytes)
+    const int a_lane = ((mh * 32 + m16) * WK_AP + 8 * kg) * 2;                  // + j*16*WK_AP*2 (co tile) + ks*64 (+ split)
+    const int b_lane = (8 * kg + (m16 >> 2)) * 32 + (m16 & 3) * 8;              // + (ks*32 + kw)*32 (+ split)
+    constexpr int A_SPLIT = 64 * WK_AP * 2, B_SPLIT = WK_BR * 32;
+    const unsigned char *Ab = reinterpret_cast<const unsigned char *>(dzA);
+    const unsigned char *Bb = reinterpret_cast<const unsigned char *>(xB);
+
+    const int row_begin = slab * a.rows_per_slab;
+    int row_end = row_begin + a.rows_per_slab;
+    if (row_end > a.B * a.H) row_end = a.B * a.H;
+    for (int rid = row_begin; rid < row_end; ++rid) {
+        const int b = rid / a.H, h = rid - b * a.H;
+        const unsigned want = (unsigned)(h & 1);
+        for (int w0 = 0; w0 < CV_PITCH; w0 += WK_CH) {
+            const int nks = (CV_PITCH - w0 >= WK_CH) ? WK_KS_MAX : (CV_PITCH - w0) / 32;     // 6 then 5
+            const int npos = nks * 32;
+            __syncthreads();                                    // previous chunk's fragments are all read
+            // ---- A: 64 co x npos positions, 4 positions per item
+            for (int i = tid; i < 64 * (WK_CH / 4); i += 256) {
+                const int co = i / (WK_CH / 4), c4 = i - co * (WK_CH / 4);
+                if (c4 * 4 < npos) {
+                    const int wq = w0 + c4 * 4;
+                    const size_t off = (((size_t)b * 64 + co) * Hp + (h >> 1)) * CV_PITCH + wq;
+                    const floatx4 gv = *reinterpret_cast<const floatx4 *>(a.G + off);
+                    const uchar4 am = *reinterpret_cast<const uchar4 *>(a.amax + off);
+                    float v[4];
+                    v[0] = (am.x == want && wq + 0 < a.Wv) ? gv[0] * S : 0.0f;
+                    v[1] = (am.y == want && wq + 1 < a.Wv) ? gv[1] * S : 0.0f;
+                    v[2] = (am.z == want && wq + 2 < a.Wv) ? gv[2] * S : 0.0f;
+                    v[3] = (am.w == want && wq + 3 < a.Wv) ? gv[3] * S : 0.0f;
+                    half4 hi, lo;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const _Float16 hh = (_Float16)v[e];
+                        hi[e] = hh;
+                        lo[e] = (_Float16)(v[e] - (float)hh);
+                    }
+                    *reinterpret_cast<half4 *>(dzA + co * WK_AP + c4 * 4) = hi;
+                    *reinterpret_cast<half4 *>(dzA + 64 * WK_AP + co * WK_AP + c4 * 4) = lo;
+                }
+            }
+            // ---- B: positions w0 - 6 .. w0 + npos + 5 of the k-vector row (b, h); 2 x 16-byte vectors per position
+            for (int i = tid; i < 2 * WK_BR * 2; i += 256) {
+                const int split = i / (WK_BR * 2), k = i - split * (WK_BR * 2);
+                const int pos = k >> 1, part = k & 1, w = w0 - 6 + pos;
+                floatx4 v = {0.f, 0.f, 0.f, 0.f};
+                if (pos < npos + 12 && w >= 0 && w < CV_PITCH)
+                    v = *reinterpret_cast<const floatx4 *>((split ? a.xk_lo : a.xk_hi) +
+                                                           (((size_t)b * a.H + h) * CV_PITCH + w) * 16 + part * 8);
+                *reinterpret_cast<floatx4 *>(xB + (size_t)split * (WK_BR * 16) + pos * 16 + part * 8) = v;
+            }
+            __syncthreads();
+            // ---- nks k-steps of 32 positions: 39 MFMAs each
+#pragma unroll 1
+            for (int ks = 0; ks < nks; ++ks) {
+                // A fragments: co tile 0, co tile 1, and co tile g once more for the middle tap (a separate read, not a
+                // register select: the optimizer would turn the select into a dynamically indexed private array)
+                half8 ah[3], al[3], bh[7], bl[7];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const int jt = j < 2 ? j : g;
+                    ah[j] = *reinterpret_cast<const half8 *>(Ab + a_lane + jt * (16 * WK_AP * 2) + ks * 64);
+                    al[j] = *reinterpret_cast<const half8 *>(Ab + A_SPLIT + a_lane + jt * (16 * WK_AP * 2) + ks * 64);
+                }
+#pragma unroll
+                for (int t = 0; t < 7; ++t) {
+                    const int kw = t < 6 ? 7 * g + t : 6;
+                    bh[t] = tr_frag16(Bb, b_lane, ks * 32 + kw);
+                    bl[t] = tr_frag16(Bb + B_SPLIT, b_lane, ks * 32 + kw);
+                }
+                // three split products, every accumulator once per pass
+#pragma unroll
+                for (int u = 0; u < 13; ++u) acc[u] = mfma_16x16x32(al[u < 12 ? (u & 1) : 2], bh[u < 12 ? (u >> 1) : 6], acc[u]);
+#pragma unroll
+                for (int u = 0; u < 13; ++u) acc[u] = mfma_16x16x32(ah[u < 12 ? (u & 1) : 2], bl[u < 12 ? (u >> 1) : 6], acc[u]);
+#pragma unroll
+                for (int u = 0; u < 13; ++u) acc[u] = mfma_16x16x32(ah[u < 12 ? (u & 1) : 2], bh[u < 12 ? (u >> 1) : 6], acc[u]);
+            }
+        }
+    }
+    // partial tiles: part[slab][kw][co][k]; D: lane l, reg r -> co row 4 (l >> 4) + r, column k = l & 15
+    // acc[2t + j]: tap 7g + t, co tile j (rows mh*32 + j*16 ..); acc[12]: tap 6, co tile g
+#pragma unroll
+    for (int u = 0; u < CV_KW; ++u) {
+        const int kw = u < 12 ? 7 * g + (u >> 1) : 6, j = u < 12 ? (u & 1) : g;
+        float *dst = a.part + (((size_t)slab * CV_KW + kw) * 64 + mh * 32 + j * 16) * 16;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dst[(4 * kg + r) * 16 + m16] = acc[u][r];
+    }
+}
+
+// dW[co][ci][kh][kw] = (1/S) * sum over slabs of part[slab][kw][co][kh*2 + ci]   (fp64 accumulate)
+__global__ __launch_bounds__(256) void wgrad_kvec_reduce_kernel(const float *__restrict__ part, int n_slabs,
+                                                                const float *__restrict__ scale, float *__restrict__ dW)
+{
+    const int total = CV_KW * 64 * 16;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= total) return;
+    const int k = j & 15, co = (j >> 4) & 63, kw = j >> 10;
+    if (k >= 2 * CV_KH) return;
+    double s = 0.0;
+    for (int i = 0; i < n_slabs; ++i) s += (double)part[(size_t)i * total + j];
+    const int kh = k >> 1, ci = k & 1;
+    dW[(((size_t)co * 2 + ci) * CV_KH + kh) * CV_KW + kw] = (float)(s * (double)scale[1]);
+}
+
+// G, amax: (B,64,H/2,352); amax_bits: the bit pattern of max|G| (mx_ln_prelu_bwd's gmax_bits) -> scale (2,) receives
+// {S, 1/S}; xk_hi/lo: (B,H,352,16) from mx_conv_prep_fwd_kvec_f16; part: workspace of ceil(B*H/rows_per_slab)*13*64*16
+// floats; dW (64,2,5,13) torch layout (overwritten).
+__global__ void wk_pow2_scale_kernel(const unsigned *__restrict__ amax_bits, float *__restrict__ scale)
+{
+    const float m = __uint_as_float(*amax_bits);
+    int e = 0;
+    if (m > 0.0f && m < 3.0e38f) {
+        frexpf(m, &e);
+        e = 10 - e;                    // max|G| * 2^e in [512, 1024)
+        e = e > 100 ? 100 : (e < -100 ? -100 : e);
+    }
+    scale[0] = ldexpf(1.0f, e);
+    scale[1] = ldexpf(1.0f, -e);
+}
+
+MX_EXPORT int mx_conv_block1_wgrad_f16(const float *G, const uint8_t *amax, const uint32_t *amax_bits, const void *xk_hi,
+                                       const void *xk_lo, int64_t B, int64_t H, int64_t Wv, int64_t rows_per_slab,
+                                       float *scale, float *part, float *dW, void *stream)
+{
+    if (!G || !amax || !amax_bits || !xk_hi || !xk_lo || !scale || !part || !dW || B <= 0 || rows_per_slab <= 0)
+        return MX_ERR_ARG;
+    if (H < 2 || (H & 1) || Wv <= 0 || Wv > CV_PITCH) return MX_ERR_UNSUPPORTED;
+    const int64_t n_slabs = (B * H + rows_per_slab - 1) / rows_per_slab;
+    if (n_slabs > 1000000) return MX_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(wk_pow2_scale_kernel, dim3(1), dim3(1), 0, st, amax_bits, scale);
+    WgradKvecArgs a{G, amax, scale, (const _Float16 *)xk_hi, (const _Float16 *)xk_lo, part, (int)B, (int)H, (int)Wv,
+                    (int)rows_per_slab, (int)n_slabs};
+    hipLaunchKernelGGL(wgrad_kvec_f16_kernel, dim3((unsigned)n_slabs), dim3(256), 0, st, a);
+    const int total = CV_KW * 64 * 16;
+    hipLaunchKernelGGL(wgrad_kvec_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, part, (int)n_slabs, scale, dW);
+    return mx_launch_status();
+}

@@ -185,6 +185,8 @@ class _CNNStack(torch.autograd.Function):
                           _hip.ptr(wk_lo), st)
                 _hip.call("mx_conv_block1_fwd_f16", _hip.ptr(xk_hi), _hip.ptr(xk_lo), _hip.ptr(wk_hi), _hip.ptr(wk_lo),
                           _hip.ptr(b.contiguous()), B, H, n_frames, _hip.ptr(p), _hip.ptr(amax), st)
+                if keep_splits:
+                    ctx.splits[l] = (xk_hi, xk_lo)              # the weight gradient consumes the same operand
                 del xk_hi, xk_lo
             else:
                 wt = _pack(w, 0)
@@ -273,6 +275,17 @@ class _CNNStack(torch.autograd.Function):
                 _hip.call("mx_conv_block_wgrad_f16", _hip.ptr(dz_hi), _hip.ptr(dz_lo), _hip.ptr(x_hi), _hip.ptr(x_lo),
                           _hip.ptr(scale), B, H, int(dilations[l]), rps, _hip.ptr(part), _hip.ptr(dW), st)
                 del part, x_hi, x_lo
+            elif l == 0 and 0 in ctx.splits and gmax_ws is not None:
+                # first block on the fp16 pipes: the kept k-vector operand, gradient routed / scaled / split on the fly
+                xk_hi, xk_lo = ctx.splits.pop(0)
+                rps = max(1, -(-rows // 2048))
+                n_slabs = -(-rows // rps)
+                part = torch.empty(n_slabs * 13 * 64 * 16, device=dev, dtype=torch.float32)
+                scale1 = torch.empty(2, device=dev, dtype=torch.float32)
+                _hip.call("mx_conv_block1_wgrad_f16", _hip.ptr(G), _hip.ptr(amax), _hip.ptr(gmax_ws), _hip.ptr(xk_hi),
+                          _hip.ptr(xk_lo), B, H, n_frames, rps, _hip.ptr(scale1), _hip.ptr(part), _hip.ptr(dW), st)
+                gmax_ws = None
+                del part, xk_hi, xk_lo
             else:
                 rps = max(1, -(-rows // (256 if cin == 64 else 1024)))
                 n_slabs = -(-rows // rps)
@@ -297,8 +310,8 @@ class _CNNStack(torch.autograd.Function):
                     DEBUG_TAP[f"dxhat{l}"] = dxhat.clone()
                 ds_part = torch.empty((B, 64), device=dev, dtype=torch.float32)
                 bsum = torch.empty((B, 64), device=dev, dtype=torch.float32)
-                gmax_ws = torch.zeros(1, device=dev, dtype=torch.int32) if _use_f16(saved[3 * (l - 1)].size(1), precision) \
-                    else None
+                want_gmax = _use_f16(saved[3 * (l - 1)].size(1), precision) or (l == 1 and 0 in ctx.splits)
+                gmax_ws = torch.zeros(1, device=dev, dtype=torch.int32) if want_gmax else None
                 _hip.call("mx_ln_prelu_bwd", _hip.ptr(x_in), _hip.ptr(dxhat), _hip.ptr(stats), _hip.ptr(slope_prev),
                           B, 64, H, n_frames, _hip.ptr(ds_part), _hip.ptr(bsum), _hip.ptr(gmax_ws), st)
                 grads[3 * (l - 1) + 2] = _reduce_rows(ds_part, B, 64)
