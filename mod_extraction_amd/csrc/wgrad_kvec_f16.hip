@@ -74,48 +74,77 @@ __global__ __launch_bounds__(256, 2) void wgrad_kvec_f16_kernel(WgradKvecArgs a)
     const int row_begin = slab * a.rows_per_slab;
     int row_end = row_begin + a.rows_per_slab;
     if (row_end > a.B * a.H) row_end = a.B * a.H;
-    for (int rid = row_begin; rid < row_end; ++rid) {
+    // staging items of a chunk (fixed per thread): A: (co, 4 positions) x 12; B: (split, position, 16-byte half) x 4.
+    // The next chunk's global loads are issued before the current chunk's MFMAs and converted / stored after them.
+    constexpr int NA = 64 * (WK_CH / 4) / 256, NB = (2 * WK_BR * 2 + 255) / 256;
+    floatx4 ga[NA], vb[NB];
+    unsigned ama[NA];
+    auto issue = [&](int rid, int w0) {
         const int b = rid / a.H, h = rid - b * a.H;
-        const unsigned want = (unsigned)(h & 1);
-        for (int w0 = 0; w0 < CV_PITCH; w0 += WK_CH) {
-            const int nks = (CV_PITCH - w0 >= WK_CH) ? WK_KS_MAX : (CV_PITCH - w0) / 32;     // 6 then 5
-            const int npos = nks * 32;
-            __syncthreads();                                    // previous chunk's fragments are all read
-            // ---- A: 64 co x npos positions, 4 positions per item
-            for (int i = tid; i < 64 * (WK_CH / 4); i += 256) {
-                const int co = i / (WK_CH / 4), c4 = i - co * (WK_CH / 4);
-                if (c4 * 4 < npos) {
-                    const int wq = w0 + c4 * 4;
-                    const size_t off = (((size_t)b * 64 + co) * Hp + (h >> 1)) * CV_PITCH + wq;
-                    const floatx4 gv = *reinterpret_cast<const floatx4 *>(a.G + off);
-                    const uchar4 am = *reinterpret_cast<const uchar4 *>(a.amax + off);
-                    float v[4];
-                    v[0] = (am.x == want && wq + 0 < a.Wv) ? gv[0] * S : 0.0f;
-                    v[1] = (am.y == want && wq + 1 < a.Wv) ? gv[1] * S : 0.0f;
-                    v[2] = (am.z == want && wq + 2 < a.Wv) ? gv[2] * S : 0.0f;
-                    v[3] = (am.w == want && wq + 3 < a.Wv) ? gv[3] * S : 0.0f;
-                    half4 hi, lo;
+        const int npos = (CV_PITCH - w0 >= WK_CH) ? WK_CH : (CV_PITCH - w0);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const _Float16 hh = (_Float16)v[e];
-                        hi[e] = hh;
-                        lo[e] = (_Float16)(v[e] - (float)hh);
-                    }
-                    *reinterpret_cast<half4 *>(dzA + co * WK_AP + c4 * 4) = hi;
-                    *reinterpret_cast<half4 *>(dzA + 64 * WK_AP + co * WK_AP + c4 * 4) = lo;
-                }
+        for (int q = 0; q < NA; ++q) {
+            const int i = tid + q * 256, co = i / (WK_CH / 4), c4 = i - co * (WK_CH / 4);
+            ga[q] = floatx4{0.f, 0.f, 0.f, 0.f};
+            ama[q] = 0x02020202u;                                   // matches neither row of the pooling pair
+            if (c4 * 4 < npos) {
+                const size_t off = (((size_t)b * 64 + co) * Hp + (h >> 1)) * CV_PITCH + w0 + c4 * 4;
+                ga[q] = *reinterpret_cast<const floatx4 *>(a.G + off);
+                ama[q] = *reinterpret_cast<const unsigned *>(a.amax + off);
             }
-            // ---- B: positions w0 - 6 .. w0 + npos + 5 of the k-vector row (b, h); 2 x 16-byte vectors per position
-            for (int i = tid; i < 2 * WK_BR * 2; i += 256) {
-                const int split = i / (WK_BR * 2), k = i - split * (WK_BR * 2);
-                const int pos = k >> 1, part = k & 1, w = w0 - 6 + pos;
-                floatx4 v = {0.f, 0.f, 0.f, 0.f};
-                if (pos < npos + 12 && w >= 0 && w < CV_PITCH)
-                    v = *reinterpret_cast<const floatx4 *>((split ? a.xk_lo : a.xk_hi) +
+        }
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+            const int i = tid + q * 256;
+            const int split = i / (WK_BR * 2), k = i - split * (WK_BR * 2);
+            const int pos = k >> 1, part = k & 1, w = w0 - 6 + pos;
+            vb[q] = floatx4{0.f, 0.f, 0.f, 0.f};
+            if (i < 2 * WK_BR * 2 && pos < npos + 12 && w >= 0 && w < CV_PITCH)
+                vb[q] = *reinterpret_cast<const floatx4 *>((split ? a.xk_lo : a.xk_hi) +
                                                            (((size_t)b * a.H + h) * CV_PITCH + w) * 16 + part * 8);
-                *reinterpret_cast<floatx4 *>(xB + (size_t)split * (WK_BR * 16) + pos * 16 + part * 8) = v;
+        }
+    };
+    auto commit = [&](int rid, int w0) {
+        const int h = rid % a.H;
+        const unsigned want = (unsigned)(h & 1);
+#pragma unroll
+        for (int q = 0; q < NA; ++q) {
+            const int i = tid + q * 256, co = i / (WK_CH / 4), c4 = i - co * (WK_CH / 4);
+            const int wq = w0 + c4 * 4;
+            half4 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bool keep = ((ama[q] >> (8 * e)) & 0xffu) == want && wq + e < a.Wv;
+                const float v = keep ? ga[q][e] * S : 0.0f;
+                const _Float16 hh = (_Float16)v;
+                hi[e] = hh;
+                lo[e] = (_Float16)(v - (float)hh);
             }
-            __syncthreads();
+            *reinterpret_cast<half4 *>(dzA + co * WK_AP + c4 * 4) = hi;
+            *reinterpret_cast<half4 *>(dzA + 64 * WK_AP + co * WK_AP + c4 * 4) = lo;
+        }
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+            const int i = tid + q * 256;
+            if (i < 2 * WK_BR * 2) {
+                const int split = i / (WK_BR * 2), k = i - split * (WK_BR * 2);
+                *reinterpret_cast<floatx4 *>(xB + (size_t)split * (WK_BR * 16) + (k >> 1) * 16 + (k & 1) * 8) = vb[q];
+            }
+        }
+    };
+
+    int rid = row_begin, w0 = 0;
+    if (rid < row_end) issue(rid, w0);
+    while (rid < row_end) {
+        const int nks = (CV_PITCH - w0 >= WK_CH) ? WK_KS_MAX : (CV_PITCH - w0) / 32;     // 6 then 5
+        int nrid = rid, nw0 = w0 + WK_CH;
+        if (nw0 >= CV_PITCH) { nw0 = 0; ++nrid; }
+        __syncthreads();                                    // previous chunk's fragments are all read
+        commit(rid, w0);
+        if (nrid < row_end) issue(nrid, nw0);               // in flight during the MFMAs below
+        __syncthreads();
+        {
+            {
             // ---- nks k-steps of 32 positions: 39 MFMAs each
 #pragma unroll 1
             for (int ks = 0; ks < nks; ++ks) {
@@ -142,7 +171,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_kvec_f16_kernel(WgradKvecArgs a)
 #pragma unroll
                 for (int u = 0; u < 13; ++u) acc[u] = mfma_16x16x32(ah[u < 12 ? (u & 1) : 2], bh[u < 12 ? (u >> 1) : 6], acc[u]);
             }
+            }
         }
+        rid = nrid;
+        w0 = nw0;
     }
     // partial tiles: part[slab][kw][co][k]; D: lane l, reg r -> co row 4 (l >> 4) + r, column k = l & 15
     // acc[2t + j]: tap 7g + t, co tile j (rows mh*32 + j*16 ..); acc[12]: tap 6, co tile g
