@@ -605,15 +605,10 @@ __global__ __launch_bounds__(256, 1) void conv_f16x3_dma_kernel(ConvF16Args a)
         SLOT_B;                                                                                  \
         __builtin_amdgcn_sched_barrier(0);                                                       \
     }
-#ifdef EXP_NO_DMA
-#define DMA_SLOT_A(J) (void)0
-#define DMA_SLOT_B(J) (void)0
-#else
         // phase A slots: 6 weight pieces (this stage's taps 7..12 -> W1), then patch pieces 0..7 of the next stage
 #define DMA_SLOT_A(J) { if ((J) < 6) dma_w(s, 7, 6, W1, (J)); else if (more) dma_p(s + 1, Pn, (J) - 6); }
         // phase B slots: 7 weight pieces (next stage's taps 0..6 -> W0), then the remaining patch pieces
 #define DMA_SLOT_B(J) { if (more) { if ((J) < 7) dma_w(s + 1, 0, 7, W0, (J)); else if ((J) + 1 < PPW) dma_p(s + 1, Pn, (J) + 1); } }
-#endif
 
         // ---- phase A: taps 0..6 from W0
 #pragma unroll

@@ -27,12 +27,7 @@ typedef short short4v __attribute__((__vector_size__(4 * sizeof(short))));
 
 __device__ __forceinline__ floatx16 mfma16w(half8 a, half8 b, floatx16 c)
 {
-#ifdef EXP_W_NOMMA
-    c[0] += (float)a[0] + (float)b[1];
-    return c;
-#else
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
-#endif
 }
 
 #define WF_CH 176                      // positions per chunk (352 = 2 x 176, 11 k-steps of 16)
@@ -175,11 +170,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_f16x3_kernel(WgradF16Args a)
     const int lag_off = g ? la1.off[0] : la0.off[0];
     while (rid < row_end) {
         __syncthreads();                                // everyone is done reading the previous tiles
-#ifdef EXP_W_NOCOMMIT
-        if (false) {
-#else
         if (PREF) {
-#endif
 #pragma unroll
             for (int q = 0; q < NV; ++q) store_vec(q, pv[q]);
         } else if (!PREF) {
@@ -188,12 +179,10 @@ __global__ __launch_bounds__(256, 1) void wgrad_f16x3_kernel(WgradF16Args a)
         }
         int nrid = rid, nch = ch;
         next_iter(nrid, nch);
-#ifndef EXP_W_NOISSUE
         if (PREF && nrid < row_end) {
 #pragma unroll
             for (int q = 0; q < NV; ++q) pv[q] = load_vec(q, nrid, nch);   // in flight during the MFMAs
         }
-#endif
         __syncthreads();
         // ---- 11 k-steps of 16 positions, 39 MFMAs each, in three phases of 13 (one per split product, every
         //      accumulator once per phase).  Fragment lifetimes are staggered so that ONE register set suffices and
@@ -221,12 +210,10 @@ __global__ __launch_bounds__(256, 1) void wgrad_f16x3_kernel(WgradF16Args a)
     }                                                                                              \
     if ((N_MFMA_TAIL) > 0) __builtin_amdgcn_sched_group_barrier(0x008, (N_MFMA_TAIL), 0);          \
     if ((N_DS_TAIL) > 0) __builtin_amdgcn_sched_group_barrier(0x100, (N_DS_TAIL), 0);
-#ifndef EXP_W_NOLDS
 #pragma unroll
         for (int j = 0; j < 3; ++j) { AL[j] = rd_a(dz_l, 0, j); AH[0][j] = rd_a(dz_h, 0, j); }
 #pragma unroll
         for (int t = 0; t < 7; ++t) BH[t] = rd_b(x_h, 0, t);
-#endif
 #pragma unroll
         for (int ks = 0; ks < WF_KS; ++ks) {
             const int p = ks & 1;
@@ -235,35 +222,29 @@ __global__ __launch_bounds__(256, 1) void wgrad_f16x3_kernel(WgradF16Args a)
             {   // phase 1
 #pragma unroll
                 for (int u = 0; u < 13; ++u) acc[u] = mfma16w(AL[u < 12 ? (u & 1) : 2], BH[u < 12 ? (u >> 1) : 6], acc[u]);
-#ifndef EXP_W_NOLDS
 #pragma unroll
                 for (int t = 0; t < 7; ++t) BL[t] = rd_b(x_l, ks, t);
                 WF_PIN(13, 0, 1)
-#endif
             }
             __builtin_amdgcn_sched_barrier(0);
             {   // phase 2
 #pragma unroll
                 for (int u = 0; u < 13; ++u) acc[u] = mfma16w(AH[p][u < 12 ? (u & 1) : 2], BH[u < 12 ? (u >> 1) : 6], acc[u]);
-#ifndef EXP_W_NOLDS
                 if (!last) {
 #pragma unroll
                     for (int j = 0; j < 3; ++j) { AL[j] = rd_a(dz_l, ks + 1, j); AH[p ^ 1][j] = rd_a(dz_h, ks + 1, j); }
                     WF_PIN(12, 1, 0)
                 }
-#endif
             }
             __builtin_amdgcn_sched_barrier(0);
             {   // phase 3
 #pragma unroll
                 for (int u = 0; u < 13; ++u) acc[u] = mfma16w(AH[p][u < 12 ? (u & 1) : 2], BL[u < 12 ? (u >> 1) : 6], acc[u]);
-#ifndef EXP_W_NOLDS
                 if (!last) {
 #pragma unroll
                     for (int t = 0; t < 7; ++t) BH[t] = rd_b(x_h, ks + 1, t);
                     WF_PIN(13, 0, 1)
                 }
-#endif
             }
             __builtin_amdgcn_sched_barrier(0);
         }

@@ -187,19 +187,30 @@ __global__ __launch_bounds__(256, 2) void wgrad_kvec_f16_kernel(WgradKvecArgs a)
     }
 }
 
-// dW[co][ci][kh][kw] = (1/S) * sum over slabs of part[slab][kw][co][kh*2 + ci]   (fp64 accumulate)
+// dW[co][ci][kh][kw] = (1/S) * sum over slabs of part[slab][kw][co][kh*2 + ci]   (fp64 accumulate, fixed order)
+// 256 threads = 16 slab lanes x 16 consecutive outputs: only 13 312 sums exist, so each is split over 16 lanes
+// (slabs i, i+16, ...) and combined through LDS instead of being one long load chain per thread.
 __global__ __launch_bounds__(256) void wgrad_kvec_reduce_kernel(const float *__restrict__ part, int n_slabs,
                                                                 const float *__restrict__ scale, float *__restrict__ dW)
 {
+    __shared__ double sh[16][17];
     const int total = CV_KW * 64 * 16;
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= total) return;
-    const int k = j & 15, co = (j >> 4) & 63, kw = j >> 10;
-    if (k >= 2 * CV_KH) return;
+    const int ol = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int j = blockIdx.x * 16 + ol;                    // total is a multiple of 16
     double s = 0.0;
-    for (int i = 0; i < n_slabs; ++i) s += (double)part[(size_t)i * total + j];
-    const int kh = k >> 1, ci = k & 1;
-    dW[(((size_t)co * 2 + ci) * CV_KH + kh) * CV_KW + kw] = (float)(s * (double)scale[1]);
+    for (int i = sl; i < n_slabs; i += 16) s += (double)part[(size_t)i * total + j];
+    sh[sl][ol] = s;
+    __syncthreads();
+    if (sl == 0) {
+        double t = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t += sh[q][ol];
+        const int k = j & 15, co = (j >> 4) & 63, kw = j >> 10;
+        if (k < 2 * CV_KH) {
+            const int kh = k >> 1, ci = k & 1;
+            dW[(((size_t)co * 2 + ci) * CV_KH + kh) * CV_KW + kw] = (float)(t * (double)scale[1]);
+        }
+    }
 }
 
 // G, amax: (B,64,H/2,352); amax_bits: the bit pattern of max|G| (mx_ln_prelu_bwd's gmax_bits) -> scale (2,) receives
@@ -233,6 +244,6 @@ MX_EXPORT int mx_conv_block1_wgrad_f16(const float *G, const uint8_t *amax, cons
                     (int)rows_per_slab, (int)n_slabs};
     hipLaunchKernelGGL(wgrad_kvec_f16_kernel, dim3((unsigned)n_slabs), dim3(256), 0, st, a);
     const int total = CV_KW * 64 * 16;
-    hipLaunchKernelGGL(wgrad_kvec_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, part, (int)n_slabs, scale, dW);
+    hipLaunchKernelGGL(wgrad_kvec_reduce_kernel, dim3(total / 16), dim3(256), 0, st, part, (int)n_slabs, scale, dW);
     return mx_launch_status();
 }

@@ -1,7 +1,7 @@
 """Kernel experiment harness for one .hip file: build variants with -D flags into separate shared objects (here, by
 cross-compilation) and time the f16x3 conv entry points on the GPU box.
 
-    python tools/exp_conv_f16.py build  name1:-DFOO name2:-DBAR=1 ...     (CPU container)
+    python tools/exp_conv_f16.py build  name1:-DFOO name2:-DBAR=1 ...     (CPU container; add the #ifdef you want to test)
     python tools/exp_conv_f16.py run [B]                                   (GPU box; every _lib/exp_*.so)
 """
 import ctypes
