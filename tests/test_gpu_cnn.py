@@ -95,7 +95,8 @@ def run_pair(dev, ref, mine, x, masks):
         amodels.DEBUG_TAP = None
     out_r, lat_r, n_kinks = oracle_forward_routed(ref, x, masks, tap, mine.n_frames)
     (_loss(out_r) + 0.1 * _loss(lat_r)).backward()
-    assert n_kinks <= 64
+    n_decisions = sum(v.numel() for k, v in tap.items() if k.startswith("amax"))
+    assert n_kinks <= 64 + 1e-5 * n_decisions          # shared decisions are rare events (every one is tie-checked)
     assert rel_err(out_m.detach().cpu(), out_r.detach()) < 1e-5
     assert rel_err(lat_m.detach().cpu(), lat_r.detach()) < 1e-5
     gr = dict(ref.named_parameters())
@@ -106,7 +107,7 @@ def run_pair(dev, ref, mine, x, masks):
 
 
 @pytest.mark.parametrize("precision", ["f16x3", "f32"])
-@pytest.mark.parametrize("n_samples,n_mels,B", [(22272, 64, 3), (88200, 256, 2)])
+@pytest.mark.parametrize("n_samples,n_mels,B", [(22272, 64, 3), (88200, 256, 2), (20000, 64, 9)])
 def test_cnn_forward_backward(dev, n_samples, n_mels, B, precision):
     """both conv arithmetic modes (split-fp16 matrix cores / exact fp32 MFMA) against the fp32 CPU oracle at
     the same 1e-5 (outputs) / 2e-5 (gradients) tolerances"""
