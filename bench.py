@@ -159,6 +159,10 @@ def main():
             return f"2x{a[6]}"
         if name == "mx_conv_block1_wgrad_f16":
             return f"2x{a[6]}"
+        if name == "mx_conv_block_wgrad_sp_f16":
+            return f"64x{a[7]}"
+        if name == "mx_conv_prep_gpool_f16":
+            return f"64x{a[4]}"
         if name == "mx_conv_block_wgrad_f16":
             return f"64x{a[6]}"
         return f"{a[6]}x{a[7]}"
@@ -167,7 +171,8 @@ def main():
     t0 = time.perf_counter()
     with _hip.KernelTimer({"mx_conv_block_fwd", "mx_conv_block_dgrad", "mx_conv_block_wgrad",
                            "mx_conv_block_fwd_f16", "mx_conv_block_dgrad_f16", "mx_conv_block_wgrad_f16",
-                           "mx_conv_block1_fwd_f16", "mx_conv_block1_wgrad_f16"}, key) as kt:
+                           "mx_conv_block1_fwd_f16", "mx_conv_block1_wgrad_f16", "mx_conv_block_wgrad_sp_f16",
+                           "mx_conv_prep_gpool_f16"}, key) as kt:
         for _ in range(args.steps):
             loss = step()
     fence()

@@ -1,0 +1,467 @@
+// wgrad_sp_f16.hip -- weight gradient of the 64->64 channel Spectral2DCNN convolutions on the SPARSE fp16 matrix
+// instruction v_smfmac_f32_32x32x32_f16, with fp32-equivalent accuracy ("f16x3", see conv_f16.hip).
+// Reference semantics: torch.nn.Conv2d backward w.r.t. weight behind MaxPool2d((2,1)) (mod_extraction/models.py:187-188):
+//   dW[co][ci][kh][kw] = sum over (b, h, w) of  dz[b][co][h][w] * xhat[b][ci][h + kh - 2][w + (kw - 6) T]
+// where dz is the pooled gradient G routed to the row of each pooling pair that won the max: of dz[.][2hp][w] and
+// dz[.][2hp+1][w] exactly one is G[.][hp][w], the other is 0.  Ordering the GEMM's K dimension as
+//   k = 2 * position + row parity
+// makes that a 2:4 structured-sparse A operand: every group of 4 consecutive k (two positions x two parities) holds two
+// non-zeros, one in {0,1} and one in {2,3}.  The sparse MFMA takes A compressed -- here simply G itself, at pooled
+// resolution -- plus 2-bit positions (the pooling argmax), multiplies it with a dense K = 32 B operand in the time
+// of a dense K = 16 instruction, and so does BOTH rows of a pooling pair at once: half the matrix instructions (and
+// half their energy: these kernels are power-limited) of the dense kernel in wgrad_f16.hip.
+//
+// Operand layouts (derived with tools/probe/probe_smfmac.py, checked numerically by tools/probe/check_smfmac.py; this
+// image has no ISA manual):
+//   A  lane l: row m = l & 31, half hh = l >> 5; compressed element j (0..7) lies in the logical group of 4 starting at
+//      k = 16 (j >> 2) + 8 hh + 4 ((j >> 1) & 1), at position (idx >> 2j) & 3 of it  ->  with k = 2 pos + parity the lane
+//      holds G at positions 4hh .. 4hh+3 and 8+4hh .. 8+4hh+3 of the 16-position k-step (two 8-byte LDS reads from a
+//      [co][position] image) and idx field j = 2 (j & 1) + argmax(position j).
+//   B  lane l: column n = l & 31, k = 16 (l >> 5) + j, j = 0..15: 16 consecutive rows of a [2 pos + parity][channel]
+//      image = four ds_read_b64_tr_b16 (x rows h + kh - 2 for the two parities are staged interleaved).
+//   D  as the dense 32x32 MFMA.
+// Everything else follows wgrad_f16.hip: workgroup = (kernel row kh, slab of POOLED rows), 4 waves = (ci tile, tap
+// group), 13 accumulators, three-phase k-steps with staggered fragment lifetimes, register prefetch of the next chunk,
+// deterministic fp64 slab reduction.
+#include "conv_common.h"
+#include <type_traits>
+
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half16 __attribute__((ext_vector_type(16)));
+typedef short short4v __attribute__((__vector_size__(4 * sizeof(short))));
+
+#define WS_ROW_KS 22                    // 352 positions = 22 k-steps of 16 positions (32 logical k)
+
+struct WgradSpArgs {
+    const _Float16 *gp_hi, *gp_lo;      // (B, 64, Hp, 352): fp16 pair of G * S at pooled resolution
+    const unsigned short *gidx;         // (B, 64, Hp, 22, 2): index word of (k-step, lane half)
+    const _Float16 *x_hi, *x_lo;        // (B, H, 4, 352, 16)
+    float *part;                        // (n_slabs, 5, 13, 64, 64)
+    int B, H, rows_per_slab, n_slabs;   // rows = pooled rows (b, hp)
+};
+
+__device__ __forceinline__ floatx16 smfmac(half8 a, half16 b, floatx16 c, int idx)
+{
+    return __builtin_amdgcn_smfmac_f32_32x32x32_f16(a, b, c, idx, 0, 0);
+}
+
+// Transposed-read lane offsets (see wgrad_f16.hip:tr_lane_offsets), for a lane half that owns 16 consecutive image rows
+struct TrLane32 { int off[4]; };
+__device__ __forceinline__ TrLane32 tr_lane_offsets32(int tile, int lane)
+{
+    const int q = (lane & 15) >> 2, p = lane & 3, g1 = (lane >> 4) & 1, h2 = lane >> 5;
+    TrLane32 L;
+#pragma unroll
+    for (int ph = 0; ph < 4; ++ph) {
+        const int swz = ((ph + q) >> 1) & 1;
+        L.off[ph] = (16 * h2 + q) * 128 + ((tile ^ swz) * 64) + 32 * g1 + 8 * p;
+    }
+    return L;
+}
+// 16 consecutive rows r0 + 16 h2 .. + 15 of this lane's channel: four transposed reads (r0 wave-uniform, ph = r0 & 3)
+__device__ __forceinline__ half16 tr_frag32(const unsigned char *img_bytes, int lane_off, int r0)
+{
+    const unsigned char *ptr = img_bytes + lane_off + r0 * 128;
+    const short4v v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4v __attribute__((address_space(3))) *)ptr);
+    const short4v v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4v __attribute__((address_space(3))) *)(ptr + 512));
+    const short4v v2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4v __attribute__((address_space(3))) *)(ptr + 1024));
+    const short4v v3 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4v __attribute__((address_space(3))) *)(ptr + 1536));
+    typedef short short8v __attribute__((__vector_size__(8 * sizeof(short))));
+    typedef short short16v __attribute__((__vector_size__(16 * sizeof(short))));
+    const short8v lo = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+    const short8v hi = __builtin_shufflevector(v2, v3, 0, 1, 2, 3, 4, 5, 6, 7);
+    const short16v all = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+    return __builtin_bit_cast(half16, all);
+}
+// compressed A fragment: positions 4hh .. 4hh+3 and 8+4hh .. 8+4hh+3 of the k-step, from a [co][position] image
+__device__ __forceinline__ half8 a_frag(const unsigned char *ptr)
+{
+    const half4 lo = *reinterpret_cast<const half4 *>(ptr);
+    const half4 hi = *reinterpret_cast<const half4 *>(ptr + 16);
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+template <int T>
+__global__ __launch_bounds__(256, 1) void wgrad_sp_f16x3_kernel(WgradSpArgs a)
+{
+    constexpr int KC = T >= 16 ? 3 : (T <= 2 ? 8 : 6);                   // k-steps per chunk
+    constexpr int NCH = (WS_ROW_KS + KC - 1) / KC;                       // chunks per row: 8,7,7 / 6,6,5,5 / 3,3,3,3,3,3,2,2
+    constexpr int KS_LO = WS_ROW_KS / NCH, KS_REM = WS_ROW_KS % NCH;
+    constexpr int CHP = KC * 16;                                         // positions per chunk (max)
+    constexpr int AP = CHP + 4;                                          // A image pitch (halfs): 8-byte aligned, bank-spreading
+    constexpr int WINP = CHP + 12 * T;                                   // x window positions (origin w0 - 6T)
+    constexpr int A_SPLIT = 64 * AP * 2, B_SPLIT = 2 * WINP * 128;       // bytes per split
+    constexpr int IDX_BYTES = 64 * KC * 2 * 2;
+    constexpr int QI = (KC * 2 + 3) / 4;                                 // index words per thread
+    constexpr int QX = (WINP + 31) / 32;                                 // x iterations per (split, parity)
+    constexpr bool PREF = T <= 4;                                        // register prefetch of the next chunk
+    constexpr int NVI = PREF ? QI : 1, NVB = PREF ? 4 * QX : 1;
+    static_assert(2 * A_SPLIT + IDX_BYTES + 2 * B_SPLIT <= 160 * 1024, "LDS budget");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char *const Aimg = smem;                                    // [split][co][AP]
+    unsigned char *const Iimg = smem + 2 * A_SPLIT;                      // [co][KC][2] u16
+    unsigned char *const Bimg = Iimg + ((IDX_BYTES + 15) / 16) * 16;     // [split][2 pos + parity][64 ch]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = wave & 1, nt = wave >> 1;
+    const int id = blockIdx.x;
+    const int kh = (id >> 3) % CV_KH;
+    const int slab = (id & 7) + 8 * (id / (8 * CV_KH));
+    if (slab >= a.n_slabs) return;
+    const int H = a.H, Hp = H >> 1;
+
+    floatx16 acc[CV_KW];
+#pragma unroll
+    for (int i = 0; i < CV_KW; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+
+    const int row_begin = slab * a.rows_per_slab;
+    int row_end = row_begin + a.rows_per_slab;
+    if (row_end > a.B * Hp) row_end = a.B * Hp;
+    // a pooled row contributes unless BOTH x rows of the pair fall outside the image
+    auto row_valid = [&](int rid) {
+        const int hx0 = 2 * (rid % Hp) + kh - 2;
+        return hx0 + 1 >= 0 && hx0 < H;
+    };
+    auto next_iter = [&](int &rid, int &ch) {
+        if (++ch < NCH) return;
+        ch = 0;
+        do { ++rid; } while (rid < row_end && !row_valid(rid));
+    };
+    auto chunk_ks = [&](int ch) { return KS_LO + (ch < KS_REM ? 1 : 0); };
+    auto chunk_k0 = [&](int ch) { return ch * KS_LO + (ch < KS_REM ? ch : KS_REM); };      // first k-step
+
+    // ---- staging: global -> registers -> LDS (next chunk in flight during the current chunk's MFMAs).  Regular maps:
+    //      every address is a per-thread constant + a compile-time multiple of the iteration index.
+    //   A   thread = (co = tid >> 2, vector c8 = (tid & 3) + 4 q of 8 positions), q < CHP / 32, per split
+    //   idx thread = (co = tid >> 2, word e = (tid & 3) + 4 q of the chunk's 2 KC), q < QI
+    //   x   thread = (position pos0 + 32 q, 16-byte vector sv), per (split, row parity)
+    constexpr int QAS = CHP / 32;                                        // A iterations per split
+    static_assert(CHP % 32 == 0 || CHP == 48, "A staging map");
+    floatx4 pa[PREF ? 2 * ((CHP + 31) / 32) : 1], pb[NVB];
+    unsigned short pi[NVI];
+    const int sv = tid & 7, pos0 = tid >> 3;
+    const int a_co = tid >> 2, a_c8 = tid & 3;
+    constexpr int QA2 = (CHP + 31) / 32;                                 // (CHP / 8 vectors per co) / 4 threads per co
+    auto load_a = [&](int k, int rid, int ch) -> floatx4 {
+        const int b = rid / Hp, hp = rid - b * Hp, ks0 = chunk_k0(ch), npos = chunk_ks(ch) * 16;
+        const int split = k / QA2, q = k - split * QA2, c8 = a_c8 + 4 * q;
+        floatx4 z = {0.f, 0.f, 0.f, 0.f};
+        if (c8 * 8 < npos)
+            z = *reinterpret_cast<const floatx4 *>((split ? a.gp_lo : a.gp_hi) + (((size_t)b * 64 + a_co) * Hp + hp) * CV_PITCH +
+                                                   ks0 * 16 + c8 * 8);
+        return z;
+    };
+    auto store_a = [&](int k, floatx4 v) {
+        const int split = k / QA2, q = k - split * QA2, c8 = a_c8 + 4 * q;
+        if (c8 * 8 < CHP) {
+            typedef float floatx2 __attribute__((ext_vector_type(2)));
+            unsigned char *dst = Aimg + split * A_SPLIT + a_co * (AP * 2) + c8 * 16;          // 8-byte aligned rows
+            reinterpret_cast<floatx2 *>(dst)[0] = floatx2{v[0], v[1]};
+            reinterpret_cast<floatx2 *>(dst)[1] = floatx2{v[2], v[3]};
+        }
+    };
+    auto load_i = [&](int q, int rid, int ch) -> unsigned short {
+        const int b = rid / Hp, hp = rid - b * Hp, ks0 = chunk_k0(ch), nks = chunk_ks(ch);
+        const int e = a_c8 + 4 * q;
+        if (e < nks * 2) return a.gidx[(((size_t)b * 64 + a_co) * Hp + hp) * (WS_ROW_KS * 2) + ks0 * 2 + e];
+        return 0;
+    };
+    auto store_i = [&](int q, unsigned short v) {
+        const int e = a_c8 + 4 * q;
+        if (e < KC * 2) reinterpret_cast<unsigned short *>(Iimg)[a_co * (KC * 2) + e] = v;
+    };
+    // x vector k = ((split * 2 + parity) * QX + q): position pos0 + 32 q of the window, 16-byte vector sv
+    auto load_b = [&](int k, int rid, int ch) -> floatx4 {
+        const int b = rid / Hp, hp = rid - b * Hp, w0 = chunk_k0(ch) * 16;
+        const int sp = k / QX, q = k - sp * QX, split = sp >> 1, par = sp & 1;
+        const int pos = pos0 + 32 * q, w = w0 - 6 * T + pos, hx = 2 * hp + par + kh - 2;
+        floatx4 z = {0.f, 0.f, 0.f, 0.f};
+        if (pos < WINP && w >= 0 && w < CV_PITCH && hx >= 0 && hx < H)
+            z = *reinterpret_cast<const floatx4 *>((split ? a.x_lo : a.x_hi) +
+                                                   (((size_t)b * H + hx) * 4 + (sv >> 1)) * (CV_PITCH * 16) + w * 16 + (sv & 1) * 8);
+        return z;
+    };
+    auto store_b = [&](int k, floatx4 v) {
+        const int sp = k / QX, q = k - sp * QX, split = sp >> 1, par = sp & 1;
+        const int pos = pos0 + 32 * q;
+        if (pos < WINP)
+            *reinterpret_cast<floatx4 *>(Bimg + split * B_SPLIT + (2 * pos + par) * 128 + ((sv ^ ((pos & 1) << 2)) * 16)) = v;
+    };
+    constexpr int NA = 2 * QA2, NI = (KC * 2 + 3) / 4;
+
+    int rid = row_begin, ch = 0;
+    while (rid < row_end && !row_valid(rid)) ++rid;
+    if (PREF && rid < row_end) {
+#pragma unroll
+        for (int q = 0; q < NA; ++q) pa[q] = load_a(q, rid, ch);
+#pragma unroll
+        for (int q = 0; q < NI; ++q) pi[q] = load_i(q, rid, ch);
+#pragma unroll
+        for (int q = 0; q < NVB; ++q) pb[q] = load_b(q, rid, ch);
+    }
+    // accumulators: acc[2k + j] = tap 7g + k (k < 6), co tile j;   acc[12] = tap 6, co tile g
+    const int m32 = lane & 31, hh = lane >> 5;
+    // The wave's seven taps sit at image-row offsets 2T i, i = 0..6, from row 12 g T of the window (g = 0: taps 0..5 then
+    // the middle tap 6; g = 1: the middle tap then taps 7..12).  A fragment = four 4-row transposed blocks; offsets
+    // that differ by a multiple of 4 rows share blocks, so the taps are read as sliding windows over block chains:
+    //   T = 1: two chains (even i: rows 0,4,..,24 = 7 blocks; odd i: rows 2,6,..,22 = 6 blocks)     13 reads, not 28
+    //   T = 2: one chain of 10 blocks;  T = 4: one chain of 16;  T >= 8: no overlap (28 blocks)
+    constexpr int NBLK = T == 1 ? 13 : (T == 2 ? 10 : (T == 4 ? 16 : 28));
+    const TrLane32 lb = tr_lane_offsets32(nt, lane);
+    const int xg_off = g * 12 * T * 128;
+    const int ph_g = (12 * T * g) & 3;
+    // A / index addressing: co tile j -> rows j*32 + m32; the middle tap uses co tile g
+    const int a_lane = m32 * (AP * 2) + hh * 8;
+    const int i_lane = m32 * (KC * 4) + hh * 2;
+    const unsigned char *Ah = Aimg, *Al = Aimg + A_SPLIT;
+    const unsigned char *x_h = Bimg, *x_l = Bimg + B_SPLIT;
+    typedef short short8v __attribute__((__vector_size__(8 * sizeof(short))));
+    typedef short short16v __attribute__((__vector_size__(16 * sizeof(short))));
+    // block index of tap i's first block, and the image row of block n
+    auto blk_of = [](int i) { return T == 1 ? ((i & 1) ? 7 + (i >> 1) : (i >> 1)) : (T == 2 ? i : (T == 4 ? 2 * i : 4 * i)); };
+    auto row_of = [](int n) { return T == 1 ? (n < 7 ? 4 * n : 2 + 4 * (n - 7)) : (T >= 8 ? (n >> 2) * 2 * T + 4 * (n & 3) : 4 * n); };
+
+    // the k-step loop, specialised on the tap group (which tap of the window is the middle one)
+    auto run_chunk = [&](auto gc, int nks) {
+        constexpr int G = decltype(gc)::value;
+        half8 AL[3], AH[2][3];                      // [co tile 0, co tile 1, co tile g]
+        int IX[2][3];
+        short4v BHb[NBLK], BLb[NBLK];               // 4-row blocks of hi(x) / lo(x)
+        auto rd_a = [&](const unsigned char *img, int ks, int j) {
+            const int tile = j < 2 ? j : G;
+            return a_frag(img + tile * (32 * AP * 2) + a_lane + ks * 32);
+        };
+        auto rd_i = [&](int ks, int j) {
+            const int tile = j < 2 ? j : G;
+            return (int)*reinterpret_cast<const unsigned short *>(Iimg + tile * (32 * KC * 4) + i_lane + ks * 4);
+        };
+        auto rd_blk = [&](const unsigned char *img, int ks, int n) {
+            const int r0 = row_of(n);
+            const unsigned char *ptr = img + ks * 4096 + xg_off + lb.off[(r0 + 12 * T * G) & 3] + r0 * 128;
+            return __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4v __attribute__((address_space(3))) *)ptr);
+        };
+        auto frag = [&](const short4v *blk, int i) {
+            const int n = blk_of(i);
+            const short8v lo = __builtin_shufflevector(blk[n], blk[n + 1], 0, 1, 2, 3, 4, 5, 6, 7);
+            const short8v hi = __builtin_shufflevector(blk[n + 2], blk[n + 3], 0, 1, 2, 3, 4, 5, 6, 7);
+            const short16v all = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+            return __builtin_bit_cast(half16, all);
+        };
+        // accumulator u -> (window tap i, A fragment): u = 2k + j (k < 6): i = k + G, A = co tile j; u = 12: middle tap
+        auto tap_of = [](int u) { return u < 12 ? (u >> 1) + G : (G ? 0 : 6); };
+        // N_DS LDS reads spread over the phase's 13 MFMAs: PER reads after each of the first PAIRS MFMAs
+#define WS_PIN(N_DS)                                                                               \
+    {                                                                                              \
+        constexpr int per_ = (N_DS) >= 13 ? (N_DS) / 13 : 1, pairs_ = (N_DS) >= 13 ? 13 : (N_DS);  \
+        _Pragma("unroll") for (int q_ = 0; q_ < pairs_; ++q_) {                                    \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                     \
+            __builtin_amdgcn_sched_group_barrier(0x100, per_, 0);                                  \
+        }                                                                                          \
+        if (13 - pairs_ > 0) __builtin_amdgcn_sched_group_barrier(0x008, 13 - pairs_, 0);          \
+        if ((N_DS) - pairs_ * per_ > 0) __builtin_amdgcn_sched_group_barrier(0x100, (N_DS) - pairs_ * per_, 0); \
+    }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { AL[j] = rd_a(Al, 0, j); AH[0][j] = rd_a(Ah, 0, j); IX[0][j] = rd_i(0, j); }
+#pragma unroll
+        for (int n = 0; n < NBLK; ++n) BHb[n] = rd_blk(x_h, 0, n);
+#pragma unroll
+        for (int ks = 0; ks < KC; ++ks) {
+            if (ks < nks) {
+                const int p = ks & 1;
+                const bool last = ks + 1 >= nks;
+                __builtin_amdgcn_sched_barrier(0);
+                {   // phase 1: lo(G) * hi(x), while lo(x) arrives
+#pragma unroll
+                    for (int u = 0; u < 13; ++u)
+                        acc[u] = smfmac(AL[u < 12 ? (u & 1) : 2], frag(BHb, tap_of(u)), acc[u], IX[p][u < 12 ? (u & 1) : 2]);
+#pragma unroll
+                    for (int n = 0; n < NBLK; ++n) BLb[n] = rd_blk(x_l, ks, n);
+                    WS_PIN(NBLK)
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                {   // phase 2: hi(G) * hi(x), while the next k-step's G and index words arrive
+#pragma unroll
+                    for (int u = 0; u < 13; ++u)
+                        acc[u] = smfmac(AH[p][u < 12 ? (u & 1) : 2], frag(BHb, tap_of(u)), acc[u], IX[p][u < 12 ? (u & 1) : 2]);
+                    if (!last) {
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) {
+                            AL[j] = rd_a(Al, ks + 1, j);
+                            AH[p ^ 1][j] = rd_a(Ah, ks + 1, j);
+                            IX[p ^ 1][j] = rd_i(ks + 1, j);
+                        }
+                        WS_PIN(15)
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                {   // phase 3: hi(G) * lo(x), while the next k-step's hi(x) arrives
+#pragma unroll
+                    for (int u = 0; u < 13; ++u)
+                        acc[u] = smfmac(AH[p][u < 12 ? (u & 1) : 2], frag(BLb, tap_of(u)), acc[u], IX[p][u < 12 ? (u & 1) : 2]);
+                    if (!last) {
+#pragma unroll
+                        for (int n = 0; n < NBLK; ++n) BHb[n] = rd_blk(x_h, ks + 1, n);
+                        WS_PIN(NBLK)
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#undef WS_PIN
+    };
+
+    while (rid < row_end) {
+        __syncthreads();                                // everyone is done reading the previous images
+        if (PREF) {
+#pragma unroll
+            for (int q = 0; q < NA; ++q) store_a(q, pa[q]);
+#pragma unroll
+            for (int q = 0; q < NI; ++q) store_i(q, pi[q]);
+#pragma unroll
+            for (int q = 0; q < NVB; ++q) store_b(q, pb[q]);
+        } else {
+#pragma unroll
+            for (int q = 0; q < NA; ++q) store_a(q, load_a(q, rid, ch));
+#pragma unroll
+            for (int q = 0; q < NI; ++q) store_i(q, load_i(q, rid, ch));
+#pragma unroll 4
+            for (int q = 0; q < 4 * QX; ++q) store_b(q, load_b(q, rid, ch));
+        }
+        const int nks = chunk_ks(ch);
+        int nrid = rid, nch = ch;
+        next_iter(nrid, nch);
+        if (PREF && nrid < row_end) {
+#pragma unroll
+            for (int q = 0; q < NA; ++q) pa[q] = load_a(q, nrid, nch);
+#pragma unroll
+            for (int q = 0; q < NI; ++q) pi[q] = load_i(q, nrid, nch);
+#pragma unroll
+            for (int q = 0; q < NVB; ++q) pb[q] = load_b(q, nrid, nch);
+        }
+        __syncthreads();
+        if (g) run_chunk(std::integral_constant<int, 1>{}, nks);
+        else run_chunk(std::integral_constant<int, 0>{}, nks);
+        rid = nrid;
+        ch = nch;
+    }
+    // partial tiles: part[slab][kh][kw][co][ci]   (D rows = co, columns = ci)
+    const int l32 = lane & 31;
+#pragma unroll
+    for (int i = 0; i < CV_KW; ++i) {
+        const int kw = i == 12 ? 6 : 7 * g + (i >> 1), mt = i == 12 ? g : (i & 1);
+        float *dst = a.part + ((((size_t)slab * CV_KH + kh) * CV_KW + kw) * 64) * 64;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dst[(mt * 32 + mfma_row(r, lane)) * 64 + nt * 32 + l32] = acc[i][r];
+    }
+}
+
+// dW[co][ci][kh][kw] = inv_scale * sum over slabs of part[slab][kh][kw][co][ci]   (fp64 accumulate)
+__global__ __launch_bounds__(256) void wgrad_sp_reduce_kernel(const float *__restrict__ part, int n_slabs,
+                                                              const float *__restrict__ scale, float *__restrict__ dW)
+{
+    const int total = CV_TAPS * 64 * 64;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= total) return;
+    double s = 0.0;
+    for (int k = 0; k < n_slabs; ++k) s += (double)part[(size_t)k * total + j];
+    const int ci = j % 64, co = (j / 64) % 64, tap = j / (64 * 64);
+    dW[((size_t)co * 64 + ci) * CV_TAPS + tap] = (float)(s * (double)scale[1]);
+}
+
+// G (B,64,Hp,352) fp32, amax (B,64,Hp,352) uint8, scale[0] = S  ->  gp_hi / gp_lo (same shape, fp16 pair of G * S) and
+// gidx (B,64,Hp,22,2): per (k-step of 16 positions, lane half hh) the 8 two-bit fields of the lane's compressed elements,
+// element j = 2 gq + e at position 16 ks + 8 (gq >> 1) + 4 hh + 2 (gq & 1) + e, field = 2 e + argmax.
+__global__ __launch_bounds__(256) void gpool_prep_kernel(const float *__restrict__ G, const unsigned char *__restrict__ amax,
+                                                         const float *__restrict__ scale, long long n_rows,
+                                                         _Float16 *__restrict__ gp_hi, _Float16 *__restrict__ gp_lo,
+                                                         unsigned short *__restrict__ gidx)
+{
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;          // (row, ks, hh)
+    if (t >= n_rows * (WS_ROW_KS * 2)) return;
+    const long long row = t / (WS_ROW_KS * 2);
+    const int e2 = (int)(t - row * (WS_ROW_KS * 2)), ks = e2 >> 1, hh = e2 & 1;
+    const float S = scale[0];
+    unsigned word = 0;
+#pragma unroll
+    for (int part = 0; part < 2; ++part) {                                   // positions 4hh..+3 and 8+4hh..+3
+        const size_t off = (size_t)row * CV_PITCH + ks * 16 + part * 8 + hh * 4;
+        const floatx4 gv = *reinterpret_cast<const floatx4 *>(G + off);
+        const uchar4 am = *reinterpret_cast<const uchar4 *>(amax + off);
+        half4 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float v = gv[e] * S;
+            const _Float16 h = (_Float16)v;
+            hi[e] = h;
+            lo[e] = (_Float16)(v - (float)h);
+        }
+        *reinterpret_cast<half4 *>(gp_hi + off) = hi;
+        *reinterpret_cast<half4 *>(gp_lo + off) = lo;
+        const unsigned a0 = am.x & 1, a1 = am.y & 1, a2 = am.z & 1, a3 = am.w & 1;
+        // elements j = 4 part + 0..3: (gq = 2 part, e = 0), (gq, 1), (gq + 1, 0), (gq + 1, 1)
+        word |= ((0u + a0) | ((2u + a1) << 2) | ((0u + a2) << 4) | ((2u + a3) << 6)) << (8 * part);
+    }
+    gidx[t] = (unsigned short)word;
+}
+
+template <int T>
+static int launch_wgrad_sp(const WgradSpArgs &a, hipStream_t st)
+{
+    constexpr int KC = T >= 16 ? 3 : (T <= 2 ? 8 : 6), CHP = KC * 16, AP = CHP + 4, WINP = CHP + 12 * T;
+    const size_t lds = 2 * (size_t)(64 * AP * 2) + ((64 * KC * 4 + 15) / 16) * 16 + 2 * (size_t)(2 * WINP * 128);
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void *)wgrad_sp_f16x3_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+            hipSuccess)
+            return MX_ERR_LAUNCH;
+        attr_done = true;
+    }
+    const int groups = (a.n_slabs + 7) / 8;
+    hipLaunchKernelGGL((wgrad_sp_f16x3_kernel<T>), dim3(groups * 8 * CV_KH), dim3(256), lds, st, a);
+    return mx_launch_status();
+}
+
+// Gradient operand of the sparse weight-gradient kernel: G, amax (B,64,H/2,352), scale = the {S, 1/S} pair of
+// mx_conv_prep_dgrad_f16 -> gp_hi, gp_lo (B,64,H/2,352) halfs, gidx (B,64,H/2,22,2) uint16.
+MX_EXPORT int mx_conv_prep_gpool_f16(const float *G, const uint8_t *amax, const float *scale, int64_t B, int64_t H,
+                                     void *gp_hi, void *gp_lo, void *gidx, void *stream)
+{
+    if (!G || !amax || !scale || !gp_hi || !gp_lo || !gidx || B <= 0 || H < 2 || (H & 1)) return MX_ERR_ARG;
+    const long long n_rows = (long long)B * 64 * (H / 2), n_thr = n_rows * (WS_ROW_KS * 2);
+    if (n_thr > (1ll << 38)) return MX_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(gpool_prep_kernel, dim3((unsigned)((n_thr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, G, amax,
+                       scale, n_rows, (_Float16 *)gp_hi, (_Float16 *)gp_lo, (unsigned short *)gidx);
+    return mx_launch_status();
+}
+
+// x_hi/lo: (B,H,4,352,16) operand pair of the block's forward pass; part: workspace of ceil(B*(H/2)/rows_per_slab)*65*64*64
+// floats (rows = pooled rows); dW (64,64,5,13).
+MX_EXPORT int mx_conv_block_wgrad_sp_f16(const void *gp_hi, const void *gp_lo, const void *gidx, const void *x_hi,
+                                         const void *x_lo, const float *scale, int64_t B, int64_t H, int32_t dilation,
+                                         int64_t rows_per_slab, float *part, float *dW, void *stream)
+{
+    if (!gp_hi || !gp_lo || !gidx || !x_hi || !x_lo || !scale || !part || !dW || B <= 0 || H < 2 || (H & 1) ||
+        rows_per_slab <= 0)
+        return MX_ERR_ARG;
+    const int64_t n_slabs = (B * (H / 2) + rows_per_slab - 1) / rows_per_slab;
+    if (n_slabs > 1000000) return MX_ERR_UNSUPPORTED;
+    WgradSpArgs a{(const _Float16 *)gp_hi, (const _Float16 *)gp_lo, (const unsigned short *)gidx, (const _Float16 *)x_hi,
+                  (const _Float16 *)x_lo, part, (int)B, (int)H, (int)rows_per_slab, (int)n_slabs};
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    switch (dilation) {
+    case 1: rc = launch_wgrad_sp<1>(a, st); break;
+    case 2: rc = launch_wgrad_sp<2>(a, st); break;
+    case 4: rc = launch_wgrad_sp<4>(a, st); break;
+    case 8: rc = launch_wgrad_sp<8>(a, st); break;
+    case 16: rc = launch_wgrad_sp<16>(a, st); break;
+    default: return MX_ERR_UNSUPPORTED;
+    }
+    if (rc != MX_OK) return rc;
+    const int total = CV_TAPS * 64 * 64;
+    hipLaunchKernelGGL(wgrad_sp_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, part, (int)n_slabs, scale, dW);
+    return mx_launch_status();
+}

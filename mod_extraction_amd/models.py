@@ -127,6 +127,8 @@ def _pack_f16(w: T, flip: int) -> Tuple[T, T]:
 
 # first block on the fp16 pipes too (MODEX_BLOCK1=f32 keeps it on the exact-fp32 MFMA kernel; A/B knob)
 BLOCK1_F16 = os.environ.get("MODEX_BLOCK1", "f16x3") != "f32"
+# weight gradient of the 64-channel blocks: sparse (2:4 along the pooling pair) or dense matrix instruction
+WGRAD_SPARSE = os.environ.get("MODEX_WGRAD", "sparse") != "dense"
 
 
 def _use_f16(cin: int, precision: str) -> bool:
@@ -269,11 +271,27 @@ class _CNNStack(torch.autograd.Function):
                     x_lo = torch.empty((B, H, 4, PITCH, 16), device=dev, dtype=torch.float16)
                     _hip.call("mx_conv_prep_fwd_f16", _hip.ptr(x_in), _hip.ptr(stats), _hip.ptr(slope_prev), B, H,
                               n_frames, _hip.ptr(x_hi), _hip.ptr(x_lo), st)
-                rps = max(1, -(-rows // 408))            # ~408 slabs x 5 kernel rows = 8 workgroups per CU
-                n_slabs = -(-rows // rps)
-                part = torch.empty(n_slabs * 65 * 64 * 64, device=dev, dtype=torch.float32)
-                _hip.call("mx_conv_block_wgrad_f16", _hip.ptr(dz_hi), _hip.ptr(dz_lo), _hip.ptr(x_hi), _hip.ptr(x_lo),
-                          _hip.ptr(scale), B, H, int(dilations[l]), rps, _hip.ptr(part), _hip.ptr(dW), st)
+                if WGRAD_SPARSE and int(dilations[l]) <= 4:
+                    # sparse matrix instruction (dilations >= 8 share no fragment blocks between taps: dense kernel): the pooled gradient is the compressed operand, the argmax its index bits
+                    Hp = H // 2
+                    gp_hi = torch.empty((B, 64, Hp, PITCH), device=dev, dtype=torch.float16)
+                    gp_lo = torch.empty((B, 64, Hp, PITCH), device=dev, dtype=torch.float16)
+                    gidx = torch.empty((B, 64, Hp, 22, 2), device=dev, dtype=torch.int16)
+                    _hip.call("mx_conv_prep_gpool_f16", _hip.ptr(G), _hip.ptr(amax), _hip.ptr(scale), B, H, _hip.ptr(gp_hi),
+                              _hip.ptr(gp_lo), _hip.ptr(gidx), st)
+                    prow = B * Hp
+                    rps = max(1, -(-prow // 408))
+                    n_slabs = -(-prow // rps)
+                    part = torch.empty(n_slabs * 65 * 64 * 64, device=dev, dtype=torch.float32)
+                    _hip.call("mx_conv_block_wgrad_sp_f16", _hip.ptr(gp_hi), _hip.ptr(gp_lo), _hip.ptr(gidx), _hip.ptr(x_hi),
+                              _hip.ptr(x_lo), _hip.ptr(scale), B, H, int(dilations[l]), rps, _hip.ptr(part), _hip.ptr(dW), st)
+                    del gp_hi, gp_lo, gidx
+                else:
+                    rps = max(1, -(-rows // 408))            # ~408 slabs x 5 kernel rows = 8 workgroups per CU
+                    n_slabs = -(-rows // rps)
+                    part = torch.empty(n_slabs * 65 * 64 * 64, device=dev, dtype=torch.float32)
+                    _hip.call("mx_conv_block_wgrad_f16", _hip.ptr(dz_hi), _hip.ptr(dz_lo), _hip.ptr(x_hi), _hip.ptr(x_lo),
+                              _hip.ptr(scale), B, H, int(dilations[l]), rps, _hip.ptr(part), _hip.ptr(dW), st)
                 del part, x_hi, x_lo
             elif l == 0 and 0 in ctx.splits and gmax_ws is not None:
                 # first block on the fp16 pipes: the kept k-vector operand, gradient routed / scaled / split on the fly
