@@ -85,7 +85,7 @@ __device__ __forceinline__ half8 a_frag(const unsigned char *ptr)
 template <int T>
 __global__ __launch_bounds__(256, 1) void wgrad_sp_f16x3_kernel(WgradSpArgs a)
 {
-    constexpr int KC = T >= 16 ? 3 : (T <= 2 ? 8 : 6);                   // k-steps per chunk
+    constexpr int KC = T >= 16 ? 3 : (T == 1 ? 8 : 6);                   // k-steps per chunk
     constexpr int NCH = (WS_ROW_KS + KC - 1) / KC;                       // chunks per row: 8,7,7 / 6,6,5,5 / 3,3,3,3,3,3,2,2
     constexpr int KS_LO = WS_ROW_KS / NCH, KS_REM = WS_ROW_KS % NCH;
     constexpr int CHP = KC * 16;                                         // positions per chunk (max)
@@ -94,9 +94,9 @@ __global__ __launch_bounds__(256, 1) void wgrad_sp_f16x3_kernel(WgradSpArgs a)
     constexpr int A_SPLIT = 64 * AP * 2, B_SPLIT = 2 * WINP * 128;       // bytes per split
     constexpr int IDX_BYTES = 64 * KC * 2 * 2;
     constexpr int QI = (KC * 2 + 3) / 4;                                 // index words per thread
-    constexpr int QX = (WINP + 31) / 32;                                 // x iterations per (split, parity)
+    constexpr int QX = (WINP + 15) / 16;                                 // x iterations per split
     constexpr bool PREF = T <= 4;                                        // register prefetch of the next chunk
-    constexpr int NVI = PREF ? QI : 1, NVB = PREF ? 4 * QX : 1;
+    constexpr int NVI = PREF ? QI : 1, NVB = PREF ? 2 * QX : 1;
     static_assert(2 * A_SPLIT + IDX_BYTES + 2 * B_SPLIT <= 160 * 1024, "LDS budget");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *const Aimg = smem;                                    // [split][co][AP]
@@ -137,12 +137,13 @@ __global__ __launch_bounds__(256, 1) void wgrad_sp_f16x3_kernel(WgradSpArgs a)
     //      every address is a per-thread constant + a compile-time multiple of the iteration index.
     //   A   thread = (co = tid >> 2, vector c8 = (tid & 3) + 4 q of 8 positions), q < CHP / 32, per split
     //   idx thread = (co = tid >> 2, word e = (tid & 3) + 4 q of the chunk's 2 KC), q < QI
-    //   x   thread = (position pos0 + 32 q, 16-byte vector sv), per (split, row parity)
+    //   x   thread = (position pos0 + 16 q, row parity, 16-byte vector sv), per split: a wave stores 8 CONSECUTIVE image
+    //       rows (alternating LDS bank halves; a fixed parity would put a whole wave on the even rows = half the banks)
     constexpr int QAS = CHP / 32;                                        // A iterations per split
     static_assert(CHP % 32 == 0 || CHP == 48, "A staging map");
     floatx4 pa[PREF ? 2 * ((CHP + 31) / 32) : 1], pb[NVB];
     unsigned short pi[NVI];
-    const int sv = tid & 7, pos0 = tid >> 3;
+    const int sv = tid & 7, xpar = (tid >> 3) & 1, pos0 = tid >> 4;
     const int a_co = tid >> 2, a_c8 = tid & 3;
     constexpr int QA2 = (CHP + 31) / 32;                                 // (CHP / 8 vectors per co) / 4 threads per co
     auto load_a = [&](int k, int rid, int ch) -> floatx4 {
@@ -173,11 +174,11 @@ __global__ __launch_bounds__(256, 1) void wgrad_sp_f16x3_kernel(WgradSpArgs a)
         const int e = a_c8 + 4 * q;
         if (e < KC * 2) reinterpret_cast<unsigned short *>(Iimg)[a_co * (KC * 2) + e] = v;
     };
-    // x vector k = ((split * 2 + parity) * QX + q): position pos0 + 32 q of the window, 16-byte vector sv
+    // x vector k = split * QX + q: position pos0 + 16 q of the window, row parity xpar, 16-byte vector sv
     auto load_b = [&](int k, int rid, int ch) -> floatx4 {
         const int b = rid / Hp, hp = rid - b * Hp, w0 = chunk_k0(ch) * 16;
-        const int sp = k / QX, q = k - sp * QX, split = sp >> 1, par = sp & 1;
-        const int pos = pos0 + 32 * q, w = w0 - 6 * T + pos, hx = 2 * hp + par + kh - 2;
+        const int split = k / QX, q = k - split * QX, par = xpar;
+        const int pos = pos0 + 16 * q, w = w0 - 6 * T + pos, hx = 2 * hp + par + kh - 2;
         floatx4 z = {0.f, 0.f, 0.f, 0.f};
         if (pos < WINP && w >= 0 && w < CV_PITCH && hx >= 0 && hx < H)
             z = *reinterpret_cast<const floatx4 *>((split ? a.x_lo : a.x_hi) +
@@ -185,8 +186,8 @@ __global__ __launch_bounds__(256, 1) void wgrad_sp_f16x3_kernel(WgradSpArgs a)
         return z;
     };
     auto store_b = [&](int k, floatx4 v) {
-        const int sp = k / QX, q = k - sp * QX, split = sp >> 1, par = sp & 1;
-        const int pos = pos0 + 32 * q;
+        const int split = k / QX, q = k - split * QX, par = xpar;
+        const int pos = pos0 + 16 * q;
         if (pos < WINP)
             *reinterpret_cast<floatx4 *>(Bimg + split * B_SPLIT + (2 * pos + par) * 128 + ((sv ^ ((pos & 1) << 2)) * 16)) = v;
     };
@@ -328,7 +329,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_sp_f16x3_kernel(WgradSpArgs a)
 #pragma unroll
             for (int q = 0; q < NI; ++q) store_i(q, load_i(q, rid, ch));
 #pragma unroll 4
-            for (int q = 0; q < 4 * QX; ++q) store_b(q, load_b(q, rid, ch));
+            for (int q = 0; q < 2 * QX; ++q) store_b(q, load_b(q, rid, ch));
         }
         const int nks = chunk_ks(ch);
         int nrid = rid, nch = ch;
@@ -410,7 +411,7 @@ __global__ __launch_bounds__(256) void gpool_prep_kernel(const float *__restrict
 template <int T>
 static int launch_wgrad_sp(const WgradSpArgs &a, hipStream_t st)
 {
-    constexpr int KC = T >= 16 ? 3 : (T <= 2 ? 8 : 6), CHP = KC * 16, AP = CHP + 4, WINP = CHP + 12 * T;
+    constexpr int KC = T >= 16 ? 3 : (T == 1 ? 8 : 6), CHP = KC * 16, AP = CHP + 4, WINP = CHP + 12 * T;
     const size_t lds = 2 * (size_t)(64 * AP * 2) + ((64 * KC * 4 + 15) / 16) * 16 + 2 * (size_t)(2 * WINP * 128);
     static bool attr_done = false;
     if (!attr_done) {
