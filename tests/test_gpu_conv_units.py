@@ -94,3 +94,84 @@ def test_block_fwd_dgrad_wgrad(dev, T, W, H, cin):
         g_cpu = dxhat.cpu()[..., :W]
         assert rel(gsum.view(B, 64).cpu(), g_cpu.sum(dim=(2, 3))) < 1e-5
         assert float(gmax.view(torch.float32).cpu()) == float(g_cpu.abs().max())
+
+
+@pytest.mark.parametrize("T", [1, 2, 4, 8, 16])
+@pytest.mark.parametrize("W,H", [(345, 8), (88, 16)])
+def test_block_f16x3_kernels(dev, T, W, H):
+    """The split-fp16 family, kernel by kernel, against torch CPU autograd at the fp32 tolerance (1e-5 of the tensor's
+    max): operand preparation, forward (LDS-DMA kernel for T <= 4, register-staged for T >= 8), data gradient, and BOTH
+    weight-gradient kernels -- dense MFMA on the routed gradient, sparse MFMA on the pooled gradient + argmax index
+    words -- which must also agree with each other."""
+    from mod_extraction_amd import _hip, models as am
+    torch.manual_seed(7 * T + W + H)
+    B = 3
+    x_in = torch.randn(B, 64, H, W) * 0.7 + 0.1
+    slope_prev = torch.rand(64) * 0.4 + 0.05
+    w = (torch.randn(64, 64, 5, 13) / np.sqrt(64 * 65)).requires_grad_(True)
+    b = (torch.randn(64) * 0.1).requires_grad_(True)
+    x_req = x_in.clone().requires_grad_(True)
+    p_r, z_r, xhat_r = ref_block(x_req, slope_prev, w, b, T, False)
+    xhat_r.retain_grad()
+    Gc = torch.randn_like(p_r)
+    (p_r * Gc).sum().backward()
+
+    st = _hip.stream()
+    x_d, sl_d = to_planes(x_in, dev), slope_prev.to(dev)
+    stats = torch.empty((B, 64, 2), device=dev)
+    _hip.call("mx_plane_stats", _hip.ptr(x_d), _hip.ptr(sl_d), B, 64, H, W, 1e-5, _hip.ptr(stats), st)
+    x_hi = torch.empty((B, H, 4, PITCH, 16), device=dev, dtype=torch.float16)
+    x_lo = torch.empty_like(x_hi)
+    _hip.call("mx_conv_prep_fwd_f16", _hip.ptr(x_d), _hip.ptr(stats), _hip.ptr(sl_d), B, H, W, _hip.ptr(x_hi), _hip.ptr(x_lo), st)
+    # the pair carries the normalised input to fp32 accuracy, channel-block major
+    xhat_pair = (x_hi.float() + x_lo.float()).permute(0, 2, 4, 1, 3).reshape(B, 64, H, PITCH)
+    assert rel(xhat_pair.cpu()[..., :W], xhat_r.detach()) < 2e-6
+    w_hi, w_lo = am._pack_f16(w.detach().to(dev), 0)
+    p = torch.empty((B, 64, H // 2, PITCH), device=dev)
+    amax = torch.empty((B, 64, H // 2, PITCH), device=dev, dtype=torch.uint8)
+    _hip.call("mx_conv_block_fwd_f16", _hip.ptr(x_hi), _hip.ptr(x_lo), _hip.ptr(w_hi), _hip.ptr(w_lo),
+              _hip.ptr(b.detach().to(dev)), B, H, W, T, _hip.ptr(p), _hip.ptr(amax), st)
+    assert rel(p.cpu()[..., :W], p_r.detach()) < 1e-5
+    am_r = (z_r[:, :, 1::2] > z_r[:, :, 0::2]).to(torch.uint8)
+    assert float((amax.cpu()[..., :W] != am_r).float().mean()) < 1e-4          # ties aside, the same argmax
+    # gradient operand from the REFERENCE's argmax, so that all gradients below are comparable element by element
+    G_d, amax_d = to_planes(Gc, dev), to_planes(am_r, dev)
+    dz_hi = torch.empty((B, H, 4, PITCH, 16), device=dev, dtype=torch.float16)
+    dz_lo = torch.empty_like(dz_hi)
+    ws = torch.empty(1, device=dev, dtype=torch.int32)
+    scale = torch.empty(2, device=dev)
+    _hip.call("mx_conv_prep_dgrad_f16", _hip.ptr(G_d), _hip.ptr(amax_d), B, H, W, _hip.ptr(ws), 0, _hip.ptr(scale),
+              _hip.ptr(dz_hi), _hip.ptr(dz_lo), st)
+    S = float(scale[0])
+    assert S == 2.0 ** round(np.log2(S)) and 512.0 <= float(Gc.abs().max()) * S < 1024.0       # power of two, in range
+    # dense weight gradient
+    rps = 3
+    n_slabs = -(-(B * H) // rps)
+    part = torch.empty(n_slabs * 65 * 64 * 64, device=dev)
+    dW_dense = torch.empty((64, 64, 5, 13), device=dev)
+    _hip.call("mx_conv_block_wgrad_f16", _hip.ptr(dz_hi), _hip.ptr(dz_lo), _hip.ptr(x_hi), _hip.ptr(x_lo), _hip.ptr(scale),
+              B, H, T, rps, _hip.ptr(part), _hip.ptr(dW_dense), st)
+    assert rel(dW_dense.cpu(), w.grad) < 1e-5, ("dense wgrad", rel(dW_dense.cpu(), w.grad))
+    # sparse weight gradient: pooled gradient pair + index words
+    Hp = H // 2
+    gp_hi = torch.empty((B, 64, Hp, PITCH), device=dev, dtype=torch.float16)
+    gp_lo = torch.empty_like(gp_hi)
+    gidx = torch.empty((B, 64, Hp, 22, 2), device=dev, dtype=torch.int16)
+    _hip.call("mx_conv_prep_gpool_f16", _hip.ptr(G_d), _hip.ptr(amax_d), _hip.ptr(scale), B, H, _hip.ptr(gp_hi), _hip.ptr(gp_lo),
+              _hip.ptr(gidx), st)
+    assert rel((gp_hi.float() + gp_lo.float()).cpu() / S, G_d.cpu()) < 2e-6
+    rps2 = 2
+    n_slabs2 = -(-(B * Hp) // rps2)
+    part2 = torch.empty(n_slabs2 * 65 * 64 * 64, device=dev)
+    dW_sp = torch.empty((64, 64, 5, 13), device=dev)
+    _hip.call("mx_conv_block_wgrad_sp_f16", _hip.ptr(gp_hi), _hip.ptr(gp_lo), _hip.ptr(gidx), _hip.ptr(x_hi), _hip.ptr(x_lo),
+              _hip.ptr(scale), B, H, T, rps2, _hip.ptr(part2), _hip.ptr(dW_sp), st)
+    assert rel(dW_sp.cpu(), w.grad) < 1e-5, ("sparse wgrad", rel(dW_sp.cpu(), w.grad))
+    assert rel(dW_sp, dW_dense) < 2e-6                                          # same sums, different order
+    # data gradient
+    wf_hi, wf_lo = am._pack_f16(w.detach().to(dev), 1)
+    dxhat = torch.empty((B, 64, H, PITCH), device=dev)
+    _hip.call("mx_conv_block_dgrad_f16", _hip.ptr(dz_hi), _hip.ptr(dz_lo), _hip.ptr(wf_hi), _hip.ptr(wf_lo), _hip.ptr(scale),
+              B, H, W, T, _hip.ptr(dxhat), st)
+    assert rel(dxhat.cpu()[..., :W], xhat_r.grad) < 1e-5
+    assert bool((dxhat[..., W:] == 0).all())
