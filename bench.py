@@ -160,7 +160,7 @@ def main():
         if name == "mx_conv_block1_wgrad_f16":
             return f"2x{a[6]}"
         if name == "mx_conv_block_wgrad_sp_f16":
-            return f"64x{a[7]}"
+            return f"64x{a[7]}"          # (.., scale, B, H, Wv, ..)
         if name == "mx_conv_prep_gpool_f16":
             return f"64x{a[4]}"
         if name == "mx_conv_block_wgrad_f16":

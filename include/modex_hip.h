@@ -172,12 +172,13 @@ int mx_conv_block_wgrad(const float *G, const uint8_t *amax, const float *x, con
  * (half the matrix instructions of mx_conv_block_wgrad_f16; identical results up to fp32 summation order).
  * mx_conv_prep_gpool_f16: G, amax (B,64,H/2,352), scale = {S, 1/S} of mx_conv_prep_dgrad_f16 -> gp_hi, gp_lo
  * (B,64,H/2,352) halfs = split of G * S, gidx (B,64,H/2,22,2) uint16 index words.  rows_per_slab counts POOLED rows;
+ * Wv <= 351 (MX_ERR_UNSUPPORTED otherwise: the zero pad column of the x operand is the kernel's halo source);
  * part: ceil(B*(H/2)/rows_per_slab)*65*64*64 floats. */
 int mx_conv_prep_gpool_f16(const float *G, const uint8_t *amax, const float *scale, int64_t B, int64_t H, void *gp_hi,
                            void *gp_lo, void *gidx, void *stream);
 int mx_conv_block_wgrad_sp_f16(const void *gp_hi, const void *gp_lo, const void *gidx, const void *x_hi, const void *x_lo,
-                               const float *scale, int64_t B, int64_t H, int32_t dilation, int64_t rows_per_slab,
-                               float *part, float *dW, void *stream);
+                               const float *scale, int64_t B, int64_t H, int64_t Wv, int32_t dilation,
+                               int64_t rows_per_slab, float *part, float *dW, void *stream);
 
 /* LayerNorm backward fused with the backward of the PReLU in front of it.  p (B,C,H,352): input of
  * that PReLU; dxhat_inout: in = grad w.r.t. the normalised tensor, out = G = dL/dp (in place);

@@ -85,7 +85,7 @@ __device__ __forceinline__ half8 a_frag(const unsigned char *ptr)
 template <int T>
 __global__ __launch_bounds__(256, 1) void wgrad_sp_f16x3_kernel(WgradSpArgs a)
 {
-    constexpr int KC = T >= 16 ? 3 : (T == 1 ? 8 : 6);                   // k-steps per chunk
+    constexpr int KC = T >= 16 ? 3 : 6;                                  // k-steps per chunk
     constexpr int NCH = (WS_ROW_KS + KC - 1) / KC;                       // chunks per row: 8,7,7 / 6,6,5,5 / 3,3,3,3,3,3,2,2
     constexpr int KS_LO = WS_ROW_KS / NCH, KS_REM = WS_ROW_KS % NCH;
     constexpr int CHP = KC * 16;                                         // positions per chunk (max)
@@ -146,14 +146,17 @@ __global__ __launch_bounds__(256, 1) void wgrad_sp_f16x3_kernel(WgradSpArgs a)
     const int sv = tid & 7, xpar = (tid >> 3) & 1, pos0 = tid >> 4;
     const int a_co = tid >> 2, a_c8 = tid & 3;
     constexpr int QA2 = (CHP + 31) / 32;                                 // (CHP / 8 vectors per co) / 4 threads per co
+    // Loads are branch-free (a predicated load costs an exec-mask branch each, 36 per chunk): out-of-range items read
+    // a clamped address whose value is either never used (k-steps past the chunk's end) or known to be zero (the
+    // pad column 351 of an operand row stands in for the halo and for rows outside the image; Wv <= 351 is checked
+    // by the entry point).
     auto load_a = [&](int k, int rid, int ch) -> floatx4 {
         const int b = rid / Hp, hp = rid - b * Hp, ks0 = chunk_k0(ch), npos = chunk_ks(ch) * 16;
-        const int split = k / QA2, q = k - split * QA2, c8 = a_c8 + 4 * q;
-        floatx4 z = {0.f, 0.f, 0.f, 0.f};
-        if (c8 * 8 < npos)
-            z = *reinterpret_cast<const floatx4 *>((split ? a.gp_lo : a.gp_hi) + (((size_t)b * 64 + a_co) * Hp + hp) * CV_PITCH +
-                                                   ks0 * 16 + c8 * 8);
-        return z;
+        const int split = k / QA2, q = k - split * QA2;
+        int c8 = a_c8 + 4 * q;
+        c8 = c8 * 8 < npos ? c8 : 0;
+        return *reinterpret_cast<const floatx4 *>((split ? a.gp_lo : a.gp_hi) + (((size_t)b * 64 + a_co) * Hp + hp) * CV_PITCH +
+                                                  ks0 * 16 + c8 * 8);
     };
     auto store_a = [&](int k, floatx4 v) {
         const int split = k / QA2, q = k - split * QA2, c8 = a_c8 + 4 * q;
@@ -166,9 +169,9 @@ __global__ __launch_bounds__(256, 1) void wgrad_sp_f16x3_kernel(WgradSpArgs a)
     };
     auto load_i = [&](int q, int rid, int ch) -> unsigned short {
         const int b = rid / Hp, hp = rid - b * Hp, ks0 = chunk_k0(ch), nks = chunk_ks(ch);
-        const int e = a_c8 + 4 * q;
-        if (e < nks * 2) return a.gidx[(((size_t)b * 64 + a_co) * Hp + hp) * (WS_ROW_KS * 2) + ks0 * 2 + e];
-        return 0;
+        int e = a_c8 + 4 * q;
+        e = e < nks * 2 ? e : 0;
+        return a.gidx[(((size_t)b * 64 + a_co) * Hp + hp) * (WS_ROW_KS * 2) + ks0 * 2 + e];
     };
     auto store_i = [&](int q, unsigned short v) {
         const int e = a_c8 + 4 * q;
@@ -179,11 +182,10 @@ __global__ __launch_bounds__(256, 1) void wgrad_sp_f16x3_kernel(WgradSpArgs a)
         const int b = rid / Hp, hp = rid - b * Hp, w0 = chunk_k0(ch) * 16;
         const int split = k / QX, q = k - split * QX, par = xpar;
         const int pos = pos0 + 16 * q, w = w0 - 6 * T + pos, hx = 2 * hp + par + kh - 2;
-        floatx4 z = {0.f, 0.f, 0.f, 0.f};
-        if (pos < WINP && w >= 0 && w < CV_PITCH && hx >= 0 && hx < H)
-            z = *reinterpret_cast<const floatx4 *>((split ? a.x_lo : a.x_hi) +
-                                                   (((size_t)b * H + hx) * 4 + (sv >> 1)) * (CV_PITCH * 16) + w * 16 + (sv & 1) * 8);
-        return z;
+        const bool ok = w >= 0 && w < CV_PITCH && hx >= 0 && hx < H;
+        const int w_eff = ok ? w : CV_PITCH - 1, hx_eff = hx < 0 ? 0 : (hx >= H ? H - 1 : hx);
+        return *reinterpret_cast<const floatx4 *>((split ? a.x_lo : a.x_hi) +
+                                                  (((size_t)b * H + hx_eff) * 4 + (sv >> 1)) * (CV_PITCH * 16) + w_eff * 16 + (sv & 1) * 8);
     };
     auto store_b = [&](int k, floatx4 v) {
         const int split = k / QX, q = k - split * QX, par = xpar;
@@ -226,7 +228,16 @@ __global__ __launch_bounds__(256, 1) void wgrad_sp_f16x3_kernel(WgradSpArgs a)
     auto row_of = [](int n) { return T == 1 ? (n < 7 ? 4 * n : 2 + 4 * (n - 7)) : (T >= 8 ? (n >> 2) * 2 * T + 4 * (n & 3) : 4 * n); };
 
     // the k-step loop, specialised on the tap group (which tap of the window is the middle one)
-    auto run_chunk = [&](auto gc, int nks) {
+    // next chunk's prefetch item q (A vectors, index words, x vectors): issued a few per k-step INSIDE the MFMA loop --
+    // as one burst between the barriers their address arithmetic alone cost 18 % of the kernel
+    constexpr int NPF = PREF ? NA + NI + NVB : 0;
+    constexpr int PF_PER = PREF ? (NPF + (KS_LO - 1) - 1) / (KS_LO - 1) : 0;      // all issued within the first KS_LO - 1 k-steps
+    auto prefetch_item = [&](int q, int nrid, int nch) {
+        if (q < NA) pa[q] = load_a(q, nrid, nch);
+        else if (q < NA + NI) pi[q - NA] = load_i(q - NA, nrid, nch);
+        else if (q < NPF) pb[q - NA - NI] = load_b(q - NA - NI, nrid, nch);
+    };
+    auto run_chunk = [&](auto gc, int nks, int nrid, int nch, bool more) {
         constexpr int G = decltype(gc)::value;
         half8 AL[3], AH[2][3];                      // [co tile 0, co tile 1, co tile g]
         int IX[2][3];
@@ -287,6 +298,10 @@ __global__ __launch_bounds__(256, 1) void wgrad_sp_f16x3_kernel(WgradSpArgs a)
 #pragma unroll
                     for (int u = 0; u < 13; ++u)
                         acc[u] = smfmac(AH[p][u < 12 ? (u & 1) : 2], frag(BHb, tap_of(u)), acc[u], IX[p][u < 12 ? (u & 1) : 2]);
+                    if (PREF && more) {
+#pragma unroll
+                        for (int q = ks * PF_PER; q < (ks + 1) * PF_PER; ++q) prefetch_item(q, nrid, nch);
+                    }
                     if (!last) {
 #pragma unroll
                         for (int j = 0; j < 3; ++j) {
@@ -334,17 +349,10 @@ __global__ __launch_bounds__(256, 1) void wgrad_sp_f16x3_kernel(WgradSpArgs a)
         const int nks = chunk_ks(ch);
         int nrid = rid, nch = ch;
         next_iter(nrid, nch);
-        if (PREF && nrid < row_end) {
-#pragma unroll
-            for (int q = 0; q < NA; ++q) pa[q] = load_a(q, nrid, nch);
-#pragma unroll
-            for (int q = 0; q < NI; ++q) pi[q] = load_i(q, nrid, nch);
-#pragma unroll
-            for (int q = 0; q < NVB; ++q) pb[q] = load_b(q, nrid, nch);
-        }
+        const bool more = nrid < row_end;
         __syncthreads();
-        if (g) run_chunk(std::integral_constant<int, 1>{}, nks);
-        else run_chunk(std::integral_constant<int, 0>{}, nks);
+        if (g) run_chunk(std::integral_constant<int, 1>{}, nks, nrid, nch, more);
+        else run_chunk(std::integral_constant<int, 0>{}, nks, nrid, nch, more);
         rid = nrid;
         ch = nch;
     }
@@ -411,7 +419,7 @@ __global__ __launch_bounds__(256) void gpool_prep_kernel(const float *__restrict
 template <int T>
 static int launch_wgrad_sp(const WgradSpArgs &a, hipStream_t st)
 {
-    constexpr int KC = T >= 16 ? 3 : (T == 1 ? 8 : 6), CHP = KC * 16, AP = CHP + 4, WINP = CHP + 12 * T;
+    constexpr int KC = T >= 16 ? 3 : 6, CHP = KC * 16, AP = CHP + 4, WINP = CHP + 12 * T;
     const size_t lds = 2 * (size_t)(64 * AP * 2) + ((64 * KC * 4 + 15) / 16) * 16 + 2 * (size_t)(2 * WINP * 128);
     static bool attr_done = false;
     if (!attr_done) {
@@ -438,15 +446,16 @@ MX_EXPORT int mx_conv_prep_gpool_f16(const float *G, const uint8_t *amax, const 
     return mx_launch_status();
 }
 
-// x_hi/lo: (B,H,4,352,16) operand pair of the block's forward pass; part: workspace of ceil(B*(H/2)/rows_per_slab)*65*64*64
+// x_hi/lo: (B,H,4,352,16) operand pair of the block's forward pass (Wv <= 351 valid columns, the rest zero); part: workspace of ceil(B*(H/2)/rows_per_slab)*65*64*64
 // floats (rows = pooled rows); dW (64,64,5,13).
 MX_EXPORT int mx_conv_block_wgrad_sp_f16(const void *gp_hi, const void *gp_lo, const void *gidx, const void *x_hi,
-                                         const void *x_lo, const float *scale, int64_t B, int64_t H, int32_t dilation,
-                                         int64_t rows_per_slab, float *part, float *dW, void *stream)
+                                         const void *x_lo, const float *scale, int64_t B, int64_t H, int64_t Wv,
+                                         int32_t dilation, int64_t rows_per_slab, float *part, float *dW, void *stream)
 {
     if (!gp_hi || !gp_lo || !gidx || !x_hi || !x_lo || !scale || !part || !dW || B <= 0 || H < 2 || (H & 1) ||
-        rows_per_slab <= 0)
+        rows_per_slab <= 0 || Wv <= 0)
         return MX_ERR_ARG;
+    if (Wv > CV_PITCH - 1) return MX_ERR_UNSUPPORTED;      // the kernel reads operand column 351 as its zero source
     const int64_t n_slabs = (B * (H / 2) + rows_per_slab - 1) / rows_per_slab;
     if (n_slabs > 1000000) return MX_ERR_UNSUPPORTED;
     WgradSpArgs a{(const _Float16 *)gp_hi, (const _Float16 *)gp_lo, (const unsigned short *)gidx, (const _Float16 *)x_hi,

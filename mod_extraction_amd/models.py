@@ -271,7 +271,7 @@ class _CNNStack(torch.autograd.Function):
                     x_lo = torch.empty((B, H, 4, PITCH, 16), device=dev, dtype=torch.float16)
                     _hip.call("mx_conv_prep_fwd_f16", _hip.ptr(x_in), _hip.ptr(stats), _hip.ptr(slope_prev), B, H,
                               n_frames, _hip.ptr(x_hi), _hip.ptr(x_lo), st)
-                if WGRAD_SPARSE and int(dilations[l]) <= 4:
+                if WGRAD_SPARSE and int(dilations[l]) <= 4 and n_frames <= PITCH - 1:
                     # sparse matrix instruction (dilations >= 8 share no fragment blocks between taps: dense kernel): the pooled gradient is the compressed operand, the argmax its index bits
                     Hp = H // 2
                     gp_hi = torch.empty((B, 64, Hp, PITCH), device=dev, dtype=torch.float16)
@@ -284,7 +284,8 @@ class _CNNStack(torch.autograd.Function):
                     n_slabs = -(-prow // rps)
                     part = torch.empty(n_slabs * 65 * 64 * 64, device=dev, dtype=torch.float32)
                     _hip.call("mx_conv_block_wgrad_sp_f16", _hip.ptr(gp_hi), _hip.ptr(gp_lo), _hip.ptr(gidx), _hip.ptr(x_hi),
-                              _hip.ptr(x_lo), _hip.ptr(scale), B, H, int(dilations[l]), rps, _hip.ptr(part), _hip.ptr(dW), st)
+                              _hip.ptr(x_lo), _hip.ptr(scale), B, H, n_frames, int(dilations[l]), rps, _hip.ptr(part),
+                              _hip.ptr(dW), st)
                     del gp_hi, gp_lo, gidx
                 else:
                     rps = max(1, -(-rows // 408))            # ~408 slabs x 5 kernel rows = 8 workgroups per CU

@@ -165,7 +165,7 @@ def test_block_f16x3_kernels(dev, T, W, H):
     part2 = torch.empty(n_slabs2 * 65 * 64 * 64, device=dev)
     dW_sp = torch.empty((64, 64, 5, 13), device=dev)
     _hip.call("mx_conv_block_wgrad_sp_f16", _hip.ptr(gp_hi), _hip.ptr(gp_lo), _hip.ptr(gidx), _hip.ptr(x_hi), _hip.ptr(x_lo),
-              _hip.ptr(scale), B, H, T, rps2, _hip.ptr(part2), _hip.ptr(dW_sp), st)
+              _hip.ptr(scale), B, H, W, T, rps2, _hip.ptr(part2), _hip.ptr(dW_sp), st)
     assert rel(dW_sp.cpu(), w.grad) < 1e-5, ("sparse wgrad", rel(dW_sp.cpu(), w.grad))
     assert rel(dW_sp, dW_dense) < 2e-6                                          # same sums, different order
     # data gradient
