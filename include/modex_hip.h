@@ -123,13 +123,15 @@ int mx_conv_block_dgrad(const float *G, const uint8_t *amax, const float *wt_fli
  *   x_hi, x_lo : (B, H, 4, 352, 16) halfs (channel-block major): forward = split of (prelu(x) - mean) * rstd;
  *                dgrad = split of the max-pool routed gradient * S_dz, S_dz = 2^k chosen from max|G|
  *                (scale (2,) device floats receives {S_dz, 1/S_dz}; amax_ws = one uint32 workspace, or with
- *                amax_ready != 0 the bits of max|G| left there by mx_ln_prelu_bwd). */
+ *                amax_ready != 0 the bits of max|G| left there by mx_ln_prelu_bwd).
+ *                mx_conv_prep_dgrad_f16's gp_hi / gp_lo / gidx (all three or NULL): by-product operand of the
+ *                sparse weight-gradient kernel below (= mx_conv_prep_gpool_f16 without a second pass over G). */
 int mx_conv_pack_weights_f16(const float *W, int32_t flip, void *w_hi, void *w_lo, void *stream);
 int mx_conv_prep_fwd_f16(const float *x, const float *stats, const float *slope, int64_t B, int64_t H,
                          int64_t Wv, void *x_hi, void *x_lo, void *stream);
 int mx_conv_prep_dgrad_f16(const float *G, const uint8_t *amax, int64_t B, int64_t H, int64_t Wv,
                            uint32_t *amax_ws, int32_t amax_ready, float *scale, void *dz_hi, void *dz_lo,
-                           void *stream);
+                           void *gp_hi, void *gp_lo, void *gidx, void *stream);
 int mx_conv_block_fwd_f16(const void *x_hi, const void *x_lo, const void *w_hi, const void *w_lo,
                           const float *bias, int64_t B, int64_t H, int64_t Wv, int32_t dilation, float *out,
                           uint8_t *out_amax, void *stream);

@@ -262,8 +262,18 @@ class _CNNStack(torch.autograd.Function):
                 ws = gmax_ws if ready else torch.empty(1, device=dev, dtype=torch.int32)
                 gmax_ws = None
                 scale = torch.empty(2, device=dev, dtype=torch.float32)
+                sparse = WGRAD_SPARSE and int(dilations[l]) <= 4 and n_frames <= PITCH - 1
+                gp_hi = gp_lo = gidx = None
+                if sparse:
+                    # sparse matrix instruction: the pooled gradient is the compressed operand, the argmax its index
+                    # bits (dilations >= 8 share no fragment blocks between taps: dense kernel); by-product of the prep
+                    Hp = H // 2
+                    gp_hi = torch.empty((B, 64, Hp, PITCH), device=dev, dtype=torch.float16)
+                    gp_lo = torch.empty((B, 64, Hp, PITCH), device=dev, dtype=torch.float16)
+                    gidx = torch.empty((B, 64, Hp, 22, 2), device=dev, dtype=torch.int16)
                 _hip.call("mx_conv_prep_dgrad_f16", _hip.ptr(G), _hip.ptr(amax), B, H, n_frames, _hip.ptr(ws),
-                          1 if ready else 0, _hip.ptr(scale), _hip.ptr(dz_hi), _hip.ptr(dz_lo), st)
+                          1 if ready else 0, _hip.ptr(scale), _hip.ptr(dz_hi), _hip.ptr(dz_lo), _hip.ptr(gp_hi),
+                          _hip.ptr(gp_lo), _hip.ptr(gidx), st)
                 if l in ctx.splits:
                     x_hi, x_lo = ctx.splits.pop(l)
                 else:

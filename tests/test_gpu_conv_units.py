@@ -140,8 +140,12 @@ def test_block_f16x3_kernels(dev, T, W, H):
     dz_lo = torch.empty_like(dz_hi)
     ws = torch.empty(1, device=dev, dtype=torch.int32)
     scale = torch.empty(2, device=dev)
+    Hp = H // 2
+    gq_hi = torch.empty((B, 64, Hp, PITCH), device=dev, dtype=torch.float16)       # by-product operand of the sparse kernel
+    gq_lo = torch.empty_like(gq_hi)
+    gqidx = torch.empty((B, 64, Hp, 22, 2), device=dev, dtype=torch.int16)
     _hip.call("mx_conv_prep_dgrad_f16", _hip.ptr(G_d), _hip.ptr(amax_d), B, H, W, _hip.ptr(ws), 0, _hip.ptr(scale),
-              _hip.ptr(dz_hi), _hip.ptr(dz_lo), st)
+              _hip.ptr(dz_hi), _hip.ptr(dz_lo), _hip.ptr(gq_hi), _hip.ptr(gq_lo), _hip.ptr(gqidx), st)
     S = float(scale[0])
     assert S == 2.0 ** round(np.log2(S)) and 512.0 <= float(Gc.abs().max()) * S < 1024.0       # power of two, in range
     # dense weight gradient
@@ -153,13 +157,14 @@ def test_block_f16x3_kernels(dev, T, W, H):
               B, H, T, rps, _hip.ptr(part), _hip.ptr(dW_dense), st)
     assert rel(dW_dense.cpu(), w.grad) < 1e-5, ("dense wgrad", rel(dW_dense.cpu(), w.grad))
     # sparse weight gradient: pooled gradient pair + index words
-    Hp = H // 2
     gp_hi = torch.empty((B, 64, Hp, PITCH), device=dev, dtype=torch.float16)
     gp_lo = torch.empty_like(gp_hi)
     gidx = torch.empty((B, 64, Hp, 22, 2), device=dev, dtype=torch.int16)
     _hip.call("mx_conv_prep_gpool_f16", _hip.ptr(G_d), _hip.ptr(amax_d), _hip.ptr(scale), B, H, _hip.ptr(gp_hi), _hip.ptr(gp_lo),
               _hip.ptr(gidx), st)
     assert rel((gp_hi.float() + gp_lo.float()).cpu() / S, G_d.cpu()) < 2e-6
+    # the stand-alone prep and the by-product of mx_conv_prep_dgrad_f16 are the same operand, bit for bit
+    assert torch.equal(gp_hi, gq_hi) and torch.equal(gp_lo, gq_lo) and torch.equal(gidx, gqidx)
     rps2 = 2
     n_slabs2 = -(-(B * Hp) // rps2)
     part2 = torch.empty(n_slabs2 * 65 * 64 * 64, device=dev)
