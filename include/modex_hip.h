@@ -182,6 +182,21 @@ int mx_conv_block_wgrad_sp_f16(const void *gp_hi, const void *gp_lo, const void 
                                const float *scale, int64_t B, int64_t H, int64_t Wv, int32_t dilation,
                                int64_t rows_per_slab, float *part, float *dW, void *stream);
 
+/* The data gradient on the sparse matrix instruction as well.  The sparse operand must be A, so tiles are computed
+ * transposed ([position][ci]) with K = (output channel, row of the pooling pair): compressed A = the pooled gradient
+ * in channels-last form, B = the weights of the two kernel rows the pair meets, packed in fragment order and read
+ * from global memory; 12 K stages instead of 20.  Same results as mx_conv_block_dgrad_f16 up to summation order.
+ *   mx_conv_pack_weights_sp_f16: W (64,64,5,13) -> w_hi, w_lo: 4*3*2*13*2*64*16 halfs each
+ *   mx_conv_prep_gpool_cl_f16: G, amax (B,64,H/2,352), scale {S, 1/S} -> g_hi, g_lo (B,H/2,4,352,16) halfs,
+ *                              g_idx (B,H/2,4,352) uint32 index words
+ *   mx_conv_block_dgrad_sp_f16: dxhat (B,64,H,352); Wv <= 351 (zero pad column = halo source) */
+int mx_conv_pack_weights_sp_f16(const float *W, void *w_hi, void *w_lo, void *stream);
+int mx_conv_prep_gpool_cl_f16(const float *G, const uint8_t *amax, const float *scale, int64_t B, int64_t H, int64_t Wv,
+                              void *g_hi, void *g_lo, void *g_idx, void *stream);
+int mx_conv_block_dgrad_sp_f16(const void *g_hi, const void *g_lo, const void *g_idx, const void *w_hi, const void *w_lo,
+                               const float *scale, int64_t B, int64_t H, int64_t Wv, int32_t dilation, float *dxhat,
+                               void *stream);
+
 /* LayerNorm backward fused with the backward of the PReLU in front of it.  p (B,C,H,352): input of
  * that PReLU; dxhat_inout: in = grad w.r.t. the normalised tensor, out = G = dL/dp (in place);
  * dslope_part (B*C,) per-plane partial of dL/dslope.  Optional by-products of the same pass (NULL = skip):

@@ -1,0 +1,357 @@
+// dgrad_sp_f16.hip -- data gradient of the 64->64 channel Spectral2DCNN convolutions on the SPARSE fp16 matrix
+// instruction v_smfmac_f32_32x32x32_f16, with fp32-equivalent accuracy ("f16x3", see conv_f16.hip).
+// Reference semantics: torch.nn.Conv2d backward w.r.t. its input, behind MaxPool2d((2,1)) (mod_extraction/models.py:187-188):
+//   dxhat[ci][h][w] = sum over (co, kh, kw) of  dz[co][h - kh + 2][w - (kw - 6) T] * W[co][ci][kh][kw]
+// with dz = the pooled gradient G routed to the row of each pooling pair that won the max (see wgrad_sp_f16.hip).
+//
+// The sparse instruction wants the sparse matrix as its A operand, so the tile is computed transposed:
+//   D^T[position][ci] += A[position][k] * B[k][ci],    k = 2 * co + row parity of the pooling pair   (K = 32 logical)
+//   A  = the gradient patch: compressed = G at pooled resolution (16 output channels of one position = 32 bytes of a
+//        channels-last image), index bits = the pooling argmax; lane l: row (position) l & 31, half hh = l >> 5 holds
+//        co 4hh..4hh+3 and 8+4hh..8+4hh+3 of the block (two 8-byte LDS reads; layout derived in tools/probe)
+//   B  = the weights of the TWO kernel rows that the pair's rows meet for this output row (kh = 4 + r - 2m - parity for
+//        output row h0 + r and pair m = -1, 0, +1 around it; rows outside 0..4 are zero), packed per (channel block, pair,
+//        output row, tap, ci tile) in fragment order and loaded straight from global memory (L2-resident, 32 bytes per
+//        lane) -- they would not fit the LDS beside the patch for both output rows.
+// K loop = 4 channel blocks x 3 pooling pairs = 12 stages of 13 taps (the dense kernel: 20 stages), 33 sparse MFMAs per
+// tap and wave.  Workgroup = (clip, output row pair), waves = (output row, position half) with the accumulator split of
+// conv_f16.hip; the patch (31 KB per stage) is register-staged into double-buffered LDS.  The epilogue transposes the
+// [position][ci] tiles through wave-private LDS and writes dxhat (B, 64, H, 352) rows coalesced.
+#include "conv_common.h"
+
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half16 __attribute__((ext_vector_type(16)));
+#define DS_WSCALE 256.0f
+#define DS_ROWB 40                      // bytes per patch row: 16 co x 2 B + 8 pad (conflict-free 8-byte reads by 32 rows)
+
+struct DgradSpArgs {
+    const _Float16 *g_hi, *g_lo;        // (B, Hp, 4, 352, 16): fp16 pair of G * S, pooled resolution, channels last
+    const unsigned *g_idx;              // (B, Hp, 4, 352): index words of lane half 0 (low 16 bits) and 1 (high)
+    const _Float16 *w_hi, *w_lo;        // [4 cb][3 m][2 r][13 kwf][2 ci tile][64 lanes][16]
+    const float *scale;                 // {S, 1/S}
+    float *out;                         // (B, 64, H, 352)
+    int H, Wv;
+};
+
+__device__ __forceinline__ floatx16 ds_smfmac(half8 a, half16 b, floatx16 c, int idx)
+{
+    return __builtin_amdgcn_smfmac_f32_32x32x32_f16(a, b, c, idx, 0, 0);
+}
+__device__ __forceinline__ half8 ds_a_frag(const unsigned char *ptr)
+{
+    const half4 lo = *reinterpret_cast<const half4 *>(ptr);
+    const half4 hi = *reinterpret_cast<const half4 *>(ptr + 16);
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+__device__ __forceinline__ half16 ds_w_frag(const _Float16 *p)
+{
+    const half8 lo = *reinterpret_cast<const half8 *>(p);
+    const half8 hi = *reinterpret_cast<const half8 *>(p + 8);
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+}
+
+template <int T>
+__global__ __launch_bounds__(256, 1) void dgrad_sp_f16x3_kernel(DgradSpArgs a)
+{
+    constexpr int PWP = CV_PITCH + 12 * T;                  // patch rows (position w = row - 6T)
+    constexpr int PA_SPLIT = PWP * DS_ROWB;                 // bytes per split
+    constexpr int IDX_BYTES = PWP * 4;
+    constexpr int BUF_BYTES = ((2 * PA_SPLIT + IDX_BYTES + 15) / 16) * 16;
+    constexpr int QP = (PWP + 127) / 128;                   // patch iterations: thread = (position (tid >> 1) + 128 q, 16-byte half)
+    constexpr int QI = (PWP + 255) / 256;
+    constexpr int N_STAGE = 12;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int row = wave >> 1, c = wave & 1, hh = lane >> 5, l32 = lane & 31;
+    int tile_id = blockIdx.y * gridDim.x + blockIdx.x;
+    {
+        const int n_tiles = gridDim.x * gridDim.y;
+        if ((n_tiles & 7) == 0) tile_id = (tile_id & 7) * (n_tiles >> 3) + (tile_id >> 3);
+    }
+    const int b = tile_id / gridDim.x, hp = tile_id - b * gridDim.x, h0 = hp * 2;
+    const int H = a.H, Hp = H >> 1;
+
+    floatx16 acc[CV_WT];
+#pragma unroll
+    for (int i = 0; i < CV_WT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+
+    // ---- patch staging (registers -> LDS), stage st = cb * 3 + m: pooled row hp + m - 1, channel block cb
+    floatx4 pv[2 * QP];
+    unsigned pidx[QI];
+    const int spos = tid >> 1, spart = tid & 1;
+    auto stage_row = [&](int st) { return hp + (st % 3) - 1; };
+    auto issue = [&](int st) {
+        const int cb = st / 3, hq = stage_row(st);
+        const int hq_eff = hq < 0 ? 0 : (hq >= Hp ? Hp - 1 : hq);       // out-of-image pairs are skipped by the caller
+        const size_t rbase = (((size_t)b * Hp + hq_eff) * 4 + cb) * CV_PITCH;
+#pragma unroll
+        for (int k = 0; k < 2 * QP; ++k) {
+            const int split = k / QP, q = k - split * QP;
+            const int pos = spos + 128 * q, w = pos - 6 * T;
+            const int w_eff = (w >= 0 && w < CV_PITCH) ? w : CV_PITCH - 1;      // column 351 is zero (Wv <= 351)
+            pv[k] = *reinterpret_cast<const floatx4 *>((split ? a.g_lo : a.g_hi) + (rbase + w_eff) * 16 + spart * 8);
+        }
+#pragma unroll
+        for (int q = 0; q < QI; ++q) {
+            const int pos = tid + 256 * q, w = pos - 6 * T;
+            const int w_eff = (w >= 0 && w < CV_PITCH) ? w : CV_PITCH - 1;
+            pidx[q] = a.g_idx[rbase + w_eff];
+        }
+    };
+    auto commit = [&](unsigned char *buf) {
+        typedef float floatx2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int k = 0; k < 2 * QP; ++k) {
+            const int split = k / QP, q = k - split * QP;
+            const int pos = spos + 128 * q;
+            if (pos < PWP) {
+                unsigned char *dst = buf + split * PA_SPLIT + pos * DS_ROWB + spart * 16;
+                reinterpret_cast<floatx2 *>(dst)[0] = floatx2{pv[k][0], pv[k][1]};
+                reinterpret_cast<floatx2 *>(dst)[1] = floatx2{pv[k][2], pv[k][3]};
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < QI; ++q) {
+            const int pos = tid + 256 * q;
+            if (pos < PWP) reinterpret_cast<unsigned *>(buf + 2 * PA_SPLIT)[pos] = pidx[q];
+        }
+    };
+    auto stage_live = [&](int st) { const int hq = stage_row(st); return hq >= 0 && hq < Hp; };
+
+    // weights of (stage, this wave's output row): fragment f = 0: ci tile c, f = 1: ci tile c ^ 1
+    auto w_ptr = [&](const _Float16 *base, int st, int kwf, int f) {
+        const int tile = f ? (c ^ 1) : c;
+        return base + ((((size_t)(st * 2 + row) * CV_KW + kwf) * 2 + tile) * 64 + lane) * 16;
+    };
+
+    int st = 0;
+    while (st < N_STAGE && !stage_live(st)) ++st;
+    if (st < N_STAGE) issue(st);
+    int bufsel = 0;
+    while (st < N_STAGE) {
+        unsigned char *const buf = smem + bufsel * BUF_BYTES;
+        commit(buf);                                    // the other buffer may still be read by slower waves
+        int nst = st + 1;
+        while (nst < N_STAGE && !stage_live(nst)) ++nst;
+        if (nst < N_STAGE) issue(nst);                  // in flight during this stage's MFMAs
+        __syncthreads();
+        // ---- 13 taps: A fragments (6 position tiles x hi/lo + index words) one tap ahead, weight fragments one tap ahead
+        const unsigned char *pa_h = buf, *pa_l = buf + PA_SPLIT, *pidx_img = buf + 2 * PA_SPLIT;
+        // position tile t < 5: tile c*6 + t; t = 5: the middle tile 5
+        const int a_lane = (l32 + c * 6 * 32) * DS_ROWB + hh * 8;
+        const int m_lane = (l32 + 5 * 32) * DS_ROWB + hh * 8;
+        const int ai_lane = (l32 + c * 6 * 32) * 4 + hh * 2, mi_lane = (l32 + 5 * 32) * 4 + hh * 2;
+        half8 AH[2][6], AL[2][6];
+        int IX[2][6];
+        half16 WH[2][2], WL[2][2];
+        auto rd_tap = [&](int f, int kwf) {
+#pragma unroll
+            for (int t = 0; t < 6; ++t) {
+                const int off = (t < 5 ? a_lane + t * 32 * DS_ROWB : m_lane) + kwf * T * DS_ROWB;
+                const int ioff = (t < 5 ? ai_lane + t * 32 * 4 : mi_lane) + kwf * T * 4;
+                AH[f][t] = ds_a_frag(pa_h + off);
+                AL[f][t] = ds_a_frag(pa_l + off);
+                IX[f][t] = (int)*reinterpret_cast<const unsigned short *>(pidx_img + ioff);
+            }
+        };
+        auto ld_w = [&](int f, int kwf) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                WH[f][j] = ds_w_frag(w_ptr(a.w_hi, st, kwf, j));
+                WL[f][j] = ds_w_frag(w_ptr(a.w_lo, st, kwf, j));
+            }
+        };
+        rd_tap(0, 0);
+        ld_w(0, 0);
+#pragma unroll
+        for (int kwf = 0; kwf < CV_KW; ++kwf) {
+            const int f = kwf & 1;
+            __builtin_amdgcn_sched_barrier(0);
+            // accumulator u = 2t + j (t < 5): position tile c*6 + t, weight fragment j; u = 10: middle tile, fragment 0
+#pragma unroll
+            for (int u = 0; u < CV_WT; ++u) {
+                const int t = u < 10 ? (u >> 1) : 5, j = u < 10 ? (u & 1) : 0;
+                acc[u] = ds_smfmac(AL[f][t], WH[f][j], acc[u], IX[f][t]);
+            }
+#pragma unroll
+            for (int u = 0; u < CV_WT; ++u) {
+                const int t = u < 10 ? (u >> 1) : 5, j = u < 10 ? (u & 1) : 0;
+                acc[u] = ds_smfmac(AH[f][t], WL[f][j], acc[u], IX[f][t]);
+            }
+#pragma unroll
+            for (int u = 0; u < CV_WT; ++u) {
+                const int t = u < 10 ? (u >> 1) : 5, j = u < 10 ? (u & 1) : 0;
+                acc[u] = ds_smfmac(AH[f][t], WH[f][j], acc[u], IX[f][t]);
+            }
+            if (kwf + 1 < CV_KW) {
+                rd_tap(f ^ 1, kwf + 1);
+                ld_w(f ^ 1, kwf + 1);
+#pragma unroll
+                for (int q_ = 0; q_ < 30; ++q_) {               // 30 LDS reads spread over the tap's 33 MFMAs
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        st = nst;
+        bufsel ^= 1;
+    }
+
+    // ---- epilogue: [position][ci] tiles -> dxhat rows, transposed through wave-private LDS (32 ci x 33 floats)
+    __syncthreads();                                            // the patch buffers are dead
+    float *scr = reinterpret_cast<float *>(smem) + wave * (32 * 33);
+    const float inv = a.scale[1] * (1.0f / DS_WSCALE);
+    const int h = h0 + row;
+#pragma unroll
+    for (int u = 0; u < CV_WT; ++u) {
+        const int ptile = u < 10 ? c * 6 + (u >> 1) : 5;
+        const int cit = u < 10 ? ((u & 1) ^ c) : c;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) scr[l32 * 33 + mfma_row(r, lane)] = acc[u][r] * inv;      // [ci local][position local]
+        __builtin_amdgcn_s_waitcnt(0xc07f);                      // lgkmcnt(0): the wave's own writes have landed
+        const int w = ptile * 32 + l32;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int cil = hh * 16 + i;
+            const float v = scr[cil * 33 + l32];
+            a.out[(((size_t)b * CV_CO + cit * 32 + cil) * H + h) * CV_PITCH + w] = w < a.Wv ? v : 0.0f;
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+    }
+}
+
+// torch (64 co, 64 ci, 5, 13) fp32 -> [cb][m][r][kwf][ci tile][lane][16] fp16 pairs of W * 256: lane l = (column n = l & 31,
+// k half s = l >> 5), element j: k = 16 s + j -> co = 16 cb + (k >> 1), parity = k & 1, kernel row kh = 4 + r - 2m - parity
+// (zero outside 0..4), kernel column kw = 12 - kwf, ci = 32 tile + n
+__global__ void pack_weights_sp_f16_kernel(const float *__restrict__ W, _Float16 *__restrict__ w_hi, _Float16 *__restrict__ w_lo)
+{
+    const int total = 4 * 3 * 2 * CV_KW * 2 * 64 * 16;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int j = i & 15, l = (i >> 4) & 63, tile = (i >> 10) & 1;
+        int rest = i >> 11;
+        const int kwf = rest % CV_KW; rest /= CV_KW;
+        const int r = rest & 1; rest >>= 1;
+        const int m = rest % 3, cb = rest / 3;
+        const int k = 16 * (l >> 5) + j, co = 16 * cb + (k >> 1), par = k & 1, kh = 4 + r - 2 * m - par;
+        const int ci = 32 * tile + (l & 31), kw = 12 - kwf;
+        float v = 0.0f;
+        if (kh >= 0 && kh < CV_KH) v = W[(((size_t)co * 64 + ci) * CV_KH + kh) * CV_KW + kw] * DS_WSCALE;
+        const _Float16 hv = (_Float16)v;
+        w_hi[i] = hv;
+        w_lo[i] = (_Float16)(v - (float)hv);
+    }
+}
+
+// G, amax (B,64,Hp,352) -> channels-last pooled operand: g_hi, g_lo (B,Hp,4,352,16) = split of G * S (columns >= Wv: 0)
+// and g_idx (B,Hp,4,352) uint32: low / high 16 bits = index word of lane half 0 / 1, element j of half hh = output
+// channel 4hh + j (j < 4) or 8 + 4hh + j - 4 of the block, field = 2 (j & 1) + argmax.
+__global__ __launch_bounds__(256) void gpool_cl_prep_kernel(const float *__restrict__ G, const unsigned char *__restrict__ amax,
+                                                            const float *__restrict__ scale, int Hp, int Wv,
+                                                            _Float16 *__restrict__ g_hi, _Float16 *__restrict__ g_lo,
+                                                            unsigned *__restrict__ g_idx)
+{
+    __shared__ float tile[64][33];
+    __shared__ unsigned char tam[64][36];
+    const int wt = blockIdx.x, hp = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
+    const float S = scale[0];
+    for (int i = tid; i < 64 * 8; i += 256) {
+        const int ch = i >> 3, c4 = i & 7, w0 = wt * 32 + c4 * 4;
+        const size_t off = (((size_t)b * 64 + ch) * Hp + hp) * CV_PITCH + w0;
+        const floatx4 v = *reinterpret_cast<const floatx4 *>(G + off);
+        const uchar4 am = *reinterpret_cast<const uchar4 *>(amax + off);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) tile[ch][c4 * 4 + e] = (w0 + e < Wv) ? v[e] * S : 0.0f;
+        tam[ch][c4 * 4 + 0] = am.x & 1; tam[ch][c4 * 4 + 1] = am.y & 1; tam[ch][c4 * 4 + 2] = am.z & 1; tam[ch][c4 * 4 + 3] = am.w & 1;
+    }
+    __syncthreads();
+    const int pos = tid >> 3, cg = tid & 7;                     // 32 positions x 8 groups of 8 channels
+    half8 hi, lo;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float v = tile[cg * 8 + j][pos];
+        const _Float16 hv = (_Float16)v;
+        hi[j] = hv;
+        lo[j] = (_Float16)(v - (float)hv);
+    }
+    const size_t o = ((((size_t)b * Hp + hp) * 4 + (cg >> 1)) * CV_PITCH + wt * 32 + pos) * 16 + (cg & 1) * 8;
+    *reinterpret_cast<half8 *>(g_hi + o) = hi;
+    *reinterpret_cast<half8 *>(g_lo + o) = lo;
+    if (cg < 4) {                                               // one thread per (position, channel block): both index words
+        unsigned word = 0;
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int col = (j < 4 ? 4 * hf + j : 8 + 4 * hf + (j - 4));
+                const unsigned f = 2u * (j & 1) + tam[cg * 16 + col][pos];
+                word |= f << (16 * hf + 2 * j);
+            }
+        g_idx[(((size_t)b * Hp + hp) * 4 + cg) * CV_PITCH + wt * 32 + pos] = word;
+    }
+}
+
+template <int T>
+static int launch_dgrad_sp(const DgradSpArgs &a, int B, hipStream_t st)
+{
+    constexpr int PWP = CV_PITCH + 12 * T;
+    constexpr size_t buf = ((2 * (size_t)PWP * DS_ROWB + PWP * 4 + 15) / 16) * 16;
+    constexpr size_t lds = 2 * buf > 4 * 32 * 33 * 4 ? 2 * buf : 4 * 32 * 33 * 4;
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void *)dgrad_sp_f16x3_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+            hipSuccess)
+            return MX_ERR_LAUNCH;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((dgrad_sp_f16x3_kernel<T>), dim3(a.H / 2, B), dim3(256), lds, st, a);
+    return mx_launch_status();
+}
+
+// W (64,64,5,13) -> w_hi, w_lo: 4*3*2*13*2*64*16 halfs each
+MX_EXPORT int mx_conv_pack_weights_sp_f16(const float *W, void *w_hi, void *w_lo, void *stream)
+{
+    if (!W || !w_hi || !w_lo) return MX_ERR_ARG;
+    hipLaunchKernelGGL(pack_weights_sp_f16_kernel, dim3(512), dim3(256), 0, (hipStream_t)stream, W, (_Float16 *)w_hi,
+                       (_Float16 *)w_lo);
+    return mx_launch_status();
+}
+
+// G, amax: (B,64,H/2,352); scale: the {S, 1/S} pair -> g_hi, g_lo (B,H/2,4,352,16) halfs, g_idx (B,H/2,4,352) uint32
+MX_EXPORT int mx_conv_prep_gpool_cl_f16(const float *G, const uint8_t *amax, const float *scale, int64_t B, int64_t H,
+                                        int64_t Wv, void *g_hi, void *g_lo, void *g_idx, void *stream)
+{
+    if (!G || !amax || !scale || !g_hi || !g_lo || !g_idx || B <= 0 || H < 2 || (H & 1) || Wv <= 0 || Wv > CV_PITCH)
+        return MX_ERR_ARG;
+    if (B > 65535 || H > 131070) return MX_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(gpool_cl_prep_kernel, dim3(CV_PITCH / 32, (unsigned)(H / 2), (unsigned)B), dim3(256), 0,
+                       (hipStream_t)stream, G, amax, scale, (int)(H / 2), (int)Wv, (_Float16 *)g_hi, (_Float16 *)g_lo,
+                       (unsigned *)g_idx);
+    return mx_launch_status();
+}
+
+// data gradient from the pooled channels-last operand and the fragment-packed weights; dxhat (B,64,H,352)
+MX_EXPORT int mx_conv_block_dgrad_sp_f16(const void *g_hi, const void *g_lo, const void *g_idx, const void *w_hi,
+                                         const void *w_lo, const float *scale, int64_t B, int64_t H, int64_t Wv,
+                                         int32_t dilation, float *dxhat, void *stream)
+{
+    if (!g_hi || !g_lo || !g_idx || !w_hi || !w_lo || !scale || !dxhat) return MX_ERR_ARG;
+    if (B <= 0 || B > 65535 || H < 2 || (H & 1) || Wv <= 0 || Wv > CV_PITCH - 1) return MX_ERR_UNSUPPORTED;
+    DgradSpArgs a{(const _Float16 *)g_hi, (const _Float16 *)g_lo, (const unsigned *)g_idx, (const _Float16 *)w_hi,
+                  (const _Float16 *)w_lo, scale, dxhat, (int)H, (int)Wv};
+    hipStream_t st = (hipStream_t)stream;
+    switch (dilation) {
+    case 1: return launch_dgrad_sp<1>(a, (int)B, st);
+    case 2: return launch_dgrad_sp<2>(a, (int)B, st);
+    case 4: return launch_dgrad_sp<4>(a, (int)B, st);
+    case 8: return launch_dgrad_sp<8>(a, (int)B, st);
+    case 16: return launch_dgrad_sp<16>(a, (int)B, st);
+    default: return MX_ERR_UNSUPPORTED;
+    }
+}

@@ -129,6 +129,7 @@ def _pack_f16(w: T, flip: int) -> Tuple[T, T]:
 BLOCK1_F16 = os.environ.get("MODEX_BLOCK1", "f16x3") != "f32"
 # weight gradient of the 64-channel blocks: sparse (2:4 along the pooling pair) or dense matrix instruction
 WGRAD_SPARSE = os.environ.get("MODEX_WGRAD", "sparse") != "dense"
+DGRAD_SPARSE = os.environ.get("MODEX_DGRAD", "sparse") != "dense"
 
 
 def _use_f16(cin: int, precision: str) -> bool:
@@ -326,7 +327,22 @@ class _CNNStack(torch.autograd.Function):
             grads[3 * l] = dW
             if l > 0:
                 dxhat = torch.empty((B, 64, H, PITCH), device=dev, dtype=torch.float32)
-                if f16:
+                if f16 and sparse and DGRAD_SPARSE:
+                    # sparse matrix instruction, transposed tiles: pooled channels-last gradient x fragment-packed weights
+                    Hp = H // 2
+                    gc_hi = torch.empty((B, Hp, 4, PITCH, 16), device=dev, dtype=torch.float16)
+                    gc_lo = torch.empty((B, Hp, 4, PITCH, 16), device=dev, dtype=torch.float16)
+                    gc_idx = torch.empty((B, Hp, 4, PITCH), device=dev, dtype=torch.int32)
+                    _hip.call("mx_conv_prep_gpool_cl_f16", _hip.ptr(G), _hip.ptr(amax), _hip.ptr(scale), B, H, n_frames,
+                              _hip.ptr(gc_hi), _hip.ptr(gc_lo), _hip.ptr(gc_idx), st)
+                    ws_hi = torch.empty(4 * 3 * 2 * 13 * 2 * 64 * 16, device=dev, dtype=torch.float16)
+                    ws_lo = torch.empty(4 * 3 * 2 * 13 * 2 * 64 * 16, device=dev, dtype=torch.float16)
+                    _hip.call("mx_conv_pack_weights_sp_f16", _hip.ptr(w.detach().contiguous()), _hip.ptr(ws_hi),
+                              _hip.ptr(ws_lo), st)
+                    _hip.call("mx_conv_block_dgrad_sp_f16", _hip.ptr(gc_hi), _hip.ptr(gc_lo), _hip.ptr(gc_idx), _hip.ptr(ws_hi),
+                              _hip.ptr(ws_lo), _hip.ptr(scale), B, H, n_frames, int(dilations[l]), _hip.ptr(dxhat), st)
+                    del gc_hi, gc_lo, gc_idx, dz_hi, dz_lo
+                elif f16:
                     w_hi, w_lo = _pack_f16(w, 1)
                     _hip.call("mx_conv_block_dgrad_f16", _hip.ptr(dz_hi), _hip.ptr(dz_lo), _hip.ptr(w_hi), _hip.ptr(w_lo),
                               _hip.ptr(scale), B, H, n_frames, int(dilations[l]), _hip.ptr(dxhat), st)

@@ -180,3 +180,20 @@ def test_block_f16x3_kernels(dev, T, W, H):
               B, H, W, T, _hip.ptr(dxhat), st)
     assert rel(dxhat.cpu()[..., :W], xhat_r.grad) < 1e-5
     assert bool((dxhat[..., W:] == 0).all())
+    # sparse data gradient: pooled channels-last operand + fragment-packed weights
+    gc_hi = torch.empty((B, Hp, 4, PITCH, 16), device=dev, dtype=torch.float16)
+    gc_lo = torch.empty_like(gc_hi)
+    gc_idx = torch.empty((B, Hp, 4, PITCH), device=dev, dtype=torch.int32)
+    _hip.call("mx_conv_prep_gpool_cl_f16", _hip.ptr(G_d), _hip.ptr(amax_d), _hip.ptr(scale), B, H, W, _hip.ptr(gc_hi),
+              _hip.ptr(gc_lo), _hip.ptr(gc_idx), st)
+    gc = (gc_hi.float() + gc_lo.float()).permute(0, 2, 4, 1, 3).reshape(B, 64, Hp, PITCH)
+    assert rel(gc.cpu()[..., :W] / S, Gc) < 2e-6 and bool((gc[..., W:] == 0).all())
+    ws_hi = torch.empty(4 * 3 * 2 * 13 * 2 * 64 * 16, device=dev, dtype=torch.float16)
+    ws_lo = torch.empty_like(ws_hi)
+    _hip.call("mx_conv_pack_weights_sp_f16", _hip.ptr(w.detach().to(dev).contiguous()), _hip.ptr(ws_hi), _hip.ptr(ws_lo), st)
+    dx_sp = torch.empty((B, 64, H, PITCH), device=dev)
+    _hip.call("mx_conv_block_dgrad_sp_f16", _hip.ptr(gc_hi), _hip.ptr(gc_lo), _hip.ptr(gc_idx), _hip.ptr(ws_hi), _hip.ptr(ws_lo),
+              _hip.ptr(scale), B, H, W, T, _hip.ptr(dx_sp), st)
+    assert rel(dx_sp.cpu()[..., :W], xhat_r.grad) < 1e-5, ("sparse dgrad", rel(dx_sp.cpu()[..., :W], xhat_r.grad))
+    assert bool((dx_sp[..., W:] == 0).all())
+    assert rel(dx_sp, dxhat) < 5e-6                                              # same sums, different order
