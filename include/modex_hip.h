@@ -188,11 +188,13 @@ int mx_conv_block_wgrad_sp_f16(const void *gp_hi, const void *gp_lo, const void 
  * from global memory; 12 K stages instead of 20.  Same results as mx_conv_block_dgrad_f16 up to summation order.
  *   mx_conv_pack_weights_sp_f16: W (64,64,5,13) -> w_hi, w_lo: 4*3*2*13*2*64*16 halfs each
  *   mx_conv_prep_gpool_cl_f16: G, amax (B,64,H/2,352), scale {S, 1/S} -> g_hi, g_lo (B,H/2,4,352,16) halfs,
- *                              g_idx (B,H/2,4,352) uint32 index words
+ *                              g_idx (B,H/2,4,352) uint32 index words; gp_hi / gp_lo / gidx (all or NULL): the planar
+ *                              operand of mx_conv_block_wgrad_sp_f16 from the same pass (mx_conv_prep_dgrad_f16 with
+ *                              dz_hi = dz_lo = NULL then only computes the scale pair)
  *   mx_conv_block_dgrad_sp_f16: dxhat (B,64,H,352); Wv <= 351 (zero pad column = halo source) */
 int mx_conv_pack_weights_sp_f16(const float *W, void *w_hi, void *w_lo, void *stream);
 int mx_conv_prep_gpool_cl_f16(const float *G, const uint8_t *amax, const float *scale, int64_t B, int64_t H, int64_t Wv,
-                              void *g_hi, void *g_lo, void *g_idx, void *stream);
+                              void *g_hi, void *g_lo, void *g_idx, void *gp_hi, void *gp_lo, void *gidx, void *stream);
 int mx_conv_block_dgrad_sp_f16(const void *g_hi, const void *g_lo, const void *g_idx, const void *w_hi, const void *w_lo,
                                const float *scale, int64_t B, int64_t H, int64_t Wv, int32_t dilation, float *dxhat,
                                void *stream);

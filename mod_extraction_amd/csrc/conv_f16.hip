@@ -742,8 +742,8 @@ MX_EXPORT int mx_conv_prep_dgrad_f16(const float *G, const uint8_t *amax, int64_
                                      uint32_t *amax_ws, int32_t amax_ready, float *scale, void *dz_hi, void *dz_lo,
                                      void *gp_hi, void *gp_lo, void *gidx, void *stream)
 {
-    if (!G || !amax || !amax_ws || !scale || !dz_hi || !dz_lo || B <= 0 || H < 2 || (H & 1) || Wv <= 0 || Wv > CV_PITCH)
-        return MX_ERR_ARG;
+    if (!G || !amax || !amax_ws || !scale || B <= 0 || H < 2 || (H & 1) || Wv <= 0 || Wv > CV_PITCH) return MX_ERR_ARG;
+    if ((dz_hi == nullptr) != (dz_lo == nullptr)) return MX_ERR_ARG;      // both NULL: only the scale pair is produced
     if (B > 65535 || H > 65535) return MX_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     if (!amax_ready) {          // otherwise *amax_ws already holds the bits of max|G| (mx_ln_prelu_bwd's gmax_bits)
@@ -753,6 +753,7 @@ MX_EXPORT int mx_conv_prep_dgrad_f16(const float *G, const uint8_t *amax, int64_
     }
     hipLaunchKernelGGL(pow2_scale_kernel, dim3(1), dim3(1), 0, st, amax_ws, scale);
     if ((gp_hi || gp_lo || gidx) && !(gp_hi && gp_lo && gidx)) return MX_ERR_ARG;     // all three by-products or none
+    if (!dz_hi) return mx_launch_status();
     hipLaunchKernelGGL((split_prep_kernel<1>), dim3(CV_PITCH / 32, (unsigned)H, (unsigned)B), dim3(256), 0, st, G, amax,
                        nullptr, nullptr, scale, (int)H, (int)Wv, (_Float16 *)dz_hi, (_Float16 *)dz_lo, (_Float16 *)gp_hi,
                        (_Float16 *)gp_lo, (unsigned char *)gidx);

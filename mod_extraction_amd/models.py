@@ -257,24 +257,38 @@ class _CNNStack(torch.autograd.Function):
             f16 = _use_f16(cin, precision)
             dW = torch.empty_like(w)
             if f16:
-                dz_hi = torch.empty((B, H, 4, PITCH, 16), device=dev, dtype=torch.float16)
-                dz_lo = torch.empty((B, H, 4, PITCH, 16), device=dev, dtype=torch.float16)
+                dz_hi = dz_lo = None
                 ready = gmax_ws is not None
                 ws = gmax_ws if ready else torch.empty(1, device=dev, dtype=torch.int32)
                 gmax_ws = None
                 scale = torch.empty(2, device=dev, dtype=torch.float32)
                 sparse = WGRAD_SPARSE and int(dilations[l]) <= 4 and n_frames <= PITCH - 1
-                gp_hi = gp_lo = gidx = None
+                sparse_d = sparse and DGRAD_SPARSE and l > 0
+                gp_hi = gp_lo = gidx = gc_hi = gc_lo = gc_idx = None
                 if sparse:
                     # sparse matrix instruction: the pooled gradient is the compressed operand, the argmax its index
-                    # bits (dilations >= 8 share no fragment blocks between taps: dense kernel); by-product of the prep
+                    # bits (dilations >= 8 share no fragment blocks between taps: dense kernels)
                     Hp = H // 2
                     gp_hi = torch.empty((B, 64, Hp, PITCH), device=dev, dtype=torch.float16)
                     gp_lo = torch.empty((B, 64, Hp, PITCH), device=dev, dtype=torch.float16)
                     gidx = torch.empty((B, 64, Hp, 22, 2), device=dev, dtype=torch.int16)
-                _hip.call("mx_conv_prep_dgrad_f16", _hip.ptr(G), _hip.ptr(amax), B, H, n_frames, _hip.ptr(ws),
-                          1 if ready else 0, _hip.ptr(scale), _hip.ptr(dz_hi), _hip.ptr(dz_lo), _hip.ptr(gp_hi),
-                          _hip.ptr(gp_lo), _hip.ptr(gidx), st)
+                if sparse_d:
+                    # both gradients on the sparse instruction: the routed full-resolution pair is not needed at all --
+                    # scale only, then one pass over G writes the channels-last (dgrad) and planar (wgrad) pooled operands
+                    _hip.call("mx_conv_prep_dgrad_f16", _hip.ptr(G), _hip.ptr(amax), B, H, n_frames, _hip.ptr(ws),
+                              1 if ready else 0, _hip.ptr(scale), None, None, None, None, None, st)
+                    gc_hi = torch.empty((B, Hp, 4, PITCH, 16), device=dev, dtype=torch.float16)
+                    gc_lo = torch.empty((B, Hp, 4, PITCH, 16), device=dev, dtype=torch.float16)
+                    gc_idx = torch.empty((B, Hp, 4, PITCH), device=dev, dtype=torch.int32)
+                    _hip.call("mx_conv_prep_gpool_cl_f16", _hip.ptr(G), _hip.ptr(amax), _hip.ptr(scale), B, H, n_frames,
+                              _hip.ptr(gc_hi), _hip.ptr(gc_lo), _hip.ptr(gc_idx), _hip.ptr(gp_hi), _hip.ptr(gp_lo),
+                              _hip.ptr(gidx), st)
+                else:
+                    dz_hi = torch.empty((B, H, 4, PITCH, 16), device=dev, dtype=torch.float16)
+                    dz_lo = torch.empty((B, H, 4, PITCH, 16), device=dev, dtype=torch.float16)
+                    _hip.call("mx_conv_prep_dgrad_f16", _hip.ptr(G), _hip.ptr(amax), B, H, n_frames, _hip.ptr(ws),
+                              1 if ready else 0, _hip.ptr(scale), _hip.ptr(dz_hi), _hip.ptr(dz_lo), _hip.ptr(gp_hi),
+                              _hip.ptr(gp_lo), _hip.ptr(gidx), st)
                 if l in ctx.splits:
                     x_hi, x_lo = ctx.splits.pop(l)
                 else:
@@ -327,21 +341,15 @@ class _CNNStack(torch.autograd.Function):
             grads[3 * l] = dW
             if l > 0:
                 dxhat = torch.empty((B, 64, H, PITCH), device=dev, dtype=torch.float32)
-                if f16 and sparse and DGRAD_SPARSE:
+                if f16 and sparse_d:
                     # sparse matrix instruction, transposed tiles: pooled channels-last gradient x fragment-packed weights
-                    Hp = H // 2
-                    gc_hi = torch.empty((B, Hp, 4, PITCH, 16), device=dev, dtype=torch.float16)
-                    gc_lo = torch.empty((B, Hp, 4, PITCH, 16), device=dev, dtype=torch.float16)
-                    gc_idx = torch.empty((B, Hp, 4, PITCH), device=dev, dtype=torch.int32)
-                    _hip.call("mx_conv_prep_gpool_cl_f16", _hip.ptr(G), _hip.ptr(amax), _hip.ptr(scale), B, H, n_frames,
-                              _hip.ptr(gc_hi), _hip.ptr(gc_lo), _hip.ptr(gc_idx), st)
                     ws_hi = torch.empty(4 * 3 * 2 * 13 * 2 * 64 * 16, device=dev, dtype=torch.float16)
                     ws_lo = torch.empty(4 * 3 * 2 * 13 * 2 * 64 * 16, device=dev, dtype=torch.float16)
                     _hip.call("mx_conv_pack_weights_sp_f16", _hip.ptr(w.detach().contiguous()), _hip.ptr(ws_hi),
                               _hip.ptr(ws_lo), st)
                     _hip.call("mx_conv_block_dgrad_sp_f16", _hip.ptr(gc_hi), _hip.ptr(gc_lo), _hip.ptr(gc_idx), _hip.ptr(ws_hi),
                               _hip.ptr(ws_lo), _hip.ptr(scale), B, H, n_frames, int(dilations[l]), _hip.ptr(dxhat), st)
-                    del gc_hi, gc_lo, gc_idx, dz_hi, dz_lo
+                    del gc_hi, gc_lo, gc_idx
                 elif f16:
                     w_hi, w_lo = _pack_f16(w, 1)
                     _hip.call("mx_conv_block_dgrad_f16", _hip.ptr(dz_hi), _hip.ptr(dz_lo), _hip.ptr(w_hi), _hip.ptr(w_lo),

@@ -184,8 +184,14 @@ def test_block_f16x3_kernels(dev, T, W, H):
     gc_hi = torch.empty((B, Hp, 4, PITCH, 16), device=dev, dtype=torch.float16)
     gc_lo = torch.empty_like(gc_hi)
     gc_idx = torch.empty((B, Hp, 4, PITCH), device=dev, dtype=torch.int32)
+    gr_hi, gr_lo, gridx = torch.empty_like(gp_hi), torch.empty_like(gp_lo), torch.empty_like(gidx)
     _hip.call("mx_conv_prep_gpool_cl_f16", _hip.ptr(G_d), _hip.ptr(amax_d), _hip.ptr(scale), B, H, W, _hip.ptr(gc_hi),
-              _hip.ptr(gc_lo), _hip.ptr(gc_idx), st)
+              _hip.ptr(gc_lo), _hip.ptr(gc_idx), _hip.ptr(gr_hi), _hip.ptr(gr_lo), _hip.ptr(gridx), st)
+    assert torch.equal(gr_hi, gp_hi) and torch.equal(gr_lo, gp_lo) and torch.equal(gridx, gidx)    # planar by-product
+    sc2 = torch.empty(2, device=dev)
+    _hip.call("mx_conv_prep_dgrad_f16", _hip.ptr(G_d), _hip.ptr(amax_d), B, H, W, _hip.ptr(ws), 0, _hip.ptr(sc2), None, None,
+              None, None, None, st)
+    assert torch.equal(sc2, scale)                                                                 # scale-only call
     gc = (gc_hi.float() + gc_lo.float()).permute(0, 2, 4, 1, 3).reshape(B, 64, Hp, PITCH)
     assert rel(gc.cpu()[..., :W] / S, Gc) < 2e-6 and bool((gc[..., W:] == 0).all())
     ws_hi = torch.empty(4 * 3 * 2 * 13 * 2 * 64 * 16, device=dev, dtype=torch.float16)
