@@ -262,33 +262,37 @@ class _CNNStack(torch.autograd.Function):
                 ws = gmax_ws if ready else torch.empty(1, device=dev, dtype=torch.int32)
                 gmax_ws = None
                 scale = torch.empty(2, device=dev, dtype=torch.float32)
+                # sparse matrix instruction: the pooled gradient is the compressed operand, the argmax its index bits.
+                # Weight gradient: dilations <= 4 (for >= 8 the taps share no fragment blocks: dense kernel on the routed
+                # full-resolution pair); data gradient: every dilation.
                 sparse = WGRAD_SPARSE and int(dilations[l]) <= 4 and n_frames <= PITCH - 1
-                sparse_d = sparse and DGRAD_SPARSE and l > 0
+                sparse_d = DGRAD_SPARSE and l > 0 and n_frames <= PITCH - 1
                 gp_hi = gp_lo = gidx = gc_hi = gc_lo = gc_idx = None
+                Hp = H // 2
                 if sparse:
-                    # sparse matrix instruction: the pooled gradient is the compressed operand, the argmax its index
-                    # bits (dilations >= 8 share no fragment blocks between taps: dense kernels)
-                    Hp = H // 2
                     gp_hi = torch.empty((B, 64, Hp, PITCH), device=dev, dtype=torch.float16)
                     gp_lo = torch.empty((B, 64, Hp, PITCH), device=dev, dtype=torch.float16)
                     gidx = torch.empty((B, 64, Hp, 22, 2), device=dev, dtype=torch.int16)
-                if sparse_d:
-                    # both gradients on the sparse instruction: the routed full-resolution pair is not needed at all --
-                    # scale only, then one pass over G writes the channels-last (dgrad) and planar (wgrad) pooled operands
+                if sparse and (sparse_d or l == 0):
+                    # the routed pair is not needed at all: scale only
                     _hip.call("mx_conv_prep_dgrad_f16", _hip.ptr(G), _hip.ptr(amax), B, H, n_frames, _hip.ptr(ws),
                               1 if ready else 0, _hip.ptr(scale), None, None, None, None, None, st)
+                else:
+                    dz_hi = torch.empty((B, H, 4, PITCH, 16), device=dev, dtype=torch.float16)
+                    dz_lo = torch.empty((B, H, 4, PITCH, 16), device=dev, dtype=torch.float16)
+                    by = sparse and not sparse_d                 # planar by-products only if no pooled pass follows
+                    _hip.call("mx_conv_prep_dgrad_f16", _hip.ptr(G), _hip.ptr(amax), B, H, n_frames, _hip.ptr(ws),
+                              1 if ready else 0, _hip.ptr(scale), _hip.ptr(dz_hi), _hip.ptr(dz_lo),
+                              _hip.ptr(gp_hi if by else None), _hip.ptr(gp_lo if by else None),
+                              _hip.ptr(gidx if by else None), st)
+                if sparse_d or (sparse and l == 0):
+                    # one pass over G: channels-last pooled operand (data gradient) + planar one (weight gradient)
                     gc_hi = torch.empty((B, Hp, 4, PITCH, 16), device=dev, dtype=torch.float16)
                     gc_lo = torch.empty((B, Hp, 4, PITCH, 16), device=dev, dtype=torch.float16)
                     gc_idx = torch.empty((B, Hp, 4, PITCH), device=dev, dtype=torch.int32)
                     _hip.call("mx_conv_prep_gpool_cl_f16", _hip.ptr(G), _hip.ptr(amax), _hip.ptr(scale), B, H, n_frames,
                               _hip.ptr(gc_hi), _hip.ptr(gc_lo), _hip.ptr(gc_idx), _hip.ptr(gp_hi), _hip.ptr(gp_lo),
                               _hip.ptr(gidx), st)
-                else:
-                    dz_hi = torch.empty((B, H, 4, PITCH, 16), device=dev, dtype=torch.float16)
-                    dz_lo = torch.empty((B, H, 4, PITCH, 16), device=dev, dtype=torch.float16)
-                    _hip.call("mx_conv_prep_dgrad_f16", _hip.ptr(G), _hip.ptr(amax), B, H, n_frames, _hip.ptr(ws),
-                              1 if ready else 0, _hip.ptr(scale), _hip.ptr(dz_hi), _hip.ptr(dz_lo), _hip.ptr(gp_hi),
-                              _hip.ptr(gp_lo), _hip.ptr(gidx), st)
                 if l in ctx.splits:
                     x_hi, x_lo = ctx.splits.pop(l)
                 else:
