@@ -300,14 +300,7 @@ class _CNNStack(torch.autograd.Function):
                     x_lo = torch.empty((B, H, 4, PITCH, 16), device=dev, dtype=torch.float16)
                     _hip.call("mx_conv_prep_fwd_f16", _hip.ptr(x_in), _hip.ptr(stats), _hip.ptr(slope_prev), B, H,
                               n_frames, _hip.ptr(x_hi), _hip.ptr(x_lo), st)
-                if WGRAD_SPARSE and int(dilations[l]) <= 4 and n_frames <= PITCH - 1:
-                    # sparse matrix instruction (dilations >= 8 share no fragment blocks between taps: dense kernel): the pooled gradient is the compressed operand, the argmax its index bits
-                    Hp = H // 2
-                    gp_hi = torch.empty((B, 64, Hp, PITCH), device=dev, dtype=torch.float16)
-                    gp_lo = torch.empty((B, 64, Hp, PITCH), device=dev, dtype=torch.float16)
-                    gidx = torch.empty((B, 64, Hp, 22, 2), device=dev, dtype=torch.int16)
-                    _hip.call("mx_conv_prep_gpool_f16", _hip.ptr(G), _hip.ptr(amax), _hip.ptr(scale), B, H, _hip.ptr(gp_hi),
-                              _hip.ptr(gp_lo), _hip.ptr(gidx), st)
+                if sparse:
                     prow = B * Hp
                     rps = max(1, -(-prow // 408))
                     n_slabs = -(-prow // rps)
