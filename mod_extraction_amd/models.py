@@ -302,7 +302,7 @@ class _CNNStack(torch.autograd.Function):
                               n_frames, _hip.ptr(x_hi), _hip.ptr(x_lo), st)
                 if sparse:
                     prow = B * Hp
-                    rps = max(1, -(-prow // 408))
+                    rps = max(1, -(-prow // 256))           # 256 slabs x 5 kernel rows = 5 full rounds of 256 workgroups
                     n_slabs = -(-prow // rps)
                     part = torch.empty(n_slabs * 65 * 64 * 64, device=dev, dtype=torch.float32)
                     _hip.call("mx_conv_block_wgrad_sp_f16", _hip.ptr(gp_hi), _hip.ptr(gp_lo), _hip.ptr(gidx), _hip.ptr(x_hi),
@@ -310,7 +310,7 @@ class _CNNStack(torch.autograd.Function):
                               _hip.ptr(dW), st)
                     del gp_hi, gp_lo, gidx
                 else:
-                    rps = max(1, -(-rows // 408))            # ~408 slabs x 5 kernel rows = 8 workgroups per CU
+                    rps = max(1, -(-rows // 256))            # 256 slabs x 5 kernel rows = 5 full rounds of 256 workgroups
                     n_slabs = -(-rows // rps)
                     part = torch.empty(n_slabs * 65 * 64 * 64, device=dev, dtype=torch.float32)
                     _hip.call("mx_conv_block_wgrad_f16", _hip.ptr(dz_hi), _hip.ptr(dz_lo), _hip.ptr(x_hi), _hip.ptr(x_lo),
