@@ -132,6 +132,13 @@ __global__ __launch_bounds__(256, 1) void dgrad_sp_f16x3_kernel(DgradSpArgs a)
     while (st < N_STAGE && !stage_live(st)) ++st;
     if (st < N_STAGE) issue(st);
     int bufsel = 0;
+    // weight fragments of the NEXT stage's first tap: fetched from global memory during the current stage's last tap
+    // (they do not depend on the barrier; an L2 round trip at the head of every stage was 15 % of the kernel)
+    half16 WNH[2], WNL[2];
+    if (st < N_STAGE) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { WNH[j] = ds_w_frag(w_ptr(a.w_hi, st, 0, j)); WNL[j] = ds_w_frag(w_ptr(a.w_lo, st, 0, j)); }
+    }
     while (st < N_STAGE) {
         unsigned char *const buf = smem + bufsel * BUF_BYTES;
         commit(buf);                                    // the other buffer may still be read by slower waves
@@ -166,7 +173,8 @@ __global__ __launch_bounds__(256, 1) void dgrad_sp_f16x3_kernel(DgradSpArgs a)
             }
         };
         rd_tap(0, 0);
-        ld_w(0, 0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { WH[0][j] = WNH[j]; WL[0][j] = WNL[j]; }
 #pragma unroll
         for (int kwf = 0; kwf < CV_KW; ++kwf) {
             const int f = kwf & 1;
@@ -196,6 +204,9 @@ __global__ __launch_bounds__(256, 1) void dgrad_sp_f16x3_kernel(DgradSpArgs a)
                     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                 }
                 __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+            } else if (nst < N_STAGE) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) { WNH[j] = ds_w_frag(w_ptr(a.w_hi, nst, 0, j)); WNL[j] = ds_w_frag(w_ptr(a.w_lo, nst, 0, j)); }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
