@@ -270,6 +270,7 @@ __global__ __launch_bounds__(256) void gpool_cl_prep_kernel(const float *__restr
 {
     __shared__ float tile[64][33];
     __shared__ unsigned char tam[64][36];
+    __shared__ __attribute__((aligned(8))) unsigned char idxb[64][8];       // the tile's 8 planar index bytes per channel
     const int wt = blockIdx.x, hp = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
     const float S = scale[0];
     for (int i = tid; i < 64 * 8; i += 256) {
@@ -295,11 +296,13 @@ __global__ __launch_bounds__(256) void gpool_cl_prep_kernel(const float *__restr
             *reinterpret_cast<half4 *>(gp_hi + off) = ghi;
             *reinterpret_cast<half4 *>(gp_lo + off) = glo;
             const unsigned byte = (am.x & 1u) | ((2u + (am.y & 1u)) << 2) | ((am.z & 1u) << 4) | ((2u + (am.w & 1u)) << 6);
-            gidx[(((((size_t)b * 64 + ch) * Hp + hp) * 22 + wt * 2 + (c4 >> 2)) * 2 + (c4 & 1)) * 2 + ((c4 >> 1) & 1)] =
-                (unsigned char)byte;
+            idxb[ch][((c4 >> 2) * 2 + (c4 & 1)) * 2 + ((c4 >> 1) & 1)] = (unsigned char)byte;     // gathered, stored 8 at a time below
         }
     }
     __syncthreads();
+    if (gp_hi && tid < 64)          // 2 k-steps x 2 lane halves x 2 bytes = 8 contiguous bytes of gidx per channel
+        *reinterpret_cast<unsigned long long *>(gidx + ((((size_t)b * 64 + tid) * Hp + hp) * 22 + wt * 2) * 4) =
+            *reinterpret_cast<const unsigned long long *>(idxb[tid]);
     const int pos = tid >> 3, cg = tid & 7;                     // 32 positions x 8 groups of 8 channels
     half8 hi, lo;
 #pragma unroll
