@@ -82,6 +82,95 @@ __device__ __forceinline__ half8 a_frag(const unsigned char *ptr)
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
+// ---- x fragments as SLIDING WINDOWS over register chains.  The seven taps of a wave read 16-row fragments whose first
+// rows differ by 2T image rows; with 4-row transposed blocks, fragments that differ by a multiple of 4 rows share blocks.
+// A fragment must be 8 consecutive VGPRs, and left to itself the compiler gives every window its own 8 registers and
+// COPIES the shared blocks into them (~30 v_accvgpr_mov clumped at the head of every 13-MFMA phase, behind a wait for
+// nearly all of the phase's LDS reads: the matrix pipe idled for a third of the kernel).  Holding a chain of blocks in
+// ONE wide vector that passes through an empty asm ("pin") makes it a single virtual register; the windows are then
+// sub-register ranges of it and cost nothing.
+typedef int int2v __attribute__((ext_vector_type(2)));
+typedef int int8v __attribute__((ext_vector_type(8)));
+typedef int int16v __attribute__((ext_vector_type(16)));
+typedef int int32v __attribute__((ext_vector_type(32)));
+
+template <int S, typename V>
+__device__ __forceinline__ half16 chain_window(const V &c)
+{
+    if constexpr (2 * S + 7 < (int)(sizeof(V) / 4)) {
+        const int8v w = __builtin_shufflevector(c, c, 2 * S, 2 * S + 1, 2 * S + 2, 2 * S + 3, 2 * S + 4, 2 * S + 5, 2 * S + 6, 2 * S + 7);
+        return __builtin_bit_cast(half16, w);
+    } else {
+        return half16{};
+    }
+}
+
+//   T = 1: two chains (even taps: rows 0,4,..,24 = 7 blocks; odd taps: rows 2,6,..,22 = 6 blocks)    13 reads, not 28
+//   T = 2: the ten blocks of rows 0,4,..,36 as two 512-bit chains (taps 0..4: blocks 0..7; taps 5,6: blocks 5..9 -- three
+//          blocks are read twice; one 1024-bit chain with 12 unused registers made the compiler shuffle)   13 reads
+//   T = 4: one chain of 16 blocks                                                                      16 reads
+template <int T>
+struct SlidingB {
+    static constexpr int NBLK = T == 4 ? 16 : 13;
+    static constexpr int NC = T == 4 ? 1 : 2;
+    static constexpr int N0 = T == 1 ? 7 : (T == 2 ? 8 : 16);          // blocks in chain 0
+    using V = std::conditional_t<T == 4, int32v, int16v>;
+    V c[NC];
+    static __device__ __forceinline__ int row_of(int n)
+    {
+        return n < N0 ? 4 * n : (T == 1 ? 2 + 4 * (n - N0) : 4 * (n - N0 + 5));
+    }
+    __device__ __forceinline__ void put(int n, short4v v)
+    {
+        const int2v b = __builtin_bit_cast(int2v, v);
+        const int ci = n >= N0 ? 1 : 0, slot = n >= N0 ? n - N0 : n;
+        c[ci][2 * slot] = b[0];
+        c[ci][2 * slot + 1] = b[1];
+    }
+    __device__ __forceinline__ void pin()
+    {
+#pragma unroll
+        for (int i = 0; i < NC; ++i) asm volatile("" : "+v"(c[i]));
+    }
+    // window of tap i (0..6 within the wave's tap group)
+    __device__ __forceinline__ half16 frag(int i) const
+    {
+        const V &v = c[T == 1 ? (i & 1) : (T == 2 && i >= 5 ? 1 : 0)];
+        const int s = T == 1 ? (i >> 1) : (T == 2 ? (i >= 5 ? i - 5 : i) : 2 * i);
+        switch (s) {
+        case 0: return chain_window<0>(v);
+        case 1: return chain_window<1>(v);
+        case 2: return chain_window<2>(v);
+        case 3: return chain_window<3>(v);
+        case 4: return chain_window<4>(v);
+        case 5: return chain_window<5>(v);
+        case 6: return chain_window<6>(v);
+        case 8: return chain_window<8>(v);
+        case 10: return chain_window<10>(v);
+        default: return chain_window<12>(v);
+        }
+    }
+};
+// T >= 8: the taps' fragments do not overlap (7 x 4 blocks)
+template <int T>
+struct FlatB {
+    static constexpr int NBLK = 28;
+    short4v blk[28];
+    static __device__ __forceinline__ int row_of(int n) { return (n >> 2) * 2 * T + 4 * (n & 3); }
+    __device__ __forceinline__ void put(int n, short4v v) { blk[n] = v; }
+    __device__ __forceinline__ void pin() {}
+    __device__ __forceinline__ half16 frag(int i) const
+    {
+        typedef short short8v __attribute__((__vector_size__(8 * sizeof(short))));
+        typedef short short16v __attribute__((__vector_size__(16 * sizeof(short))));
+        const int n = 4 * i;
+        const short8v lo = __builtin_shufflevector(blk[n], blk[n + 1], 0, 1, 2, 3, 4, 5, 6, 7);
+        const short8v hi = __builtin_shufflevector(blk[n + 2], blk[n + 3], 0, 1, 2, 3, 4, 5, 6, 7);
+        const short16v all = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+        return __builtin_bit_cast(half16, all);
+    }
+};
+
 template <int T>
 __global__ __launch_bounds__(256, 1) void wgrad_sp_f16x3_kernel(WgradSpArgs a)
 {
@@ -208,11 +297,9 @@ __global__ __launch_bounds__(256, 1) void wgrad_sp_f16x3_kernel(WgradSpArgs a)
     // accumulators: acc[2k + j] = tap 7g + k (k < 6), co tile j;   acc[12] = tap 6, co tile g
     const int m32 = lane & 31, hh = lane >> 5;
     // The wave's seven taps sit at image-row offsets 2T i, i = 0..6, from row 12 g T of the window (g = 0: taps 0..5 then
-    // the middle tap 6; g = 1: the middle tap then taps 7..12).  A fragment = four 4-row transposed blocks; offsets
-    // that differ by a multiple of 4 rows share blocks, so the taps are read as sliding windows over block chains:
-    //   T = 1: two chains (even i: rows 0,4,..,24 = 7 blocks; odd i: rows 2,6,..,22 = 6 blocks)     13 reads, not 28
-    //   T = 2: one chain of 10 blocks;  T = 4: one chain of 16;  T >= 8: no overlap (28 blocks)
-    constexpr int NBLK = T == 1 ? 13 : (T == 2 ? 10 : (T == 4 ? 16 : 28));
+    // the middle tap 6; g = 1: the middle tap then taps 7..12); see SlidingB for how their fragments share blocks.
+    using BFrags = std::conditional_t<(T <= 4), SlidingB<T>, FlatB<T>>;
+    constexpr int NBLK = BFrags::NBLK;
     const TrLane32 lb = tr_lane_offsets32(nt, lane);
     const int xg_off = g * 12 * T * 128;
     const int ph_g = (12 * T * g) & 3;
@@ -221,11 +308,6 @@ __global__ __launch_bounds__(256, 1) void wgrad_sp_f16x3_kernel(WgradSpArgs a)
     const int i_lane = m32 * (KC * 4) + hh * 2;
     const unsigned char *Ah = Aimg, *Al = Aimg + A_SPLIT;
     const unsigned char *x_h = Bimg, *x_l = Bimg + B_SPLIT;
-    typedef short short8v __attribute__((__vector_size__(8 * sizeof(short))));
-    typedef short short16v __attribute__((__vector_size__(16 * sizeof(short))));
-    // block index of tap i's first block, and the image row of block n
-    auto blk_of = [](int i) { return T == 1 ? ((i & 1) ? 7 + (i >> 1) : (i >> 1)) : (T == 2 ? i : (T == 4 ? 2 * i : 4 * i)); };
-    auto row_of = [](int n) { return T == 1 ? (n < 7 ? 4 * n : 2 + 4 * (n - 7)) : (T >= 8 ? (n >> 2) * 2 * T + 4 * (n & 3) : 4 * n); };
 
     // the k-step loop, specialised on the tap group (which tap of the window is the middle one)
     // next chunk's prefetch item q (A vectors, index words, x vectors): issued a few per k-step INSIDE the MFMA loop --
@@ -239,88 +321,82 @@ __global__ __launch_bounds__(256, 1) void wgrad_sp_f16x3_kernel(WgradSpArgs a)
     };
     auto run_chunk = [&](auto gc, int nks, int nrid, int nch, bool more) {
         constexpr int G = decltype(gc)::value;
-        half8 AL[3], AH[2][3];                      // [co tile 0, co tile 1, co tile g]
-        int IX[2][3];
-        short4v BHb[NBLK], BLb[NBLK];               // 4-row blocks of hi(x) / lo(x)
-        auto rd_a = [&](const unsigned char *img, int ks, int j) {
-            const int tile = j < 2 ? j : G;
-            return a_frag(img + tile * (32 * AP * 2) + a_lane + ks * 32);
-        };
+        half8 AL[2], AH[2][2];                      // [co tile]; the middle tap uses co tile G
+        int IX[2][2];
+        BFrags BH, BL;                              // 4-row blocks of hi(x) / lo(x)
+        auto rd_a = [&](const unsigned char *img, int ks, int j) { return a_frag(img + j * (32 * AP * 2) + a_lane + ks * 32); };
         auto rd_i = [&](int ks, int j) {
-            const int tile = j < 2 ? j : G;
-            return (int)*reinterpret_cast<const unsigned short *>(Iimg + tile * (32 * KC * 4) + i_lane + ks * 4);
+            return (int)*reinterpret_cast<const unsigned short *>(Iimg + j * (32 * KC * 4) + i_lane + ks * 4);
         };
         auto rd_blk = [&](const unsigned char *img, int ks, int n) {
-            const int r0 = row_of(n);
+            const int r0 = BFrags::row_of(n);
             const unsigned char *ptr = img + ks * 4096 + xg_off + lb.off[(r0 + 12 * T * G) & 3] + r0 * 128;
             return __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4v __attribute__((address_space(3))) *)ptr);
         };
-        auto frag = [&](const short4v *blk, int i) {
-            const int n = blk_of(i);
-            const short8v lo = __builtin_shufflevector(blk[n], blk[n + 1], 0, 1, 2, 3, 4, 5, 6, 7);
-            const short8v hi = __builtin_shufflevector(blk[n + 2], blk[n + 3], 0, 1, 2, 3, 4, 5, 6, 7);
-            const short16v all = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
-            return __builtin_bit_cast(half16, all);
-        };
-        // accumulator u -> (window tap i, A fragment): u = 2k + j (k < 6): i = k + G, A = co tile j; u = 12: middle tap
+        // accumulator u -> (window tap i, co tile): u = 2k + j (k < 6): i = k + G, co tile j; u = 12: middle tap, co tile G
         auto tap_of = [](int u) { return u < 12 ? (u >> 1) + G : (G ? 0 : 6); };
-        // N_DS LDS reads spread over the phase's 13 MFMAs: PER reads after each of the first PAIRS MFMAs
-#define WS_PIN(N_DS)                                                                               \
+        auto ct_of = [](int u) { return u < 12 ? (u & 1) : G; };
+        // N_DS LDS reads spread over the phase's 13 MFMAs, PER after each MFMA until they are all issued
+#define WS_PIN(N_DS, PER)                                                                          \
     {                                                                                              \
-        constexpr int per_ = (N_DS) >= 13 ? (N_DS) / 13 : 1, pairs_ = (N_DS) >= 13 ? 13 : (N_DS);  \
+        constexpr int pairs_ = (N_DS) / (PER) < 13 ? (N_DS) / (PER) : 13;                          \
         _Pragma("unroll") for (int q_ = 0; q_ < pairs_; ++q_) {                                    \
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                     \
-            __builtin_amdgcn_sched_group_barrier(0x100, per_, 0);                                  \
+            __builtin_amdgcn_sched_group_barrier(0x100, (PER), 0);                                 \
         }                                                                                          \
-        if (13 - pairs_ > 0) __builtin_amdgcn_sched_group_barrier(0x008, 13 - pairs_, 0);          \
-        if ((N_DS) - pairs_ * per_ > 0) __builtin_amdgcn_sched_group_barrier(0x100, (N_DS) - pairs_ * per_, 0); \
+        if ((N_DS) - pairs_ * (PER) > 0) {                                                         \
+            if (pairs_ < 13) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                    \
+            __builtin_amdgcn_sched_group_barrier(0x100, (N_DS) - pairs_ * (PER), 0);               \
+        }                                                                                          \
+        if (13 - pairs_ - ((N_DS) - pairs_ * (PER) > 0 ? 1 : 0) > 0)                               \
+            __builtin_amdgcn_sched_group_barrier(0x008, 13 - pairs_ - ((N_DS) - pairs_ * (PER) > 0 ? 1 : 0), 0); \
     }
 #pragma unroll
-        for (int j = 0; j < 3; ++j) { AL[j] = rd_a(Al, 0, j); AH[0][j] = rd_a(Ah, 0, j); IX[0][j] = rd_i(0, j); }
+        for (int j = 0; j < 2; ++j) { AL[j] = rd_a(Al, 0, j); AH[0][j] = rd_a(Ah, 0, j); IX[0][j] = rd_i(0, j); }
 #pragma unroll
-        for (int n = 0; n < NBLK; ++n) BHb[n] = rd_blk(x_h, 0, n);
+        for (int n = 0; n < NBLK; ++n) BH.put(n, rd_blk(x_h, 0, n));
 #pragma unroll
         for (int ks = 0; ks < KC; ++ks) {
             if (ks < nks) {
                 const int p = ks & 1;
                 const bool last = ks + 1 >= nks;
                 __builtin_amdgcn_sched_barrier(0);
+                BH.pin();
                 {   // phase 1: lo(G) * hi(x), while lo(x) arrives
 #pragma unroll
-                    for (int u = 0; u < 13; ++u)
-                        acc[u] = smfmac(AL[u < 12 ? (u & 1) : 2], frag(BHb, tap_of(u)), acc[u], IX[p][u < 12 ? (u & 1) : 2]);
+                    for (int u = 0; u < 13; ++u) acc[u] = smfmac(AL[ct_of(u)], BH.frag(tap_of(u)), acc[u], IX[p][ct_of(u)]);
 #pragma unroll
-                    for (int n = 0; n < NBLK; ++n) BLb[n] = rd_blk(x_l, ks, n);
-                    WS_PIN(NBLK)
+                    for (int n = 0; n < NBLK; ++n) BL.put(n, rd_blk(x_l, ks, n));
+                    WS_PIN(NBLK, NBLK > 13 ? 2 : 1)
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 {   // phase 2: hi(G) * hi(x), while the next k-step's G and index words arrive
 #pragma unroll
-                    for (int u = 0; u < 13; ++u)
-                        acc[u] = smfmac(AH[p][u < 12 ? (u & 1) : 2], frag(BHb, tap_of(u)), acc[u], IX[p][u < 12 ? (u & 1) : 2]);
+                    for (int u = 0; u < 13; ++u) acc[u] = smfmac(AH[p][ct_of(u)], BH.frag(tap_of(u)), acc[u], IX[p][ct_of(u)]);
                     if (PREF && more) {
 #pragma unroll
                         for (int q = ks * PF_PER; q < (ks + 1) * PF_PER; ++q) prefetch_item(q, nrid, nch);
                     }
                     if (!last) {
 #pragma unroll
-                        for (int j = 0; j < 3; ++j) {
+                        for (int j = 0; j < 2; ++j) {
                             AL[j] = rd_a(Al, ks + 1, j);
                             AH[p ^ 1][j] = rd_a(Ah, ks + 1, j);
                             IX[p ^ 1][j] = rd_i(ks + 1, j);
                         }
-                        WS_PIN(15)
+                        WS_PIN(10, 1)
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                {   // phase 3: hi(G) * lo(x), while the next k-step's hi(x) arrives
+                BL.pin();
+                {   // phase 3: hi(G) * lo(x); the next k-step's hi(x) is requested in the FIRST half of the phase (phase 1
+                    // of the next k-step needs all of it at once)
 #pragma unroll
-                    for (int u = 0; u < 13; ++u)
-                        acc[u] = smfmac(AH[p][u < 12 ? (u & 1) : 2], frag(BLb, tap_of(u)), acc[u], IX[p][u < 12 ? (u & 1) : 2]);
+                    for (int u = 0; u < 13; ++u) acc[u] = smfmac(AH[p][ct_of(u)], BL.frag(tap_of(u)), acc[u], IX[p][ct_of(u)]);
                     if (!last) {
 #pragma unroll
-                        for (int n = 0; n < NBLK; ++n) BHb[n] = rd_blk(x_h, ks + 1, n);
-                        WS_PIN(NBLK)
+                        for (int n = 0; n < NBLK; ++n) BH.put(n, rd_blk(x_h, ks + 1, n));
+                        WS_PIN(NBLK, 2)
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
