@@ -228,7 +228,6 @@ __global__ __launch_bounds__(256, 1) void wgrad_sp_f16x3_kernel(WgradSpArgs a)
     //   idx thread = (co = tid >> 2, word e = (tid & 3) + 4 q of the chunk's 2 KC), q < QI
     //   x   thread = (position pos0 + 16 q, row parity, 16-byte vector sv), per split: a wave stores 8 CONSECUTIVE image
     //       rows (alternating LDS bank halves; a fixed parity would put a whole wave on the even rows = half the banks)
-    constexpr int QAS = CHP / 32;                                        // A iterations per split
     static_assert(CHP % 32 == 0 || CHP == 48, "A staging map");
     floatx4 pa[PREF ? 2 * ((CHP + 31) / 32) : 1], pb[NVB];
     unsigned short pi[NVI];
@@ -238,14 +237,45 @@ __global__ __launch_bounds__(256, 1) void wgrad_sp_f16x3_kernel(WgradSpArgs a)
     // Loads are branch-free (a predicated load costs an exec-mask branch each, 36 per chunk): out-of-range items read
     // a clamped address whose value is either never used (k-steps past the chunk's end) or known to be zero (the
     // pad column 351 of an operand row stands in for the halo and for rows outside the image; Wv <= 351 is checked
-    // by the entry point).
-    auto load_a = [&](int k, int rid, int ch) -> floatx4 {
-        const int b = rid / Hp, hp = rid - b * Hp, ks0 = chunk_k0(ch), npos = chunk_ks(ch) * 16;
+    // by the entry point).  Every address is a wave-uniform base (scalar arithmetic on (row, chunk)) plus a 32-bit
+    // lane offset that is constant over the kernel up to one select: the loads sit between the MFMAs of phase 2, where
+    // 64-bit lane arithmetic (a dozen VALU operations per load) delays the matrix instructions behind it.
+    struct ChunkBase {
+        const unsigned char *a_hi, *a_lo, *idx, *x_hi, *x_lo;   // uniform
+        int npos, nks2, w_first;                                // positions / index words in the chunk; window origin
+        unsigned row_off;                                       // lane: byte offset of its x row (parity) from the base row
+        bool row_ok;                                            // lane: its x row is inside the image
+    };
+    const unsigned a_thr = (unsigned)a_co * (unsigned)Hp * (CV_PITCH * 2);          // gp: (B,64,Hp,352) halfs
+    const unsigned i_thr = (unsigned)a_co * (unsigned)Hp * (WS_ROW_KS * 4);         // gidx: (B,64,Hp,22,2) u16
+    const unsigned x_thr = (unsigned)(sv >> 1) * (CV_PITCH * 32) + (unsigned)(sv & 1) * 16;   // x: (B,H,4,352,16) halfs
+    auto chunk_base = [&](int rid, int ch) {
+        ChunkBase c;
+        const int b = rid / Hp, hp = rid - b * Hp, ks0 = chunk_k0(ch);
+        const size_t arow = ((size_t)b * 64 * Hp + hp) * (CV_PITCH * 2) + (size_t)ks0 * 32;
+        c.a_hi = reinterpret_cast<const unsigned char *>(a.gp_hi) + arow;
+        c.a_lo = reinterpret_cast<const unsigned char *>(a.gp_lo) + arow;
+        c.idx = reinterpret_cast<const unsigned char *>(a.gidx) + ((size_t)b * 64 * Hp + hp) * (WS_ROW_KS * 4) + ks0 * 4;
+        c.npos = chunk_ks(ch) * 16;
+        c.nks2 = chunk_ks(ch) * 2;
+        c.w_first = ks0 * 16 - 6 * T;
+        // x rows 2hp + kh - 2 (parity 0) and + 1 (parity 1), clamped into the image; the base is the parity-0 row
+        const int hx0 = 2 * hp + kh - 2, hx1 = hx0 + 1;
+        const int r0 = hx0 < 0 ? 0 : (hx0 >= H ? H - 1 : hx0), r1 = hx1 < 0 ? 0 : (hx1 >= H ? H - 1 : hx1);
+        const size_t xrow = ((size_t)b * H + r0) * (4 * CV_PITCH * 32);
+        c.x_hi = reinterpret_cast<const unsigned char *>(a.x_hi) + xrow;
+        c.x_lo = reinterpret_cast<const unsigned char *>(a.x_lo) + xrow;
+        const unsigned d1 = (unsigned)(r1 - r0) * (4 * CV_PITCH * 32);
+        const bool ok0 = hx0 >= 0 && hx0 < H, ok1 = hx1 >= 0 && hx1 < H;
+        c.row_off = xpar ? d1 : 0u;
+        c.row_ok = xpar ? ok1 : ok0;
+        return c;
+    };
+    auto load_a = [&](int k, const ChunkBase &c) -> floatx4 {
         const int split = k / QA2, q = k - split * QA2;
-        int c8 = a_c8 + 4 * q;
-        c8 = c8 * 8 < npos ? c8 : 0;
-        return *reinterpret_cast<const floatx4 *>((split ? a.gp_lo : a.gp_hi) + (((size_t)b * 64 + a_co) * Hp + hp) * CV_PITCH +
-                                                  ks0 * 16 + c8 * 8);
+        const int c8 = a_c8 + 4 * q;
+        const unsigned off = a_thr + (c8 * 8 < c.npos ? (unsigned)c8 * 16 : 0u);
+        return *reinterpret_cast<const floatx4 *>((split ? c.a_lo : c.a_hi) + off);
     };
     auto store_a = [&](int k, floatx4 v) {
         const int split = k / QA2, q = k - split * QA2, c8 = a_c8 + 4 * q;
@@ -256,25 +286,22 @@ __global__ __launch_bounds__(256, 1) void wgrad_sp_f16x3_kernel(WgradSpArgs a)
             reinterpret_cast<floatx2 *>(dst)[1] = floatx2{v[2], v[3]};
         }
     };
-    auto load_i = [&](int q, int rid, int ch) -> unsigned short {
-        const int b = rid / Hp, hp = rid - b * Hp, ks0 = chunk_k0(ch), nks = chunk_ks(ch);
-        int e = a_c8 + 4 * q;
-        e = e < nks * 2 ? e : 0;
-        return a.gidx[(((size_t)b * 64 + a_co) * Hp + hp) * (WS_ROW_KS * 2) + ks0 * 2 + e];
+    auto load_i = [&](int q, const ChunkBase &c) -> unsigned short {
+        const int e = a_c8 + 4 * q;
+        const unsigned off = i_thr + (e < c.nks2 ? (unsigned)e * 2 : 0u);
+        return *reinterpret_cast<const unsigned short *>(c.idx + off);
     };
     auto store_i = [&](int q, unsigned short v) {
         const int e = a_c8 + 4 * q;
         if (e < KC * 2) reinterpret_cast<unsigned short *>(Iimg)[a_co * (KC * 2) + e] = v;
     };
     // x vector k = split * QX + q: position pos0 + 16 q of the window, row parity xpar, 16-byte vector sv
-    auto load_b = [&](int k, int rid, int ch) -> floatx4 {
-        const int b = rid / Hp, hp = rid - b * Hp, w0 = chunk_k0(ch) * 16;
-        const int split = k / QX, q = k - split * QX, par = xpar;
-        const int pos = pos0 + 16 * q, w = w0 - 6 * T + pos, hx = 2 * hp + par + kh - 2;
-        const bool ok = w >= 0 && w < CV_PITCH && hx >= 0 && hx < H;
-        const int w_eff = ok ? w : CV_PITCH - 1, hx_eff = hx < 0 ? 0 : (hx >= H ? H - 1 : hx);
-        return *reinterpret_cast<const floatx4 *>((split ? a.x_lo : a.x_hi) +
-                                                  (((size_t)b * H + hx_eff) * 4 + (sv >> 1)) * (CV_PITCH * 16) + w_eff * 16 + (sv & 1) * 8);
+    auto load_b = [&](int k, const ChunkBase &c) -> floatx4 {
+        const int split = k / QX, q = k - split * QX;
+        const int w = c.w_first + pos0 + 16 * q;
+        const bool ok = (unsigned)w < (unsigned)CV_PITCH && c.row_ok;
+        const unsigned off = ok ? c.row_off + x_thr + (unsigned)w * 32 : x_thr + (CV_PITCH - 1) * 32;
+        return *reinterpret_cast<const floatx4 *>((split ? c.x_lo : c.x_hi) + off);
     };
     auto store_b = [&](int k, floatx4 v) {
         const int split = k / QX, q = k - split * QX, par = xpar;
@@ -287,12 +314,13 @@ __global__ __launch_bounds__(256, 1) void wgrad_sp_f16x3_kernel(WgradSpArgs a)
     int rid = row_begin, ch = 0;
     while (rid < row_end && !row_valid(rid)) ++rid;
     if (PREF && rid < row_end) {
+        const ChunkBase c0 = chunk_base(rid, ch);
 #pragma unroll
-        for (int q = 0; q < NA; ++q) pa[q] = load_a(q, rid, ch);
+        for (int q = 0; q < NA; ++q) pa[q] = load_a(q, c0);
 #pragma unroll
-        for (int q = 0; q < NI; ++q) pi[q] = load_i(q, rid, ch);
+        for (int q = 0; q < NI; ++q) pi[q] = load_i(q, c0);
 #pragma unroll
-        for (int q = 0; q < NVB; ++q) pb[q] = load_b(q, rid, ch);
+        for (int q = 0; q < NVB; ++q) pb[q] = load_b(q, c0);
     }
     // accumulators: acc[2k + j] = tap 7g + k (k < 6), co tile j;   acc[12] = tap 6, co tile g
     const int m32 = lane & 31, hh = lane >> 5;
@@ -302,7 +330,6 @@ __global__ __launch_bounds__(256, 1) void wgrad_sp_f16x3_kernel(WgradSpArgs a)
     constexpr int NBLK = BFrags::NBLK;
     const TrLane32 lb = tr_lane_offsets32(nt, lane);
     const int xg_off = g * 12 * T * 128;
-    const int ph_g = (12 * T * g) & 3;
     // A / index addressing: co tile j -> rows j*32 + m32; the middle tap uses co tile g
     const int a_lane = m32 * (AP * 2) + hh * 8;
     const int i_lane = m32 * (KC * 4) + hh * 2;
@@ -314,12 +341,12 @@ __global__ __launch_bounds__(256, 1) void wgrad_sp_f16x3_kernel(WgradSpArgs a)
     // as one burst between the barriers their address arithmetic alone cost 18 % of the kernel
     constexpr int NPF = PREF ? NA + NI + NVB : 0;
     constexpr int PF_PER = PREF ? (NPF + (KS_LO - 1) - 1) / (KS_LO - 1) : 0;      // all issued within the first KS_LO - 1 k-steps
-    auto prefetch_item = [&](int q, int nrid, int nch) {
-        if (q < NA) pa[q] = load_a(q, nrid, nch);
-        else if (q < NA + NI) pi[q - NA] = load_i(q - NA, nrid, nch);
-        else if (q < NPF) pb[q - NA - NI] = load_b(q - NA - NI, nrid, nch);
+    auto prefetch_item = [&](int q, const ChunkBase &c) {
+        if (q < NA) pa[q] = load_a(q, c);
+        else if (q < NA + NI) pi[q - NA] = load_i(q - NA, c);
+        else if (q < NPF) pb[q - NA - NI] = load_b(q - NA - NI, c);
     };
-    auto run_chunk = [&](auto gc, int nks, int nrid, int nch, bool more) {
+    auto run_chunk = [&](auto gc, int nks, const ChunkBase &nxt, bool more) {
         constexpr int G = decltype(gc)::value;
         half8 AL[2], AH[2][2];                      // [co tile]; the middle tap uses co tile G
         int IX[2][2];
@@ -373,9 +400,10 @@ __global__ __launch_bounds__(256, 1) void wgrad_sp_f16x3_kernel(WgradSpArgs a)
                 {   // phase 2: hi(G) * hi(x), while the next k-step's G and index words arrive
 #pragma unroll
                     for (int u = 0; u < 13; ++u) acc[u] = smfmac(AH[p][ct_of(u)], BH.frag(tap_of(u)), acc[u], IX[p][ct_of(u)]);
-                    if (PREF && more) {
+                    if (PREF) {         // unconditional (after the slab's last chunk it re-reads that chunk): a branch here
+                                        // would put the loads in their own block BEHIND the phase's MFMAs
 #pragma unroll
-                        for (int q = ks * PF_PER; q < (ks + 1) * PF_PER; ++q) prefetch_item(q, nrid, nch);
+                        for (int q = ks * PF_PER; q < (ks + 1) * PF_PER; ++q) prefetch_item(q, nxt);
                     }
                     if (!last) {
 #pragma unroll
@@ -415,20 +443,22 @@ __global__ __launch_bounds__(256, 1) void wgrad_sp_f16x3_kernel(WgradSpArgs a)
 #pragma unroll
             for (int q = 0; q < NVB; ++q) store_b(q, pb[q]);
         } else {
+            const ChunkBase cc = chunk_base(rid, ch);
 #pragma unroll
-            for (int q = 0; q < NA; ++q) store_a(q, load_a(q, rid, ch));
+            for (int q = 0; q < NA; ++q) store_a(q, load_a(q, cc));
 #pragma unroll
-            for (int q = 0; q < NI; ++q) store_i(q, load_i(q, rid, ch));
+            for (int q = 0; q < NI; ++q) store_i(q, load_i(q, cc));
 #pragma unroll 4
-            for (int q = 0; q < 2 * QX; ++q) store_b(q, load_b(q, rid, ch));
+            for (int q = 0; q < 2 * QX; ++q) store_b(q, load_b(q, cc));
         }
         const int nks = chunk_ks(ch);
         int nrid = rid, nch = ch;
         next_iter(nrid, nch);
         const bool more = nrid < row_end;
         __syncthreads();
-        if (g) run_chunk(std::integral_constant<int, 1>{}, nks, nrid, nch, more);
-        else run_chunk(std::integral_constant<int, 0>{}, nks, nrid, nch, more);
+        const ChunkBase nxt = chunk_base(more ? nrid : rid, more ? nch : ch);
+        if (g) run_chunk(std::integral_constant<int, 1>{}, nks, nxt, more);
+        else run_chunk(std::integral_constant<int, 0>{}, nks, nxt, more);
         rid = nrid;
         ch = nch;
     }
