@@ -191,23 +191,28 @@ int mx_conv_block_wgrad_sp_f16(const void *gp_hi, const void *gp_lo, const void 
  *                              g_idx (B,H/2,4,352) uint32 index words; gp_hi / gp_lo / gidx (all or NULL): the planar
  *                              operand of mx_conv_block_wgrad_sp_f16 from the same pass (mx_conv_prep_dgrad_f16 with
  *                              dz_hi = dz_lo = NULL then only computes the scale pair)
- *   mx_conv_block_dgrad_sp_f16: dxhat (B,64,H,352); Wv <= 351 (zero pad column = halo source) */
+ *   mx_conv_block_dgrad_sp_f16: dxhat (B,64,H,352); Wv <= 351 (zero pad column = halo source).  x_hi, x_lo, ln_part
+ *                              (all or NULL): the block's forward operand pair (B,H,4,352,16) = the normalised input
+ *                              xhat, and ln_part (B,64,H,2,2) floats <- {sum dxhat, sum dxhat * xhat} per (plane, row,
+ *                              position half): the plane statistics mx_ln_prelu_bwd needs, taken while the values are
+ *                              in registers instead of by a sweep over dxhat and p */
 int mx_conv_pack_weights_sp_f16(const float *W, void *w_hi, void *w_lo, void *stream);
 int mx_conv_prep_gpool_cl_f16(const float *G, const uint8_t *amax, const float *scale, int64_t B, int64_t H, int64_t Wv,
                               void *g_hi, void *g_lo, void *g_idx, void *gp_hi, void *gp_lo, void *gidx, void *stream);
 int mx_conv_block_dgrad_sp_f16(const void *g_hi, const void *g_lo, const void *g_idx, const void *w_hi, const void *w_lo,
                                const float *scale, int64_t B, int64_t H, int64_t Wv, int32_t dilation, float *dxhat,
-                               void *stream);
+                               const void *x_hi, const void *x_lo, float *ln_part, void *stream);
 
 /* LayerNorm backward fused with the backward of the PReLU in front of it.  p (B,C,H,352): input of
  * that PReLU; dxhat_inout: in = grad w.r.t. the normalised tensor, out = G = dL/dp (in place);
  * dslope_part (B*C,) per-plane partial of dL/dslope.  Optional by-products of the same pass (NULL = skip):
  * gsum_part (B*C,) = per-plane sum of G (the bias gradient partials mx_plane_sum would produce) and
  * gmax_bits: atomicMax of the bit pattern of |G| into one zero-initialised uint32 (the amax_ready input of
- * mx_conv_prep_dgrad_f16). */
+ * mx_conv_prep_dgrad_f16).  ln_part (NULL = compute them here): (B,C,H,2,2) partial sums {sum dxhat, sum dxhat *
+ * xhat} left by mx_conv_block_dgrad_sp_f16; with them the kernel reads each tensor once instead of twice. */
 int mx_ln_prelu_bwd(const float *p, float *dxhat_inout, const float *stats, const float *slope, int64_t B,
                     int64_t C, int64_t H, int64_t Wv, float *dslope_part, float *gsum_part, uint32_t *gmax_bits,
-                    void *stream);
+                    const float *ln_part, void *stream);
 
 /* out[c] (+)= sum_r part[r*C + c]  (fp64 accumulate; deterministic) */
 int mx_reduce_rows(const float *part, int64_t R, int64_t C, int32_t accumulate, float *out, void *stream);

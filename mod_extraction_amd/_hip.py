@@ -45,11 +45,11 @@ SIGNATURES = {
     "mx_conv_block_wgrad_sp_f16": [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I32, _I64, _P, _P, _P],
     "mx_conv_pack_weights_sp_f16": [_P, _P, _P, _P],
     "mx_conv_prep_gpool_cl_f16": [_P, _P, _P, _I64, _I64, _I64, _P, _P, _P, _P, _P, _P, _P],
-    "mx_conv_block_dgrad_sp_f16": [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I32, _P, _P],
+    "mx_conv_block_dgrad_sp_f16": [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I32, _P, _P, _P, _P, _P],
     "mx_conv_block1_wgrad_f16": [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _P, _P, _P, _P],
     "mx_conv_block_wgrad_f16": [_P, _P, _P, _P, _P, _I64, _I64, _I32, _I64, _P, _P, _P],
     "mx_conv_block_wgrad": [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I32, _I64, _P, _P, _P],
-    "mx_ln_prelu_bwd": [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _P, _P, _P, _P],
+    "mx_ln_prelu_bwd": [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _P, _P, _P, _P, _P],
     "mx_reduce_rows": [_P, _I64, _I64, _I32, _P, _P],
     "mx_plane_sum": [_P, _I64, _I64, _I64, _P, _P],
     "mx_head_fwd": [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _P, _P, _P],

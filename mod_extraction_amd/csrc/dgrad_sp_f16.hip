@@ -32,6 +32,8 @@ struct DgradSpArgs {
     const float *scale;                 // {S, 1/S}
     float *out;                         // (B, 64, H, 352)
     int H, Wv;
+    const _Float16 *x_hi, *x_lo;        // LN only: (B, H, 4, 352, 16) operand pair of the block's forward pass (= xhat)
+    float *ln_part;                     // LN only: (B, 64, H, 2, 2) partial sums {dxhat, dxhat * xhat} per (row, position half)
 };
 
 __device__ __forceinline__ floatx16 ds_smfmac(half8 a, half16 b, floatx16 c, int idx)
@@ -51,7 +53,7 @@ __device__ __forceinline__ half16 ds_w_frag(const _Float16 *p)
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
 }
 
-template <int T>
+template <int T, bool LN>
 __global__ __launch_bounds__(256, 1) void dgrad_sp_f16x3_kernel(DgradSpArgs a)
 {
     constexpr int PWP = CV_PITCH + 12 * T;                  // patch rows (position w = row - 6T)
@@ -214,26 +216,75 @@ __global__ __launch_bounds__(256, 1) void dgrad_sp_f16x3_kernel(DgradSpArgs a)
         bufsel ^= 1;
     }
 
-    // ---- epilogue: [position][ci] tiles -> dxhat rows, transposed through wave-private LDS (32 ci x 33 floats)
+    // ---- epilogue: [position][ci] tiles -> dxhat rows, transposed through wave-private LDS (32 ci x 33 floats).
+    // LN: the LayerNorm backward that consumes dxhat needs sum(dxhat) and sum(dxhat * xhat) per (clip, channel) plane
+    // before it can touch an element -- a whole extra sweep over two tensors if it computes them itself.  Here every
+    // value is in a register next to its position's 16 channels of xhat (one 32-byte vector of each operand half), so
+    // the wave accumulates both sums per channel and writes one partial per (plane, row, position half).
     __syncthreads();                                            // the patch buffers are dead
     float *scr = reinterpret_cast<float *>(smem) + wave * (32 * 33);
     const float inv = a.scale[1] * (1.0f / DS_WSCALE);
     const int h = h0 + row;
+    float s1a[2][16], s2a[2][16];                               // [weight fragment j: ci tile j ^ c][channel hh*16 + i]
+    half8 xh[LN ? CV_WT : 1][2], xl[LN ? CV_WT : 1][2];         // all of the wave's xhat vectors, requested up front: one
+    if (LN) {                                                   // memory round trip per workgroup instead of eleven
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { s1a[j][i] = 0.0f; s2a[j][i] = 0.0f; }
+#pragma unroll
+        for (int u = 0; u < CV_WT; ++u) {
+            const int ptile = u < 10 ? c * 6 + (u >> 1) : 5, cit = (u < 10 ? (u & 1) : 0) ^ c;
+            const size_t xo = ((((size_t)b * H + h) * 4 + cit * 2 + hh) * CV_PITCH + ptile * 32 + l32) * 16;
+            xh[u][0] = *reinterpret_cast<const half8 *>(a.x_hi + xo);
+            xh[u][1] = *reinterpret_cast<const half8 *>(a.x_hi + xo + 8);
+            xl[u][0] = *reinterpret_cast<const half8 *>(a.x_lo + xo);
+            xl[u][1] = *reinterpret_cast<const half8 *>(a.x_lo + xo + 8);
+        }
+    }
 #pragma unroll
     for (int u = 0; u < CV_WT; ++u) {
         const int ptile = u < 10 ? c * 6 + (u >> 1) : 5;
-        const int cit = u < 10 ? ((u & 1) ^ c) : c;
+        const int jf = u < 10 ? (u & 1) : 0;
+        const int cit = jf ^ c;
+        const int w = ptile * 32 + l32;
 #pragma unroll
         for (int r = 0; r < 16; ++r) scr[l32 * 33 + mfma_row(r, lane)] = acc[u][r] * inv;      // [ci local][position local]
         __builtin_amdgcn_s_waitcnt(0xc07f);                      // lgkmcnt(0): the wave's own writes have landed
-        const int w = ptile * 32 + l32;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int cil = hh * 16 + i;
-            const float v = scr[cil * 33 + l32];
-            a.out[(((size_t)b * CV_CO + cit * 32 + cil) * H + h) * CV_PITCH + w] = w < a.Wv ? v : 0.0f;
+            const float v = w < a.Wv ? scr[cil * 33 + l32] : 0.0f;
+            a.out[(((size_t)b * CV_CO + cit * 32 + cil) * H + h) * CV_PITCH + w] = v;
+            if (LN) {
+                const float xv = (float)xh[u][i >> 3][i & 7] + (float)xl[u][i >> 3][i & 7];
+                s1a[jf][i] += v;
+                s2a[jf][i] += v * xv;
+            }
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);
+    }
+    if (LN) {
+        // sum over the 32 positions held by the lanes of each half (same hh), in a fixed order, through wave-private
+        // LDS: lane (hh, l32) writes its 32 partials [q = j*16 + i] as column l32, then sums row q = l32
+        __syncthreads();                                        // every wave is done with its transposition scratch
+        float *red = reinterpret_cast<float *>(smem) + wave * (2 * 32 * 33) + hh * (32 * 33);
+        float tot[2];
+#pragma unroll
+        for (int kind = 0; kind < 2; ++kind) {
+#pragma unroll
+            for (int q = 0; q < 32; ++q) red[q * 33 + l32] = kind ? s2a[q >> 4][q & 15] : s1a[q >> 4][q & 15];
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            float t = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 32; ++k) t += red[l32 * 33 + k];
+            tot[kind] = t;
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+        }
+        const int j = l32 >> 4, i = l32 & 15;
+        const int ci = (j ^ c) * 32 + hh * 16 + i;
+        typedef float floatx2 __attribute__((ext_vector_type(2)));
+        *reinterpret_cast<floatx2 *>(a.ln_part + ((((size_t)b * CV_CO + ci) * H + h) * 2 + c) * 2) = floatx2{tot[0], tot[1]};
     }
 }
 
@@ -329,21 +380,22 @@ __global__ __launch_bounds__(256) void gpool_cl_prep_kernel(const float *__restr
     }
 }
 
-template <int T>
+template <int T, bool LN>
 static int launch_dgrad_sp(const DgradSpArgs &a, int B, hipStream_t st)
 {
     constexpr int PWP = CV_PITCH + 12 * T;
     constexpr size_t buf = ((2 * (size_t)PWP * DS_ROWB + PWP * 4 + 15) / 16) * 16;
-    constexpr size_t lds = 2 * buf > 4 * 32 * 33 * 4 ? 2 * buf : 4 * 32 * 33 * 4;
+    constexpr size_t scratch = 4 * 2 * 32 * 33 * 4;              // epilogue: transposition tiles, then the LN partial reduction
+    constexpr size_t lds = 2 * buf > scratch ? 2 * buf : scratch;
     static_assert(lds <= 160 * 1024, "LDS budget");
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute((const void *)dgrad_sp_f16x3_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+        if (hipFuncSetAttribute((const void *)dgrad_sp_f16x3_kernel<T, LN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
             hipSuccess)
             return MX_ERR_LAUNCH;
         attr_done = true;
     }
-    hipLaunchKernelGGL((dgrad_sp_f16x3_kernel<T>), dim3(a.H / 2, B), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((dgrad_sp_f16x3_kernel<T, LN>), dim3(a.H / 2, B), dim3(256), lds, st, a);
     return mx_launch_status();
 }
 
@@ -372,22 +424,28 @@ MX_EXPORT int mx_conv_prep_gpool_cl_f16(const float *G, const uint8_t *amax, con
     return mx_launch_status();
 }
 
-// data gradient from the pooled channels-last operand and the fragment-packed weights; dxhat (B,64,H,352)
+// data gradient from the pooled channels-last operand and the fragment-packed weights; dxhat (B,64,H,352).
+// x_hi, x_lo, ln_part (all or none): the block's forward operand pair (B,H,4,352,16) and the (B,64,H,2,2) partial sums
+// {sum dxhat, sum dxhat * xhat} that mx_ln_prelu_bwd takes in place of its own statistics sweep.
 MX_EXPORT int mx_conv_block_dgrad_sp_f16(const void *g_hi, const void *g_lo, const void *g_idx, const void *w_hi,
                                          const void *w_lo, const float *scale, int64_t B, int64_t H, int64_t Wv,
-                                         int32_t dilation, float *dxhat, void *stream)
+                                         int32_t dilation, float *dxhat, const void *x_hi, const void *x_lo,
+                                         float *ln_part, void *stream)
 {
     if (!g_hi || !g_lo || !g_idx || !w_hi || !w_lo || !scale || !dxhat) return MX_ERR_ARG;
+    if ((x_hi || x_lo || ln_part) && !(x_hi && x_lo && ln_part)) return MX_ERR_ARG;
     if (B <= 0 || B > 65535 || H < 2 || (H & 1) || Wv <= 0 || Wv > CV_PITCH - 1) return MX_ERR_UNSUPPORTED;
     DgradSpArgs a{(const _Float16 *)g_hi, (const _Float16 *)g_lo, (const unsigned *)g_idx, (const _Float16 *)w_hi,
-                  (const _Float16 *)w_lo, scale, dxhat, (int)H, (int)Wv};
+                  (const _Float16 *)w_lo, scale, dxhat, (int)H, (int)Wv, (const _Float16 *)x_hi, (const _Float16 *)x_lo,
+                  ln_part};
     hipStream_t st = (hipStream_t)stream;
+    const bool ln = ln_part != nullptr;
     switch (dilation) {
-    case 1: return launch_dgrad_sp<1>(a, (int)B, st);
-    case 2: return launch_dgrad_sp<2>(a, (int)B, st);
-    case 4: return launch_dgrad_sp<4>(a, (int)B, st);
-    case 8: return launch_dgrad_sp<8>(a, (int)B, st);
-    case 16: return launch_dgrad_sp<16>(a, (int)B, st);
+    case 1: return ln ? launch_dgrad_sp<1, true>(a, (int)B, st) : launch_dgrad_sp<1, false>(a, (int)B, st);
+    case 2: return ln ? launch_dgrad_sp<2, true>(a, (int)B, st) : launch_dgrad_sp<2, false>(a, (int)B, st);
+    case 4: return ln ? launch_dgrad_sp<4, true>(a, (int)B, st) : launch_dgrad_sp<4, false>(a, (int)B, st);
+    case 8: return ln ? launch_dgrad_sp<8, true>(a, (int)B, st) : launch_dgrad_sp<8, false>(a, (int)B, st);
+    case 16: return ln ? launch_dgrad_sp<16, true>(a, (int)B, st) : launch_dgrad_sp<16, false>(a, (int)B, st);
     default: return MX_ERR_UNSUPPORTED;
     }
 }

@@ -79,7 +79,7 @@ __global__ __launch_bounds__(LNB_THREADS) void ln_prelu_bwd_kernel(const float *
                                                            const float *__restrict__ stats,
                                                            const float *__restrict__ slope, int C, int H, int Wv,
                                                            float *__restrict__ dslope_part, float *__restrict__ gsum_part,
-                                                           unsigned *__restrict__ gmax_bits)
+                                                           unsigned *__restrict__ gmax_bits, const float *__restrict__ ln_part)
 {
     __shared__ double sh[32];
     const int plane = blockIdx.x;
@@ -91,6 +91,17 @@ __global__ __launch_bounds__(LNB_THREADS) void ln_prelu_bwd_kernel(const float *
     // fp64 accumulators are fed once per 4-element vector (the 4 terms are summed in fp32): the pass is
     // otherwise limited by the fp64 add rate, not by HBM
     double s1 = 0.0, s2 = 0.0;
+    if (ln_part) {
+        // the producer of dxhat (mx_conv_block_dgrad_sp_f16) left {sum dxhat, sum dxhat * xhat} per (row, position
+        // half): 2H pairs per plane instead of a sweep over the plane's two tensors
+        typedef float floatx2 __attribute__((ext_vector_type(2)));
+        const floatx2 *lp = reinterpret_cast<const floatx2 *>(ln_part) + (size_t)plane * (2 * H);
+        for (int i = threadIdx.x; i < 2 * H; i += LNB_THREADS) {
+            const floatx2 v = lp[i];
+            s1 += (double)v[0];
+            s2 += (double)v[1];
+        }
+    } else
     for (int i = threadIdx.x; i < n4; i += LNB_THREADS) {
         const int w0 = (i % (CV_PITCH / 4)) * 4;
         floatx4 pv = pp[i], gv = gp[i];
@@ -148,13 +159,13 @@ __global__ __launch_bounds__(LNB_THREADS) void ln_prelu_bwd_kernel(const float *
 
 MX_EXPORT int mx_ln_prelu_bwd(const float *p, float *dxhat_inout, const float *stats, const float *slope,
                               int64_t B, int64_t C, int64_t H, int64_t Wv, float *dslope_part, float *gsum_part,
-                              uint32_t *gmax_bits, void *stream)
+                              uint32_t *gmax_bits, const float *ln_part, void *stream)
 {
     if (!p || !dxhat_inout || !stats || !slope || !dslope_part || B <= 0 || C <= 0 || H <= 0 || Wv <= 0 ||
         Wv > CV_PITCH)
         return MX_ERR_ARG;
     hipLaunchKernelGGL(ln_prelu_bwd_kernel, dim3((unsigned)(B * C)), dim3(LNB_THREADS), 0, (hipStream_t)stream, p,
-                       dxhat_inout, stats, slope, (int)C, (int)H, (int)Wv, dslope_part, gsum_part, gmax_bits);
+                       dxhat_inout, stats, slope, (int)C, (int)H, (int)Wv, dslope_part, gsum_part, gmax_bits, ln_part);
     return mx_launch_status();
 }
 

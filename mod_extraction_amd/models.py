@@ -130,6 +130,7 @@ BLOCK1_F16 = os.environ.get("MODEX_BLOCK1", "f16x3") != "f32"
 # weight gradient of the 64-channel blocks: sparse (2:4 along the pooling pair) or dense matrix instruction
 WGRAD_SPARSE = os.environ.get("MODEX_WGRAD", "sparse") != "dense"
 DGRAD_SPARSE = os.environ.get("MODEX_DGRAD", "sparse") != "dense"
+LN_FUSED = os.environ.get("MODEX_LN", "fused") != "sweep"      # LayerNorm-backward statistics from the data-gradient epilogue
 
 
 def _use_f16(cin: int, precision: str) -> bool:
@@ -315,7 +316,9 @@ class _CNNStack(torch.autograd.Function):
                     part = torch.empty(n_slabs * 65 * 64 * 64, device=dev, dtype=torch.float32)
                     _hip.call("mx_conv_block_wgrad_f16", _hip.ptr(dz_hi), _hip.ptr(dz_lo), _hip.ptr(x_hi), _hip.ptr(x_lo),
                               _hip.ptr(scale), B, H, int(dilations[l]), rps, _hip.ptr(part), _hip.ptr(dW), st)
-                del part, x_hi, x_lo
+                del part
+                if not (sparse_d and LN_FUSED):
+                    del x_hi, x_lo
             elif l == 0 and 0 in ctx.splits and gmax_ws is not None:
                 # first block on the fp16 pipes: the kept k-vector operand, gradient routed / scaled / split on the fly
                 xk_hi, xk_lo = ctx.splits.pop(0)
@@ -338,14 +341,24 @@ class _CNNStack(torch.autograd.Function):
             grads[3 * l] = dW
             if l > 0:
                 dxhat = torch.empty((B, 64, H, PITCH), device=dev, dtype=torch.float32)
+                ln_part = None
                 if f16 and sparse_d:
                     # sparse matrix instruction, transposed tiles: pooled channels-last gradient x fragment-packed weights
                     ws_hi = torch.empty(4 * 3 * 2 * 13 * 2 * 64 * 16, device=dev, dtype=torch.float16)
                     ws_lo = torch.empty(4 * 3 * 2 * 13 * 2 * 64 * 16, device=dev, dtype=torch.float16)
                     _hip.call("mx_conv_pack_weights_sp_f16", _hip.ptr(w.detach().contiguous()), _hip.ptr(ws_hi),
                               _hip.ptr(ws_lo), st)
-                    _hip.call("mx_conv_block_dgrad_sp_f16", _hip.ptr(gc_hi), _hip.ptr(gc_lo), _hip.ptr(gc_idx), _hip.ptr(ws_hi),
-                              _hip.ptr(ws_lo), _hip.ptr(scale), B, H, n_frames, int(dilations[l]), _hip.ptr(dxhat), st)
+                    if LN_FUSED:
+                        # the epilogue also leaves the plane statistics of the LayerNorm backward below (x = xhat)
+                        ln_part = torch.empty((B, 64, H, 2, 2), device=dev, dtype=torch.float32)
+                        _hip.call("mx_conv_block_dgrad_sp_f16", _hip.ptr(gc_hi), _hip.ptr(gc_lo), _hip.ptr(gc_idx),
+                                  _hip.ptr(ws_hi), _hip.ptr(ws_lo), _hip.ptr(scale), B, H, n_frames, int(dilations[l]),
+                                  _hip.ptr(dxhat), _hip.ptr(x_hi), _hip.ptr(x_lo), _hip.ptr(ln_part), st)
+                        del x_hi, x_lo
+                    else:
+                        _hip.call("mx_conv_block_dgrad_sp_f16", _hip.ptr(gc_hi), _hip.ptr(gc_lo), _hip.ptr(gc_idx),
+                                  _hip.ptr(ws_hi), _hip.ptr(ws_lo), _hip.ptr(scale), B, H, n_frames, int(dilations[l]),
+                                  _hip.ptr(dxhat), None, None, None, st)
                     del gc_hi, gc_lo, gc_idx
                 elif f16:
                     w_hi, w_lo = _pack_f16(w, 1)
@@ -363,7 +376,7 @@ class _CNNStack(torch.autograd.Function):
                 want_gmax = _use_f16(saved[3 * (l - 1)].size(1), precision) or (l == 1 and 0 in ctx.splits)
                 gmax_ws = torch.zeros(1, device=dev, dtype=torch.int32) if want_gmax else None
                 _hip.call("mx_ln_prelu_bwd", _hip.ptr(x_in), _hip.ptr(dxhat), _hip.ptr(stats), _hip.ptr(slope_prev),
-                          B, 64, H, n_frames, _hip.ptr(ds_part), _hip.ptr(bsum), _hip.ptr(gmax_ws), st)
+                          B, 64, H, n_frames, _hip.ptr(ds_part), _hip.ptr(bsum), _hip.ptr(gmax_ws), _hip.ptr(ln_part), st)
                 grads[3 * (l - 1) + 2] = _reduce_rows(ds_part, B, 64)
                 G = dxhat
         return (None, None, None, None, *grads)

@@ -88,7 +88,7 @@ def test_block_fwd_dgrad_wgrad(dev, T, W, H, cin):
         gsum = torch.empty(B * 64, device=dev)
         gmax = torch.zeros(1, device=dev, dtype=torch.int32)
         _hip.call("mx_ln_prelu_bwd", _hip.ptr(x_d), _hip.ptr(dxhat), _hip.ptr(stats), _hip.ptr(sl_d), B, 64, H, W,
-                  _hip.ptr(ds_part), _hip.ptr(gsum), _hip.ptr(gmax), st)
+                  _hip.ptr(ds_part), _hip.ptr(gsum), _hip.ptr(gmax), None, st)
         assert rel(dxhat.cpu()[..., :W], x_req.grad) < 1e-5, ("ln_prelu_bwd", rel(dxhat.cpu()[..., :W], x_req.grad))
         # by-products of the same pass: per-plane sums and the bit pattern of max|G|
         g_cpu = dxhat.cpu()[..., :W]
@@ -199,7 +199,33 @@ def test_block_f16x3_kernels(dev, T, W, H):
     _hip.call("mx_conv_pack_weights_sp_f16", _hip.ptr(w.detach().to(dev).contiguous()), _hip.ptr(ws_hi), _hip.ptr(ws_lo), st)
     dx_sp = torch.empty((B, 64, H, PITCH), device=dev)
     _hip.call("mx_conv_block_dgrad_sp_f16", _hip.ptr(gc_hi), _hip.ptr(gc_lo), _hip.ptr(gc_idx), _hip.ptr(ws_hi), _hip.ptr(ws_lo),
-              _hip.ptr(scale), B, H, W, T, _hip.ptr(dx_sp), st)
+              _hip.ptr(scale), B, H, W, T, _hip.ptr(dx_sp), None, None, None, st)
     assert rel(dx_sp.cpu()[..., :W], xhat_r.grad) < 1e-5, ("sparse dgrad", rel(dx_sp.cpu()[..., :W], xhat_r.grad))
     assert bool((dx_sp[..., W:] == 0).all())
     assert rel(dx_sp, dxhat) < 5e-6                                              # same sums, different order
+    # the same kernel with the LayerNorm-backward statistics taken in its epilogue: identical dxhat, and per (plane,
+    # row, position half) the sums of dxhat and dxhat * xhat
+    dx_ln = torch.empty((B, 64, H, PITCH), device=dev)
+    ln_part = torch.full((B, 64, H, 2, 2), float("nan"), device=dev)
+    _hip.call("mx_conv_block_dgrad_sp_f16", _hip.ptr(gc_hi), _hip.ptr(gc_lo), _hip.ptr(gc_idx), _hip.ptr(ws_hi), _hip.ptr(ws_lo),
+              _hip.ptr(scale), B, H, W, T, _hip.ptr(dx_ln), _hip.ptr(x_hi), _hip.ptr(x_lo), _hip.ptr(ln_part), st)
+    assert torch.equal(dx_ln, dx_sp)
+    d64, x64 = dx_sp.double().cpu(), xhat_pair.double().cpu()
+    halves = [slice(0, 192), slice(192, PITCH)]                                  # position tiles 0..5 (incl. the shared 5) / 6..10
+    want = torch.stack([torch.stack([d64[..., sl].sum(-1), (d64[..., sl] * x64[..., sl]).sum(-1)], -1) for sl in halves], -2)
+    got = ln_part.double().cpu()
+    assert bool(torch.isfinite(got).all())
+    # the middle tile (positions 160..191) is computed by the waves of position half 0 or 1 depending on the wave: only
+    # the sum over both halves is pinned
+    tot_scale = float(want.abs().sum((2, 3)).max()) + 1e-30
+    assert float((got.sum(3) - want.sum(3)).abs().max()) / tot_scale < 1e-6
+    # LayerNorm + PReLU backward from those partials == its own two-sweep statistics
+    ds_a, gs_a = torch.empty(B * 64, device=dev), torch.empty(B * 64, device=dev)
+    ds_b, gs_b = torch.empty(B * 64, device=dev), torch.empty(B * 64, device=dev)
+    g_a, g_b = dx_sp.clone(), dx_sp.clone()
+    _hip.call("mx_ln_prelu_bwd", _hip.ptr(x_d), _hip.ptr(g_a), _hip.ptr(stats), _hip.ptr(sl_d), B, 64, H, W, _hip.ptr(ds_a),
+              _hip.ptr(gs_a), None, None, st)
+    _hip.call("mx_ln_prelu_bwd", _hip.ptr(x_d), _hip.ptr(g_b), _hip.ptr(stats), _hip.ptr(sl_d), B, 64, H, W, _hip.ptr(ds_b),
+              _hip.ptr(gs_b), None, _hip.ptr(ln_part), st)
+    assert rel(g_b, g_a) < 2e-6 and rel(ds_b, ds_a) < 2e-6 and rel(gs_b, gs_a) < 1e-5
+    assert rel(g_b.cpu()[..., :W], x_req.grad) < 1e-5, ("ln_prelu_bwd from partials", rel(g_b.cpu()[..., :W], x_req.grad))

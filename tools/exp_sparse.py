@@ -74,10 +74,13 @@ def run(B=64):
                                                       vp(x_hi.data_ptr()), vp(x_lo.data_ptr()), vp(scale.data_ptr()), i64(B), i64(H),
                                                       i64(345), i32(T), i64(rps), vp(part.data_ptr()), vp(dW.data_ptr()), st)
 
+            ln_part = torch.empty((B, 64, H, 2, 2), device=dev)
+            ln_args = (vp(x_hi.data_ptr()), vp(x_lo.data_ptr()), vp(ln_part.data_ptr())) if os.environ.get('EXP_LN') else (vp(0), vp(0), vp(0))
+
             def dgr():
                 return lib.mx_conv_block_dgrad_sp_f16(vp(gc_hi.data_ptr()), vp(gc_lo.data_ptr()), vp(gc_idx.data_ptr()),
                                                       vp(w_hi.data_ptr()), vp(w_lo.data_ptr()), vp(scale.data_ptr()), i64(B), i64(H),
-                                                      i64(345), i32(T), vp(dx.data_ptr()), st)
+                                                      i64(345), i32(T), vp(dx.data_ptr()), *ln_args, st)
             for fn, tag in ((wgr, "wgrad"), (dgr, "dgrad")):
                 if tag not in only:
                     continue
