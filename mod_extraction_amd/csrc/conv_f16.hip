@@ -70,6 +70,53 @@ __global__ void pow2_scale_kernel(const unsigned *__restrict__ amax_bits, float 
 // NCHW fp32 planes -> channels-last fp16 pairs.  One workgroup per (b, h, 32-column tile): 64 channels x
 // 32 columns are read along w (coalesced), transformed, transposed through LDS and written as 16-byte
 // vectors of 8 channels into the (B, H, 4, 352, 16) operand (1 KB contiguous per channel block).  MODE 0: xhat = (prelu(x) - mean) * rstd.  MODE 1: dz = routed G * S.
+// Forward operand (MODE 0 of split_prep_kernel) with ROWS image rows per workgroup: all of a thread's 2 * ROWS 16-byte
+// loads are in flight together (the one-row kernel had 2), and the transposing LDS pass is amortised over more bytes.
+template <int ROWS>
+__global__ __launch_bounds__(256) void split_prep_fwd_kernel(const float *__restrict__ x, const float *__restrict__ stats,
+                                                             const float *__restrict__ slope, int H, int Wv,
+                                                             _Float16 *__restrict__ out_hi, _Float16 *__restrict__ out_lo)
+{
+    __shared__ float tile[ROWS][64][33];
+    const int wt = blockIdx.x, h0 = blockIdx.y * ROWS, b = blockIdx.z, tid = threadIdx.x;
+    floatx4 v[ROWS][2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int i = tid + 256 * k, c = i >> 3, c4 = i & 7;
+        const size_t off = (((size_t)b * 64 + c) * H + h0) * CV_PITCH + wt * 32 + c4 * 4;
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) v[r][k] = *reinterpret_cast<const floatx4 *>(x + off + (size_t)r * CV_PITCH);
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int i = tid + 256 * k, c = i >> 3, c4 = i & 7, w0 = wt * 32 + c4 * 4;
+        const float mean = stats[((size_t)b * 64 + c) * 2], rstd = stats[((size_t)b * 64 + c) * 2 + 1], sl = slope[c];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float t = v[r][k][e] > 0.0f ? v[r][k][e] : sl * v[r][k][e];
+                tile[r][c][c4 * 4 + e] = (w0 + e < Wv) ? (t - mean) * rstd : 0.0f;
+            }
+    }
+    __syncthreads();
+    const int pos = tid >> 3, cg = tid & 7;                     // 32 positions x 64 channels: thread -> (position, 8 channels)
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        half8 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float t = tile[r][cg * 8 + j][pos];
+            const _Float16 hh = (_Float16)t;
+            hi[j] = hh;
+            lo[j] = (_Float16)(t - (float)hh);
+        }
+        const size_t o = ((((size_t)b * H + h0 + r) * 4 + (cg >> 1)) * CV_PITCH + wt * 32 + pos) * 16 + (cg & 1) * 8;
+        *reinterpret_cast<half8 *>(out_hi + o) = hi;
+        *reinterpret_cast<half8 *>(out_lo + o) = lo;
+    }
+}
+
 template <int MODE>
 __global__ __launch_bounds__(256) void split_prep_kernel(const float *__restrict__ x,
                                                          const unsigned char *__restrict__ amax,
@@ -727,9 +774,12 @@ MX_EXPORT int mx_conv_prep_fwd_f16(const float *x, const float *stats, const flo
 {
     if (!x || !stats || !slope || !x_hi || !x_lo || B <= 0 || H <= 0 || Wv <= 0 || Wv > CV_PITCH) return MX_ERR_ARG;
     if (B > 65535 || H > 65535) return MX_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL((split_prep_kernel<0>), dim3(CV_PITCH / 32, (unsigned)H, (unsigned)B), dim3(256), 0,
-                       (hipStream_t)stream, x, nullptr, stats, slope, nullptr, (int)H, (int)Wv, (_Float16 *)x_hi,
-                       (_Float16 *)x_lo);
+    if (H % 4 == 0)
+        hipLaunchKernelGGL((split_prep_fwd_kernel<4>), dim3(CV_PITCH / 32, (unsigned)(H / 4), (unsigned)B), dim3(256), 0,
+                           (hipStream_t)stream, x, stats, slope, (int)H, (int)Wv, (_Float16 *)x_hi, (_Float16 *)x_lo);
+    else
+        hipLaunchKernelGGL((split_prep_fwd_kernel<1>), dim3(CV_PITCH / 32, (unsigned)H, (unsigned)B), dim3(256), 0,
+                           (hipStream_t)stream, x, stats, slope, (int)H, (int)Wv, (_Float16 *)x_hi, (_Float16 *)x_lo);
     return mx_launch_status();
 }
 

@@ -21,7 +21,10 @@ __device__ __forceinline__ void block_sum2(double &a, double &b, double *sh)
 }
 
 // stats[plane] = (mean, rstd) of f(x) over the H x Wv valid region, f = PReLU(slope[c]) or identity.
-__global__ __launch_bounds__(256) void plane_stats_kernel(const float *__restrict__ x,
+#ifndef PST_THREADS
+#define PST_THREADS 256
+#endif
+__global__ __launch_bounds__(PST_THREADS) void plane_stats_kernel(const float *__restrict__ x,
                                                           const float *__restrict__ slope, int C, int H,
                                                           int Wv, float eps, float *__restrict__ stats)
 {
@@ -31,18 +34,30 @@ __global__ __launch_bounds__(256) void plane_stats_kernel(const float *__restric
     const floatx4 *p = reinterpret_cast<const floatx4 *>(x + (size_t)plane * H * CV_PITCH);
     double s = 0.0, ss = 0.0;
     const int n4 = H * (CV_PITCH / 4);
-    for (int i = threadIdx.x; i < n4; i += 256) {
-        const int w0 = (i % (CV_PITCH / 4)) * 4;
-        floatx4 v = p[i];
+    // branch-free (pad columns and the tail are masked with selects), four 16-byte loads in flight per thread; the
+    // fp64 accumulators take the same terms in the same order as a one-vector-at-a-time loop
+    for (int i0 = threadIdx.x; i0 < n4; i0 += 4 * PST_THREADS) {
+        floatx4 v[4];
+        int col[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            if (w0 + e < Wv) {
-                float t = v[e];
-                if (slope) t = t > 0.0f ? t : sl * t;
-                s += (double)t;
-                ss += (double)t * (double)t;
-            }
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * PST_THREADS;
+            const bool ok = i < n4;
+            const int ic = ok ? i : (int)threadIdx.x;
+            col[u] = ok ? (ic % (CV_PITCH / 4)) * 4 : CV_PITCH;
+            v[u] = p[ic];
         }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float t = v[u][e];
+                if (slope) t = t > 0.0f ? t : sl * t;
+                const bool valid = col[u] + e < Wv;
+                const double td = valid ? (double)t : 0.0;
+                s += td;
+                ss += td * td;
+            }
     }
     block_sum2(s, ss, sh);
     if (threadIdx.x == 0) {
@@ -59,7 +74,7 @@ MX_EXPORT int mx_plane_stats(const float *x, const float *slope, int64_t B, int6
                              float eps, float *stats, void *stream)
 {
     if (!x || !stats || B <= 0 || C <= 0 || H <= 0 || Wv <= 0 || Wv > CV_PITCH) return MX_ERR_ARG;
-    hipLaunchKernelGGL(plane_stats_kernel, dim3((unsigned)(B * C)), dim3(256), 0, (hipStream_t)stream, x, slope,
+    hipLaunchKernelGGL(plane_stats_kernel, dim3((unsigned)(B * C)), dim3(PST_THREADS), 0, (hipStream_t)stream, x, slope,
                        (int)C, (int)H, (int)Wv, eps, stats);
     return mx_launch_status();
 }
