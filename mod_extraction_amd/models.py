@@ -129,6 +129,7 @@ def _pack_f16(w: T, flip: int) -> Tuple[T, T]:
 BLOCK1_F16 = os.environ.get("MODEX_BLOCK1", "f16x3") != "f32"
 # weight gradient of the 64-channel blocks: sparse (2:4 along the pooling pair) or dense matrix instruction
 WGRAD_SPARSE = os.environ.get("MODEX_WGRAD", "sparse") != "dense"
+WGRAD_SPARSE_MAX_T = int(os.environ.get("MODEX_WGRAD_SP_MAXT", "4"))     # dilations above it: dense kernel (no shared fragment blocks)
 DGRAD_SPARSE = os.environ.get("MODEX_DGRAD", "sparse") != "dense"
 LN_FUSED = os.environ.get("MODEX_LN", "fused") != "sweep"      # LayerNorm-backward statistics from the data-gradient epilogue
 
@@ -266,7 +267,7 @@ class _CNNStack(torch.autograd.Function):
                 # sparse matrix instruction: the pooled gradient is the compressed operand, the argmax its index bits.
                 # Weight gradient: dilations <= 4 (for >= 8 the taps share no fragment blocks: dense kernel on the routed
                 # full-resolution pair); data gradient: every dilation.
-                sparse = WGRAD_SPARSE and int(dilations[l]) <= 4 and n_frames <= PITCH - 1
+                sparse = WGRAD_SPARSE and int(dilations[l]) <= WGRAD_SPARSE_MAX_T and n_frames <= PITCH - 1
                 sparse_d = DGRAD_SPARSE and l > 0 and n_frames <= PITCH - 1
                 gp_hi = gp_lo = gidx = gc_hi = gc_lo = gc_idx = None
                 Hp = H // 2
