@@ -266,9 +266,9 @@ __global__ __launch_bounds__(256, 1) void dgrad_sp_f16x3_kernel(DgradSpArgs a)
     }
     if (LN) {
         // sum over the 32 positions held by the lanes of each half (same hh), in a fixed order, through wave-private
-        // LDS: lane (hh, l32) writes its 32 partials [q = j*16 + i] as column l32, then sums row q = l32
-        __syncthreads();                                        // every wave is done with its transposition scratch
-        float *red = reinterpret_cast<float *>(smem) + wave * (2 * 32 * 33) + hh * (32 * 33);
+        // LDS (behind the four transposition tiles): lane (hh, l32) writes its 32 partials [q = j*16 + i] as column
+        // l32, then sums row q = l32
+        float *red = reinterpret_cast<float *>(smem) + 4 * (32 * 33) + wave * (2 * 32 * 33) + hh * (32 * 33);
         float tot[2];
 #pragma unroll
         for (int kind = 0; kind < 2; ++kind) {
@@ -385,7 +385,7 @@ static int launch_dgrad_sp(const DgradSpArgs &a, int B, hipStream_t st)
 {
     constexpr int PWP = CV_PITCH + 12 * T;
     constexpr size_t buf = ((2 * (size_t)PWP * DS_ROWB + PWP * 4 + 15) / 16) * 16;
-    constexpr size_t scratch = 4 * 2 * 32 * 33 * 4;              // epilogue: transposition tiles, then the LN partial reduction
+    constexpr size_t scratch = 4 * 3 * 32 * 33 * 4;              // epilogue: transposition tiles + the LN partial reduction
     constexpr size_t lds = 2 * buf > scratch ? 2 * buf : scratch;
     static_assert(lds <= 160 * 1024, "LDS budget");
     static bool attr_done = false;
