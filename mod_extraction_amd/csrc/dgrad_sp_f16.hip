@@ -157,9 +157,9 @@ __global__ __launch_bounds__(256, 1) void dgrad_sp_f16x3_kernel(DgradSpArgs a)
         half8 AH[2][6], AL[2][6];
         int IX[2][6];
         half16 WH[2][2], WL[2][2];
-        auto rd_tap = [&](int f, int kwf) {
+        auto rd_tap = [&](int f, int kwf, int t0, int t1) {
 #pragma unroll
-            for (int t = 0; t < 6; ++t) {
+            for (int t = t0; t < t1; ++t) {
                 const int off = (t < 5 ? a_lane + t * 32 * DS_ROWB : m_lane) + kwf * T * DS_ROWB;
                 const int ioff = (t < 5 ? ai_lane + t * 32 * 4 : mi_lane) + kwf * T * 4;
                 AH[f][t] = ds_a_frag(pa_h + off);
@@ -174,19 +174,38 @@ __global__ __launch_bounds__(256, 1) void dgrad_sp_f16x3_kernel(DgradSpArgs a)
                 WL[f][j] = ds_w_frag(w_ptr(a.w_lo, st, kwf, j));
             }
         };
-        rd_tap(0, 0);
+        rd_tap(0, 0, 0, 6);
 #pragma unroll
         for (int j = 0; j < 2; ++j) { WH[0][j] = WNH[j]; WL[0][j] = WNL[j]; }
 #pragma unroll
         for (int kwf = 0; kwf < CV_KW; ++kwf) {
             const int f = kwf & 1;
+            const bool more_taps = kwf + 1 < CV_KW;
             __builtin_amdgcn_sched_barrier(0);
             // accumulator u = 2t + j (t < 5): position tile c*6 + t, weight fragment j; u = 10: middle tile, fragment 0
+            // Segment 1 (11 MFMAs): the next tap's 8 weight loads are fenced into it -- left to itself the scheduler
+            // sinks them to the END of the tap, reuses this tap's registers and waits an L2 round trip at the head of
+            // every tap -- together with the first half of the next tap's LDS reads, one per MFMA.
 #pragma unroll
             for (int u = 0; u < CV_WT; ++u) {
                 const int t = u < 10 ? (u >> 1) : 5, j = u < 10 ? (u & 1) : 0;
                 acc[u] = ds_smfmac(AL[f][t], WH[f][j], acc[u], IX[f][t]);
             }
+            if (more_taps) {
+                ld_w(f ^ 1, kwf + 1);
+                rd_tap(f ^ 1, kwf + 1, 0, 3);
+#pragma unroll
+                for (int q_ = 0; q_ < 9; ++q_) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            } else if (nst < N_STAGE) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) { WNH[j] = ds_w_frag(w_ptr(a.w_hi, nst, 0, j)); WNL[j] = ds_w_frag(w_ptr(a.w_lo, nst, 0, j)); }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // Segment 2 (22 MFMAs) with the other half of the reads
 #pragma unroll
             for (int u = 0; u < CV_WT; ++u) {
                 const int t = u < 10 ? (u >> 1) : 5, j = u < 10 ? (u & 1) : 0;
@@ -197,18 +216,14 @@ __global__ __launch_bounds__(256, 1) void dgrad_sp_f16x3_kernel(DgradSpArgs a)
                 const int t = u < 10 ? (u >> 1) : 5, j = u < 10 ? (u & 1) : 0;
                 acc[u] = ds_smfmac(AH[f][t], WH[f][j], acc[u], IX[f][t]);
             }
-            if (kwf + 1 < CV_KW) {
-                rd_tap(f ^ 1, kwf + 1);
-                ld_w(f ^ 1, kwf + 1);
+            if (more_taps) {
+                rd_tap(f ^ 1, kwf + 1, 3, 6);
 #pragma unroll
-                for (int q_ = 0; q_ < 30; ++q_) {               // 30 LDS reads spread over the tap's 33 MFMAs
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                for (int q_ = 0; q_ < 9; ++q_) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
                     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                 }
-                __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
-            } else if (nst < N_STAGE) {
-#pragma unroll
-                for (int j = 0; j < 2; ++j) { WNH[j] = ds_w_frag(w_ptr(a.w_hi, nst, 0, j)); WNL[j] = ds_w_frag(w_ptr(a.w_lo, nst, 0, j)); }
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
         }

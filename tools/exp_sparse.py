@@ -1,7 +1,7 @@
 """Kernel experiment harness for the sparse gradient kernels: build -D variants of wgrad_sp_f16.hip / dgrad_sp_f16.hip into
 separate shared objects (CPU container) and time the entry points on the GPU box with realistic operands.
 
-    python tools/exp_sparse.py build name1:-DFOO name2:-DBAR=1,-DBAZ ...
+    python tools/exp_sparse.py build [--clean] name1:-DFOO name2:-DBAR=1,-DBAZ ...     (--clean removes earlier variants)
     python tools/exp_sparse.py run [B]
 """
 import ctypes
@@ -16,8 +16,10 @@ SRC = os.path.join(ROOT, "mod_extraction_amd", "csrc")
 
 
 def build(specs):
-    for old in glob.glob(os.path.join(LIB, "exps_*.so")):
-        os.remove(old)
+    if specs and specs[0] == "--clean":
+        for old in glob.glob(os.path.join(LIB, "exps_*.so")):
+            os.remove(old)
+        specs = specs[1:]
     for spec in specs:
         name, _, flags = spec.partition(":")
         out = os.path.join(LIB, f"exps_{name}.so")
