@@ -588,28 +588,41 @@ __global__ __launch_bounds__(256, 1) void conv_f16x3_dma_kernel(ConvF16Args a)
                              xl = (unsigned long long)a.x_lo, wh = (unsigned long long)a.w_hi, wlo = (unsigned long long)a.w_lo;
     const int H = a.H;
 
+    // A DMA slot = (lane source address, wave LDS base).  The address arithmetic is separated from the issue and every
+    // slot is issued UNCONDITIONALLY: a slot without a piece (no next stage; a wave's last, out-of-range piece) repeats
+    // a harmless one -- the current stage's data into the buffer nobody reads any more, or the wave's previous piece
+    // once more.  Without conditions the ~15 VALU / SALU instructions of the address are straight-line code in front
+    // of the slot and execute in the shadow of the MFMAs there; behind a branch they were sunk into the slot's own
+    // basic block, a matrix-pipe bubble twice per tap.
+    struct DmaSlot { unsigned long long src; unsigned lds; };
     // weights of (stage, taps [t0, t0 + nt)) -> Wb; piece pw of the 2 * nt * 2 covers one (split, tap, khalf) plane
-    auto dma_w = [&](int st, int t0, int nt, unsigned char *Wb, int j) {
+    auto slot_w = [&](int st, int t0, int nt, unsigned char *Wb, int j) {
         const int pw = wave + 4 * j, per = 2 * nt;
         const int split = pw / per, rem = pw - split * per;
-        const unsigned long long src = (split ? wlo : wh) + ((unsigned long long)st * WSL + (t0 * 2 + rem) * 512 + lane * 8) * 2;
-        glds16(src, lds0 + (unsigned)(Wb - smem) + split * W_SPLIT + rem * 1024);
+        DmaSlot d;
+        d.src = (split ? wlo : wh) + ((unsigned long long)st * WSL + (t0 * 2 + rem) * 512 + lane * 8) * 2;
+        d.lds = lds0 + (unsigned)(Wb - smem) + split * W_SPLIT + rem * 1024;
+        return d;
     };
-    // patch piece k of stage st -> Pb
-    auto dma_p = [&](int st, unsigned char *Pb, int k) {
-        const int pp = wave + 4 * k;
-        if (pp < P_PIECES) {
-            const int cb = st / NKH, kh = st - cb * NKH, hx0 = h0 + kh - NKH / 2;
-            const bool v0 = hx0 >= 0 && hx0 < H, v1 = hx0 + 1 >= 0 && hx0 + 1 < H;
-            const long long st_off = (((long long)b * H + hx0) * NCB + cb) * (CV_PITCH * 32);
-            const unsigned long long base_h = xh + st_off, base_l = xl + st_off;
-            const int d = desc[k];
-            const bool ok = d >= 0 && ((d & (1 << 29)) ? v1 : v0);
-            unsigned long long src = ((d & (1 << 30)) ? base_l : base_h) + (unsigned)(d & 0xFFFFF);
-            src = ok ? src : zero_src;
-            glds16(src, lds0 + (unsigned)(Pb - smem) + pp * 1024);
-        }
+    // patch piece k of stage st -> Pb (k >= 1 when the wave's piece k can be out of range: then piece k - 1 again)
+    auto slot_p = [&](int st, unsigned char *Pb, int k) {
+        const bool in_range = wave + 4 * k < P_PIECES;
+        const int pp = in_range ? wave + 4 * k : wave + 4 * (k - 1);
+        const int d = in_range ? desc[k] : desc[k > 0 ? k - 1 : 0];
+        const int cb = st / NKH, kh = st - cb * NKH, hx0 = h0 + kh - NKH / 2;
+        const bool v0 = hx0 >= 0 && hx0 < H, v1 = hx0 + 1 >= 0 && hx0 + 1 < H;
+        const long long st_off = (((long long)b * H + hx0) * NCB + cb) * (CV_PITCH * 32);
+        const unsigned long long base_h = xh + st_off, base_l = xl + st_off;
+        const bool ok = d >= 0 && ((d & (1 << 29)) ? v1 : v0);
+        const unsigned long long src = ((d & (1 << 30)) ? base_l : base_h) + (unsigned)(d & 0xFFFFF);
+        DmaSlot r;
+        r.src = ok ? src : zero_src;
+        r.lds = lds0 + (unsigned)(Pb - smem) + pp * 1024;
+        return r;
     };
+    auto slot_issue = [&](const DmaSlot &d) { glds16(d.src, d.lds); };
+    auto dma_w = [&](int st, int t0, int nt, unsigned char *Wb, int j) { slot_issue(slot_w(st, t0, nt, Wb, j)); };
+    auto dma_p = [&](int st, unsigned char *Pb, int k) { if (wave + 4 * k < P_PIECES) slot_issue(slot_p(st, Pb, k)); };
 
     // prologue: taps 0..6 of stage 0 and its patch
 #pragma unroll
@@ -623,6 +636,7 @@ __global__ __launch_bounds__(256, 1) void conv_f16x3_dma_kernel(ConvF16Args a)
     for (int s = 0; s < N_STAGE; ++s) {
         unsigned char *const Pc = P0 + (s & 1) * P_BYTES, *const Pn = P0 + ((s + 1) & 1) * P_BYTES;
         const bool more = s + 1 < N_STAGE;
+        const int sn = more ? s + 1 : s;             // the stage whose operands the DMA slots fetch (see DmaSlot)
         const unsigned char *b_p = Pc + (row * 2 + half) * PLANE + (c * 6 * 32 + l32) * 16;      // + split*4*PLANE + (t*32 + kw*T)*16
         const unsigned char *bm_p = Pc + (row * 2 + half) * PLANE + (5 * 32 + l32) * 16;         // middle tile
         // fragments of one tap, double buffered (FA: a0h a0l a1h a1l; FBH/FBL: tiles 0..4 + the middle tile)
@@ -654,6 +668,7 @@ __global__ __launch_bounds__(256, 1) void conv_f16x3_dma_kernel(ConvF16Args a)
 #define DMA_TAP(F, WB, TLN, KWN, R_LO, SLOT_A, SLOT_B)                                           \
     {                                                                                            \
         __builtin_amdgcn_sched_barrier(0);                                                       \
+        const DmaSlot sa_ = SLOT_A;                                                              \
         _Pragma("unroll") for (int i = 0; i < 16; ++i) mma(F, i);                                \
         _Pragma("unroll") for (int r = 0; r < 8; ++r) if (r >= (R_LO)) rd((F) ^ 1, WB, TLN, KWN, r); \
         _Pragma("unroll") for (int g = 0; g < 8; ++g) {                                          \
@@ -661,8 +676,9 @@ __global__ __launch_bounds__(256, 1) void conv_f16x3_dma_kernel(ConvF16Args a)
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                   \
         }                                                                                        \
         __builtin_amdgcn_sched_barrier(0);                                                       \
-        SLOT_A;                                                                                  \
+        slot_issue(sa_);                                                                         \
         __builtin_amdgcn_sched_barrier(0);                                                       \
+        const DmaSlot sb_ = SLOT_B;                                                              \
         _Pragma("unroll") for (int i = 16; i < 33; ++i) mma(F, i);                               \
         _Pragma("unroll") for (int r = 8; r < 16; ++r) if (r >= (R_LO)) rd((F) ^ 1, WB, TLN, KWN, r); \
         _Pragma("unroll") for (int g = 0; g < 8; ++g) {                                          \
@@ -671,13 +687,13 @@ __global__ __launch_bounds__(256, 1) void conv_f16x3_dma_kernel(ConvF16Args a)
         }                                                                                        \
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                       \
         __builtin_amdgcn_sched_barrier(0);                                                       \
-        SLOT_B;                                                                                  \
+        slot_issue(sb_);                                                                         \
         __builtin_amdgcn_sched_barrier(0);                                                       \
     }
         // phase A slots: 6 weight pieces (this stage's taps 7..12 -> W1), then patch pieces 0..7 of the next stage
-#define DMA_SLOT_A(J) { if ((J) < 6) dma_w(s, 7, 6, W1, (J)); else if (more) dma_p(s + 1, Pn, (J) - 6); }
+#define DMA_SLOT_A(J) ((J) < 6 ? slot_w(s, 7, 6, W1, (J)) : slot_p(sn, Pn, (J) - 6))
         // phase B slots: 7 weight pieces (next stage's taps 0..6 -> W0), then the remaining patch pieces
-#define DMA_SLOT_B(J) { if (more) { if ((J) < 7) dma_w(s + 1, 0, 7, W0, (J)); else if ((J) + 1 < PPW) dma_p(s + 1, Pn, (J) + 1); } }
+#define DMA_SLOT_B(J) ((J) < 7 ? slot_w(sn, 0, 7, W0, (J)) : slot_p(sn, Pn, (J) + 1 < PPW ? (J) + 1 : PPW - 1))
 
         // ---- phase A: taps 0..6 from W0
 #pragma unroll
