@@ -665,10 +665,10 @@ __global__ __launch_bounds__(256, 1) void conv_f16x3_dma_kernel(ConvF16Args a)
         // One tap: 33 MFMAs on set f, the next tap's 16 fragment reads into set f^1 (r_lo..15; r_lo = 4 skips the
         // weights, 16 skips everything), one read after every second MFMA, and two DMA slots.  The wave issues in
         // order, so anything clustered between MFMA groups is a matrix-pipe bubble: the interleave is pinned.
-#define DMA_TAP(F, WB, TLN, KWN, R_LO, SLOT_A, SLOT_B)                                           \
+#define DMA_TAP(F, WB, TLN, KWN, R_LO, NA, SLOT_A, SLOT_A2, NB, SLOT_B, SLOT_B2)                  \
     {                                                                                            \
         __builtin_amdgcn_sched_barrier(0);                                                       \
-        const DmaSlot sa_ = SLOT_A;                                                              \
+        const DmaSlot sa_ = SLOT_A, sa2_ = SLOT_A2;                                              \
         _Pragma("unroll") for (int i = 0; i < 16; ++i) mma(F, i);                                \
         _Pragma("unroll") for (int r = 0; r < 8; ++r) if (r >= (R_LO)) rd((F) ^ 1, WB, TLN, KWN, r); \
         _Pragma("unroll") for (int g = 0; g < 8; ++g) {                                          \
@@ -676,9 +676,10 @@ __global__ __launch_bounds__(256, 1) void conv_f16x3_dma_kernel(ConvF16Args a)
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                   \
         }                                                                                        \
         __builtin_amdgcn_sched_barrier(0);                                                       \
-        slot_issue(sa_);                                                                         \
+        if ((NA) >= 1) slot_issue(sa_);                                                          \
+        if ((NA) >= 2) slot_issue(sa2_);                                                         \
         __builtin_amdgcn_sched_barrier(0);                                                       \
-        const DmaSlot sb_ = SLOT_B;                                                              \
+        const DmaSlot sb_ = SLOT_B, sb2_ = SLOT_B2;                                              \
         _Pragma("unroll") for (int i = 16; i < 33; ++i) mma(F, i);                               \
         _Pragma("unroll") for (int r = 8; r < 16; ++r) if (r >= (R_LO)) rd((F) ^ 1, WB, TLN, KWN, r); \
         _Pragma("unroll") for (int g = 0; g < 8; ++g) {                                          \
@@ -687,37 +688,47 @@ __global__ __launch_bounds__(256, 1) void conv_f16x3_dma_kernel(ConvF16Args a)
         }                                                                                        \
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                       \
         __builtin_amdgcn_sched_barrier(0);                                                       \
-        slot_issue(sb_);                                                                         \
+        if ((NB) >= 1) slot_issue(sb_);                                                          \
+        if ((NB) >= 2) slot_issue(sb2_);                                                         \
         __builtin_amdgcn_sched_barrier(0);                                                       \
     }
-        // phase A slots: 6 weight pieces (this stage's taps 7..12 -> W1), then patch pieces 0..7 of the next stage
+        // DMA schedule.  The end of a phase waits for the pieces its successor reads, so nothing it needs is issued
+        // late: a piece requested in the last slot cost a full memory round trip at the barrier, twice per stage.
+        //   phase A (14 slots): W1 <- this stage's taps 7..12 in slots 0..5, then patch pieces 0..7 of the next stage;
+        //           its end waits with vmcnt(8): the six weight pieces, not the eight patch pieces behind them
+        //   phase B (12 slots): W0 <- the next stage's taps 0..6 in slots 0..6 and the remaining patch pieces 8.. riding
+        //           along in slots 0.. (two pieces per slot); the last five slots are empty
+        static_assert(PPW >= 12 && PPW <= 15, "DMA schedule");
 #define DMA_SLOT_A(J) ((J) < 6 ? slot_w(s, 7, 6, W1, (J)) : slot_p(sn, Pn, (J) - 6))
-        // phase B slots: 7 weight pieces (next stage's taps 0..6 -> W0), then the remaining patch pieces
-#define DMA_SLOT_B(J) ((J) < 7 ? slot_w(sn, 0, 7, W0, (J)) : slot_p(sn, Pn, (J) + 1 < PPW ? (J) + 1 : PPW - 1))
+#define DMA_NB(J) (((J) < 7 ? 1 : 0) + ((J) + 8 < PPW ? 1 : 0))
+#define DMA_SLOT_B(J) slot_w(sn, 0, 7, W0, (J) < 7 ? (J) : 0)
+#define DMA_SLOT_B2(J) slot_p(sn, Pn, (J) + 8 < PPW ? (J) + 8 : PPW - 1)
 
         // ---- phase A: taps 0..6 from W0
 #pragma unroll
         for (int r = 0; r < 16; ++r) rd(0, W0, 0, 0, r);
 #pragma unroll
         for (int t = 0; t < 7; ++t) {
-            if (t < 6) DMA_TAP(t & 1, W0, t + 1, t + 1, 0, DMA_SLOT_A(2 * t), DMA_SLOT_A(2 * t + 1))
-            else DMA_TAP(t & 1, W0, 0, 7, 4, DMA_SLOT_A(2 * t), DMA_SLOT_A(2 * t + 1))     // tap 7's patch fragments only
+            if (t < 6) DMA_TAP(t & 1, W0, t + 1, t + 1, 0, 1, DMA_SLOT_A(2 * t), DMA_SLOT_A(2 * t), 1, DMA_SLOT_A(2 * t + 1), DMA_SLOT_A(2 * t + 1))
+            else DMA_TAP(t & 1, W0, 0, 7, 4, 1, DMA_SLOT_A(2 * t), DMA_SLOT_A(2 * t), 1, DMA_SLOT_A(2 * t + 1), DMA_SLOT_A(2 * t + 1))     // tap 7's patch fragments only
         }
-        DMA_WAIT();                            // this wave's pieces landed ...
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // this wave's W1 pieces landed (8 patch pieces may be in flight) ...
         __syncthreads();                       // ... and everyone's did
         // ---- phase B: taps 7..12 from W1 (fragment set 1 holds tap 7's patch fragments)
 #pragma unroll
         for (int r = 0; r < 4; ++r) rd(1, W1, 0, 7, r);
 #pragma unroll
         for (int t = 0; t < 6; ++t) {
-            if (t < 5) DMA_TAP((t + 1) & 1, W1, t + 1, 8 + t, 0, DMA_SLOT_B(2 * t), DMA_SLOT_B(2 * t + 1))
-            else DMA_TAP((t + 1) & 1, W1, 0, 0, 16, DMA_SLOT_B(2 * t), DMA_SLOT_B(2 * t + 1))
+            if (t < 5) DMA_TAP((t + 1) & 1, W1, t + 1, 8 + t, 0, DMA_NB(2 * t), DMA_SLOT_B(2 * t), DMA_SLOT_B2(2 * t), DMA_NB(2 * t + 1), DMA_SLOT_B(2 * t + 1), DMA_SLOT_B2(2 * t + 1))
+            else DMA_TAP((t + 1) & 1, W1, 0, 0, 16, DMA_NB(2 * t), DMA_SLOT_B(2 * t), DMA_SLOT_B2(2 * t), DMA_NB(2 * t + 1), DMA_SLOT_B(2 * t + 1), DMA_SLOT_B2(2 * t + 1))
         }
         DMA_WAIT();
         __syncthreads();
 #undef DMA_TAP
 #undef DMA_SLOT_A
 #undef DMA_SLOT_B
+#undef DMA_SLOT_B2
+#undef DMA_NB
     }
     conv_f16_epilogue<OUTMODE>(acc, a, smem, b, h0, row, c, lane);
 }
