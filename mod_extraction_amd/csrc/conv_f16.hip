@@ -388,32 +388,33 @@ __global__ __launch_bounds__(256, 1) void conv_f16x3_kernel(ConvF16Args a)
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
 
     floatx4 wv[NWV], pv[NPV];
-    auto issue = [&](int s) {                                   // global loads of stage s = (cb, kh)
+    // global loads of stage s = (cb, kh).  Branch-free: a predicated load is an exec-mask branch, and the 27 of them
+    // with their address arithmetic sat between the two barriers of every stage; halo / out-of-image items read a
+    // clamped (valid) address and are zeroed with a select.
+    auto issue = [&](int s) {
         const int cb = s / CV_KH, kh = s - cb * CV_KH;
 #pragma unroll
         for (int q = 0; q < NWV; ++q) {
-            const int i = tid + q * 256;
-            wv[q] = floatx4{0.f, 0.f, 0.f, 0.f};
-            if (i < 2 * (WSL / 8)) {
-                const int split = i / (WSL / 8), j = i - split * (WSL / 8);
-                const _Float16 *src = (split ? a.w_lo : a.w_hi) + (size_t)(cb * CV_KH + kh) * WSL + (size_t)j * 8;
-                wv[q] = *reinterpret_cast<const floatx4 *>(src);
-            }
+            int i = tid + q * 256;
+            const bool in = (2 * (WSL / 8)) % 256 == 0 || i < 2 * (WSL / 8);
+            i = in ? i : 0;
+            const int split = i / (WSL / 8), j = i - split * (WSL / 8);
+            const _Float16 *src = (split ? a.w_lo : a.w_hi) + (size_t)(cb * CV_KH + kh) * WSL + (size_t)j * 8;
+            wv[q] = *reinterpret_cast<const floatx4 *>(src);
         }
 #pragma unroll
         for (int q = 0; q < NPV; ++q) {
-            const int i = tid + q * 256;
-            pv[q] = floatx4{0.f, 0.f, 0.f, 0.f};
-            if (i < NPI) {
-                const int part = i & 1, pos = (i >> 1) % PWP, sr = (i >> 1) / PWP;     // sr = split * 2 + row
-                const int split = sr >> 1, r = sr & 1;
-                const int hx = h0 + r + kh - 2, w = pos - 6 * T;
-                if (hx >= 0 && hx < a.H && w >= 0 && w < CV_PITCH) {
-                    const _Float16 *src = (split ? a.x_lo : a.x_hi) +
-                                          ((((size_t)b * a.H + hx) * 4 + cb) * CV_PITCH + w) * 16 + part * 8;
-                    pv[q] = *reinterpret_cast<const floatx4 *>(src);
-                }
-            }
+            int i = tid + q * 256;
+            const bool in = NPI % 256 == 0 || i < NPI;
+            i = in ? i : 0;
+            const int part = i & 1, pos = (i >> 1) % PWP, sr = (i >> 1) / PWP;     // sr = split * 2 + row
+            const int split = sr >> 1, r = sr & 1;
+            const int hx = h0 + r + kh - 2, w = pos - 6 * T;
+            const bool ok = hx >= 0 && hx < a.H && w >= 0 && w < CV_PITCH;
+            const int hx_c = hx < 0 ? 0 : (hx >= a.H ? a.H - 1 : hx), w_c = w < 0 ? 0 : (w >= CV_PITCH ? CV_PITCH - 1 : w);
+            const _Float16 *src = (split ? a.x_lo : a.x_hi) + ((((size_t)b * a.H + hx_c) * 4 + cb) * CV_PITCH + w_c) * 16 + part * 8;
+            const floatx4 v = *reinterpret_cast<const floatx4 *>(src);
+            pv[q] = ok ? v : floatx4{0.f, 0.f, 0.f, 0.f};
         }
     };
     auto commit = [&]() {                                       // registers -> LDS
@@ -421,13 +422,13 @@ __global__ __launch_bounds__(256, 1) void conv_f16x3_kernel(ConvF16Args a)
 #pragma unroll
         for (int q = 0; q < NWV; ++q) {
             const int i = tid + q * 256;
-            if (i < 2 * (WSL / 8)) wd[i] = wv[q];             // the packed weights are the LDS image
+            if ((2 * (WSL / 8)) % 256 == 0 || i < 2 * (WSL / 8)) wd[i] = wv[q];             // the packed weights are the LDS image
         }
         floatx4 *pd = reinterpret_cast<floatx4 *>(pl);
 #pragma unroll
         for (int q = 0; q < NPV; ++q) {
             const int i = tid + q * 256;
-            if (i < NPI) {
+            if (NPI % 256 == 0 || i < NPI) {
                 // item i = ((split*2 + row)*PWP + pos)*2 + part  ->  LDS [split][row][part][pos]
                 const int part = i & 1, pos = (i >> 1) % PWP, sr = (i >> 1) / PWP;
                 pd[(sr * 2 + part) * PWP + pos] = pv[q];
