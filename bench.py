@@ -237,7 +237,7 @@ def main():
             "roofline": roofline,
             "kernels": kernels,
             "conv_ms_per_step": round(mfma_ms, 2),
-            "final_loss": None if loss is None else float(loss),
+            "final_loss": None if loss is None else float(loss.detach()),
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
