@@ -328,29 +328,44 @@ __global__ void pack_weights_sp_f16_kernel(const float *__restrict__ W, _Float16
 // G, amax (B,64,Hp,352) -> channels-last pooled operand: g_hi, g_lo (B,Hp,4,352,16) = split of G * S (columns >= Wv: 0)
 // and g_idx (B,Hp,4,352) uint32: low / high 16 bits = index word of lane half 0 / 1, element j of half hh = output
 // channel 4hh + j (j < 4) or 8 + 4hh + j - 4 of the block, field = 2 (j & 1) + argmax.
+// Workgroup = (64-position tile, pooled row, clip): per channel it reads 256 B of G and 64 B of argmax and writes 128 B of
+// each planar half -- whole cache lines (a 32-position tile moved half lines: 3.7 TB/s); the last of the six tiles of a
+// row is half empty (352 = 5.5 x 64).
+#define GP_TW 64
 __global__ __launch_bounds__(256) void gpool_cl_prep_kernel(const float *__restrict__ G, const unsigned char *__restrict__ amax,
                                                             const float *__restrict__ scale, int Hp, int Wv,
                                                             _Float16 *__restrict__ g_hi, _Float16 *__restrict__ g_lo,
                                                             unsigned *__restrict__ g_idx, _Float16 *__restrict__ gp_hi,
                                                             _Float16 *__restrict__ gp_lo, unsigned char *__restrict__ gidx)
 {
-    __shared__ float tile[64][33];
-    __shared__ unsigned char tam[64][36];
-    __shared__ __attribute__((aligned(8))) unsigned char idxb[64][8];       // the tile's 8 planar index bytes per channel
+    __shared__ float tile[64][GP_TW + 1];
+    __shared__ unsigned char tam[64][GP_TW + 4];
+    __shared__ __attribute__((aligned(16))) unsigned char idxb[64][16];     // the tile's 16 planar index bytes per channel
     const int wt = blockIdx.x, hp = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
     const float S = scale[0];
-    for (int i = tid; i < 64 * 8; i += 256) {
-        const int ch = i >> 3, c4 = i & 7, w0 = wt * 32 + c4 * 4;
-        const size_t off = (((size_t)b * 64 + ch) * Hp + hp) * CV_PITCH + w0;
-        const floatx4 v = *reinterpret_cast<const floatx4 *>(G + off);
-        const uchar4 am = *reinterpret_cast<const uchar4 *>(amax + off);
+    constexpr int NIT = 64 * (GP_TW / 4) / 256;                 // (channel, 4 positions) items per thread
+    floatx4 gv[NIT];
+    uchar4 av[NIT];
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {                             // all loads first: NIT x (16 + 4) bytes in flight per thread
+        const int i = tid + 256 * k, ch = i / (GP_TW / 4), c4 = i % (GP_TW / 4), w0 = wt * GP_TW + c4 * 4;
+        const size_t off = (((size_t)b * 64 + ch) * Hp + hp) * CV_PITCH + (w0 < CV_PITCH ? w0 : 0);
+        gv[k] = *reinterpret_cast<const floatx4 *>(G + off);
+        av[k] = *reinterpret_cast<const uchar4 *>(amax + off);
+    }
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+        const int i = tid + 256 * k, ch = i / (GP_TW / 4), c4 = i % (GP_TW / 4), w0 = wt * GP_TW + c4 * 4;
+        const bool in_row = w0 < CV_PITCH;
+        const floatx4 v = gv[k];
+        const uchar4 am = av[k];
 #pragma unroll
         for (int e = 0; e < 4; ++e) tile[ch][c4 * 4 + e] = (w0 + e < Wv) ? v[e] * S : 0.0f;
         tam[ch][c4 * 4 + 0] = am.x & 1; tam[ch][c4 * 4 + 1] = am.y & 1; tam[ch][c4 * 4 + 2] = am.z & 1; tam[ch][c4 * 4 + 3] = am.w & 1;
         if (gp_hi) {
             // the planar operand of the sparse WEIGHT-gradient kernel from the same pass (wgrad_sp_f16.hip: the pair at
-            // pooled resolution + this thread's byte of the index word: (k-step, lane half, word byte) =
-            // (2 wt + (c4 >> 2), c4 & 1, (c4 >> 1) & 1))
+            // pooled resolution + this thread's byte of the index words: (k-step, lane half, word byte) =
+            // (4 wt + (c4 >> 2), c4 & 1, (c4 >> 1) & 1))
             half4 ghi, glo;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -359,39 +374,50 @@ __global__ __launch_bounds__(256) void gpool_cl_prep_kernel(const float *__restr
                 ghi[e] = hv;
                 glo[e] = (_Float16)(gs - (float)hv);
             }
-            *reinterpret_cast<half4 *>(gp_hi + off) = ghi;
-            *reinterpret_cast<half4 *>(gp_lo + off) = glo;
+            if (in_row) {
+                const size_t off = (((size_t)b * 64 + ch) * Hp + hp) * CV_PITCH + w0;
+                *reinterpret_cast<half4 *>(gp_hi + off) = ghi;
+                *reinterpret_cast<half4 *>(gp_lo + off) = glo;
+            }
             const unsigned byte = (am.x & 1u) | ((2u + (am.y & 1u)) << 2) | ((am.z & 1u) << 4) | ((2u + (am.w & 1u)) << 6);
-            idxb[ch][((c4 >> 2) * 2 + (c4 & 1)) * 2 + ((c4 >> 1) & 1)] = (unsigned char)byte;     // gathered, stored 8 at a time below
+            idxb[ch][(((c4 >> 2) * 2 + (c4 & 1)) * 2) + ((c4 >> 1) & 1)] = (unsigned char)byte;   // gathered, stored 8 at a time below
         }
     }
     __syncthreads();
-    if (gp_hi && tid < 64)          // 2 k-steps x 2 lane halves x 2 bytes = 8 contiguous bytes of gidx per channel
-        *reinterpret_cast<unsigned long long *>(gidx + ((((size_t)b * 64 + tid) * Hp + hp) * 22 + wt * 2) * 4) =
-            *reinterpret_cast<const unsigned long long *>(idxb[tid]);
-    const int pos = tid >> 3, cg = tid & 7;                     // 32 positions x 8 groups of 8 channels
-    half8 hi, lo;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const float v = tile[cg * 8 + j][pos];
-        const _Float16 hv = (_Float16)v;
-        hi[j] = hv;
-        lo[j] = (_Float16)(v - (float)hv);
+    if (gp_hi && tid < 128) {       // per channel and k-step pair: 2 k-steps x 2 lane halves x 2 bytes = 8 contiguous bytes of gidx
+        const int ch = tid >> 1, pr = tid & 1, ks0 = wt * (GP_TW / 16) + pr * 2;
+        if (ks0 < 22)
+            *reinterpret_cast<unsigned long long *>(gidx + ((((size_t)b * 64 + ch) * Hp + hp) * 22 + ks0) * 4) =
+                *reinterpret_cast<const unsigned long long *>(&idxb[ch][pr * 8]);
     }
-    const size_t o = ((((size_t)b * Hp + hp) * 4 + (cg >> 1)) * CV_PITCH + wt * 32 + pos) * 16 + (cg & 1) * 8;
-    *reinterpret_cast<half8 *>(g_hi + o) = hi;
-    *reinterpret_cast<half8 *>(g_lo + o) = lo;
-    if (cg < 4) {                                               // one thread per (position, channel block): both index words
-        unsigned word = 0;
+    // 64 positions x 64 channels: thread -> (position, 8-channel group), two positions per thread
 #pragma unroll
-        for (int hf = 0; hf < 2; ++hf)
+    for (int it = 0; it < GP_TW / 32; ++it) {
+        const int pos = (tid >> 3) + 32 * it, cg = tid & 7, w = wt * GP_TW + pos;
+        if (w >= CV_PITCH) continue;
+        half8 hi, lo;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int col = (j < 4 ? 4 * hf + j : 8 + 4 * hf + (j - 4));
-                const unsigned f = 2u * (j & 1) + tam[cg * 16 + col][pos];
-                word |= f << (16 * hf + 2 * j);
-            }
-        g_idx[(((size_t)b * Hp + hp) * 4 + cg) * CV_PITCH + wt * 32 + pos] = word;
+        for (int j = 0; j < 8; ++j) {
+            const float v = tile[cg * 8 + j][pos];
+            const _Float16 hv = (_Float16)v;
+            hi[j] = hv;
+            lo[j] = (_Float16)(v - (float)hv);
+        }
+        const size_t o = ((((size_t)b * Hp + hp) * 4 + (cg >> 1)) * CV_PITCH + w) * 16 + (cg & 1) * 8;
+        *reinterpret_cast<half8 *>(g_hi + o) = hi;
+        *reinterpret_cast<half8 *>(g_lo + o) = lo;
+        if (cg < 4) {                                               // one thread per (position, channel block): both index words
+            unsigned word = 0;
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int col = (j < 4 ? 4 * hf + j : 8 + 4 * hf + (j - 4));
+                    const unsigned f = 2u * (j & 1) + tam[cg * 16 + col][pos];
+                    word |= f << (16 * hf + 2 * j);
+                }
+            g_idx[(((size_t)b * Hp + hp) * 4 + cg) * CV_PITCH + w] = word;
+        }
     }
 }
 
@@ -433,7 +459,7 @@ MX_EXPORT int mx_conv_prep_gpool_cl_f16(const float *G, const uint8_t *amax, con
         return MX_ERR_ARG;
     if ((gp_hi || gp_lo || gidx) && !(gp_hi && gp_lo && gidx)) return MX_ERR_ARG;     // all three planar by-products or none
     if (B > 65535 || H > 131070) return MX_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(gpool_cl_prep_kernel, dim3(CV_PITCH / 32, (unsigned)(H / 2), (unsigned)B), dim3(256), 0,
+    hipLaunchKernelGGL(gpool_cl_prep_kernel, dim3((CV_PITCH + GP_TW - 1) / GP_TW, (unsigned)(H / 2), (unsigned)B), dim3(256), 0,
                        (hipStream_t)stream, G, amax, scale, (int)(H / 2), (int)Wv, (_Float16 *)g_hi, (_Float16 *)g_lo,
                        (unsigned *)g_idx, (_Float16 *)gp_hi, (_Float16 *)gp_lo, (unsigned char *)gidx);
     return mx_launch_status();
