@@ -87,6 +87,9 @@ MX_EXPORT int mx_plane_stats(const float *x, const float *slope, int64_t B, int6
 //   dslope_part (B*C,): per-plane partial of dL/dslope (summed over B by mx_reduce_rows)
 // LN backward:  dx = rstd * (dxhat - mean(dxhat) - xhat * mean(dxhat * xhat))
 // PReLU bwd  :  G = dx * (p > 0 ? 1 : slope);  dslope += dx * (p > 0 ? 0 : p)
+#ifndef LNB_UNROLL
+#define LNB_UNROLL 4
+#endif
 #ifndef LNB_THREADS
 #define LNB_THREADS 64     // one wavefront per plane: many planes in flight per CU hide the two sweeps' latency and the reduction between them (256: +1 ms per step, 1024: +10 ms)
 #endif
@@ -138,28 +141,43 @@ __global__ __launch_bounds__(LNB_THREADS) void ln_prelu_bwd_kernel(const float *
     const float m1 = (float)(s1 / n), m2 = (float)(s2 / n);
     double ds = 0.0, gs = 0.0;
     float gmax = 0.0f;
-    for (int i = threadIdx.x; i < n4; i += LNB_THREADS) {
-        const int w0 = (i % (CV_PITCH / 4)) * 4;
-        floatx4 pv = pp[i], gv = gp[i], o;
-        float tds = 0.0f, tgs = 0.0f;
+    // branch-free (pad columns and the tail are masked with selects), LNB_UNROLL vectors of each tensor per trip: the
+    // wave keeps 2 x LNB_UNROLL 16-byte loads in flight; same terms in the same order as one vector per trip
+    constexpr int U = LNB_UNROLL;
+    for (int i0 = threadIdx.x; i0 < n4; i0 += U * LNB_THREADS) {
+        floatx4 pv[U], gv[U];
+        int col[U];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float r = 0.0f;
-            if (w0 + e < Wv) {
-                const bool pos = pv[e] > 0.0f;
-                float x = pos ? pv[e] : sl * pv[e];
-                float xh = (x - mean) * rstd;
-                float dx = rstd * (gv[e] - m1 - xh * m2);
-                r = pos ? dx : sl * dx;
-                if (!pos) tds += dx * pv[e];
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + u * LNB_THREADS;
+            const bool ok = i < n4;
+            const int ic = ok ? i : (int)threadIdx.x;
+            col[u] = ok ? (ic % (CV_PITCH / 4)) * 4 : CV_PITCH;          // tail: every element masked
+            pv[u] = pp[ic];
+            gv[u] = gp[ic];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            floatx4 o;
+            float tds = 0.0f, tgs = 0.0f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bool valid = col[u] + e < Wv;
+                const bool pos = pv[u][e] > 0.0f;
+                const float x = pos ? pv[u][e] : sl * pv[u][e];
+                const float xh = (x - mean) * rstd;
+                const float dx = rstd * (gv[u][e] - m1 - xh * m2);
+                const float r = valid ? (pos ? dx : sl * dx) : 0.0f;
+                tds += (valid && !pos) ? dx * pv[u][e] : 0.0f;
                 tgs += r;
                 gmax = fmaxf(gmax, fabsf(r));
+                o[e] = r;
             }
-            o[e] = r;
+            ds += (double)tds;
+            gs += (double)tgs;
+            const int i = i0 + u * LNB_THREADS;
+            if (i < n4) gp[i] = o;
         }
-        ds += (double)tds;
-        gs += (double)tgs;
-        gp[i] = o;
     }
     block_sum2(ds, gs, sh);
     if (threadIdx.x == 0) {
