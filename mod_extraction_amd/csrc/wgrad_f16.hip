@@ -267,13 +267,42 @@ __global__ __launch_bounds__(256, 1) void wgrad_f16x3_kernel(WgradF16Args a)
 __global__ __launch_bounds__(256) void wgrad_f16_reduce_kernel(const float *__restrict__ part, int n_slabs,
                                                                const float *__restrict__ scale, float *__restrict__ dW)
 {
-    const int total = CV_TAPS * 64 * 64;
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= total) return;
-    double s = 0.0;
-    for (int k = 0; k < n_slabs; ++k) s += (double)part[(size_t)k * total + j];
-    const int ci = j % 64, co = (j / 64) % 64, tap = j / (64 * 64);
-    dW[((size_t)co * 64 + ci) * CV_TAPS + tap] = (float)(s * (double)scale[1]);
+    // 256 threads = 64 groups of 4 consecutive outputs x 4 quarters of the slab range: 16-byte loads, four of them in
+    // flight per thread, quarters combined through LDS in a fixed order (one output per thread over all slabs was a
+    // single 4-byte load stream per lane: 1.5 TB/s)
+    __shared__ double sh[4][64][4];
+    const int total = CV_TAPS * 64 * 64;                      // a multiple of 256
+    const int jq = threadIdx.x & 63, kq = threadIdx.x >> 6;
+    const int j = (blockIdx.x * 64 + jq) * 4;
+    const int k0 = (int)((long long)n_slabs * kq / 4), k1 = (int)((long long)n_slabs * (kq + 1) / 4);
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
+    const float *src = part + (size_t)k0 * total + j;
+    int k = k0;
+    for (; k + 4 <= k1; k += 4) {
+        floatx4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const floatx4 *>(src + (size_t)u * total);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s[e] += (double)v[u][e];
+        src += (size_t)4 * total;
+    }
+    for (; k < k1; ++k) {
+        const floatx4 v = *reinterpret_cast<const floatx4 *>(src);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s[e] += (double)v[e];
+        src += total;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) sh[kq][jq][e] = s[e];
+    __syncthreads();
+    {
+        const int e = kq, jj = j + e;                         // thread (jq, kq) finishes output 4 (block group) + kq
+        const double t = ((sh[0][jq][e] + sh[1][jq][e]) + sh[2][jq][e]) + sh[3][jq][e];
+        const int ci = jj % 64, co = (jj / 64) % 64, tap = jj / (64 * 64);
+        dW[((size_t)co * 64 + ci) * CV_TAPS + tap] = (float)(t * (double)scale[1]);
+    }
 }
 
 template <int T>
