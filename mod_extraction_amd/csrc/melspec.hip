@@ -2,11 +2,14 @@
 // Reference: mod_extraction/models.py:170-181,199-208 (torchaudio.transforms.MelSpectrogram with
 // n_fft 1024, hop 256, periodic hann, centre + reflect pad, power 2, HTK mels, no norm).
 //
-// One 256-thread workgroup produces MEL_FR consecutive frames of one (clip, channel) plane.
-// Per frame: windowed, reflect-padded load -> 1024-point complex radix-4 Stockham FFT in LDS
-// (5 passes, twiddles from a host-built fp64->fp32 table) -> power of bins 0..512 -> each thread
-// accumulates one mel band over its non-zero filter range [lo, hi).  The MEL_FR results per band
-// are buffered in LDS and written as 64-byte runs along the frame axis.
+// One 256-thread workgroup produces MEL_FR consecutive frames of one (clip, channel) plane, ONE FRAME PER WAVEFRONT at a
+// time: windowed, reflect-padded load -> 1024-point complex radix-4 Stockham FFT in wave-private LDS (5 passes, 4
+// butterflies per lane and pass, twiddles from a host-built fp64->fp32 table) -> power of bins 0..512 -> each lane
+// accumulates its mel bands over their non-zero filter range [lo, hi).  A wave executes in lockstep and the LDS serves
+// its instructions in order, so a pass reads all its inputs into registers and writes the outputs back IN PLACE with no
+// workgroup barrier at all (the first version spread a frame over the 256 threads: nine __syncthreads per frame, 144
+// per workgroup, and the kernel was bound by them; same butterflies in the same order -> same bits).  The MEL_FR
+// results per band are buffered in LDS and written as 64-byte runs along the frame axis.
 // Output planes use a padded row pitch (`out_pitch` floats, 352 for 345 frames) so that the conv
 // kernels can load 16-byte aligned vectors; columns >= n_frames are written as 0.
 //
@@ -33,73 +36,167 @@ __global__ __launch_bounds__(256) void melspec_kernel(
     const float2 *__restrict__ twiddle,     // exp(-2 pi i m / 1024), m in [0,1024)
     const float *__restrict__ fb,           // (513, n_mels) row-major (torchaudio mel_scale.fb)
     const int *__restrict__ band_lo, const int *__restrict__ band_hi, int n_mels, int hop,
-    int n_frames, int out_pitch, float eps, int f0, int f1, int t0, int t1, float *__restrict__ out)
+    int n_frames, int out_pitch, float eps, int f0, int f1, int t0, int t1, int coef_cap, float *__restrict__ out)
 {
-    __shared__ cfloat bufA[MEL_NFFT];
-    __shared__ cfloat bufB[MEL_NFFT];
-    __shared__ float power[MEL_NFFT / 2 + 1];
-    extern __shared__ float melbuf[];       // n_mels * (MEL_FR + 1)
-    const int tid = threadIdx.x;
+    __shared__ cfloat fftbuf[4][MEL_NFFT + 64];   // exchange buffer of a wave (padded layouts, see below)
+    __shared__ float powbuf[4][MEL_NFFT / 2 + 1];
+    __shared__ float2 tw_s[MEL_NFFT];        // the twiddle table: 12 global loads per lane and pass otherwise
+    extern __shared__ float melbuf[];       // n_mels * (MEL_FR + 1) results, then the filter bank's non-zero coefficients
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int plane = blockIdx.y;           // clip * in_ch + channel
     const int tile0 = blockIdx.x * MEL_FR;
     const float *xp = x + (size_t)plane * N;
-
-    for (int fl = 0; fl < MEL_FR; ++fl) {
-        const int t = tile0 + fl;
-        if (t < n_frames) {                                   // block-uniform
-            // ---- windowed load, centre=True reflect padding (torch.stft) ----
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int n = tid + q * 256;
-                int s = t * hop + n - MEL_NFFT / 2;
-                if (s < 0) s = -s;
-                if (s >= N) s = 2 * (N - 1) - s;
-                s = s < 0 ? 0 : s;                            // clips shorter than n_fft/2 are rejected on the host
-                bufA[n].re = xp[s] * window[n];
-                bufA[n].im = 0.0f;
-            }
-            __syncthreads();
-            // ---- 5 radix-4 Stockham passes: A->B->A->B->A->B ----
-            cfloat *src = bufA, *dst = bufB;
-#pragma unroll
-            for (int pass = 0; pass < 5; ++pass) {
-                const int Ns = 1 << (2 * pass);
-                const int j = tid;
-                const int k = j & (Ns - 1);
-                const int tw_step = k * (MEL_NFFT / (Ns * 4));
-                cfloat v0 = src[j], v1 = src[j + 256], v2 = src[j + 512], v3 = src[j + 768];
-                if (pass > 0) {
-                    float2 w1 = twiddle[tw_step], w2 = twiddle[2 * tw_step], w3 = twiddle[3 * tw_step];
-                    v1 = cmul(v1, {w1.x, w1.y});
-                    v2 = cmul(v2, {w2.x, w2.y});
-                    v3 = cmul(v3, {w3.x, w3.y});
-                }
-                cfloat a0 = cadd(v0, v2), a1 = csub(v0, v2), a2 = cadd(v1, v3), d = csub(v1, v3);
-                cfloat a3 = {d.im, -d.re};                    // -i * (v1 - v3)
-                const int j0 = ((j - k) << 2) + k;
-                dst[j0] = cadd(a0, a2);
-                dst[j0 + Ns] = cadd(a1, a3);
-                dst[j0 + 2 * Ns] = csub(a0, a2);
-                dst[j0 + 3 * Ns] = csub(a1, a3);
-                __syncthreads();
-                cfloat *tmp = src; src = dst; dst = tmp;
-            }
-            // result is in `src` (= bufB after 5 swaps)
-            for (int kk = tid; kk <= MEL_NFFT / 2; kk += 256) {
-                cfloat z = src[kk];
-                float mag = sqrtf(z.re * z.re + z.im * z.im);  // torchaudio: spec.abs().pow(2)
-                power[kk] = mag * mag;
-            }
-            __syncthreads();
-            for (int m = tid; m < n_mels; m += 256) {
-                float acc = 0.0f;
-                const int lo = band_lo[m], hi = band_hi[m];
-                for (int kk = lo; kk < hi; ++kk) acc = fmaf(fb[(size_t)kk * n_mels + m], power[kk], acc);
-                melbuf[m * (MEL_FR + 1) + fl] = acc;
-            }
-            __syncthreads();
+    cfloat *buf = fftbuf[wave];
+    float *power = powbuf[wave];
+    // The non-zero filter coefficients of every band, packed band after band in LDS once per workgroup: the band loop
+    // below read them from global memory with one dependent L2 round trip per bin and frame.  boff[m] = start of band m
+    // (exclusive prefix sum of the band widths, serial: n_mels is a few hundred); coef_cap floats are available.
+    float *coef = melbuf + n_mels * (MEL_FR + 1);
+    int *boff = reinterpret_cast<int *>(coef + coef_cap);
+    for (int i = tid; i < MEL_NFFT; i += 256) tw_s[i] = twiddle[i];
+    if (tid == 0) {
+        int acc = 0;
+        for (int m = 0; m < n_mels; ++m) { boff[m] = acc; acc += band_hi[m] - band_lo[m]; }
+        boff[n_mels] = acc;
+    }
+    __syncthreads();
+    const bool packed = boff[n_mels] <= coef_cap;              // block-uniform; otherwise the bands read fb directly
+    if (packed) {
+        for (int m = tid; m < n_mels; m += 256) {
+            const int lo = band_lo[m], hi = band_hi[m], o = boff[m];
+            for (int kk = lo; kk < hi; ++kk) coef[o + kk - lo] = fb[(size_t)kk * n_mels + m];
         }
     }
+    __syncthreads();
+
+    for (int fl = wave; fl < MEL_FR; fl += 4) {
+        const int t = tile0 + fl;
+        if (t >= n_frames) continue;                           // wave-uniform
+        // ---- windowed load, centre=True reflect padding (torch.stft), straight into registers: lane a computes the
+        //      butterflies j = a + 64 b (b = 0..3) of pass 0, whose inputs are samples j + 256 c ----
+        cfloat R[4][4];
+#pragma unroll
+        for (int bq = 0; bq < 4; ++bq)
+#pragma unroll
+            for (int cq = 0; cq < 4; ++cq) {
+                const int n = lane + 64 * bq + 256 * cq;
+                int sidx = t * hop + n - MEL_NFFT / 2;
+                if (sidx < 0) sidx = -sidx;
+                if (sidx >= N) sidx = 2 * (N - 1) - sidx;
+                sidx = sidx < 0 ? 0 : sidx;                    // clips shorter than n_fft/2 are rejected on the host
+                R[bq][cq].re = xp[sidx] * window[n];
+                R[bq][cq].im = 0.0f;
+            }
+        // One radix-4 Stockham butterfly of pass `pass` (Ns = 4^pass): inputs v[c] = src[j + 256 c], outputs o[r] =
+        // dst[j0 + r Ns].  The arithmetic (and so every bit of the result) does not depend on which lane runs it.
+        auto bfly = [&](int pass, int j, const cfloat (&vin)[4], cfloat (&o)[4]) {
+            const int Ns = 1 << (2 * pass);
+            const int k = j & (Ns - 1);
+            const int tw_step = k * (MEL_NFFT / (Ns * 4));
+            cfloat v0 = vin[0], v1 = vin[1], v2 = vin[2], v3 = vin[3];
+            if (pass > 0) {
+                float2 w1 = tw_s[tw_step], w2 = tw_s[2 * tw_step], w3 = tw_s[3 * tw_step];
+                v1 = cmul(v1, {w1.x, w1.y});
+                v2 = cmul(v2, {w2.x, w2.y});
+                v3 = cmul(v3, {w3.x, w3.y});
+            }
+            cfloat a0 = cadd(v0, v2), a1 = csub(v0, v2), a2 = cadd(v1, v3), d = csub(v1, v3);
+            cfloat a3 = {d.im, -d.re};                        // -i * (v1 - v3)
+            o[0] = cadd(a0, a2);
+            o[1] = cadd(a1, a3);
+            o[2] = csub(a0, a2);
+            o[3] = csub(a1, a3);
+        };
+        auto out_pos = [](int pass, int j, int r) {
+            const int Ns = 1 << (2 * pass), k = j & (Ns - 1);
+            return ((j - k) << 2) + k + r * Ns;
+        };
+        // The five passes run in THREE register stages.  A lane that computes butterflies a + 64 b of an even pass p
+        // holds exactly the inputs of four butterflies of pass p + 1 (positions j' + 256 c with j' = out_pos(p, a, r)),
+        // so passes (0,1) and (2,3) need no exchange between them; two LDS exchanges remain (was: five LDS round trips
+        // of the whole frame, the kernel's bottleneck), both with padded layouts that spread a half-wave over all banks.
+        cfloat O[4][4], P[4][4];
+        // -- passes 0 + 1
+#pragma unroll
+        for (int bq = 0; bq < 4; ++bq) bfly(0, lane + 64 * bq, R[bq], O[bq]);      // O[b][r] = position 4 a + 256 b + r
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const cfloat vin[4] = {O[0][r], O[1][r], O[2][r], O[3][r]};
+            bfly(1, 4 * lane + r, vin, P[r]);                                          // positions 16 a + r + 4 r'
+        }
+        // -- exchange 1: position q lives at q + (q >> 4)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int r2 = 0; r2 < 4; ++r2) {
+                const int q = out_pos(1, 4 * lane + r, r2);
+                buf[q + (q >> 4)] = P[r][r2];
+            }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int bq = 0; bq < 4; ++bq)
+#pragma unroll
+            for (int cq = 0; cq < 4; ++cq) {
+                const int q = lane + 64 * bq + 256 * cq;
+                R[bq][cq] = buf[q + (q >> 4)];
+            }
+        __builtin_amdgcn_wave_barrier();
+        // -- passes 2 + 3
+        const int k2 = lane & 15;
+#pragma unroll
+        for (int bq = 0; bq < 4; ++bq) bfly(2, lane + 64 * bq, R[bq], O[bq]);      // O[b][r] = position 4 (a - k2) + k2 + 16 r + 256 b
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const cfloat vin[4] = {O[0][r], O[1][r], O[2][r], O[3][r]};
+            bfly(3, 4 * (lane - k2) + k2 + 16 * r, vin, P[r]);
+        }
+        // -- exchange 2: position q lives at q + 16 (q >> 8)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int r2 = 0; r2 < 4; ++r2) {
+                const int q = out_pos(3, 4 * (lane - k2) + k2 + 16 * r, r2);
+                buf[q + 16 * (q >> 8)] = P[r][r2];
+            }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int bq = 0; bq < 4; ++bq)
+#pragma unroll
+            for (int cq = 0; cq < 4; ++cq) {
+                const int q = lane + 64 * bq + 256 * cq;
+                R[bq][cq] = buf[q + 16 * (q >> 8)];
+            }
+        __builtin_amdgcn_wave_barrier();
+        // -- pass 4: butterfly j = a + 64 b delivers bins j + 256 r; the power of bins 0..512 goes to LDS for the bands
+#pragma unroll
+        for (int bq = 0; bq < 4; ++bq) {
+            const int j = lane + 64 * bq;
+            bfly(4, j, R[bq], O[bq]);
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const int bin = j + 256 * r;
+                if (bin <= MEL_NFFT / 2) {
+                    const cfloat z = O[bq][r];
+                    const float mag = sqrtf(z.re * z.re + z.im * z.im);  // torchaudio: spec.abs().pow(2)
+                    power[bin] = mag * mag;
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int m = lane; m < n_mels; m += 64) {
+            float acc = 0.0f;
+            const int lo = band_lo[m], hi = band_hi[m];
+            if (packed) {
+                const float *cm = coef + boff[m] - lo;
+                for (int kk = lo; kk < hi; ++kk) acc = fmaf(cm[kk], power[kk], acc);
+            } else {
+                for (int kk = lo; kk < hi; ++kk) acc = fmaf(fb[(size_t)kk * n_mels + m], power[kk], acc);
+            }
+            melbuf[m * (MEL_FR + 1) + fl] = acc;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
     // ---- mask, clip, log, store (runs of MEL_FR frames per band) ----
     float *op = out + (size_t)plane * n_mels * out_pitch;
     for (int idx = tid; idx < n_mels * MEL_FR; idx += 256) {
@@ -131,9 +228,10 @@ MX_EXPORT int mx_logmel_fwd(const float *x, int64_t planes, int64_t N, const flo
         out_pitch < n_frames)
         return MX_ERR_UNSUPPORTED;
     const int tiles = (int)((out_pitch + MEL_FR - 1) / MEL_FR);
-    const size_t lds = (size_t)n_mels * (MEL_FR + 1) * sizeof(float);
+    const int coef_cap = 2 * (MEL_NFFT / 2 + 1) + 2 * (int)n_mels;      // triangular filters: every bin lies in <= 2 bands
+    const size_t lds = ((size_t)n_mels * (MEL_FR + 1) + coef_cap + n_mels + 1) * sizeof(float);
     hipLaunchKernelGGL(melspec_kernel, dim3(tiles, (unsigned)planes), dim3(256), lds, (hipStream_t)stream,
                        x, (int)N, window, (const float2 *)twiddle, fb, band_lo, band_hi, (int)n_mels, (int)hop,
-                       (int)n_frames, (int)out_pitch, eps, f0, f1, t0, t1, out);
+                       (int)n_frames, (int)out_pitch, eps, f0, f1, t0, t1, coef_cap, out);
     return mx_launch_status();
 }
