@@ -101,12 +101,6 @@ int mx_conv_pack_weights(const float *W, int64_t Cout, int64_t Cin, int32_t flip
  * f = PReLU(slope[c]) if slope != NULL else identity.  stats (B, C, 2). */
 int mx_plane_stats(const float *x, const float *slope, int64_t B, int64_t C, int64_t H, int64_t Wv,
                    float eps, float *stats, void *stream);
-/* The same statistics (models.py:186 LayerNorm of the PReLU output) from partial sums: part (planes, n_part, 2) =
- * {sum, sum of squares} of f(x) over pieces of each plane, as left by the forward convolution of the previous block
- * (stat_part of mx_conv_block_fwd_f16 / mx_conv_block1_fwd_f16: n_part = 4 * rows of the pooled plane); H x Wv = the
- * plane's valid extent.  Saves the sweep over the tensor. */
-int mx_plane_stats_finish(const float *part, int64_t planes, int64_t n_part, int64_t H, int64_t Wv, float eps,
-                          float *stats, void *stream);
 
 /* LayerNorm -> Conv2d(5x13, dilation (1,dilation), same) -> +bias -> MaxPool(2,1), fused.
  * in (B,Cin,H,352): log-mel (first_layer=1) or the previous block's pooled pre-activations (their
@@ -138,11 +132,9 @@ int mx_conv_prep_fwd_f16(const float *x, const float *stats, const float *slope,
 int mx_conv_prep_dgrad_f16(const float *G, const uint8_t *amax, int64_t B, int64_t H, int64_t Wv,
                            uint32_t *amax_ws, int32_t amax_ready, float *scale, void *dz_hi, void *dz_lo,
                            void *gp_hi, void *gp_lo, void *gidx, void *stream);
-/* slope_next, stat_part (both or NULL): slope (64,) of the PReLU that follows this block and (B,64,H/2,4,2) floats <-
- * per (plane, pooled row, wave) {sum, sum of squares} of PReLU(out): input of mx_plane_stats_finish. */
 int mx_conv_block_fwd_f16(const void *x_hi, const void *x_lo, const void *w_hi, const void *w_lo,
                           const float *bias, int64_t B, int64_t H, int64_t Wv, int32_t dilation, float *out,
-                          uint8_t *out_amax, const float *slope_next, float *stat_part, void *stream);
+                          uint8_t *out_amax, void *stream);
 int mx_conv_block_dgrad_f16(const void *dz_hi, const void *dz_lo, const void *w_hi, const void *w_lo,
                             const float *scale, int64_t B, int64_t H, int64_t Wv, int32_t dilation,
                             float *dxhat, void *stream);
@@ -154,8 +146,7 @@ int mx_conv_pack_weights_kvec_f16(const float *W, void *w_hi, void *w_lo, void *
 int mx_conv_prep_fwd_kvec_f16(const float *x, const float *stats, int64_t B, int64_t H, int64_t Wv, void *xk_hi,
                               void *xk_lo, void *stream);
 int mx_conv_block1_fwd_f16(const void *xk_hi, const void *xk_lo, const void *w_hi, const void *w_lo, const float *bias,
-                           int64_t B, int64_t H, int64_t Wv, float *out, uint8_t *out_amax, const float *slope_next,
-                           float *stat_part, void *stream);
+                           int64_t B, int64_t H, int64_t Wv, float *out, uint8_t *out_amax, void *stream);
 /* weight gradient of the first block from the same k-vector operand (torch Conv2d backward w.r.t. weight,
  * models.py:187).  G, amax (B,64,H/2,352): gradient w.r.t. the pooled output and the pooling argmax; amax_bits: bit
  * pattern of max|G| (mx_ln_prelu_bwd's gmax_bits); scale (2,) receives {S, 1/S}; part: workspace of

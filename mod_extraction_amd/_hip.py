@@ -31,17 +31,16 @@ SIGNATURES = {
                       _I32, _I32, _P, _P],
     "mx_conv_pack_weights": [_P, _I64, _I64, _I32, _P, _P],
     "mx_plane_stats": [_P, _P, _I64, _I64, _I64, _I64, _F32, _P, _P],
-    "mx_plane_stats_finish": [_P, _I64, _I64, _I64, _I64, _F32, _P, _P],
     "mx_conv_block_fwd": [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I32, _I32, _P, _P, _P],
     "mx_conv_block_dgrad": [_P, _P, _P, _I64, _I64, _I64, _I32, _P, _P],
     "mx_conv_pack_weights_f16": [_P, _I32, _P, _P, _P],
     "mx_conv_prep_fwd_f16": [_P, _P, _P, _I64, _I64, _I64, _P, _P, _P],
     "mx_conv_prep_dgrad_f16": [_P, _P, _I64, _I64, _I64, _P, _I32, _P, _P, _P, _P, _P, _P, _P],
-    "mx_conv_block_fwd_f16": [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I32, _P, _P, _P, _P, _P],
+    "mx_conv_block_fwd_f16": [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I32, _P, _P, _P],
     "mx_conv_block_dgrad_f16": [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I32, _P, _P],
     "mx_conv_pack_weights_kvec_f16": [_P, _P, _P, _P],
     "mx_conv_prep_fwd_kvec_f16": [_P, _P, _I64, _I64, _I64, _P, _P, _P],
-    "mx_conv_block1_fwd_f16": [_P, _P, _P, _P, _P, _I64, _I64, _I64, _P, _P, _P, _P, _P],
+    "mx_conv_block1_fwd_f16": [_P, _P, _P, _P, _P, _I64, _I64, _I64, _P, _P, _P],
     "mx_conv_prep_gpool_f16": [_P, _P, _P, _I64, _I64, _P, _P, _P, _P],
     "mx_conv_block_wgrad_sp_f16": [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I32, _I64, _P, _P, _P],
     "mx_conv_pack_weights_sp_f16": [_P, _P, _P, _P],

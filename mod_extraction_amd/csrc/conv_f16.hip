@@ -276,8 +276,6 @@ struct ConvF16Args {
     float *out;                    // forward: (B, 64, H/2, 352) pooled pre-activations; dgrad: (B, 64, H, 352)
     unsigned char *out_amax;       // forward
     int H, Wv;
-    const float *slope_next;       // forward, optional: slope (64,) of the PReLU that follows this block
-    float *stat_part;              // forward, optional: (B, 64, H/2, 4, 2) partial {sum, sum of squares} of PReLU(out) per wave
 };
 
 // Epilogue shared by the conv kernels.  Wave = (output row, column half c); accumulator layout
@@ -317,18 +315,6 @@ __device__ __forceinline__ void conv_f16_epilogue(floatx16 (&acc)[CV_WT], const 
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) bias_r[j][r] = a.bias[j * 32 + mfma_row(r, lane)];
-        // LayerNorm statistics of the NEXT block's input, PReLU(out), taken while the pooled values are in registers
-        // (stat_part: the separate sweep mx_plane_stats would make over the tensor just written is not needed):
-        // per lane, sum and sum of squares per (channel-half selector jf, row r); channel half = jf ^ c
-        float sl_r[2][16], s1a[2][16], s2a[2][16];
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                sl_r[j][r] = a.slope_next ? a.slope_next[j * 32 + mfma_row(r, lane)] : 1.0f;
-                s1a[j][r] = 0.0f;
-                s2a[j][r] = 0.0f;
-            }
         __syncthreads();                                              // the K loop's LDS images are dead
         if (row == 1) {
 #pragma unroll
@@ -355,38 +341,9 @@ __device__ __forceinline__ void conv_f16_epilogue(floatx16 (&acc)[CV_WT], const 
                 const bool take_bot = bot > top;                      // ties keep the first row (torch)
                 const float m = (take_bot ? bot : top) * inv + (chh ? bias_r[1][r] : bias_r[0][r]);
                 const size_t off = (((size_t)b * CV_CO + co) * Hp + hp) * CV_PITCH + w;
-                const float mv = w < a.Wv ? m : 0.0f;
-                a.out[off] = mv;
+                a.out[off] = w < a.Wv ? m : 0.0f;
                 a.out_amax[off] = take_bot ? 1 : 0;
-                const int jf = i == 10 ? 0 : (i & 1);
-                const float sl = chh ? sl_r[1][r] : sl_r[0][r];
-                const float tv = mv > 0.0f ? mv : sl * mv;
-                s1a[jf][r] += tv;
-                s2a[jf][r] += tv * tv;
             }
-        }
-        if (a.stat_part) {
-            // sum over the 32 positions held by the lanes of each half, fixed order, through wave-private LDS: lane
-            // (hh, l32) writes its 32 partials [q = jf*16 + r] as column l32, then sums row q = l32
-            __syncthreads();                                          // the exchange buffers are dead
-            const int wave = row * 2 + c, hh = lane >> 5;
-            float *red = reinterpret_cast<float *>(smem) + wave * (2 * 32 * 33) + hh * (32 * 33);
-            float tot[2];
-#pragma unroll
-            for (int kind = 0; kind < 2; ++kind) {
-#pragma unroll
-                for (int q = 0; q < 32; ++q) red[q * 33 + l32] = kind ? s2a[q >> 4][q & 15] : s1a[q >> 4][q & 15];
-                __builtin_amdgcn_s_waitcnt(0xc07f);
-                float t = 0.0f;
-#pragma unroll
-                for (int k = 0; k < 32; ++k) t += red[l32 * 33 + k];
-                tot[kind] = t;
-                __builtin_amdgcn_s_waitcnt(0xc07f);
-            }
-            const int jf = l32 >> 4, r = l32 & 15;
-            const int co = (jf ^ c) * 32 + mfma_row(r, lane);
-            typedef float floatx2 __attribute__((ext_vector_type(2)));
-            *reinterpret_cast<floatx2 *>(a.stat_part + ((((size_t)b * CV_CO + co) * Hp + hp) * 4 + wave) * 2) = floatx2{tot[0], tot[1]};
         }
     }
 }
@@ -882,17 +839,14 @@ MX_EXPORT int mx_conv_prep_dgrad_f16(const float *G, const uint8_t *amax, int64_
 }
 
 // forward conv (64 -> 64 channels, dilation in {1,2,4}) from prepared operands
-// slope_next, stat_part (both or none): slope (64,) of the PReLU that follows the block and (B,64,H/2,4,2) partial
-// {sum, sum of squares} of PReLU(out) for mx_plane_stats_finish -- the LayerNorm statistics of the next block's input
 MX_EXPORT int mx_conv_block_fwd_f16(const void *x_hi, const void *x_lo, const void *w_hi, const void *w_lo,
                                     const float *bias, int64_t B, int64_t H, int64_t Wv, int32_t dilation, float *out,
-                                    uint8_t *out_amax, const float *slope_next, float *stat_part, void *stream)
+                                    uint8_t *out_amax, void *stream)
 {
     if (!x_hi || !x_lo || !w_hi || !w_lo || !bias || !out || !out_amax) return MX_ERR_ARG;
-    if ((slope_next == nullptr) != (stat_part == nullptr)) return MX_ERR_ARG;
     if (B <= 0 || B > 65535 || H < 2 || (H & 1) || Wv <= 0 || Wv > CV_PITCH) return MX_ERR_UNSUPPORTED;
     ConvF16Args a{(const _Float16 *)x_hi, (const _Float16 *)x_lo, (const _Float16 *)w_hi, (const _Float16 *)w_lo, bias,
-                  nullptr, out, out_amax, (int)H, (int)Wv, slope_next, stat_part};
+                  nullptr, out, out_amax, (int)H, (int)Wv};
     return dispatch_f16(dilation, 0, a, (int)B, (hipStream_t)stream);
 }
 
@@ -904,7 +858,7 @@ MX_EXPORT int mx_conv_block_dgrad_f16(const void *dz_hi, const void *dz_lo, cons
     if (!dz_hi || !dz_lo || !w_hi || !w_lo || !scale || !dxhat) return MX_ERR_ARG;
     if (B <= 0 || B > 65535 || H < 2 || (H & 1) || Wv <= 0 || Wv > CV_PITCH) return MX_ERR_UNSUPPORTED;
     ConvF16Args a{(const _Float16 *)dz_hi, (const _Float16 *)dz_lo, (const _Float16 *)w_hi, (const _Float16 *)w_lo,
-                  nullptr, scale, dxhat, nullptr, (int)H, (int)Wv, nullptr, nullptr};
+                  nullptr, scale, dxhat, nullptr, (int)H, (int)Wv};
     return dispatch_f16(dilation, 1, a, (int)B, (hipStream_t)stream);
 }
 
@@ -933,12 +887,11 @@ MX_EXPORT int mx_conv_prep_fwd_kvec_f16(const float *x, const float *stats, int6
 // forward conv of the first block (2 -> 64 channels, dilation 1) + bias + max-pool from the k-vector operand
 MX_EXPORT int mx_conv_block1_fwd_f16(const void *xk_hi, const void *xk_lo, const void *w_hi, const void *w_lo,
                                      const float *bias, int64_t B, int64_t H, int64_t Wv, float *out, uint8_t *out_amax,
-                                     const float *slope_next, float *stat_part, void *stream)
+                                     void *stream)
 {
     if (!xk_hi || !xk_lo || !w_hi || !w_lo || !bias || !out || !out_amax) return MX_ERR_ARG;
-    if ((slope_next == nullptr) != (stat_part == nullptr)) return MX_ERR_ARG;
     if (B <= 0 || B > 65535 || H < 2 || (H & 1) || Wv <= 0 || Wv > CV_PITCH) return MX_ERR_UNSUPPORTED;
     ConvF16Args a{(const _Float16 *)xk_hi, (const _Float16 *)xk_lo, (const _Float16 *)w_hi, (const _Float16 *)w_lo, bias,
-                  nullptr, out, out_amax, (int)H, (int)Wv, slope_next, stat_part};
+                  nullptr, out, out_amax, (int)H, (int)Wv};
     return launch_f16_dma<1, 0, 1, 1>(a, (int)B, (hipStream_t)stream);
 }

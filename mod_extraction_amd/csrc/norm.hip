@@ -79,41 +79,6 @@ MX_EXPORT int mx_plane_stats(const float *x, const float *slope, int64_t B, int6
     return mx_launch_status();
 }
 
-// stats[plane] = (mean, rstd) from n_part partial {sum, sum of squares} pairs per plane (left by the forward convolution's
-// epilogue, mx_conv_block_fwd_f16 / mx_conv_block1_fwd_f16): same result as mx_plane_stats on the tensor itself up to the
-// summation order (fp32 within a partial, fp64 across partials).
-__global__ __launch_bounds__(64) void plane_stats_finish_kernel(const float *__restrict__ part, int n_part, double n_valid,
-                                                                float eps, float *__restrict__ stats)
-{
-    __shared__ double sh[2];
-    typedef float floatx2 __attribute__((ext_vector_type(2)));
-    const int plane = blockIdx.x;
-    const floatx2 *pp = reinterpret_cast<const floatx2 *>(part) + (size_t)plane * n_part;
-    double s = 0.0, ss = 0.0;
-    for (int i = threadIdx.x; i < n_part; i += 64) {
-        const floatx2 v = pp[i];
-        s += (double)v[0];
-        ss += (double)v[1];
-    }
-    block_sum2(s, ss, sh);
-    if (threadIdx.x == 0) {
-        const double mean = s / n_valid;
-        double var = ss / n_valid - mean * mean;
-        var = var > 0.0 ? var : 0.0;
-        stats[plane * 2] = (float)mean;
-        stats[plane * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
-    }
-}
-
-MX_EXPORT int mx_plane_stats_finish(const float *part, int64_t planes, int64_t n_part, int64_t H, int64_t Wv, float eps,
-                                    float *stats, void *stream)
-{
-    if (!part || !stats || planes <= 0 || n_part <= 0 || H <= 0 || Wv <= 0) return MX_ERR_ARG;
-    hipLaunchKernelGGL(plane_stats_finish_kernel, dim3((unsigned)planes), dim3(64), 0, (hipStream_t)stream, part, (int)n_part,
-                       (double)H * (double)Wv, eps, stats);
-    return mx_launch_status();
-}
-
 // LayerNorm backward fused with the backward of the PReLU in front of it.
 //   p      (B,C,H,352): pooled pre-activations of the previous block (input of PReLU)
 //   dxhat  (B,C,H,352): gradient w.r.t. the normalised tensor (from mx_conv_block_dgrad); overwritten

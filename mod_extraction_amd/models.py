@@ -131,7 +131,6 @@ BLOCK1_F16 = os.environ.get("MODEX_BLOCK1", "f16x3") != "f32"
 WGRAD_SPARSE = os.environ.get("MODEX_WGRAD", "sparse") != "dense"
 WGRAD_SPARSE_MAX_T = int(os.environ.get("MODEX_WGRAD_SP_MAXT", "4"))     # dilations above it: dense kernel (no shared fragment blocks)
 DGRAD_SPARSE = os.environ.get("MODEX_DGRAD", "sparse") != "dense"
-STATS_FUSED = os.environ.get("MODEX_STATS", "fused") != "sweep"   # LayerNorm statistics from the forward convolution's epilogue
 LN_FUSED = os.environ.get("MODEX_LN", "fused") != "sweep"      # LayerNorm-backward statistics from the data-gradient epilogue
 
 
@@ -161,20 +160,11 @@ class _CNNStack(torch.autograd.Function):
         # will follow (5.9 GB at 256 clips x 2 s: cheaper than re-deriving them from the saved activations)
         keep_splits = any(ctx.needs_input_grad)
         ctx.splits = {}
-        stat_part = None                 # LayerNorm statistics of `cur` as partial sums from the convolution that wrote it
         for l in range(n_blocks):
             w, b, a = params[3 * l], params[3 * l + 1], params[3 * l + 2]
             stats = torch.empty((B, cin, 2), device=dev, dtype=torch.float32)
-            if stat_part is not None:
-                _hip.call("mx_plane_stats_finish", _hip.ptr(stat_part), B * cin, stat_part.size(2) * 4, H, n_frames, LN_EPS,
-                          _hip.ptr(stats), st)
-            else:
-                _hip.call("mx_plane_stats", _hip.ptr(cur), _hip.ptr(slope), B, cin, H, n_frames, LN_EPS,
-                          _hip.ptr(stats), st)
-            stat_part = None
-            # the f16x3 forward kernels leave the statistics of THEIR output for the next block (not after the last one)
-            want_part = STATS_FUSED and l + 1 < n_blocks
-            slope_next = a.contiguous() if want_part else None
+            _hip.call("mx_plane_stats", _hip.ptr(cur), _hip.ptr(slope), B, cin, H, n_frames, LN_EPS,
+                      _hip.ptr(stats), st)
             p = torch.empty((B, 64, H // 2, PITCH), device=dev, dtype=torch.float32)
             amax = torch.empty((B, 64, H // 2, PITCH), device=dev, dtype=torch.uint8)
             if _use_f16(cin, precision):
@@ -183,11 +173,8 @@ class _CNNStack(torch.autograd.Function):
                 _hip.call("mx_conv_prep_fwd_f16", _hip.ptr(cur), _hip.ptr(stats), _hip.ptr(slope), B, H, n_frames,
                           _hip.ptr(x_hi), _hip.ptr(x_lo), st)
                 w_hi, w_lo = _pack_f16(w, 0)
-                if want_part:
-                    stat_part = torch.empty((B, 64, H // 2, 4, 2), device=dev, dtype=torch.float32)
                 _hip.call("mx_conv_block_fwd_f16", _hip.ptr(x_hi), _hip.ptr(x_lo), _hip.ptr(w_hi), _hip.ptr(w_lo),
-                          _hip.ptr(b.contiguous()), B, H, n_frames, int(dilations[l]), _hip.ptr(p), _hip.ptr(amax),
-                          _hip.ptr(slope_next if want_part else None), _hip.ptr(stat_part), st)
+                          _hip.ptr(b.contiguous()), B, H, n_frames, int(dilations[l]), _hip.ptr(p), _hip.ptr(amax), st)
                 if keep_splits:
                     ctx.splits[l] = (x_hi, x_lo)
                 del x_hi, x_lo
@@ -201,11 +188,8 @@ class _CNNStack(torch.autograd.Function):
                 wk_lo = torch.empty(13 * 2 * 64 * 8, device=dev, dtype=torch.float16)
                 _hip.call("mx_conv_pack_weights_kvec_f16", _hip.ptr(w.detach().contiguous()), _hip.ptr(wk_hi),
                           _hip.ptr(wk_lo), st)
-                if want_part:
-                    stat_part = torch.empty((B, 64, H // 2, 4, 2), device=dev, dtype=torch.float32)
                 _hip.call("mx_conv_block1_fwd_f16", _hip.ptr(xk_hi), _hip.ptr(xk_lo), _hip.ptr(wk_hi), _hip.ptr(wk_lo),
-                          _hip.ptr(b.contiguous()), B, H, n_frames, _hip.ptr(p), _hip.ptr(amax),
-                          _hip.ptr(slope_next if want_part else None), _hip.ptr(stat_part), st)
+                          _hip.ptr(b.contiguous()), B, H, n_frames, _hip.ptr(p), _hip.ptr(amax), st)
                 if keep_splits:
                     ctx.splits[l] = (xk_hi, xk_lo)              # the weight gradient consumes the same operand
                 del xk_hi, xk_lo

@@ -130,21 +130,8 @@ def test_block_f16x3_kernels(dev, T, W, H):
     p = torch.empty((B, 64, H // 2, PITCH), device=dev)
     amax = torch.empty((B, 64, H // 2, PITCH), device=dev, dtype=torch.uint8)
     _hip.call("mx_conv_block_fwd_f16", _hip.ptr(x_hi), _hip.ptr(x_lo), _hip.ptr(w_hi), _hip.ptr(w_lo),
-              _hip.ptr(b.detach().to(dev)), B, H, W, T, _hip.ptr(p), _hip.ptr(amax), None, None, st)
+              _hip.ptr(b.detach().to(dev)), B, H, W, T, _hip.ptr(p), _hip.ptr(amax), st)
     assert rel(p.cpu()[..., :W], p_r.detach()) < 1e-5
-    # the same launch also leaves the LayerNorm statistics of PReLU(p) for the next block: identical p / argmax, and
-    # mx_plane_stats_finish on the partial sums == mx_plane_stats on p (fp32 partials: 1e-6)
-    sl_next = (torch.rand(64) * 0.4 + 0.05).to(dev)
-    p2, amax2 = torch.empty_like(p), torch.empty_like(amax)
-    spart = torch.full((B, 64, H // 2, 4, 2), float("nan"), device=dev)
-    _hip.call("mx_conv_block_fwd_f16", _hip.ptr(x_hi), _hip.ptr(x_lo), _hip.ptr(w_hi), _hip.ptr(w_lo),
-              _hip.ptr(b.detach().to(dev)), B, H, W, T, _hip.ptr(p2), _hip.ptr(amax2), _hip.ptr(sl_next), _hip.ptr(spart), st)
-    assert torch.equal(p2, p) and torch.equal(amax2, amax) and bool(torch.isfinite(spart).all())
-    st_a, st_b = torch.empty((B, 64, 2), device=dev), torch.empty((B, 64, 2), device=dev)
-    _hip.call("mx_plane_stats", _hip.ptr(p), _hip.ptr(sl_next), B, 64, H // 2, W, 1e-5, _hip.ptr(st_a), st)
-    _hip.call("mx_plane_stats_finish", _hip.ptr(spart), B * 64, (H // 2) * 4, H // 2, W, 1e-5, _hip.ptr(st_b), st)
-    assert float((st_b[..., 0] - st_a[..., 0]).abs().max()) < 1e-6 * float(p.abs().max())
-    assert float(((st_b[..., 1] - st_a[..., 1]) / st_a[..., 1]).abs().max()) < 2e-6
     am_r = (z_r[:, :, 1::2] > z_r[:, :, 0::2]).to(torch.uint8)
     assert float((amax.cpu()[..., :W] != am_r).float().mean()) < 1e-4          # ties aside, the same argmax
     # gradient operand from the REFERENCE's argmax, so that all gradients below are comparable element by element
