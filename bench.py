@@ -161,8 +161,6 @@ def main():
             return f"2x{a[6]}"
         if name == "mx_conv_block_wgrad_sp_f16":
             return f"64x{a[7]}"          # (.., scale, B, H, Wv, ..)
-        if name == "mx_conv_prep_gpool_f16":
-            return f"64x{a[4]}"
         if name == "mx_conv_block_dgrad_sp_f16":
             return f"64x{a[7]}"
         if name == "mx_conv_prep_gpool_cl_f16":
@@ -176,7 +174,7 @@ def main():
     with _hip.KernelTimer({"mx_conv_block_fwd", "mx_conv_block_dgrad", "mx_conv_block_wgrad",
                            "mx_conv_block_fwd_f16", "mx_conv_block_dgrad_f16", "mx_conv_block_wgrad_f16",
                            "mx_conv_block1_fwd_f16", "mx_conv_block1_wgrad_f16", "mx_conv_block_wgrad_sp_f16",
-                           "mx_conv_prep_gpool_f16", "mx_conv_block_dgrad_sp_f16", "mx_conv_prep_gpool_cl_f16"}, key) as kt:
+                           "mx_conv_block_dgrad_sp_f16", "mx_conv_prep_gpool_cl_f16"}, key) as kt:
         for _ in range(args.steps):
             loss = step()
     fence()

@@ -123,15 +123,14 @@ int mx_conv_block_dgrad(const float *G, const uint8_t *amax, const float *wt_fli
  *   x_hi, x_lo : (B, H, 4, 352, 16) halfs (channel-block major): forward = split of (prelu(x) - mean) * rstd;
  *                dgrad = split of the max-pool routed gradient * S_dz, S_dz = 2^k chosen from max|G|
  *                (scale (2,) device floats receives {S_dz, 1/S_dz}; amax_ws = one uint32 workspace, or with
- *                amax_ready != 0 the bits of max|G| left there by mx_ln_prelu_bwd).
- *                mx_conv_prep_dgrad_f16's gp_hi / gp_lo / gidx (all three or NULL): by-product operand of the
- *                sparse weight-gradient kernel below (= mx_conv_prep_gpool_f16 without a second pass over G). */
+ *                amax_ready != 0 the bits of max|G| left there by mx_ln_prelu_bwd).  dz_hi = dz_lo = NULL: only the
+ *                scale pair is produced (the sparse kernels below take the POOLED operand instead). */
 int mx_conv_pack_weights_f16(const float *W, int32_t flip, void *w_hi, void *w_lo, void *stream);
 int mx_conv_prep_fwd_f16(const float *x, const float *stats, const float *slope, int64_t B, int64_t H,
                          int64_t Wv, void *x_hi, void *x_lo, void *stream);
 int mx_conv_prep_dgrad_f16(const float *G, const uint8_t *amax, int64_t B, int64_t H, int64_t Wv,
                            uint32_t *amax_ws, int32_t amax_ready, float *scale, void *dz_hi, void *dz_lo,
-                           void *gp_hi, void *gp_lo, void *gidx, void *stream);
+                           void *stream);
 int mx_conv_block_fwd_f16(const void *x_hi, const void *x_lo, const void *w_hi, const void *w_lo,
                           const float *bias, int64_t B, int64_t H, int64_t Wv, int32_t dilation, float *out,
                           uint8_t *out_amax, void *stream);
@@ -172,13 +171,12 @@ int mx_conv_block_wgrad(const float *G, const uint8_t *amax, const float *x, con
  * (position, row of the pooling pair) the routed gradient is 2:4 structured sparse -- its compressed form is the pooled
  * gradient G itself, its index bits are the pooling argmax -- so one instruction covers both rows of a pooling pair
  * (half the matrix instructions of mx_conv_block_wgrad_f16; identical results up to fp32 summation order).
- * mx_conv_prep_gpool_f16: G, amax (B,64,H/2,352), scale = {S, 1/S} of mx_conv_prep_dgrad_f16 -> gp_hi, gp_lo
- * (B,64,H/2,352) halfs = split of G * S, gidx (B,64,H/2,22,2) uint16 index words.  rows_per_slab counts POOLED rows;
+ * g_hi, g_lo (B,H/2,4,352,16) halfs = the channels-last split of G * S and gidx (B,64,H/2,22,2) uint16 index words, both
+ * from mx_conv_prep_gpool_cl_f16 below (the pair is the operand of the sparse data gradient as well; its [position]
+ * [channel] rows become the A fragments through transposing LDS reads).  rows_per_slab counts POOLED rows;
  * Wv <= 351 (MX_ERR_UNSUPPORTED otherwise: the zero pad column of the x operand is the kernel's halo source);
  * part: ceil(B*(H/2)/rows_per_slab)*65*64*64 floats. */
-int mx_conv_prep_gpool_f16(const float *G, const uint8_t *amax, const float *scale, int64_t B, int64_t H, void *gp_hi,
-                           void *gp_lo, void *gidx, void *stream);
-int mx_conv_block_wgrad_sp_f16(const void *gp_hi, const void *gp_lo, const void *gidx, const void *x_hi, const void *x_lo,
+int mx_conv_block_wgrad_sp_f16(const void *g_hi, const void *g_lo, const void *gidx, const void *x_hi, const void *x_lo,
                                const float *scale, int64_t B, int64_t H, int64_t Wv, int32_t dilation,
                                int64_t rows_per_slab, float *part, float *dW, void *stream);
 
@@ -188,9 +186,9 @@ int mx_conv_block_wgrad_sp_f16(const void *gp_hi, const void *gp_lo, const void 
  * from global memory; 12 K stages instead of 20.  Same results as mx_conv_block_dgrad_f16 up to summation order.
  *   mx_conv_pack_weights_sp_f16: W (64,64,5,13) -> w_hi, w_lo: 4*3*2*13*2*64*16 halfs each
  *   mx_conv_prep_gpool_cl_f16: G, amax (B,64,H/2,352), scale {S, 1/S} -> g_hi, g_lo (B,H/2,4,352,16) halfs,
- *                              g_idx (B,H/2,4,352) uint32 index words; gp_hi / gp_lo / gidx (all or NULL): the planar
- *                              operand of mx_conv_block_wgrad_sp_f16 from the same pass (mx_conv_prep_dgrad_f16 with
- *                              dz_hi = dz_lo = NULL then only computes the scale pair)
+ *                              g_idx (B,H/2,4,352) uint32 index words of the data gradient; gidx (or NULL):
+ *                              (B,64,H/2,22,2) uint16 index words of mx_conv_block_wgrad_sp_f16 from the same pass
+ *                              (mx_conv_prep_dgrad_f16 with dz_hi = dz_lo = NULL then only computes the scale pair)
  *   mx_conv_block_dgrad_sp_f16: dxhat (B,64,H,352); Wv <= 351 (zero pad column = halo source).  x_hi, x_lo, ln_part
  *                              (all or NULL): the block's forward operand pair (B,H,4,352,16) = the normalised input
  *                              xhat, and ln_part (B,64,H,2,2) floats <- {sum dxhat, sum dxhat * xhat} per (plane, row,
@@ -198,7 +196,7 @@ int mx_conv_block_wgrad_sp_f16(const void *gp_hi, const void *gp_lo, const void 
  *                              in registers instead of by a sweep over dxhat and p */
 int mx_conv_pack_weights_sp_f16(const float *W, void *w_hi, void *w_lo, void *stream);
 int mx_conv_prep_gpool_cl_f16(const float *G, const uint8_t *amax, const float *scale, int64_t B, int64_t H, int64_t Wv,
-                              void *g_hi, void *g_lo, void *g_idx, void *gp_hi, void *gp_lo, void *gidx, void *stream);
+                              void *g_hi, void *g_lo, void *g_idx, void *gidx, void *stream);
 int mx_conv_block_dgrad_sp_f16(const void *g_hi, const void *g_lo, const void *g_idx, const void *w_hi, const void *w_lo,
                                const float *scale, int64_t B, int64_t H, int64_t Wv, int32_t dilation, float *dxhat,
                                const void *x_hi, const void *x_lo, float *ln_part, void *stream);

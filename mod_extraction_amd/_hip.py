@@ -35,16 +35,15 @@ SIGNATURES = {
     "mx_conv_block_dgrad": [_P, _P, _P, _I64, _I64, _I64, _I32, _P, _P],
     "mx_conv_pack_weights_f16": [_P, _I32, _P, _P, _P],
     "mx_conv_prep_fwd_f16": [_P, _P, _P, _I64, _I64, _I64, _P, _P, _P],
-    "mx_conv_prep_dgrad_f16": [_P, _P, _I64, _I64, _I64, _P, _I32, _P, _P, _P, _P, _P, _P, _P],
+    "mx_conv_prep_dgrad_f16": [_P, _P, _I64, _I64, _I64, _P, _I32, _P, _P, _P, _P],
     "mx_conv_block_fwd_f16": [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I32, _P, _P, _P],
     "mx_conv_block_dgrad_f16": [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I32, _P, _P],
     "mx_conv_pack_weights_kvec_f16": [_P, _P, _P, _P],
     "mx_conv_prep_fwd_kvec_f16": [_P, _P, _I64, _I64, _I64, _P, _P, _P],
     "mx_conv_block1_fwd_f16": [_P, _P, _P, _P, _P, _I64, _I64, _I64, _P, _P, _P],
-    "mx_conv_prep_gpool_f16": [_P, _P, _P, _I64, _I64, _P, _P, _P, _P],
     "mx_conv_block_wgrad_sp_f16": [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I32, _I64, _P, _P, _P],
     "mx_conv_pack_weights_sp_f16": [_P, _P, _P, _P],
-    "mx_conv_prep_gpool_cl_f16": [_P, _P, _P, _I64, _I64, _I64, _P, _P, _P, _P, _P, _P, _P],
+    "mx_conv_prep_gpool_cl_f16": [_P, _P, _P, _I64, _I64, _I64, _P, _P, _P, _P, _P],
     "mx_conv_block_dgrad_sp_f16": [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I32, _P, _P, _P, _P, _P],
     "mx_conv_block1_wgrad_f16": [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _P, _P, _P, _P],
     "mx_conv_block_wgrad_f16": [_P, _P, _P, _P, _P, _I64, _I64, _I32, _I64, _P, _P, _P],

@@ -123,10 +123,7 @@ __global__ __launch_bounds__(256) void split_prep_kernel(const float *__restrict
                                                          const float *__restrict__ stats,
                                                          const float *__restrict__ slope,
                                                          const float *__restrict__ scale, int H, int Wv,
-                                                         _Float16 *__restrict__ out_hi, _Float16 *__restrict__ out_lo,
-                                                         _Float16 *__restrict__ gp_hi = nullptr,
-                                                         _Float16 *__restrict__ gp_lo = nullptr,
-                                                         unsigned char *__restrict__ gidx = nullptr)
+                                                         _Float16 *__restrict__ out_hi, _Float16 *__restrict__ out_lo)
 {
     __shared__ float tile[64][33];
     const int wt = blockIdx.x, h = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
@@ -140,25 +137,6 @@ __global__ __launch_bounds__(256) void split_prep_kernel(const float *__restrict
         if (MODE == 1) {
             const uchar4 am = *reinterpret_cast<const uchar4 *>(amax + off);
             const unsigned want = (unsigned)(h & 1);
-            if (gp_hi && want == 0) {
-                // by-product for the sparse weight-gradient kernel (wgrad_sp_f16.hip), once per pooling pair: the UNROUTED
-                // gradient pair at pooled resolution and this thread's byte of the index word (4 positions x 2 bits:
-                // field = 2 (position & 1) + argmax); (k-step, lane half, word byte) = (c4 >> 2, c4 & 1, (c4 >> 1) & 1)
-                typedef _Float16 half4_ __attribute__((ext_vector_type(4)));
-                half4_ ghi, glo;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float gs = v[e] * S;
-                    const _Float16 hh = (_Float16)gs;
-                    ghi[e] = hh;
-                    glo[e] = (_Float16)(gs - (float)hh);
-                }
-                *reinterpret_cast<half4_ *>(gp_hi + off) = ghi;
-                *reinterpret_cast<half4_ *>(gp_lo + off) = glo;
-                const unsigned byte = (am.x & 1u) | ((2u + (am.y & 1u)) << 2) | ((am.z & 1u) << 4) | ((2u + (am.w & 1u)) << 6);
-                const int ks = wt * 2 + (c4 >> 2);
-                gidx[(((((size_t)b * 64 + c) * Hin + hin) * 22 + ks) * 2 + (c4 & 1)) * 2 + ((c4 >> 1) & 1)] = (unsigned char)byte;
-            }
             v[0] = am.x == want ? v[0] * S : 0.0f;
             v[1] = am.y == want ? v[1] * S : 0.0f;
             v[2] = am.z == want ? v[2] * S : 0.0f;
@@ -813,12 +791,12 @@ MX_EXPORT int mx_conv_prep_fwd_f16(const float *x, const float *stats, const flo
 
 // dgrad operand: G, amax (B,64,H/2,352) -> dz_hi, dz_lo (B,H,4,352,16) fp16 = split of routed G * S_dz;
 // scale (2,) device floats receives {S_dz, 1/S_dz} (S_dz = power of two from max|G|); amax_ws: 1 uint workspace,
-// or -- amax_ready != 0 -- the bit pattern of max|G| that the producer of G already left there;
-// gp_hi, gp_lo, gidx (all or none, NULL = skip): the operand of the sparse weight-gradient kernel as a by-product
-// (what mx_conv_prep_gpool_f16 computes; saves re-reading G and amax)
+// or -- amax_ready != 0 -- the bit pattern of max|G| that the producer of G already left there.
+// dz_hi = dz_lo = NULL: only the scale pair is produced (the sparse kernels take the pooled operand of
+// mx_conv_prep_gpool_cl_f16 instead of the routed one).
 MX_EXPORT int mx_conv_prep_dgrad_f16(const float *G, const uint8_t *amax, int64_t B, int64_t H, int64_t Wv,
                                      uint32_t *amax_ws, int32_t amax_ready, float *scale, void *dz_hi, void *dz_lo,
-                                     void *gp_hi, void *gp_lo, void *gidx, void *stream)
+                                     void *stream)
 {
     if (!G || !amax || !amax_ws || !scale || B <= 0 || H < 2 || (H & 1) || Wv <= 0 || Wv > CV_PITCH) return MX_ERR_ARG;
     if ((dz_hi == nullptr) != (dz_lo == nullptr)) return MX_ERR_ARG;      // both NULL: only the scale pair is produced
@@ -830,11 +808,9 @@ MX_EXPORT int mx_conv_prep_dgrad_f16(const float *G, const uint8_t *amax, int64_
         hipLaunchKernelGGL(absmax_kernel, dim3(2048), dim3(256), 0, st, G, n4, amax_ws);
     }
     hipLaunchKernelGGL(pow2_scale_kernel, dim3(1), dim3(1), 0, st, amax_ws, scale);
-    if ((gp_hi || gp_lo || gidx) && !(gp_hi && gp_lo && gidx)) return MX_ERR_ARG;     // all three by-products or none
     if (!dz_hi) return mx_launch_status();
     hipLaunchKernelGGL((split_prep_kernel<1>), dim3(CV_PITCH / 32, (unsigned)H, (unsigned)B), dim3(256), 0, st, G, amax,
-                       nullptr, nullptr, scale, (int)H, (int)Wv, (_Float16 *)dz_hi, (_Float16 *)dz_lo, (_Float16 *)gp_hi,
-                       (_Float16 *)gp_lo, (unsigned char *)gidx);
+                       nullptr, nullptr, scale, (int)H, (int)Wv, (_Float16 *)dz_hi, (_Float16 *)dz_lo);
     return mx_launch_status();
 }
 

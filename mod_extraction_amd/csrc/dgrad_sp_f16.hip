@@ -335,8 +335,7 @@ __global__ void pack_weights_sp_f16_kernel(const float *__restrict__ W, _Float16
 __global__ __launch_bounds__(256) void gpool_cl_prep_kernel(const float *__restrict__ G, const unsigned char *__restrict__ amax,
                                                             const float *__restrict__ scale, int Hp, int Wv,
                                                             _Float16 *__restrict__ g_hi, _Float16 *__restrict__ g_lo,
-                                                            unsigned *__restrict__ g_idx, _Float16 *__restrict__ gp_hi,
-                                                            _Float16 *__restrict__ gp_lo, unsigned char *__restrict__ gidx)
+                                                            unsigned *__restrict__ g_idx, unsigned char *__restrict__ gidx)
 {
     __shared__ float tile[64][GP_TW + 1];
     __shared__ unsigned char tam[64][GP_TW + 4];
@@ -356,35 +355,20 @@ __global__ __launch_bounds__(256) void gpool_cl_prep_kernel(const float *__restr
 #pragma unroll
     for (int k = 0; k < NIT; ++k) {
         const int i = tid + 256 * k, ch = i / (GP_TW / 4), c4 = i % (GP_TW / 4), w0 = wt * GP_TW + c4 * 4;
-        const bool in_row = w0 < CV_PITCH;
         const floatx4 v = gv[k];
         const uchar4 am = av[k];
 #pragma unroll
         for (int e = 0; e < 4; ++e) tile[ch][c4 * 4 + e] = (w0 + e < Wv) ? v[e] * S : 0.0f;
         tam[ch][c4 * 4 + 0] = am.x & 1; tam[ch][c4 * 4 + 1] = am.y & 1; tam[ch][c4 * 4 + 2] = am.z & 1; tam[ch][c4 * 4 + 3] = am.w & 1;
-        if (gp_hi) {
-            // the planar operand of the sparse WEIGHT-gradient kernel from the same pass (wgrad_sp_f16.hip: the pair at
-            // pooled resolution + this thread's byte of the index words: (k-step, lane half, word byte) =
-            // (4 wt + (c4 >> 2), c4 & 1, (c4 >> 1) & 1))
-            half4 ghi, glo;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float gs = v[e] * S;
-                const _Float16 hv = (_Float16)gs;
-                ghi[e] = hv;
-                glo[e] = (_Float16)(gs - (float)hv);
-            }
-            if (in_row) {
-                const size_t off = (((size_t)b * 64 + ch) * Hp + hp) * CV_PITCH + w0;
-                *reinterpret_cast<half4 *>(gp_hi + off) = ghi;
-                *reinterpret_cast<half4 *>(gp_lo + off) = glo;
-            }
+        if (gidx) {
+            // this thread's byte of the PLANAR index words of the sparse weight-gradient kernel (wgrad_sp_f16.hip; the
+            // pair itself is shared): (k-step, lane half, word byte) = (4 wt + (c4 >> 2), c4 & 1, (c4 >> 1) & 1)
             const unsigned byte = (am.x & 1u) | ((2u + (am.y & 1u)) << 2) | ((am.z & 1u) << 4) | ((2u + (am.w & 1u)) << 6);
             idxb[ch][(((c4 >> 2) * 2 + (c4 & 1)) * 2) + ((c4 >> 1) & 1)] = (unsigned char)byte;   // gathered, stored 8 at a time below
         }
     }
     __syncthreads();
-    if (gp_hi && tid < 128) {       // per channel and k-step pair: 2 k-steps x 2 lane halves x 2 bytes = 8 contiguous bytes of gidx
+    if (gidx && tid < 128) {       // per channel and k-step pair: 2 k-steps x 2 lane halves x 2 bytes = 8 contiguous bytes of gidx
         const int ch = tid >> 1, pr = tid & 1, ks0 = wt * (GP_TW / 16) + pr * 2;
         if (ks0 < 22)
             *reinterpret_cast<unsigned long long *>(gidx + ((((size_t)b * 64 + ch) * Hp + hp) * 22 + ks0) * 4) =
@@ -449,19 +433,18 @@ MX_EXPORT int mx_conv_pack_weights_sp_f16(const float *W, void *w_hi, void *w_lo
     return mx_launch_status();
 }
 
-// G, amax: (B,64,H/2,352); scale: the {S, 1/S} pair -> g_hi, g_lo (B,H/2,4,352,16) halfs, g_idx (B,H/2,4,352) uint32;
-// gp_hi, gp_lo, gidx (all or none): the planar operand of mx_conv_block_wgrad_sp_f16 from the same pass over G
+// G, amax: (B,64,H/2,352); scale: the {S, 1/S} pair -> g_hi, g_lo (B,H/2,4,352,16) halfs = the pooled operand of BOTH
+// sparse gradient kernels, g_idx (B,H/2,4,352) uint32 index words of the data gradient; gidx (optional): (B,64,H/2,22,2)
+// uint16 index words of the weight gradient (mx_conv_block_wgrad_sp_f16)
 MX_EXPORT int mx_conv_prep_gpool_cl_f16(const float *G, const uint8_t *amax, const float *scale, int64_t B, int64_t H,
-                                        int64_t Wv, void *g_hi, void *g_lo, void *g_idx, void *gp_hi, void *gp_lo,
-                                        void *gidx, void *stream)
+                                        int64_t Wv, void *g_hi, void *g_lo, void *g_idx, void *gidx, void *stream)
 {
     if (!G || !amax || !scale || !g_hi || !g_lo || !g_idx || B <= 0 || H < 2 || (H & 1) || Wv <= 0 || Wv > CV_PITCH)
         return MX_ERR_ARG;
-    if ((gp_hi || gp_lo || gidx) && !(gp_hi && gp_lo && gidx)) return MX_ERR_ARG;     // all three planar by-products or none
     if (B > 65535 || H > 131070) return MX_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(gpool_cl_prep_kernel, dim3((CV_PITCH + GP_TW - 1) / GP_TW, (unsigned)(H / 2), (unsigned)B), dim3(256), 0,
                        (hipStream_t)stream, G, amax, scale, (int)(H / 2), (int)Wv, (_Float16 *)g_hi, (_Float16 *)g_lo,
-                       (unsigned *)g_idx, (_Float16 *)gp_hi, (_Float16 *)gp_lo, (unsigned char *)gidx);
+                       (unsigned *)g_idx, (unsigned char *)gidx);
     return mx_launch_status();
 }
 

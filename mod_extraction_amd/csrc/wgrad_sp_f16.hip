@@ -15,8 +15,9 @@
 // image has no ISA manual):
 //   A  lane l: row m = l & 31, half hh = l >> 5; compressed element j (0..7) lies in the logical group of 4 starting at
 //      k = 16 (j >> 2) + 8 hh + 4 ((j >> 1) & 1), at position (idx >> 2j) & 3 of it  ->  with k = 2 pos + parity the lane
-//      holds G at positions 4hh .. 4hh+3 and 8+4hh .. 8+4hh+3 of the 16-position k-step (two 8-byte LDS reads from a
-//      [co][position] image) and idx field j = 2 (j & 1) + argmax(position j).
+//      holds G at positions 4hh .. 4hh+3 and 8+4hh .. 8+4hh+3 of the 16-position k-step (two transposed 4-row reads from
+//      a [position][channel] image: the channels-last pooled pair that the sparse data gradient consumes as well) and idx
+//      field j = 2 (j & 1) + argmax(position j).
 //   B  lane l: column n = l & 31, k = 16 (l >> 5) + j, j = 0..15: 16 consecutive rows of a [2 pos + parity][channel]
 //      image = four ds_read_b64_tr_b16 (x rows h + kh - 2 for the two parities are staged interleaved).
 //   D  as the dense 32x32 MFMA.
@@ -34,7 +35,8 @@ typedef short short4v __attribute__((__vector_size__(4 * sizeof(short))));
 #define WS_ROW_KS 22                    // 352 positions = 22 k-steps of 16 positions (32 logical k)
 
 struct WgradSpArgs {
-    const _Float16 *gp_hi, *gp_lo;      // (B, 64, Hp, 352): fp16 pair of G * S at pooled resolution
+    const _Float16 *gp_hi, *gp_lo;      // (B, Hp, 4, 352, 16): fp16 pair of G * S at pooled resolution, channels last
+                                        // (the operand of the sparse data gradient: one pooled pair feeds both)
     const unsigned short *gidx;         // (B, 64, Hp, 22, 2): index word of (k-step, lane half)
     const _Float16 *x_hi, *x_lo;        // (B, H, 4, 352, 16)
     float *part;                        // (n_slabs, 5, 13, 64, 64)
@@ -73,13 +75,6 @@ __device__ __forceinline__ half16 tr_frag32(const unsigned char *img_bytes, int 
     const short8v hi = __builtin_shufflevector(v2, v3, 0, 1, 2, 3, 4, 5, 6, 7);
     const short16v all = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
     return __builtin_bit_cast(half16, all);
-}
-// compressed A fragment: positions 4hh .. 4hh+3 and 8+4hh .. 8+4hh+3 of the k-step, from a [co][position] image
-__device__ __forceinline__ half8 a_frag(const unsigned char *ptr)
-{
-    const half4 lo = *reinterpret_cast<const half4 *>(ptr);
-    const half4 hi = *reinterpret_cast<const half4 *>(ptr + 16);
-    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
 // ---- x fragments as SLIDING WINDOWS over register chains.  The seven taps of a wave read 16-row fragments whose first
@@ -178,9 +173,8 @@ __global__ __launch_bounds__(256, 1) void wgrad_sp_f16x3_kernel(WgradSpArgs a)
     constexpr int NCH = (WS_ROW_KS + KC - 1) / KC;                       // chunks per row: 8,7,7 / 6,6,5,5 / 3,3,3,3,3,3,2,2
     constexpr int KS_LO = WS_ROW_KS / NCH, KS_REM = WS_ROW_KS % NCH;
     constexpr int CHP = KC * 16;                                         // positions per chunk (max)
-    constexpr int AP = CHP + 4;                                          // A image pitch (halfs): 8-byte aligned, bank-spreading
     constexpr int WINP = CHP + 12 * T;                                   // x window positions (origin w0 - 6T)
-    constexpr int A_SPLIT = 64 * AP * 2, B_SPLIT = 2 * WINP * 128;       // bytes per split
+    constexpr int A_SPLIT = CHP * 128, B_SPLIT = 2 * WINP * 128;         // bytes per split
     constexpr int IDX_BYTES = 64 * KC * 2 * 2;
     constexpr int QI = (KC * 2 + 3) / 4;                                 // index words per thread
     constexpr int QX = (WINP + 15) / 16;                                 // x iterations per split
@@ -188,7 +182,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_sp_f16x3_kernel(WgradSpArgs a)
     constexpr int NVI = PREF ? QI : 1, NVB = PREF ? 2 * QX : 1;
     static_assert(2 * A_SPLIT + IDX_BYTES + 2 * B_SPLIT <= 160 * 1024, "LDS budget");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char *const Aimg = smem;                                    // [split][co][AP]
+    unsigned char *const Aimg = smem;                                    // [split][position][64 co], 64-B halves swizzled
     unsigned char *const Iimg = smem + 2 * A_SPLIT;                      // [co][KC][2] u16
     unsigned char *const Bimg = Iimg + ((IDX_BYTES + 15) / 16) * 16;     // [split][2 pos + parity][64 ch]
 
@@ -232,8 +226,9 @@ __global__ __launch_bounds__(256, 1) void wgrad_sp_f16x3_kernel(WgradSpArgs a)
     floatx4 pa[PREF ? 2 * ((CHP + 31) / 32) : 1], pb[NVB];
     unsigned short pi[NVI];
     const int sv = tid & 7, xpar = (tid >> 3) & 1, pos0 = tid >> 4;
-    const int a_co = tid >> 2, a_c8 = tid & 3;
-    constexpr int QA2 = (CHP + 31) / 32;                                 // (CHP / 8 vectors per co) / 4 threads per co
+    const int a_co = tid >> 2, a_c8 = tid & 3;                           // index words: (co, word)
+    const int a_pos = tid >> 3, a_sv = tid & 7;                          // G: (position a_pos + 32 q, 16-byte vector = 8 channels)
+    constexpr int QA2 = (CHP + 31) / 32;                                 // G iterations per split
     // Loads are branch-free (a predicated load costs an exec-mask branch each, 36 per chunk): out-of-range items read
     // a clamped address whose value is either never used (k-steps past the chunk's end) or known to be zero (the
     // pad column 351 of an operand row stands in for the halo and for rows outside the image; Wv <= 351 is checked
@@ -246,13 +241,13 @@ __global__ __launch_bounds__(256, 1) void wgrad_sp_f16x3_kernel(WgradSpArgs a)
         unsigned row_off;                                       // lane: byte offset of its x row (parity) from the base row
         bool row_ok;                                            // lane: its x row is inside the image
     };
-    const unsigned a_thr = (unsigned)a_co * (unsigned)Hp * (CV_PITCH * 2);          // gp: (B,64,Hp,352) halfs
+    const unsigned a_thr = (unsigned)(a_sv >> 1) * (CV_PITCH * 32) + (unsigned)(a_sv & 1) * 16 + (unsigned)a_pos * 32;   // gp: (B,Hp,4,352,16) halfs
     const unsigned i_thr = (unsigned)a_co * (unsigned)Hp * (WS_ROW_KS * 4);         // gidx: (B,64,Hp,22,2) u16
     const unsigned x_thr = (unsigned)(sv >> 1) * (CV_PITCH * 32) + (unsigned)(sv & 1) * 16;   // x: (B,H,4,352,16) halfs
     auto chunk_base = [&](int rid, int ch) {
         ChunkBase c;
         const int b = rid / Hp, hp = rid - b * Hp, ks0 = chunk_k0(ch);
-        const size_t arow = ((size_t)b * 64 * Hp + hp) * (CV_PITCH * 2) + (size_t)ks0 * 32;
+        const size_t arow = ((size_t)b * Hp + hp) * (4 * CV_PITCH * 32) + (size_t)ks0 * (16 * 32);
         c.a_hi = reinterpret_cast<const unsigned char *>(a.gp_hi) + arow;
         c.a_lo = reinterpret_cast<const unsigned char *>(a.gp_lo) + arow;
         c.idx = reinterpret_cast<const unsigned char *>(a.gidx) + ((size_t)b * 64 * Hp + hp) * (WS_ROW_KS * 4) + ks0 * 4;
@@ -271,20 +266,17 @@ __global__ __launch_bounds__(256, 1) void wgrad_sp_f16x3_kernel(WgradSpArgs a)
         c.row_ok = xpar ? ok1 : ok0;
         return c;
     };
+    // G vector k = split * QA2 + q: position a_pos + 32 q of the chunk, channels 8 a_sv .. + 7
     auto load_a = [&](int k, const ChunkBase &c) -> floatx4 {
         const int split = k / QA2, q = k - split * QA2;
-        const int c8 = a_c8 + 4 * q;
-        const unsigned off = a_thr + (c8 * 8 < c.npos ? (unsigned)c8 * 16 : 0u);
+        const int pos = a_pos + 32 * q;
+        const unsigned off = a_thr + (pos < c.npos ? (unsigned)q * 1024 : 0u - (unsigned)a_pos * 32);   // past the chunk: position 0 (unused)
         return *reinterpret_cast<const floatx4 *>((split ? c.a_lo : c.a_hi) + off);
     };
     auto store_a = [&](int k, floatx4 v) {
-        const int split = k / QA2, q = k - split * QA2, c8 = a_c8 + 4 * q;
-        if (c8 * 8 < CHP) {
-            typedef float floatx2 __attribute__((ext_vector_type(2)));
-            unsigned char *dst = Aimg + split * A_SPLIT + a_co * (AP * 2) + c8 * 16;          // 8-byte aligned rows
-            reinterpret_cast<floatx2 *>(dst)[0] = floatx2{v[0], v[1]};
-            reinterpret_cast<floatx2 *>(dst)[1] = floatx2{v[2], v[3]};
-        }
+        const int split = k / QA2, q = k - split * QA2, pos = a_pos + 32 * q;
+        if (pos < CHP)
+            *reinterpret_cast<floatx4 *>(Aimg + split * A_SPLIT + pos * 128 + ((a_sv ^ (((pos >> 1) & 1) << 2)) * 16)) = v;
     };
     auto load_i = [&](int q, const ChunkBase &c) -> unsigned short {
         const int e = a_c8 + 4 * q;
@@ -331,7 +323,15 @@ __global__ __launch_bounds__(256, 1) void wgrad_sp_f16x3_kernel(WgradSpArgs a)
     const TrLane32 lb = tr_lane_offsets32(nt, lane);
     const int xg_off = g * 12 * T * 128;
     // A / index addressing: co tile j -> rows j*32 + m32; the middle tap uses co tile g
-    const int a_lane = m32 * (AP * 2) + hh * 8;
+    // G fragment of co tile j: positions 4hh .. 4hh+3 and 8+4hh .. of the k-step for channel j*32 + m32 = two transposed
+    // 4-row blocks of the [position][channel] image (rows 4 hh + q, lane (q, p, g1) as in tr_lane_offsets32; the swizzle
+    // phase of a block starting on a multiple of 4 rows is (q >> 1) & 1)
+    int a_lane[2];
+    {
+        const int q4 = (lane & 15) >> 2, p4 = lane & 3, g1 = (lane >> 4) & 1, swz = (q4 >> 1) & 1;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) a_lane[j] = (4 * hh + q4) * 128 + ((j ^ swz) * 64) + 32 * g1 + 8 * p4;
+    }
     const int i_lane = m32 * (KC * 4) + hh * 2;
     const unsigned char *Ah = Aimg, *Al = Aimg + A_SPLIT;
     const unsigned char *x_h = Bimg, *x_l = Bimg + B_SPLIT;
@@ -351,7 +351,14 @@ __global__ __launch_bounds__(256, 1) void wgrad_sp_f16x3_kernel(WgradSpArgs a)
         half8 AL[2], AH[2][2];                      // [co tile]; the middle tap uses co tile G
         int IX[2][2];
         BFrags BH, BL;                              // 4-row blocks of hi(x) / lo(x)
-        auto rd_a = [&](const unsigned char *img, int ks, int j) { return a_frag(img + j * (32 * AP * 2) + a_lane + ks * 32); };
+        auto rd_a = [&](const unsigned char *img, int ks, int j) {
+            const unsigned char *ptr = img + ks * 2048 + a_lane[j];
+            const short4v v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4v __attribute__((address_space(3))) *)ptr);
+            const short4v v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4v __attribute__((address_space(3))) *)(ptr + 1024));
+            typedef short short8v __attribute__((__vector_size__(8 * sizeof(short))));
+            const short8v both = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+            return __builtin_bit_cast(half8, both);
+        };
         auto rd_i = [&](int ks, int j) {
             return (int)*reinterpret_cast<const unsigned short *>(Iimg + j * (32 * KC * 4) + i_lane + ks * 4);
         };
@@ -515,47 +522,11 @@ __global__ __launch_bounds__(256) void wgrad_sp_reduce_kernel(const float *__res
     }
 }
 
-// G (B,64,Hp,352) fp32, amax (B,64,Hp,352) uint8, scale[0] = S  ->  gp_hi / gp_lo (same shape, fp16 pair of G * S) and
-// gidx (B,64,Hp,22,2): per (k-step of 16 positions, lane half hh) the 8 two-bit fields of the lane's compressed elements,
-// element j = 2 gq + e at position 16 ks + 8 (gq >> 1) + 4 hh + 2 (gq & 1) + e, field = 2 e + argmax.
-__global__ __launch_bounds__(256) void gpool_prep_kernel(const float *__restrict__ G, const unsigned char *__restrict__ amax,
-                                                         const float *__restrict__ scale, long long n_rows,
-                                                         _Float16 *__restrict__ gp_hi, _Float16 *__restrict__ gp_lo,
-                                                         unsigned short *__restrict__ gidx)
-{
-    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;          // (row, ks, hh)
-    if (t >= n_rows * (WS_ROW_KS * 2)) return;
-    const long long row = t / (WS_ROW_KS * 2);
-    const int e2 = (int)(t - row * (WS_ROW_KS * 2)), ks = e2 >> 1, hh = e2 & 1;
-    const float S = scale[0];
-    unsigned word = 0;
-#pragma unroll
-    for (int part = 0; part < 2; ++part) {                                   // positions 4hh..+3 and 8+4hh..+3
-        const size_t off = (size_t)row * CV_PITCH + ks * 16 + part * 8 + hh * 4;
-        const floatx4 gv = *reinterpret_cast<const floatx4 *>(G + off);
-        const uchar4 am = *reinterpret_cast<const uchar4 *>(amax + off);
-        half4 hi, lo;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float v = gv[e] * S;
-            const _Float16 h = (_Float16)v;
-            hi[e] = h;
-            lo[e] = (_Float16)(v - (float)h);
-        }
-        *reinterpret_cast<half4 *>(gp_hi + off) = hi;
-        *reinterpret_cast<half4 *>(gp_lo + off) = lo;
-        const unsigned a0 = am.x & 1, a1 = am.y & 1, a2 = am.z & 1, a3 = am.w & 1;
-        // elements j = 4 part + 0..3: (gq = 2 part, e = 0), (gq, 1), (gq + 1, 0), (gq + 1, 1)
-        word |= ((0u + a0) | ((2u + a1) << 2) | ((0u + a2) << 4) | ((2u + a3) << 6)) << (8 * part);
-    }
-    gidx[t] = (unsigned short)word;
-}
-
 template <int T>
 static int launch_wgrad_sp(const WgradSpArgs &a, hipStream_t st)
 {
-    constexpr int KC = T >= 16 ? 3 : 6, CHP = KC * 16, AP = CHP + 4, WINP = CHP + 12 * T;
-    const size_t lds = 2 * (size_t)(64 * AP * 2) + ((64 * KC * 4 + 15) / 16) * 16 + 2 * (size_t)(2 * WINP * 128);
+    constexpr int KC = T >= 16 ? 3 : 6, CHP = KC * 16, WINP = CHP + 12 * T;
+    const size_t lds = 2 * (size_t)(CHP * 128) + ((64 * KC * 4 + 15) / 16) * 16 + 2 * (size_t)(2 * WINP * 128);
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute((const void *)wgrad_sp_f16x3_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
@@ -568,20 +539,8 @@ static int launch_wgrad_sp(const WgradSpArgs &a, hipStream_t st)
     return mx_launch_status();
 }
 
-// Gradient operand of the sparse weight-gradient kernel: G, amax (B,64,H/2,352), scale = the {S, 1/S} pair of
-// mx_conv_prep_dgrad_f16 -> gp_hi, gp_lo (B,64,H/2,352) halfs, gidx (B,64,H/2,22,2) uint16.
-MX_EXPORT int mx_conv_prep_gpool_f16(const float *G, const uint8_t *amax, const float *scale, int64_t B, int64_t H,
-                                     void *gp_hi, void *gp_lo, void *gidx, void *stream)
-{
-    if (!G || !amax || !scale || !gp_hi || !gp_lo || !gidx || B <= 0 || H < 2 || (H & 1)) return MX_ERR_ARG;
-    const long long n_rows = (long long)B * 64 * (H / 2), n_thr = n_rows * (WS_ROW_KS * 2);
-    if (n_thr > (1ll << 38)) return MX_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(gpool_prep_kernel, dim3((unsigned)((n_thr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, G, amax,
-                       scale, n_rows, (_Float16 *)gp_hi, (_Float16 *)gp_lo, (unsigned short *)gidx);
-    return mx_launch_status();
-}
-
-// x_hi/lo: (B,H,4,352,16) operand pair of the block's forward pass (Wv <= 351 valid columns, the rest zero); part: workspace of ceil(B*(H/2)/rows_per_slab)*65*64*64
+// gp_hi/lo: (B,H/2,4,352,16) channels-last pooled gradient pair, gidx: (B,64,H/2,22,2) planar index words -- both from
+// mx_conv_prep_gpool_cl_f16;  x_hi/lo: (B,H,4,352,16) operand pair of the block's forward pass (Wv <= 351 valid columns, the rest zero); part: workspace of ceil(B*(H/2)/rows_per_slab)*65*64*64
 // floats (rows = pooled rows); dW (64,64,5,13).
 MX_EXPORT int mx_conv_block_wgrad_sp_f16(const void *gp_hi, const void *gp_lo, const void *gidx, const void *x_hi,
                                          const void *x_lo, const float *scale, int64_t B, int64_t H, int64_t Wv,

@@ -269,32 +269,24 @@ class _CNNStack(torch.autograd.Function):
                 # full-resolution pair); data gradient: every dilation.
                 sparse = WGRAD_SPARSE and int(dilations[l]) <= WGRAD_SPARSE_MAX_T and n_frames <= PITCH - 1
                 sparse_d = DGRAD_SPARSE and l > 0 and n_frames <= PITCH - 1
-                gp_hi = gp_lo = gidx = gc_hi = gc_lo = gc_idx = None
+                gidx = gc_hi = gc_lo = gc_idx = None
                 Hp = H // 2
-                if sparse:
-                    gp_hi = torch.empty((B, 64, Hp, PITCH), device=dev, dtype=torch.float16)
-                    gp_lo = torch.empty((B, 64, Hp, PITCH), device=dev, dtype=torch.float16)
-                    gidx = torch.empty((B, 64, Hp, 22, 2), device=dev, dtype=torch.int16)
-                if sparse and (sparse_d or l == 0):
-                    # the routed pair is not needed at all: scale only
-                    _hip.call("mx_conv_prep_dgrad_f16", _hip.ptr(G), _hip.ptr(amax), B, H, n_frames, _hip.ptr(ws),
-                              1 if ready else 0, _hip.ptr(scale), None, None, None, None, None, st)
-                else:
+                need_routed = (not sparse) or (l > 0 and not sparse_d)   # a dense kernel consumes the routed full-resolution pair
+                if need_routed:
                     dz_hi = torch.empty((B, H, 4, PITCH, 16), device=dev, dtype=torch.float16)
                     dz_lo = torch.empty((B, H, 4, PITCH, 16), device=dev, dtype=torch.float16)
-                    by = sparse and not sparse_d                 # planar by-products only if no pooled pass follows
-                    _hip.call("mx_conv_prep_dgrad_f16", _hip.ptr(G), _hip.ptr(amax), B, H, n_frames, _hip.ptr(ws),
-                              1 if ready else 0, _hip.ptr(scale), _hip.ptr(dz_hi), _hip.ptr(dz_lo),
-                              _hip.ptr(gp_hi if by else None), _hip.ptr(gp_lo if by else None),
-                              _hip.ptr(gidx if by else None), st)
-                if sparse_d or (sparse and l == 0):
-                    # one pass over G: channels-last pooled operand (data gradient) + planar one (weight gradient)
+                _hip.call("mx_conv_prep_dgrad_f16", _hip.ptr(G), _hip.ptr(amax), B, H, n_frames, _hip.ptr(ws),
+                          1 if ready else 0, _hip.ptr(scale), _hip.ptr(dz_hi), _hip.ptr(dz_lo), st)
+                if sparse or sparse_d:
+                    # one pass over G: the channels-last pooled pair both sparse kernels read, the data gradient's index
+                    # words and (for the weight gradient) the planar ones
                     gc_hi = torch.empty((B, Hp, 4, PITCH, 16), device=dev, dtype=torch.float16)
                     gc_lo = torch.empty((B, Hp, 4, PITCH, 16), device=dev, dtype=torch.float16)
                     gc_idx = torch.empty((B, Hp, 4, PITCH), device=dev, dtype=torch.int32)
+                    if sparse:
+                        gidx = torch.empty((B, 64, Hp, 22, 2), device=dev, dtype=torch.int16)
                     _hip.call("mx_conv_prep_gpool_cl_f16", _hip.ptr(G), _hip.ptr(amax), _hip.ptr(scale), B, H, n_frames,
-                              _hip.ptr(gc_hi), _hip.ptr(gc_lo), _hip.ptr(gc_idx), _hip.ptr(gp_hi), _hip.ptr(gp_lo),
-                              _hip.ptr(gidx), st)
+                              _hip.ptr(gc_hi), _hip.ptr(gc_lo), _hip.ptr(gc_idx), _hip.ptr(gidx), st)
                 if l in ctx.splits:
                     x_hi, x_lo = ctx.splits.pop(l)
                 else:
@@ -307,10 +299,10 @@ class _CNNStack(torch.autograd.Function):
                     rps = max(1, -(-prow // 256))           # 256 slabs x 5 kernel rows = 5 full rounds of 256 workgroups
                     n_slabs = -(-prow // rps)
                     part = torch.empty(n_slabs * 65 * 64 * 64, device=dev, dtype=torch.float32)
-                    _hip.call("mx_conv_block_wgrad_sp_f16", _hip.ptr(gp_hi), _hip.ptr(gp_lo), _hip.ptr(gidx), _hip.ptr(x_hi),
+                    _hip.call("mx_conv_block_wgrad_sp_f16", _hip.ptr(gc_hi), _hip.ptr(gc_lo), _hip.ptr(gidx), _hip.ptr(x_hi),
                               _hip.ptr(x_lo), _hip.ptr(scale), B, H, n_frames, int(dilations[l]), rps, _hip.ptr(part),
                               _hip.ptr(dW), st)
-                    del gp_hi, gp_lo, gidx
+                    del gidx
                 else:
                     rps = max(1, -(-rows // 256))            # 256 slabs x 5 kernel rows = 5 full rounds of 256 workgroups
                     n_slabs = -(-rows // rps)

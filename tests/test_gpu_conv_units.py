@@ -141,11 +141,8 @@ def test_block_f16x3_kernels(dev, T, W, H):
     ws = torch.empty(1, device=dev, dtype=torch.int32)
     scale = torch.empty(2, device=dev)
     Hp = H // 2
-    gq_hi = torch.empty((B, 64, Hp, PITCH), device=dev, dtype=torch.float16)       # by-product operand of the sparse kernel
-    gq_lo = torch.empty_like(gq_hi)
-    gqidx = torch.empty((B, 64, Hp, 22, 2), device=dev, dtype=torch.int16)
     _hip.call("mx_conv_prep_dgrad_f16", _hip.ptr(G_d), _hip.ptr(amax_d), B, H, W, _hip.ptr(ws), 0, _hip.ptr(scale),
-              _hip.ptr(dz_hi), _hip.ptr(dz_lo), _hip.ptr(gq_hi), _hip.ptr(gq_lo), _hip.ptr(gqidx), st)
+              _hip.ptr(dz_hi), _hip.ptr(dz_lo), st)
     S = float(scale[0])
     assert S == 2.0 ** round(np.log2(S)) and 512.0 <= float(Gc.abs().max()) * S < 1024.0       # power of two, in range
     # dense weight gradient
@@ -156,20 +153,37 @@ def test_block_f16x3_kernels(dev, T, W, H):
     _hip.call("mx_conv_block_wgrad_f16", _hip.ptr(dz_hi), _hip.ptr(dz_lo), _hip.ptr(x_hi), _hip.ptr(x_lo), _hip.ptr(scale),
               B, H, T, rps, _hip.ptr(part), _hip.ptr(dW_dense), st)
     assert rel(dW_dense.cpu(), w.grad) < 1e-5, ("dense wgrad", rel(dW_dense.cpu(), w.grad))
-    # sparse weight gradient: pooled gradient pair + index words
-    gp_hi = torch.empty((B, 64, Hp, PITCH), device=dev, dtype=torch.float16)
-    gp_lo = torch.empty_like(gp_hi)
+    # the POOLED operand of both sparse kernels: channels-last pair of G * S, index words of the data gradient, planar
+    # index words of the weight gradient -- one pass over G
+    gc_hi = torch.empty((B, Hp, 4, PITCH, 16), device=dev, dtype=torch.float16)
+    gc_lo = torch.empty_like(gc_hi)
+    gc_idx = torch.empty((B, Hp, 4, PITCH), device=dev, dtype=torch.int32)
     gidx = torch.empty((B, 64, Hp, 22, 2), device=dev, dtype=torch.int16)
-    _hip.call("mx_conv_prep_gpool_f16", _hip.ptr(G_d), _hip.ptr(amax_d), _hip.ptr(scale), B, H, _hip.ptr(gp_hi), _hip.ptr(gp_lo),
-              _hip.ptr(gidx), st)
-    assert rel((gp_hi.float() + gp_lo.float()).cpu() / S, G_d.cpu()) < 2e-6
-    # the stand-alone prep and the by-product of mx_conv_prep_dgrad_f16 are the same operand, bit for bit
-    assert torch.equal(gp_hi, gq_hi) and torch.equal(gp_lo, gq_lo) and torch.equal(gidx, gqidx)
+    _hip.call("mx_conv_prep_gpool_cl_f16", _hip.ptr(G_d), _hip.ptr(amax_d), _hip.ptr(scale), B, H, W, _hip.ptr(gc_hi),
+              _hip.ptr(gc_lo), _hip.ptr(gc_idx), _hip.ptr(gidx), st)
+    gc = (gc_hi.float() + gc_lo.float()).permute(0, 2, 4, 1, 3).reshape(B, 64, Hp, PITCH)
+    assert rel(gc.cpu()[..., :W] / S, Gc) < 2e-6 and bool((gc[..., W:] == 0).all())
+    # planar index words: per (k-step of 16 positions, lane half hh) the 8 two-bit fields of the lane's compressed
+    # elements; element j = 2 gq + e sits at position 16 ks + 8 (gq >> 1) + 4 hh + 2 (gq & 1) + e, field = 2 e + argmax
+    am_np = amax_d.cpu().numpy().astype(np.int64) & 1
+    want_idx = np.zeros((B, 64, Hp, 22, 2), dtype=np.int64)
+    for hh_ in range(2):
+        for j_ in range(8):
+            gq_, e_ = j_ >> 1, j_ & 1
+            pos_ = 16 * np.arange(22) + 8 * (gq_ >> 1) + 4 * hh_ + 2 * (gq_ & 1) + e_
+            want_idx[..., hh_] |= (2 * e_ + am_np[..., pos_]) << (2 * j_)
+    assert np.array_equal(gidx.cpu().numpy().astype(np.int64) & 0xFFFF, want_idx)
+    # same call without the weight-gradient words
+    gd_hi, gd_lo, gd_idx = torch.empty_like(gc_hi), torch.empty_like(gc_lo), torch.empty_like(gc_idx)
+    _hip.call("mx_conv_prep_gpool_cl_f16", _hip.ptr(G_d), _hip.ptr(amax_d), _hip.ptr(scale), B, H, W, _hip.ptr(gd_hi),
+              _hip.ptr(gd_lo), _hip.ptr(gd_idx), None, st)
+    assert torch.equal(gd_hi, gc_hi) and torch.equal(gd_lo, gc_lo) and torch.equal(gd_idx, gc_idx)
+    # sparse weight gradient
     rps2 = 2
     n_slabs2 = -(-(B * Hp) // rps2)
     part2 = torch.empty(n_slabs2 * 65 * 64 * 64, device=dev)
     dW_sp = torch.empty((64, 64, 5, 13), device=dev)
-    _hip.call("mx_conv_block_wgrad_sp_f16", _hip.ptr(gp_hi), _hip.ptr(gp_lo), _hip.ptr(gidx), _hip.ptr(x_hi), _hip.ptr(x_lo),
+    _hip.call("mx_conv_block_wgrad_sp_f16", _hip.ptr(gc_hi), _hip.ptr(gc_lo), _hip.ptr(gidx), _hip.ptr(x_hi), _hip.ptr(x_lo),
               _hip.ptr(scale), B, H, W, T, rps2, _hip.ptr(part2), _hip.ptr(dW_sp), st)
     assert rel(dW_sp.cpu(), w.grad) < 1e-5, ("sparse wgrad", rel(dW_sp.cpu(), w.grad))
     assert rel(dW_sp, dW_dense) < 2e-6                                          # same sums, different order
@@ -180,20 +194,10 @@ def test_block_f16x3_kernels(dev, T, W, H):
               B, H, W, T, _hip.ptr(dxhat), st)
     assert rel(dxhat.cpu()[..., :W], xhat_r.grad) < 1e-5
     assert bool((dxhat[..., W:] == 0).all())
-    # sparse data gradient: pooled channels-last operand + fragment-packed weights
-    gc_hi = torch.empty((B, Hp, 4, PITCH, 16), device=dev, dtype=torch.float16)
-    gc_lo = torch.empty_like(gc_hi)
-    gc_idx = torch.empty((B, Hp, 4, PITCH), device=dev, dtype=torch.int32)
-    gr_hi, gr_lo, gridx = torch.empty_like(gp_hi), torch.empty_like(gp_lo), torch.empty_like(gidx)
-    _hip.call("mx_conv_prep_gpool_cl_f16", _hip.ptr(G_d), _hip.ptr(amax_d), _hip.ptr(scale), B, H, W, _hip.ptr(gc_hi),
-              _hip.ptr(gc_lo), _hip.ptr(gc_idx), _hip.ptr(gr_hi), _hip.ptr(gr_lo), _hip.ptr(gridx), st)
-    assert torch.equal(gr_hi, gp_hi) and torch.equal(gr_lo, gp_lo) and torch.equal(gridx, gidx)    # planar by-product
+    # sparse data gradient: the same pooled operand + fragment-packed weights
     sc2 = torch.empty(2, device=dev)
-    _hip.call("mx_conv_prep_dgrad_f16", _hip.ptr(G_d), _hip.ptr(amax_d), B, H, W, _hip.ptr(ws), 0, _hip.ptr(sc2), None, None,
-              None, None, None, st)
+    _hip.call("mx_conv_prep_dgrad_f16", _hip.ptr(G_d), _hip.ptr(amax_d), B, H, W, _hip.ptr(ws), 0, _hip.ptr(sc2), None, None, st)
     assert torch.equal(sc2, scale)                                                                 # scale-only call
-    gc = (gc_hi.float() + gc_lo.float()).permute(0, 2, 4, 1, 3).reshape(B, 64, Hp, PITCH)
-    assert rel(gc.cpu()[..., :W] / S, Gc) < 2e-6 and bool((gc[..., W:] == 0).all())
     ws_hi = torch.empty(4 * 3 * 2 * 13 * 2 * 64 * 16, device=dev, dtype=torch.float16)
     ws_lo = torch.empty_like(ws_hi)
     _hip.call("mx_conv_pack_weights_sp_f16", _hip.ptr(w.detach().to(dev).contiguous()), _hip.ptr(ws_hi), _hip.ptr(ws_lo), st)

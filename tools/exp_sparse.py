@@ -52,15 +52,13 @@ def run(B=64):
             scale = torch.tensor([256.0, 1 / 256.0], device=dev)
             W = torch.randn((64, 64, 5, 13), generator=g).to(dev) * 0.05
             st = vp(torch.cuda.current_stream().cuda_stream)
-            gp_hi = torch.empty((B, 64, Hp, 352), device=dev, dtype=torch.half)
-            gp_lo = torch.empty_like(gp_hi)
             gidx = torch.empty((B, 64, Hp, 22, 2), device=dev, dtype=torch.int16)
             gc_hi = torch.empty((B, Hp, 4, 352, 16), device=dev, dtype=torch.half)
             gc_lo = torch.empty_like(gc_hi)
             gc_idx = torch.empty((B, Hp, 4, 352), device=dev, dtype=torch.int32)
             rc = lib.mx_conv_prep_gpool_cl_f16(vp(G.data_ptr()), vp(amax.data_ptr()), vp(scale.data_ptr()), i64(B), i64(H), i64(345),
                                                vp(gc_hi.data_ptr()), vp(gc_lo.data_ptr()), vp(gc_idx.data_ptr()),
-                                               vp(gp_hi.data_ptr()), vp(gp_lo.data_ptr()), vp(gidx.data_ptr()), st)
+                                               vp(gidx.data_ptr()), st)
             assert rc == 0, rc
             w_hi = torch.empty(4 * 3 * 2 * 13 * 2 * 64 * 16, device=dev, dtype=torch.half)
             w_lo = torch.empty_like(w_hi)
@@ -72,7 +70,7 @@ def run(B=64):
             dx = torch.empty((B, 64, H, 352), device=dev)
 
             def wgr():
-                return lib.mx_conv_block_wgrad_sp_f16(vp(gp_hi.data_ptr()), vp(gp_lo.data_ptr()), vp(gidx.data_ptr()),
+                return lib.mx_conv_block_wgrad_sp_f16(vp(gc_hi.data_ptr()), vp(gc_lo.data_ptr()), vp(gidx.data_ptr()),
                                                       vp(x_hi.data_ptr()), vp(x_lo.data_ptr()), vp(scale.data_ptr()), i64(B), i64(H),
                                                       i64(345), i32(T), i64(rps), vp(part.data_ptr()), vp(dW.data_ptr()), st)
 
