@@ -125,7 +125,7 @@ def instantiate(spec: Any, **extra: Any) -> Any:
 def load_weights(module: torch.nn.Module, path: str) -> None:
     """Lightning ``.ckpt`` (``state_dict`` with ``model.`` / ``effect_model.`` / ``lfo_model.`` prefixes) or a
     bare ``.pt`` state dict."""
-    blob = torch.load(path, map_location="cpu")
+    blob = torch.load(path, map_location="cpu", weights_only=False)
     sd = blob.get("state_dict", blob) if isinstance(blob, dict) else blob
     own = module.state_dict()
     if not set(sd).issubset(set(own)):          # bare sub-module weights: find the attribute they belong to
@@ -137,60 +137,114 @@ def load_weights(module: torch.nn.Module, path: str) -> None:
     missing, unexpected = module.load_state_dict(sd, strict=False)
     if unexpected:
         raise KeyError(f"unexpected keys in {path}: {unexpected[:5]}")
+    # a bare sub-module file legitimately leaves the other sub-modules alone (e.g. LSTM weights into a module
+    # that also holds the frozen LFO net); anything missing INSIDE a sub-module the file does cover is an error
+    covered = {k.split(".")[0] for k in sd}
+    bad = [k for k in missing if k.split(".")[0] in covered]
+    if bad:
+        raise KeyError(f"checkpoint {path} lacks {len(bad)} keys of the sub-modules it covers: {bad[:5]}")
     if missing:
-        log.warning("checkpoint %s leaves %d keys untouched", path, len(missing))
+        log.info("checkpoint %s leaves %d keys of other sub-modules untouched", path, len(missing))
+
+
+def _next_version_dir(root: str) -> str:
+    """TensorBoardLogger(save_dir="lightning_logs", name=None) of the reference (cli.py:39-45):
+    ``lightning_logs/version_<n>``, checkpoints under ``checkpoints/``."""
+    n = 0
+    if os.path.isdir(root):
+        taken = [int(d[8:]) for d in os.listdir(root) if d.startswith("version_") and d[8:].isdigit()]
+        n = max(taken) + 1 if taken else 0
+    return os.path.join(root, f"version_{n}")
+
+
+def seed_everything(seed: int) -> None:
+    import random
+    import numpy as np
+    random.seed(seed); np.random.seed(seed % (2 ** 32)); torch.manual_seed(seed)
 
 
 class CustomLightningCLI:
     """``CustomLightningCLI(args=["fit" | "validate", "-c", config.yml])`` as in scripts/train.py:30 and
     scripts/validate.py:25.  With ``run=False`` only the object graph is built (``.model``,
-    ``.datamodule``, ``.optimizer_spec``, ``.trainer``)."""
+    ``.datamodule``, ``.optimizer_spec``, ``.trainer``).
+
+    ``fit`` installs the reference's ModelCheckpoint policy (cli.py:29-37,145-150: best ``val/loss`` + last,
+    ``{model_name}__{dataset_name}__epoch_{e}_step_{s}.ckpt`` under ``lightning_logs/version_N/checkpoints``);
+    ``ckpt_path`` must exist (Lightning raises too) unless ``allow_missing_ckpt`` -- the pretrained blobs of the
+    reference are not part of its repository -- and, for ``fit``, is a resume (optimizer state, epoch, step).
+    Seeding: the model is built under the common ``seed_everything`` value so that all DDP replicas start identical;
+    the host RNGs that drive the data stream are then re-seeded with ``seed + rank`` (Lightning gives each rank its
+    own stream through the distributed sampler and per-worker seeds)."""
 
     def __init__(self, args: List[str], trainer_defaults: Optional[Dict[str, Any]] = None, run: bool = True,
-                 device: Optional[torch.device] = None) -> None:
+                 device: Optional[torch.device] = None, allow_missing_ckpt: Optional[bool] = None,
+                 log_dir: str = "lightning_logs") -> None:
         assert args and args[0] in ("fit", "validate")
         self.subcommand = args[0]
         cfg_path = args[args.index("-c") + 1] if "-c" in args else args[args.index("--config") + 1]
         self.config = apply_links(load_config(cfg_path))
-        seed = self.config.get("seed_everything")
-        if seed is not None:
-            import random
-            import numpy as np
-            random.seed(seed); np.random.seed(seed); torch.manual_seed(seed)
+        self.seed = self.config.get("seed_everything")
+        if self.seed is not None:
+            seed_everything(int(self.seed))
         from . import trainer as tr
         self.env = tr.init_distributed()
         if device is None:
             device = torch.device("cuda", self.env["local_rank"])
         self.device = device
         self.custom = self.config.get("custom", {}) or {}
+        keys = ("max_epochs", "num_sanity_val_steps", "limit_train_batches", "limit_val_batches")
         tkw = dict(trainer_defaults or {})
-        tkw.update({k: v for k, v in (self.config.get("trainer") or {}).items()
-                    if k in ("max_epochs", "num_sanity_val_steps", "limit_train_batches", "limit_val_batches")})
-        tkw = {k: v for k, v in tkw.items() if k in ("max_epochs", "num_sanity_val_steps", "limit_train_batches",
-                                                      "limit_val_batches", "log_fn")}
+        tkw.update({k: v for k, v in (self.config.get("trainer") or {}).items() if k in keys})
+        tkw = {k: v for k, v in tkw.items() if k in keys + ("log_fn", "checkpoints")}
+        if self.subcommand == "fit" and run and "checkpoints" not in tkw:
+            tkw["checkpoints"] = tr.CheckpointKeeper(
+                os.path.join(_next_version_dir(log_dir), "checkpoints"),
+                self.custom.get("model_name", "local_model"), self.custom.get("dataset_name", "local_dataset"),
+                hyper_parameters={"config": copy.deepcopy(self.config)})
         self.trainer = tr.Trainer(**tkw)
         self.datamodule = instantiate(self.config["data"])
         self.model = instantiate(self.config["model"]).to(device)
         self.optimizer_spec = self.config.get("optimizer")
         self.optimizer = None
+        self.ckpt_file = None
         ckpt = self.config.get("ckpt_path")
+        if allow_missing_ckpt is None:
+            allow_missing_ckpt = os.environ.get("MODEX_ALLOW_MISSING_CKPT", "0") == "1"
         if ckpt:
             found = _find(ckpt, [os.getcwd(), os.path.dirname(os.path.abspath(cfg_path))])
             if found:
                 load_weights(self.model, found)
+                self.ckpt_file = found
+            elif allow_missing_ckpt:
+                log.warning("ckpt_path %s not found (large blobs are not part of the repository): continuing with "
+                            "freshly initialised weights because allow_missing_ckpt is set", ckpt)
             else:
-                log.warning("ckpt_path %s not found (large blobs are not part of the repository)", ckpt)
+                raise FileNotFoundError(f"ckpt_path {ckpt!r} not found (pass allow_missing_ckpt=True or set "
+                                        f"MODEX_ALLOW_MISSING_CKPT=1 to run with random weights)")
         if run:
             self.run()
 
+    def prepare_data_stream(self) -> None:
+        """Per-rank host RNG stream (parameter draws, chunk search, SpecAugment masks) + data-module setup."""
+        seed = int(self.seed) if self.seed is not None else 43
+        rank = self.env["rank"]
+        seed_everything(seed + rank)
+        self.datamodule.setup(self.device, rank=rank, seed=seed)
+
     def run(self):
-        self.datamodule.setup(self.device, rank=self.env["rank"], seed=self.config.get("seed_everything") or 43)
+        from . import trainer as tr
+        rank = self.env["rank"]
+        self.prepare_data_stream()
         if self.subcommand == "validate":
             self.model.eval()
             metrics = self.trainer.validate(self.model, self.datamodule)
-            if self.env["rank"] == 0:
+            if rank == 0:
                 print(metrics)
             return metrics
         params = [p for p in self.model.parameters() if p.requires_grad]
         self.optimizer = instantiate(self.optimizer_spec, params=params)
+        if self.env["world_size"] > 1:          # replicas must start identical whatever the RNG history
+            torch.distributed.broadcast(self.optimizer.flat_param, src=0)
+        if self.ckpt_file is not None:
+            tr.resume_from_checkpoint(self.ckpt_file, self.model, self.optimizer, self.trainer)
         return self.trainer.fit(self.model, self.datamodule, self.optimizer)

@@ -108,6 +108,7 @@ class SyntheticFxBatcher:
         self.src, self.audio = self._src[0], self._audio[0]
         # recorded audio is gathered on the host into a pinned staging buffer and copied over in one piece
         self._host = None
+        self._host_ev = None                  # recorded after each async copy out of the pinned staging buffer
         if chunk_source is not None:
             self._host = torch.empty((batch_size, n_samples + self.max_lead), dtype=torch.float32)
             if device.type == "cuda":
@@ -178,8 +179,13 @@ class SyntheticFxBatcher:
         if self.chunk_source is not None:
             # recorded audio: one non-silent chunk per clip (phaser clips: n + sr/rate samples, datasets.py:433-436)
             extra = p.get("proc_extra", torch.zeros(B, dtype=torch.int64))
+            if self._host_ev is not None:
+                self._host_ev.synchronize()       # the previous async H2D copy must have read the staging buffer
             self.chunk_source.fill(self._host, (extra + N).clamp(max=self._host.size(1)))
             self.src.copy_(self._host, non_blocking=True)
+            if dev.type == "cuda":
+                self._host_ev = torch.cuda.Event()
+                self._host_ev.record(torch.cuda.current_stream(dev))
         else:
             # synthetic dry audio: uniform noise at `peak`
             self.src.uniform_(-self.peak, self.peak, generator=self.gen)

@@ -47,21 +47,53 @@ def allreduce_flat_grad(flat_grad: torch.Tensor, world_size: int) -> float:
     return 1.0
 
 
-def reduce_metrics(logged: Dict[str, List[torch.Tensor]], world_size: int) -> Dict[str, float]:
-    """Epoch means of the logged scalars, averaged over ranks (Lightning sync_dist=True)."""
-    names = sorted(logged.keys())
+def reduce_metrics(logged: Dict[str, List[torch.Tensor]], world_size: int,
+                   names: Optional[List[str]] = None) -> Dict[str, float]:
+    """Epoch means of the logged scalars, averaged over the ranks that logged them (Lightning
+    ``on_epoch=True, sync_dist=True``).  Under DDP ``names`` must be the same list on every rank (the
+    trainer derives it from the module's ``loss_dict``): a rank that logged nothing for a name -- a TBPTT
+    rank whose every batch had no valid LFO -- still takes part in the collective with count 0, so the
+    all-reduce shapes always match."""
+    if names is None:
+        if world_size > 1:
+            raise ValueError("reduce_metrics under DDP needs the fixed metric-name list")
+        names = sorted(logged.keys())
     if not names:
         return {}
-    vals = torch.stack([torch.stack([v.float().reshape(()) for v in logged[n]]).mean() for n in names])
+    dev = next((v[0].device for v in logged.values() if v), torch.device("cpu"))
+    sums = torch.zeros(2, len(names), dtype=torch.float64, device=dev)
+    for i, n in enumerate(names):
+        vals = [v.double().reshape(()) for v in logged.get(n, []) if v is not None]
+        if vals:
+            sums[0, i] = torch.stack(vals).mean()
+            sums[1, i] = 1.0
     if world_size > 1:
-        dist.all_reduce(vals, op=dist.ReduceOp.SUM)
-        vals = vals / world_size
-    return {n: float(v) for n, v in zip(names, vals.cpu())}
+        if dist.get_backend() == "gloo":
+            sums = sums.cpu()
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+    sums = sums.cpu()
+    return {n: float(sums[0, i] / sums[1, i]) for i, n in enumerate(names) if float(sums[1, i]) > 0}
+
+
+def metric_names(module, prefix: str) -> List[str]:
+    """The scalars a BaseLightingModule logs per step under ``prefix`` (lightning.py:33-62)."""
+    return [f"{prefix}/{k}" for k in getattr(module, "loss_dict", {})] + [f"{prefix}/loss"]
+
+
+def _limit(n: int, limit) -> int:
+    """Lightning's ``limit_*_batches``: an int caps the count, a float in [0, 1] is a fraction of it."""
+    if limit is None:
+        return n
+    if isinstance(limit, float) and not float(limit).is_integer():
+        assert 0.0 <= limit <= 1.0, "fractional limit_*_batches must be in [0, 1]"
+        return int(n * limit)
+    if isinstance(limit, float) and limit == 1.0:
+        return n
+    return min(n, int(limit))
 
 
 class Trainer:
-    def __init__(self, max_epochs: int = 1, limit_train_batches: Optional[int] = None,
-                 limit_val_batches: Optional[int] = None, num_sanity_val_steps: int = 0,
+    def __init__(self, max_epochs: int = 1, limit_train_batches=None, limit_val_batches=None, num_sanity_val_steps: int = 0,
                  log_fn: Optional[Callable[[str], None]] = print, checkpoints: Optional["CheckpointKeeper"] = None,
                  **ignored: Any) -> None:
         self.max_epochs = max_epochs
@@ -71,6 +103,7 @@ class Trainer:
         self.checkpoints = checkpoints
         self.env = dist_env()
         self.history: List[Dict[str, float]] = []
+        self.start_epoch = 0            # > 0 after resume_from_checkpoint
 
     def _say(self, msg: str) -> None:
         if self.log_fn is not None and self.env["rank"] == 0:
@@ -82,19 +115,19 @@ class Trainer:
         loss = module.training_step(batch, 0)
         if loss is not None:
             loss.backward()
-        scale = allreduce_flat_grad(optimizer.flat_grad, self.env["world_size"])
+        elif self.env["world_size"] == 1:
+            return None                 # Lightning skips the optimizer step when training_step returns None
+        scale = allreduce_flat_grad(optimizer.flat_grad, self.env["world_size"])   # DDP: stay in lock-step
         optimizer.step(grad_scale=scale)
         return loss
 
     def validate(self, module, datamodule, n_steps: Optional[int] = None) -> Dict[str, float]:
         module.eval()
         module.logged.clear()
-        n = n_steps or datamodule.val_steps_per_epoch()
-        if self.limit_val_batches is not None:
-            n = min(n, self.limit_val_batches)
+        n = n_steps or _limit(datamodule.val_steps_per_epoch(), self.limit_val_batches)
         for i in range(n):
             module.validation_step(datamodule.val_batch(), i)
-        out = reduce_metrics(module.logged, self.env["world_size"])
+        out = reduce_metrics(module.logged, self.env["world_size"], metric_names(module, "val"))
         module.logged.clear()
         return out
 
@@ -102,12 +135,10 @@ class Trainer:
         manual = getattr(module, "automatic_optimization", True) is False
         if self.num_sanity_val_steps:
             self.validate(module, datamodule, self.num_sanity_val_steps)
-        for epoch in range(self.max_epochs):
+        for epoch in range(self.start_epoch, self.max_epochs):
             module.train()
             module.logged.clear()
-            n = datamodule.train_steps_per_epoch()
-            if self.limit_train_batches is not None:
-                n = min(n, self.limit_train_batches)
+            n = _limit(datamodule.train_steps_per_epoch(), self.limit_train_batches)
             t0 = time.time()
             for i in range(n):
                 batch = datamodule.train_batch()
@@ -115,7 +146,7 @@ class Trainer:
                     module.training_step(batch, i, optimizer=optimizer, world_size=self.env["world_size"])
                 else:
                     self.train_step(module, optimizer, batch)
-            metrics = reduce_metrics(module.logged, self.env["world_size"])
+            metrics = reduce_metrics(module.logged, self.env["world_size"], metric_names(module, "train"))
             metrics.update(self.validate(module, datamodule))
             metrics["epoch"] = epoch
             metrics["epoch_time_s"] = time.time() - t0
@@ -130,20 +161,83 @@ class Trainer:
 # ---- checkpoints (reference: cli.py:29-37,145-150 ModelCheckpoint(monitor="val/loss", save_top_k=1,
 # save_last=True), filename "{model_name}__{dataset_name}__epoch_{e}_step_{s}"; lightning.py:237-241 and
 # scripts/extract_model_weights.py:38-47 for the consumers of the format) --------------------------------
+LIGHTNING_VERSION = "2.0.2"         # requirements_pipchill.txt: pytorch-lightning==2.0.2; Lightning's
+#                                     migrate_checkpoint parses this field with packaging.Version
+
+
+def adamw_state_dict(optimizer: FlatAdamW) -> Dict[str, Any]:
+    """The flat optimizer state in ``torch.optim.AdamW.state_dict()`` layout (one entry per parameter, in
+    ``optimizer.params`` order = the order the reference hands ``model.parameters()`` to AdamW), so that the
+    reference -- or plain torch -- can ``load_state_dict`` it."""
+    state, off = {}, 0
+    for i, p in enumerate(optimizer.params):
+        k = p.numel()
+        state[i] = {"step": torch.tensor(float(optimizer.step_count)),
+                    "exp_avg": optimizer.exp_avg[off:off + k].view(p.shape).detach().cpu().clone(),
+                    "exp_avg_sq": optimizer.exp_avg_sq[off:off + k].view(p.shape).detach().cpu().clone()}
+        off += k
+    group = {"lr": optimizer.lr, "betas": tuple(optimizer.betas), "eps": optimizer.eps,
+             "weight_decay": optimizer.weight_decay, "amsgrad": False, "maximize": False, "foreach": None,
+             "capturable": False, "differentiable": False, "fused": None,
+             "params": list(range(len(optimizer.params)))}
+    return {"state": state, "param_groups": [group]}
+
+
+def load_adamw_state_dict(optimizer: FlatAdamW, sd: Dict[str, Any]) -> None:
+    """Inverse of ``adamw_state_dict`` (also accepts a state dict written by ``torch.optim.AdamW`` itself)."""
+    state = sd["state"]
+    assert len(state) in (0, len(optimizer.params)), "optimizer state does not match the parameter list"
+    off, step = 0, 0
+    for i, p in enumerate(optimizer.params):
+        k = p.numel()
+        if i in state:
+            st = state[i]
+            optimizer.exp_avg[off:off + k].copy_(st["exp_avg"].reshape(-1))
+            optimizer.exp_avg_sq[off:off + k].copy_(st["exp_avg_sq"].reshape(-1))
+            step = int(float(st["step"]))
+        off += k
+    optimizer.step_count = step
+    g = sd["param_groups"][0]
+    optimizer.lr, optimizer.betas = float(g["lr"]), (float(g["betas"][0]), float(g["betas"][1]))
+    optimizer.eps, optimizer.weight_decay = float(g["eps"]), float(g["weight_decay"])
+
+
 def save_checkpoint(path: str, module, optimizer: Optional[FlatAdamW], epoch: int, global_step: int,
-                    extra: Optional[Dict[str, Any]] = None) -> None:
-    """Lightning-compatible layout: ``state_dict`` keyed like the LightningModule (``model.`` /
-    ``effect_model.`` / ``lfo_model.`` prefixes come from the attribute names), ``epoch``,
-    ``global_step``; the flat AdamW state goes under ``optimizer_states``."""
-    blob = {"state_dict": {k: v.detach().cpu() for k, v in module.state_dict().items()}, "epoch": epoch,
-            "global_step": global_step, "pytorch-lightning_version": "mod_extraction_amd"}
+                    extra: Optional[Dict[str, Any]] = None, callbacks: Optional[Dict[str, Any]] = None,
+                    hyper_parameters: Optional[Dict[str, Any]] = None) -> None:
+    """A checkpoint the reference's Lightning 2.0.2 stack can read back (``Trainer.validate/fit(ckpt_path=)``,
+    ``scripts/extract_model_weights.py``): ``state_dict`` keyed like the LightningModule (``model.`` /
+    ``effect_model.`` / ``lfo_model.`` prefixes come from the attribute names), ``epoch``, ``global_step``,
+    a real ``pytorch-lightning_version``, ``optimizer_states`` in torch AdamW layout, ``lr_schedulers``,
+    ``callbacks`` (the ModelCheckpoint bookkeeping) and ``hyper_parameters``."""
+    blob = {"epoch": epoch, "global_step": global_step, "pytorch-lightning_version": LIGHTNING_VERSION,
+            "state_dict": {k: v.detach().cpu() for k, v in module.state_dict().items()},
+            "callbacks": callbacks or {}, "optimizer_states": [], "lr_schedulers": [],
+            "hparams_name": "kwargs", "hyper_parameters": hyper_parameters or {}}
+    # no "loops" entry: Lightning restores loop progress only when the key is present, and falls back to
+    # epoch / global_step otherwise
     if optimizer is not None:
-        blob["optimizer_states"] = [{k: (v.cpu() if isinstance(v, torch.Tensor) else v)
-                                     for k, v in optimizer.state_dict().items()}]
+        blob["optimizer_states"] = [adamw_state_dict(optimizer)]
     if extra:
         blob.update(extra)
     os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
     torch.save(blob, path)
+
+
+def resume_from_checkpoint(path: str, module, optimizer: Optional[FlatAdamW], trainer: Optional["Trainer"] = None
+                           ) -> Dict[str, Any]:
+    """``fit`` with ``ckpt_path`` is a resume under Lightning: weights, optimizer moments and step count,
+    epoch.  Bare ``.pt`` state dicts carry weights only."""
+    blob = torch.load(path, map_location="cpu", weights_only=False)
+    if not (isinstance(blob, dict) and "state_dict" in blob):
+        return {}
+    if optimizer is not None and blob.get("optimizer_states"):
+        load_adamw_state_dict(optimizer, blob["optimizer_states"][0])
+    if trainer is not None:
+        trainer.start_epoch = int(blob.get("epoch", -1)) + 1
+        if trainer.checkpoints is not None:
+            trainer.checkpoints.load_state(blob.get("callbacks") or {})
+    return blob
 
 
 def extract_model_weights(ckpt_path: str, out_path: str, prefix: str = "model.") -> Dict[str, torch.Tensor]:
@@ -157,20 +251,42 @@ def extract_model_weights(ckpt_path: str, out_path: str, prefix: str = "model.")
 class CheckpointKeeper:
     """save_top_k=1 on ``val/loss`` (mode min) + save_last, with the reference's file-name rule."""
 
-    def __init__(self, dirpath: str, model_name: str = "local_model", dataset_name: str = "local_dataset") -> None:
+    STATE_KEY = ("ModelCheckpoint{'monitor': 'val/loss', 'mode': 'min', 'every_n_train_steps': 0, "
+                 "'every_n_epochs': 1, 'train_time_interval': None}")          # Lightning's callback state_key
+
+    def __init__(self, dirpath: str, model_name: str = "local_model", dataset_name: str = "local_dataset",
+                 hyper_parameters: Optional[Dict[str, Any]] = None) -> None:
         self.dirpath, self.model_name, self.dataset_name = dirpath, model_name, dataset_name
         self.best, self.best_path = float("inf"), None
+        self.hyper_parameters = hyper_parameters
 
     def name(self, epoch: int, step: int) -> str:
         return f"{self.model_name}__{self.dataset_name}__epoch_{epoch}_step_{step}.ckpt"
 
+    def state(self, current: Optional[float] = None) -> Dict[str, Any]:
+        last = os.path.join(self.dirpath, "last.ckpt")
+        return {self.STATE_KEY: {"monitor": "val/loss", "best_model_score": None if self.best_path is None else torch.tensor(self.best),
+                                 "best_model_path": self.best_path or "", "current_score": None if current is None else torch.tensor(current),
+                                 "dirpath": self.dirpath, "best_k_models": {} if self.best_path is None else {self.best_path: torch.tensor(self.best)},
+                                 "kth_best_model_path": self.best_path or "", "kth_value": torch.tensor(self.best),
+                                 "last_model_path": last}}
+
+    def load_state(self, callbacks: Dict[str, Any]) -> None:
+        for key, st in callbacks.items():
+            if str(key).startswith("ModelCheckpoint") and st.get("best_model_score") is not None:
+                self.best = float(st["best_model_score"])
+                self.best_path = st.get("best_model_path") or None
+
     def update(self, module, optimizer, epoch: int, step: int, metrics: Dict[str, float], rank: int = 0) -> None:
         if rank != 0:
             return
-        save_checkpoint(os.path.join(self.dirpath, "last.ckpt"), module, optimizer, epoch, step)
         v = metrics.get("val/loss")
-        if v is not None and v < self.best:
+        improved = v is not None and v < self.best
+        if improved:
             if self.best_path and os.path.exists(self.best_path):
                 os.remove(self.best_path)
             self.best, self.best_path = v, os.path.join(self.dirpath, self.name(epoch, step))
-            save_checkpoint(self.best_path, module, optimizer, epoch, step)
+        kw = dict(callbacks=self.state(v), hyper_parameters=self.hyper_parameters)
+        if improved:
+            save_checkpoint(self.best_path, module, optimizer, epoch, step, **kw)
+        save_checkpoint(os.path.join(self.dirpath, "last.ckpt"), module, optimizer, epoch, step, **kw)

@@ -46,3 +46,74 @@ def test_checkpoint_round_trip(tmp_path):
     m3 = small_module()
     cli.load_weights(m3, str(tmp_path / "lfo.pt"))
     assert torch.equal(m3.model.output.weight, m.model.output.weight)
+
+
+class _FlatState:
+    """the optimizer-state half of optim.FlatAdamW on the CPU (the step kernel itself needs a GPU)"""
+
+    def __init__(self, params, lr=1e-4, betas=(0.8, 0.99), eps=1e-8, weight_decay=0.01):
+        self.params = [p for p in params if p.requires_grad]
+        n = sum(p.numel() for p in self.params)
+        self.exp_avg, self.exp_avg_sq = torch.randn(n), torch.rand(n)
+        self.step_count, self.lr, self.betas, self.eps, self.weight_decay = 37, lr, betas, eps, weight_decay
+
+
+def test_checkpoint_is_loadable_by_the_reference_stack(tmp_path):
+    """A .ckpt written here must be readable by what the reference uses: packaging.Version on the version field
+    (Lightning's migrate_checkpoint), torch.optim.AdamW.load_state_dict on optimizer_states[0], and
+    load_state_dict(strict=True) of the reference-equivalent modules under the LightningModule prefixes."""
+    from packaging.version import Version
+    from oracle import models as om
+    torch.manual_seed(3)
+    m = small_module()
+    opt = _FlatState(m.parameters())
+    keeper = trainer.CheckpointKeeper(str(tmp_path), "lfo_2dcnn", "synth", hyper_parameters={"config": {"a": 1}})
+    keeper.update(m, opt, epoch=4, step=400, metrics={"val/loss": 0.25})
+    blob = torch.load(tmp_path / "last.ckpt", weights_only=False)
+    assert Version(blob["pytorch-lightning_version"]) >= Version("1.9.4")
+    for key in ("epoch", "global_step", "state_dict", "optimizer_states", "lr_schedulers", "callbacks", "hyper_parameters"):
+        assert key in blob, key
+    assert blob["lr_schedulers"] == [] and blob["hyper_parameters"] == {"config": {"a": 1}}
+    (cb_key, cb), = blob["callbacks"].items()
+    assert cb_key.startswith("ModelCheckpoint") and cb["monitor"] == "val/loss" and float(cb["best_model_score"]) == 0.25
+    assert cb["best_model_path"].endswith("lfo_2dcnn__synth__epoch_4_step_400.ckpt")
+    # (a) the reference-equivalent extractor (oracle.models.Spectral2DCNN uses the reference's module tree) loads the
+    #     "model."-prefixed weights strictly
+    ref = om.Spectral2DCNN(in_ch=2, n_samples=22272, n_mels=64, out_channels=[64] * 6, temp_dilations=[1, 1, 2, 4, 8, 16],
+                           pool_size=(2, 1))
+    sd = {k[len("model."):]: v for k, v in blob["state_dict"].items() if k.startswith("model.")}
+    ref.load_state_dict(sd, strict=True)
+    # (b) torch.optim.AdamW takes the optimizer state as is, parameter by parameter
+    t_opt = torch.optim.AdamW(ref.parameters(), lr=1.0)
+    t_opt.load_state_dict(blob["optimizer_states"][0])
+    g = t_opt.param_groups[0]
+    assert g["lr"] == 1e-4 and tuple(g["betas"]) == (0.8, 0.99) and g["weight_decay"] == 0.01
+    off = 0
+    for p in ref.parameters():
+        st = t_opt.state[p]
+        assert float(st["step"]) == 37.0
+        assert torch.equal(st["exp_avg"].reshape(-1), opt.exp_avg[off:off + p.numel()])
+        assert torch.equal(st["exp_avg_sq"].reshape(-1), opt.exp_avg_sq[off:off + p.numel()])
+        off += p.numel()
+    assert off == opt.exp_avg.numel()
+    # (c) resume: moments, step count, epoch and the best-score bookkeeping come back
+    opt2 = _FlatState(small_module().parameters())
+    opt2.exp_avg.zero_(); opt2.exp_avg_sq.zero_(); opt2.step_count = 0
+    t2 = trainer.Trainer(max_epochs=10, log_fn=None, checkpoints=trainer.CheckpointKeeper(str(tmp_path / "x")))
+    trainer.resume_from_checkpoint(str(tmp_path / "last.ckpt"), m, opt2, t2)
+    assert opt2.step_count == 37 and torch.equal(opt2.exp_avg, opt.exp_avg) and torch.equal(opt2.exp_avg_sq, opt.exp_avg_sq)
+    assert t2.start_epoch == 5 and t2.checkpoints.best == 0.25
+
+
+def test_tbptt_checkpoint_prefixes(tmp_path):
+    """effect_model. / lfo_model. prefixes of TBPTTLFOEffectModeling (lightning.py:237-246) load strictly into the
+    reference-equivalent LSTM."""
+    from oracle import models as om
+    cnn = models.Spectral2DCNN(in_ch=2, n_samples=22272, n_mels=64, out_channels=[64] * 6,
+                               temp_dilations=[1, 1, 2, 4, 8, 16], pool_size=(2, 1))
+    tb = lightning.TBPTTLFOEffectModeling(1024, 1024, models.LSTMEffectModel(), lfo_model=cnn)
+    trainer.save_checkpoint(str(tmp_path / "em.ckpt"), tb, None, 0, 83)
+    sd = torch.load(tmp_path / "em.ckpt", weights_only=False)["state_dict"]
+    assert {k.split(".")[0] for k in sd} == {"effect_model", "lfo_model"}
+    ref = om.LSTMEffectModel()
+    ref.load_state_dict({k[len("effect_model."):]: v for k, v in sd.items() if k.startswith("effect_model.")}, strict=True)

@@ -16,7 +16,8 @@ def build(path, cwd):
     old = os.getcwd()
     os.chdir(cwd)
     try:
-        return cli.CustomLightningCLI(args=["fit", "-c", path], run=False, device=CPU)
+        # the pretrained extractor blob eval_lfo.yml names is not part of the reference repository
+        return cli.CustomLightningCLI(args=["fit", "-c", path], run=False, device=CPU, allow_missing_ckpt=True)
     finally:
         os.chdir(old)
 
@@ -77,3 +78,20 @@ def test_lstm_state_dict_round_trip(golden_dir):
     m.load_state_dict(sd, strict=True)
     assert list(m.state_dict().keys()) == ["lstm.weight_ih_l0", "lstm.weight_hh_l0", "lstm.bias_ih_l0",
                                            "lstm.bias_hh_l0", "fc.weight", "fc.bias"]
+
+
+def test_missing_ckpt_path_raises():
+    """Lightning raises for a ckpt_path that does not exist; so does this entry layer (no silent random weights)."""
+    old = os.getcwd()
+    os.chdir(os.path.join(ROOT, "scripts"))
+    try:
+        with pytest.raises(FileNotFoundError):
+            cli.CustomLightningCLI(args=["validate", "-c", "../configs/eval_lfo.yml"], run=False, device=CPU)
+    finally:
+        os.chdir(old)
+
+
+def test_fractional_batch_limits():
+    from mod_extraction_amd import trainer
+    assert trainer._limit(100, None) == 100 and trainer._limit(100, 7) == 7 and trainer._limit(5, 7) == 5
+    assert trainer._limit(100, 0.1) == 10 and trainer._limit(100, 1.0) == 100 and trainer._limit(100, 2.0) == 2

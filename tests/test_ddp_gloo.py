@@ -66,7 +66,10 @@ def _worker(rank, world, port, out):
     res["grad"] = (g * scale).tolist()
     # (2) metric reduction = mean over ranks of the per-rank epoch means
     logged = {"train/l1": [torch.tensor(1.0 + rank), torch.tensor(3.0 + rank)], "train/loss": [torch.tensor(float(rank))]}
-    res["metrics"] = tr.reduce_metrics(logged, world)
+    names = ["train/l1", "train/esr", "train/loss"]
+    res["metrics"] = tr.reduce_metrics(logged, world, names)
+    # a rank that logged nothing (TBPTT: no valid LFO in any batch) still joins the collective, with count 0
+    res["metrics_ragged"] = tr.reduce_metrics(logged if rank == 0 else {}, world, names)
     # (3) TBPTT lock-step: rank 1 gets only flat (invalid) LFOs
     al.smoothen, al.stretch_corners = omod.smoothen, omod.stretch_corners
     al.valid_mod_sig_mask = lambda m: torch.tensor([1 if i in omod.find_valid_mod_sig_indices(m) else 0
@@ -111,6 +114,7 @@ def test_two_rank_host_logic():
     r0, r1 = results[0], results[1]
     assert r0["grad"] == r1["grad"] == [1.5] * 10                     # (1 + 2) / 2
     assert r0["metrics"] == r1["metrics"] == {"train/l1": 2.5, "train/loss": 0.5}
+    assert r0["metrics_ragged"] == r1["metrics_ragged"] == {"train/l1": 2.0, "train/loss": 0.0}
     assert r0["loss_is_none"] is False and r1["loss_is_none"] is True   # rank 1 had no valid LFO ...
     n_chunks = (3000 - 256) // 256
     assert r0["steps"] == r1["steps"] == n_chunks                       # ... yet took part in every step
@@ -130,3 +134,41 @@ def test_per_rank_seeding_of_the_batch_sampler():
         draws.append(torch.cat([p["rate_hz"], p["feedback"], p["lead"].float()]))
     assert torch.equal(draws[0], draws[2]) and not torch.equal(draws[0], draws[1])
     assert b.kinds == ["flanger", "chorus", "phaser"] * 2
+
+
+def _cli_worker(rank, world, port, cfg, cwd, out):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    os.chdir(cwd)
+    from mod_extraction_amd import cli, trainer as tr
+    tr.init_distributed(backend="gloo")
+    c = cli.CustomLightningCLI(args=["fit", "-c", cfg], run=False, device=torch.device("cpu"))
+    c.prepare_data_stream()
+    p = c.datamodule._batcher.sample_params()
+    masks = c.model.model.train().draw_masks()
+    flat = torch.cat([v.detach().reshape(-1) for v in c.model.parameters()])
+    out.put((rank, {"draw": torch.cat([p["rate_hz"], p["feedback"], p["lead"].float()]).tolist(), "masks": list(masks),
+                    "param_sum": float(flat.double().sum()), "param_abs": float(flat.double().abs().sum())}))
+    dist.destroy_process_group()
+
+
+def test_cli_gives_each_rank_its_own_data_stream_and_identical_replicas():
+    """with one seed_everything value on all ranks every rank drew the same batch.  Through
+    CustomLightningCLI the replicas must start identical while parameter draws and SpecAugment masks differ."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_cli_worker, args=(r, 2, port, "../configs/train_lfo_interwoven_all.yml",
+                                                   os.path.join(root, "scripts"), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=240) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    r0, r1 = results[0], results[1]
+    assert r0["param_sum"] == r1["param_sum"] and r0["param_abs"] == r1["param_abs"]
+    assert r0["draw"] != r1["draw"]
+    assert r0["masks"] != r1["masks"]

@@ -28,6 +28,7 @@ def test_fit_and_validate_lfo_extraction(tmp_path, dev):
     write(tmp_path, "small_cnn.yml", MODEL)          # referenced by path: exercises the YAML indirection
     cfg = write(tmp_path, "lfo.yml", f"""
         seed_everything: 43
+        custom: {{model_name: lfo_small, dataset_name: synth}}
         trainer: {{max_epochs: 2, num_sanity_val_steps: 1, limit_train_batches: 3, limit_val_batches: 2}}
         data:
           class_path: mod_extraction.data_modules.InterwovenDataModule
@@ -48,13 +49,32 @@ def test_fit_and_validate_lfo_extraction(tmp_path, dev):
           class_path: torch.optim.AdamW
           init_args: {{lr: 1e-3, betas: [0.8, 0.99]}}
     """)
-    c = cli.CustomLightningCLI(args=["fit", "-c", cfg], trainer_defaults={"log_fn": None})
+    c = cli.CustomLightningCLI(args=["fit", "-c", cfg], trainer_defaults={"log_fn": None}, log_dir=str(tmp_path / "logs"))
     hist = c.trainer.history
     assert len(hist) == 2 and c.optimizer.step_count == 6
+    # ModelCheckpoint policy of the reference (cli.py:29-37,145-150): last + best val/loss, named from custom.*
+    ckpt_dir = tmp_path / "logs" / "version_0" / "checkpoints"
+    files = sorted(os.listdir(ckpt_dir))
+    assert "last.ckpt" in files and len(files) == 2
+    best = [f for f in files if f != "last.ckpt"][0]
+    assert best.startswith("lfo_small__synth__epoch_") and best.endswith(".ckpt")
+    blob = torch.load(ckpt_dir / "last.ckpt", weights_only=False)
+    assert blob["epoch"] == 1 and blob["global_step"] == 6 and len(blob["optimizer_states"][0]["state"]) == len(c.optimizer.params)
+    # fit with ckpt_path = resume: weights, AdamW moments, step count and epoch continue
+    cfg2 = write(tmp_path, "lfo_resume.yml", open(cfg).read().replace("max_epochs: 2", "max_epochs: 3")
+                 + f"\nckpt_path: {ckpt_dir / 'last.ckpt'}\n")
+    r = cli.CustomLightningCLI(args=["fit", "-c", cfg2], trainer_defaults={"log_fn": None}, run=False,
+                               log_dir=str(tmp_path / "logs"))
+    for (k, a), (_, b) in zip(c.model.state_dict().items(), r.model.state_dict().items()):
+        assert torch.equal(a, b), k
+    r.trainer.checkpoints = None
+    r.run()
+    assert r.trainer.start_epoch == 2 and len(r.trainer.history) == 1 and r.optimizer.step_count == 9
     for k in ("train/l1", "train/fdl1", "train/sdl1", "train/mse", "train/loss", "val/l1", "val/loss"):
         assert k in hist[0] and hist[0][k] == hist[0][k]           # present and not NaN
     assert c.model.model.n_frames == 88                             # n_samples linked into the extractor
     v = cli.CustomLightningCLI(args=["validate", "-c", cfg], trainer_defaults={"log_fn": None}, run=False)
+    assert v.trainer.checkpoints is None
     v.model.model_smooth_n_frames = 4                               # eval_lfo.yml-style smoothing (K9 kernel)
     m = v.run()
     assert set(m) == {"val/l1", "val/fdl1", "val/sdl1", "val/mse", "val/loss"}
@@ -90,7 +110,8 @@ def test_fit_effect_model_tbptt(tmp_path, dev):
           class_path: torch.optim.AdamW
           init_args: {{lr: 1e-4, betas: [0.8, 0.99]}}
     """)
-    c = cli.CustomLightningCLI(args=["fit", "-c", cfg], trainer_defaults={"log_fn": None})
+    c = cli.CustomLightningCLI(args=["fit", "-c", cfg], trainer_defaults={"log_fn": None}, log_dir=str(tmp_path / "logs"))
+    assert os.path.isfile(tmp_path / "logs" / "version_0" / "checkpoints" / "last.ckpt")
     n = int((81 / 88) * 22272)                      # frames 88 -> 81 after 8-frame smoothing
     assert c.optimizer.numel == 17473 and c.optimizer.step_count == (n - 1024) // 1024
     h = c.trainer.history[0]
