@@ -3,89 +3,217 @@
 // loss fused (lightning.py:355-384: one 1024-sample chunk = one forward, one backward, one
 // optimizer step, hidden state carried and detached between chunks).
 //
-// One 256-thread workgroup per clip; thread j owns gate row j (gate order i, f, g, o like torch,
-// unit u = j & 63).  The recurrent state never leaves the CU: h lives in LDS, c in registers of
-// wave 0, the 256x64 recurrent matrix in registers (64 per thread).  Each time step is
-//   all threads : pre[j] = W_ih[j]·(lfo_t, x_t) + b_ih[j] + W_hh[j]·h + b_hh[j]; activation -> LDS
-//   wave 0      : c, h update, y_t = tanh(fc·h + b + x_t)
-// with two workgroup barriers.  Inputs are staged 256 samples at a time (coalesced), outputs
-// likewise.  For BPTT the forward stores (i, f, g, o, c, h) per step (1536 B/sample, the figure
-// SURVEY.md section 8d quotes); the backward walks the chunk in reverse, accumulating the
-// 17 473 parameter gradients of its clip in registers and writing one partial row per clip,
-// which mx_reduce_rows sums over the batch (deterministic, no atomics).
-// The kernel is bound by the serial dependency chain (1024 dependent steps per launch), not by
-// HBM or MFMA: per step it moves 12 B of audio and 1.5 KB of stash against ~33 kFLOP.
-#include "common.h"
+// The recurrence is a chain of T dependent steps per clip, each a 256x64 mat-vec; at the shipped batch
+// (128 clips) the chip has more CUs than clips, so a launch lasts T x (latency of one step) and everything
+// here is about that latency.  Measured on the part (tools/probe/ubench_valu.hip): a wave issues one vector
+// instruction per ~4.8 cycles whatever its neighbours on the SIMD do (up to 4 waves per SIMD), and an
+// LDS write -> barrier -> read round trip costs ~250 cycles with 8 waves: a step costs
+// (instructions per wave) x 2 ns + ~100 ns.  Hence: one 512-thread workgroup (8 waves) per clip, as few
+// instructions per wave and step as possible, exactly ONE barrier per step.
+//
+//  forward   lane = (unit u, gate pair gp, quarter kq of the 64 h values): 2 gates x 16 k = 16 v_pk_fma_f32
+//            (both gates of the pair in one packed FMA, the h value broadcast to both halves by op_sel), four
+//            ds_read_b128 of h per lane.  The quarters are summed by two DPP quad_perm adds per gate, every lane
+//            applies ONE gate's activation (one exp + one rcp), the 8 lanes of a unit exchange i, f, g, o by DPP
+//            (row_half_mirror + quad_perm), c stays in registers, h goes to the next row of a 256-step history in
+//            LDS -- rows never collide, hence one barrier per step.  y_t = tanh(fc h_t + b + x_t) is not on the
+//            recurrent path: it is evaluated for 256 steps at a time from the history, one step per thread.
+//  backward  (serial part) lane = (pair of hidden units, group rg of 16 gate rows): dh_prev[k] = sum_r W[r][k] dg[r]
+//            as 16 v_pk_fma_f32 (two units per packed FMA), an all-reduce over the 16 groups by four DPP adds per
+//            unit, and the element-wise gate derivatives computed by the lanes rg < 8 (one (unit, gate) each) from a
+//            slab of the forward stash that is staged through LDS 32 steps at a time (coalesced, double buffered).
+//            The gate gradients dg (B, T, 256) are written out ...
+//  wgrad     ... and the weight gradients, which do not feed the recurrence, are one GEMM per chunk on the
+//            matrix cores afterwards: dW_hh = sum_t dg_t (x) h_{t-1} with v_mfma_f32_32x32x2_f32 (exact fp32),
+//            K = T split over the workgroups; dW_ih / biases / fc ride along on the VALU.
+// Per-workgroup partial rows (state-dict order) are summed by mx_reduce_rows (deterministic, no atomics).
+//
+// Activations use v_exp_f32 / v_rcp_f32 (1 ulp each): sigmoid(x) = 1 / (1 + 2^(-x log2 e)),
+// tanh(x) = 2 sigmoid(2x) - 1 (absolute error ~1e-7, the recurrent path carries 1e-5 parity, tests/test_gpu_lstm.py).
+// Algorithmic HBM traffic: 12 B/sample I/O + 1536 B/sample stash (written, read once) + 1024 B/sample dg.
+#include "conv_common.h"
 
 #define LS_H 64
-#define LS_G 256
-#define LS_STASH 384        // floats per time step: gates 256 + c 64 + h 64
-#define LS_BLK 256          // samples staged per block
+#define LS_STASH 384        // floats per time step: gates 256 (i, f, g, o) + c 64 + h 64
+#define LS_TB 256           // steps per history block (forward)
+#define LS_HP 68            // history row pitch (floats): 17 x 16 B, conflict-free for the per-step row reads
 #define LS_NPARAM 17473     // 512 + 16384 + 256 + 256 + 64 + 1
+#define LS_THREADS 512
+#define LS_SLAB 32          // steps per stash slab (backward)
+#define LS_PP 72            // plane pitch inside a slab row (64 + 8: the four gate planes land on different banks)
+#define LS_ROWP (6 * LS_PP) // slab row pitch (floats)
 
-__device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
-
-__global__ __launch_bounds__(256) void lstm_fwd_kernel(const float *__restrict__ x, long long xs,
-                                                       const float *__restrict__ lfo, long long ls,
-                                                       const float *__restrict__ w_ih,
-                                                       const float *__restrict__ w_hh,
-                                                       const float *__restrict__ b_ih,
-                                                       const float *__restrict__ b_hh,
-                                                       const float *__restrict__ fc_w,
-                                                       const float *__restrict__ fc_b, float *__restrict__ h_io,
-                                                       float *__restrict__ c_io, float *__restrict__ y, long long ys,
-                                                       float *__restrict__ stash, int T)
-{
-    __shared__ float hbuf[LS_H], gates[LS_G], xin[LS_BLK], lin[LS_BLK], ybuf[LS_BLK];
-    const int b = blockIdx.x, j = threadIdx.x, q = j >> 6, u = j & 63;
-    float w[LS_H];
-#pragma unroll
-    for (int k = 0; k < LS_H; ++k) w[k] = w_hh[j * LS_H + k];
-    const float wi0 = w_ih[j * 2], wi1 = w_ih[j * 2 + 1], bi = b_ih[j], bh = b_hh[j];
-    const float fcw = fc_w[u], fcb = fc_b[0];
-    float c_reg = 0.0f;
-    if (j < LS_H) {
-        hbuf[j] = h_io[(size_t)b * LS_H + j];
-        c_reg = c_io[(size_t)b * LS_H + j];
+typedef float ls_f2 __attribute__((ext_vector_type(2)));
+// acc(2) += W[j](2) * v[j] for j = 0..15: 16 packed FMAs in ONE asm block (the compiler pads an s_nop after every
+// inline-asm statement that holds vector instructions); v[j] is element j & 1 of the register pair P(j/2),
+// broadcast to both halves of the product by op_sel / op_sel_hi
+#define LS_PK_LO " op_sel_hi:[1,0,1]\n\t"
+#define LS_PK_HI " op_sel:[0,1,0]\n\t"
+#define LS_PK16(acc, W, A, B, C, D) \
+    {                                                                                                                \
+        ls_f2 acc_b = {0.0f, 0.0f};                                                                                  \
+        LS_PK16_2(acc, acc_b, W, A, B, C, D);                                                                        \
+        acc += acc_b;                                                                                                \
     }
+#define LS_PK16_2(acc, accb, W, A, B, C, D)                                                              \
+    asm("v_pk_fma_f32 %0, %2, %18, %0" LS_PK_LO "v_pk_fma_f32 %1, %3, %18, %1" LS_PK_HI                              \
+        "v_pk_fma_f32 %0, %4, %19, %0" LS_PK_LO "v_pk_fma_f32 %1, %5, %19, %1" LS_PK_HI                              \
+        "v_pk_fma_f32 %0, %6, %20, %0" LS_PK_LO "v_pk_fma_f32 %1, %7, %20, %1" LS_PK_HI                              \
+        "v_pk_fma_f32 %0, %8, %21, %0" LS_PK_LO "v_pk_fma_f32 %1, %9, %21, %1" LS_PK_HI                              \
+        "v_pk_fma_f32 %0, %10, %22, %0" LS_PK_LO "v_pk_fma_f32 %1, %11, %22, %1" LS_PK_HI                            \
+        "v_pk_fma_f32 %0, %12, %23, %0" LS_PK_LO "v_pk_fma_f32 %1, %13, %23, %1" LS_PK_HI                            \
+        "v_pk_fma_f32 %0, %14, %24, %0" LS_PK_LO "v_pk_fma_f32 %1, %15, %24, %1" LS_PK_HI                            \
+        "v_pk_fma_f32 %0, %16, %25, %0" LS_PK_LO "v_pk_fma_f32 %1, %17, %25, %1 op_sel:[0,1,0]"                      \
+        : "+v"(acc), "+v"(accb)                                                                                      \
+        : "v"(W[0]), "v"(W[1]), "v"(W[2]), "v"(W[3]), "v"(W[4]), "v"(W[5]), "v"(W[6]), "v"(W[7]), "v"(W[8]),          \
+          "v"(W[9]), "v"(W[10]), "v"(W[11]), "v"(W[12]), "v"(W[13]), "v"(W[14]), "v"(W[15]),                         \
+          "v"((ls_f2){A.x, A.y}), "v"((ls_f2){A.z, A.w}), "v"((ls_f2){B.x, B.y}), "v"((ls_f2){B.z, B.w}),             \
+          "v"((ls_f2){C.x, C.y}), "v"((ls_f2){C.z, C.w}), "v"((ls_f2){D.x, D.y}), "v"((ls_f2){D.z, D.w}))
+template <int CTRL> __device__ __forceinline__ float ls_dpp(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+// s * sigmoid(s * x) + (1 - s): sigmoid for s = 1, tanh for s = 2; nsl2e = -s * log2(e), oms = 1 - s
+__device__ __forceinline__ float ls_act(float x, float nsl2e, float s, float oms)
+{
+    const float e = __builtin_amdgcn_exp2f(x * nsl2e);
+    return fmaf(__builtin_amdgcn_rcpf(1.0f + e), s, oms);
+}
+__device__ __forceinline__ float ls_tanh(float x) { return ls_act(x, -2.8853900817779268f, 2.0f, -1.0f); }
+#ifndef LS_ABL
+#define LS_ABL 0    // probe builds only (tools/probe/lstm_probe.hip): bit 0 no h reads, 1 no activations, 2 no barrier, 3 no h write,
+#endif              // 4 no packed FMAs, 5 no stash store
+#ifdef LS_DIAG      // tools/probe/lstm_probe.hip: per-phase cycle totals of one forward / backward step (never in the product build)
+__device__ unsigned long long ls_diag[8 * 8];
+#define LS_STAMP(i)                                                        \
+    {                                                                      \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime();        \
+        dg_acc[i] += t_ - dg_last;                                         \
+        dg_last = t_;                                                      \
+    }
+#define LS_DIAG_INIT unsigned long long dg_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dg_last = __builtin_amdgcn_s_memtime();
+#define LS_DIAG_DUMP                                                                             \
+    if (blockIdx.x == 0 && (threadIdx.x & 63) == 0)                                              \
+        for (int i_ = 0; i_ < 8; ++i_) ls_diag[(threadIdx.x >> 6) * 8 + i_] = dg_acc[i_];
+#else
+#define LS_STAMP(i)
+#define LS_DIAG_INIT
+#define LS_DIAG_DUMP
+#endif
+__device__ __forceinline__ void ls_barrier()      // LDS-only: outstanding global stores keep flying
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+__global__ __launch_bounds__(LS_THREADS) void lstm_fwd_kernel(const float *__restrict__ x, long long xs,
+                                                              const float *__restrict__ lfo, long long ls,
+                                                              const float *__restrict__ w_ih,
+                                                              const float *__restrict__ w_hh,
+                                                              const float *__restrict__ b_ih,
+                                                              const float *__restrict__ b_hh,
+                                                              const float *__restrict__ fc_w,
+                                                              const float *__restrict__ fc_b, float *__restrict__ h_io,
+                                                              float *__restrict__ c_io, float *__restrict__ y,
+                                                              long long ys, float *__restrict__ stash, int T)
+{
+    __shared__ __attribute__((aligned(16))) float hist[(LS_TB + 1) * LS_HP];   // row 0 = state entering the block
+    __shared__ __attribute__((aligned(16))) float2 xl[LS_TB];                   // (lfo, x) of the block
+    __shared__ float dummy[LS_THREADS];                                          // sink of the lanes that hold no h
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int kq = lane & 3, gp = (lane >> 2) & 1, u = wv * 8 + (lane >> 3);
+    const int q = 2 * gp + (kq & 1);                // the gate this lane activates (lanes kq >= 2 duplicate kq - 2)
+    const int ra = (2 * gp) * LS_H + u, rb = (2 * gp + 1) * LS_H + u;
+    ls_f2 wp[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) wp[j] = (ls_f2){w_hh[ra * LS_H + 16 * kq + j], w_hh[rb * LS_H + 16 * kq + j]};
+    // the input term and both biases enter through the kq = 0 quarter only (input order (lfo, audio): models.py:328)
+    const bool k0 = kq == 0;
+    const ls_f2 wi0 = k0 ? (ls_f2){w_ih[ra * 2], w_ih[rb * 2]} : (ls_f2){0.f, 0.f};
+    const ls_f2 wi1 = k0 ? (ls_f2){w_ih[ra * 2 + 1], w_ih[rb * 2 + 1]} : (ls_f2){0.f, 0.f};
+    const ls_f2 bias = k0 ? (ls_f2){b_ih[ra] + b_hh[ra], b_ih[rb] + b_hh[rb]} : (ls_f2){0.f, 0.f};
+    const float s = q == 2 ? 2.0f : 1.0f, nsl2e = -s * 1.4426950408889634f, oms = 1.0f - s;
+    const bool odd = kq & 1;
+    const float fcb = fc_b[0];
+    float c = c_io[(size_t)b * LS_H + u];
+    if (tid < LS_H) hist[tid] = h_io[(size_t)b * LS_H + tid];
     const float *xb = x + (size_t)b * xs, *lb = lfo + (size_t)b * ls;
     float *yb = y + (size_t)b * ys;
     float *sb = stash ? stash + (size_t)b * T * LS_STASH : nullptr;
-    for (int t0 = 0; t0 < T; t0 += LS_BLK) {
-        const int cnt = min(LS_BLK, T - t0);
+    // quads gp = 0 see (i, f) in their own lanes and (o, g) mirrored: they carry c and h; quads gp = 1 compute junk
+    const bool valid = gp == 0;
+    float *hw = valid ? hist + LS_HP + u : dummy + tid;          // where this lane's h goes (row 1 = step 0)
+    const int hw_step = valid ? LS_HP : 0;
+    // stash slot of this lane: its gate activation; the spare lanes kq = 2, 3 of the valid quads store c and h
+    const bool st_c = valid && kq == 2, st_h = valid && kq == 3;
+    const int st_off = st_c ? 256 + u : (st_h ? 320 + u : q * LS_H + u);
+
+    for (int t0 = 0; t0 < T; t0 += LS_TB) {
+        const int cnt = min(LS_TB, T - t0);
+        __syncthreads();                            // the previous block's y pass is done with hist / xl
+        if (t0 > 0 && tid < LS_H) hist[tid] = hist[LS_TB * LS_HP + tid];
+        if (tid < cnt) xl[tid] = make_float2(lb[t0 + tid], xb[t0 + tid]);
         __syncthreads();
-        if (j < cnt) { xin[j] = xb[t0 + j]; lin[j] = lb[t0 + j]; }
-        __syncthreads();
+        const float *hr = hist + 16 * kq;
+        float *hwp = hw;
+        LS_DIAG_INIT
+        float *st = sb + (size_t)t0 * LS_STASH + st_off;       // dereferenced only when sb != NULL (wave-uniform test)
         for (int tt = 0; tt < cnt; ++tt) {
-            const float xv = xin[tt], lv = lin[tt];
-            float ih = fmaf(wi1, xv, fmaf(wi0, lv, bi));       // input order: (lfo, audio), models.py:328
-            float hh = bh;
-#pragma unroll
-            for (int k = 0; k < LS_H; ++k) hh = fmaf(w[k], hbuf[k], hh);
-            const float pre = ih + hh;
-            const float act = q == 2 ? tanhf(pre) : sigmoidf_(pre);
-            gates[j] = act;
-            if (sb) sb[(size_t)(t0 + tt) * LS_STASH + j] = act;
-            __syncthreads();
-            if (j < LS_H) {
-                const float ig = gates[u], fg = gates[64 + u], gg = gates[128 + u], og = gates[192 + u];
-                c_reg = fmaf(fg, c_reg, ig * gg);
-                const float hv = og * tanhf(c_reg);
-                if (sb) {
-                    sb[(size_t)(t0 + tt) * LS_STASH + 256 + u] = c_reg;
-                    sb[(size_t)(t0 + tt) * LS_STASH + 320 + u] = hv;
-                }
-                const float s = wave_sum_f32(fcw * hv);
-                if (u == 0) ybuf[tt] = tanhf(s + fcb + xv);  // models.py:335-337
-                hbuf[u] = hv;
+            float4 h0, h1, h2, h3;
+            if (LS_ABL & 1) {
+                h0 = h1 = h2 = h3 = make_float4(c, c, c, c);
+            } else {
+                h0 = *(const float4 *)hr; h1 = *(const float4 *)(hr + 4); h2 = *(const float4 *)(hr + 8);
+                h3 = *(const float4 *)(hr + 12);
             }
-            __syncthreads();
+            const float2 in = xl[tt];
+            LS_STAMP(0)                                         // LDS reads landed
+            ls_f2 acc = wi1 * in.y + (wi0 * in.x + bias);
+            if (!(LS_ABL & 16)) {
+                LS_PK16(acc, wp, h0, h1, h2, h3);
+            } else {
+                acc += (ls_f2){h0.x, h3.w};
+            }
+            float pa = acc.x, pb = acc.y;
+            LS_STAMP(1)                                         // packed FMAs
+            pa += ls_dpp<0xB1>(pa); pb += ls_dpp<0xB1>(pb);     // quad_perm [1,0,3,2]
+            pa += ls_dpp<0x4E>(pa); pb += ls_dpp<0x4E>(pb);     // quad_perm [2,3,0,1]: all four quarters
+            const float a = (LS_ABL & 2) ? (odd ? pb : pa) * 0.01f : ls_act(odd ? pb : pa, nsl2e, s, oms);
+            const float m = ls_dpp<0x141>(a);                   // row_half_mirror: the other gate pair of the unit
+            const float gi = ls_dpp<0x00>(a), gf = ls_dpp<0x55>(a), gg = ls_dpp<0x55>(m), go = ls_dpp<0x00>(m);
+            c = fmaf(gf, c, gi * gg);
+            const float hv = go * ((LS_ABL & 2) ? c * 0.5f : ls_tanh(c));
+            LS_STAMP(2)                                         // reduce, activation, exchange, cell update
+            if (!(LS_ABL & 8)) *hwp = hv;
+            if (sb && !(LS_ABL & 32)) {
+                *st = st_c ? c : (st_h ? hv : a);
+                st += LS_STASH;
+            }
+            hr += LS_HP;
+            hwp += hw_step;
+            LS_STAMP(3)                                         // h write landed, stash store issued
+            if (!(LS_ABL & 4)) ls_barrier();
+            LS_STAMP(4)                                         // barrier
         }
-        if (j < cnt) yb[t0 + j] = ybuf[j];
-    }
-    if (j < LS_H) {
-        h_io[(size_t)b * LS_H + j] = hbuf[j];
-        c_io[(size_t)b * LS_H + j] = c_reg;
+        LS_DIAG_DUMP
+        // y_t = tanh(fc . h_t + b + x_t) (models.py:335-337), one step per thread, off the recurrent path
+        if (tid < cnt) {
+            const float *hr = hist + (tid + 1) * LS_HP;
+            float acc = fcb;
+#pragma unroll
+            for (int k = 0; k < LS_H; k += 4) {
+                const float4 h4 = *(const float4 *)(hr + k);
+                acc = fmaf(fc_w[k], h4.x, acc);
+                acc = fmaf(fc_w[k + 1], h4.y, acc);
+                acc = fmaf(fc_w[k + 2], h4.z, acc);
+                acc = fmaf(fc_w[k + 3], h4.w, acc);
+            }
+            yb[t0 + tid] = tanhf(acc + xl[tid].y);
+        }
+        if (t0 + cnt >= T) {
+            if (tid < LS_H) h_io[(size_t)b * LS_H + tid] = hist[cnt * LS_HP + tid];
+            if (valid && kq == 0) c_io[(size_t)b * LS_H + u] = c;
+        }
     }
 }
 
@@ -100,129 +228,303 @@ MX_EXPORT int mx_lstm_fwd(const float *x, int64_t x_stride, const float *lfo, in
 {
     if (!x || !lfo || !w_ih || !w_hh || !b_ih || !b_hh || !fc_w || !fc_b || !h_io || !c_io || !y || B <= 0 || T <= 0)
         return MX_ERR_ARG;
-    hipLaunchKernelGGL(lstm_fwd_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, x, (long long)x_stride,
-                       lfo, (long long)lfo_stride, w_ih, w_hh, b_ih, b_hh, fc_w, fc_b, h_io, c_io, y,
-                       (long long)y_stride, stash, (int)T);
+    if (T >= (1ll << 30)) return MX_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(lstm_fwd_kernel, dim3((unsigned)B), dim3(LS_THREADS), 0, (hipStream_t)stream, x,
+                       (long long)x_stride, lfo, (long long)lfo_stride, w_ih, w_hh, b_ih, b_hh, fc_w, fc_b, h_io, c_io,
+                       y, (long long)y_stride, stash, (int)T);
     return mx_launch_status();
 }
 
-// ---- truncated BPTT of one chunk with the L1 loss fused -----------------------------------------
-// loss = loss_scale_total * sum_{b,t} |y - wet|  (loss_scale = w_l1 / (B*T) for nn.L1Loss 'mean').
-// part (B, 17473): per-clip gradient rows in state-dict order
-//   [lstm.weight_ih_l0 (256,2) | lstm.weight_hh_l0 (256,64) | lstm.bias_ih_l0 | lstm.bias_hh_l0 | fc.weight | fc.bias]
-__global__ __launch_bounds__(256) void lstm_bwd_kernel(const float *__restrict__ x, long long xs,
-                                                       const float *__restrict__ lfo, long long ls,
-                                                       const float *__restrict__ y, long long ys,
-                                                       const float *__restrict__ wet, long long ws,
-                                                       const float *__restrict__ stash,
-                                                       const float *__restrict__ w_hh,
-                                                       const float *__restrict__ fc_w,
-                                                       const float *__restrict__ h_init,
-                                                       const float *__restrict__ c_init, float loss_scale,
-                                                       float *__restrict__ part, int T)
+// ---- truncated BPTT of one chunk with the L1 loss fused: the serial part --------------------------
+// loss = loss_scale * sum_{b,t} |y - wet|  (loss_scale = w_l1 / (B*T) for nn.L1Loss 'mean').
+// dgate (B, T, 256): d loss / d pre-activation of every gate row and step, consumed by lstm_wgrad_kernel.
+__device__ __forceinline__ int ls_dg_slot(int r)   // LDS slot of gate row r: [16-byte chunk of the 16-run][16-run][4]
 {
-    __shared__ float dgat[LS_G], hprev[LS_H], pdh[4][LS_H];
-    __shared__ float xin[LS_BLK], lin[LS_BLK], yin[LS_BLK], win[LS_BLK];
-    const int b = blockIdx.x, j = threadIdx.x, q = j >> 6, u = j & 63;
-    float wT[LS_H], dW[LS_H];
-#pragma unroll
-    for (int k = 0; k < LS_H; ++k) {
-        wT[k] = w_hh[(q * LS_H + k) * LS_H + u];     // column u of gate block q
-        dW[k] = 0.0f;
-    }
-    float dwi0 = 0.0f, dwi1 = 0.0f, db = 0.0f;
-    const float fcw = fc_w[u];
-    float dfcw = 0.0f, dfcb = 0.0f, dh_next = 0.0f, dc_next = 0.0f;
-    const float *xb = x + (size_t)b * xs, *lb = lfo + (size_t)b * ls, *yb = y + (size_t)b * ys,
-                *wb = wet + (size_t)b * ws;
-    const float *sb = stash + (size_t)b * T * LS_STASH;
-    const float h0 = j < LS_H ? h_init[(size_t)b * LS_H + u] : 0.0f;
-    const float c0 = j < LS_H ? c_init[(size_t)b * LS_H + u] : 0.0f;
+    return ((r & 15) >> 2) * 64 + (r >> 4) * 4 + (r & 3);
+}
 
-    // wave-0 register pipeline over the stash: values of step t are loaded during step t+1
-    float n_i = 0.f, n_f = 0.f, n_g = 0.f, n_o = 0.f, n_c = 0.f, n_h = 0.f;      // step t (current)
-    float cm1 = 0.f, hm1 = 0.f;                                                  // step t-1
-    if (j < LS_H) {
-        const float *s = sb + (size_t)(T - 1) * LS_STASH;
-        n_i = s[u]; n_f = s[64 + u]; n_g = s[128 + u]; n_o = s[192 + u]; n_c = s[256 + u]; n_h = s[320 + u];
-        if (T > 1) { cm1 = s[256 + u - LS_STASH]; hm1 = s[320 + u - LS_STASH]; } else { cm1 = c0; hm1 = h0; }
-    }
-    const int n_blocks = (T + LS_BLK - 1) / LS_BLK;
-    for (int blk = n_blocks - 1; blk >= 0; --blk) {
-        const int t0 = blk * LS_BLK, cnt = min(LS_BLK, T - t0);
-        __syncthreads();
-        if (j < cnt) { xin[j] = xb[t0 + j]; lin[j] = lb[t0 + j]; yin[j] = yb[t0 + j]; win[j] = wb[t0 + j]; }
-        __syncthreads();
-        for (int tt = cnt - 1; tt >= 0; --tt) {
-            const int t = t0 + tt;
-            if (j < LS_H) {
-                // prefetch step t-1 (gates) and t-2 (c, h) while step t is processed
-                float p_i = 0.f, p_f = 0.f, p_g = 0.f, p_o = 0.f, p_c = c0, p_h = h0;
-                if (t >= 1) {
-                    const float *s = sb + (size_t)(t - 1) * LS_STASH;
-                    p_i = s[u]; p_f = s[64 + u]; p_g = s[128 + u]; p_o = s[192 + u];
-                    if (t >= 2) { p_c = s[256 + u - LS_STASH]; p_h = s[320 + u - LS_STASH]; }
-                }
-                const float yv = yin[tt];
-                const float e = yv - win[tt];
-                const float dy = loss_scale * (e > 0.0f ? 1.0f : (e < 0.0f ? -1.0f : 0.0f));
-                const float dzy = dy * (1.0f - yv * yv);
-                dfcw = fmaf(dzy, n_h, dfcw);
-                dfcb += dzy;
-                const float dh = fmaf(dzy, fcw, dh_next);
-                const float tc = tanhf(n_c);
-                const float d_o = dh * tc;
-                const float dc = fmaf(dh * n_o, 1.0f - tc * tc, dc_next);
-                dgat[u] = dc * n_g * n_i * (1.0f - n_i);
-                dgat[64 + u] = dc * cm1 * n_f * (1.0f - n_f);
-                dgat[128 + u] = dc * n_i * (1.0f - n_g * n_g);
-                dgat[192 + u] = d_o * n_o * (1.0f - n_o);
-                dc_next = dc * n_f;
-                hprev[u] = hm1;
-                // rotate the pipeline: step t-1 becomes current
-                n_i = p_i; n_f = p_f; n_g = p_g; n_o = p_o; n_c = cm1; n_h = hm1; cm1 = p_c; hm1 = p_h;
-            }
-            __syncthreads();
-            {
-                const float d = dgat[j];
-                const float xv = xin[tt], lv = lin[tt];
-                dwi0 = fmaf(d, lv, dwi0);
-                dwi1 = fmaf(d, xv, dwi1);
-                db += d;
-                float p = 0.0f;
+__global__ __launch_bounds__(LS_THREADS) void lstm_bwd_kernel(const float *__restrict__ y, long long ys,
+                                                              const float *__restrict__ wet, long long ws,
+                                                              const float *__restrict__ stash,
+                                                              const float *__restrict__ w_hh,
+                                                              const float *__restrict__ fc_w,
+                                                              const float *__restrict__ c_init, float loss_scale,
+                                                              float *__restrict__ dgate, int T)
+{
+    // slab buffer = [row -1 (only its c plane: c of the step before the slab)] [32 rows of 6 planes] ; dzy (32)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int slab_floats = (LS_SLAB + 1) * LS_ROWP + LS_SLAB;
+    float *slab0 = smem, *slab1 = smem + slab_floats;
+    float *dgl = smem + 2 * slab_floats;                       // 2 x 256 gate gradients (double buffer)
+    float *dummy = dgl + 512;                                  // sink of the lanes that hold no gate gradient
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int rg = lane & 15, kp = wv * 4 + (lane >> 4);       // 16 gate rows 16 rg .. 16 rg + 15, hidden units 2 kp, 2 kp + 1
+    const int e = rg & 7, q = e & 3, k = 2 * kp + (e >> 2);    // the (unit, gate) this lane differentiates (rg >= 8: duplicate)
+    const bool second = e >> 2;
+    ls_f2 wp[16];
 #pragma unroll
-                for (int k = 0; k < LS_H; ++k) {
-                    dW[k] = fmaf(d, hprev[k], dW[k]);
-                    p = fmaf(wT[k], dgat[q * LS_H + k], p);
-                }
-                pdh[q][u] = p;
-            }
-            __syncthreads();
-            if (j < LS_H) dh_next = (pdh[0][u] + pdh[1][u]) + (pdh[2][u] + pdh[3][u]);
+    for (int j = 0; j < 16; ++j) wp[j] = *(const ls_f2 *)(w_hh + (16 * rg + j) * LS_H + 2 * kp);
+    const float fcw = fc_w[k];
+    // derivative of the own gate: D = alpha + a * (beta - a)   (sigmoid: a (1 - a); tanh: 1 - a^2)
+    const float alpha = q == 2 ? 1.0f : 0.0f, beta = q == 2 ? 0.0f : 1.0f;
+    // per-lane slab offsets (floats, relative to the row of the step)
+    const int off_a = q * LS_PP + k;
+    const int off_p = q == 0 ? 2 * LS_PP + k : (q == 1 ? 4 * LS_PP + k - LS_ROWP : (q == 2 ? k : 3 * LS_PP + k));
+    const int off_f = 1 * LS_PP + k, off_o = 3 * LS_PP + k, off_c = 4 * LS_PP + k;
+    const int dg_rd = rg * 4;                                  // + 64 c: the c-th 16-byte chunk of this lane's run of 16 rows
+    const bool owner = rg < 8;
+    const int dg_wr = ls_dg_slot(q * LS_H + k);
+    const float *yb = y + (size_t)b * ys, *wb = wet + (size_t)b * ws;
+    const float *sb = stash + (size_t)b * T * LS_STASH;
+    float *dgb = dgate + (size_t)b * T * 256;
+
+    const int n_slabs = (T + LS_SLAB - 1) / LS_SLAB;
+    float4 pre[6];
+    float pre_c = 0.0f, pre_dzy = 0.0f;
+    // slab S -> registers (global, coalesced: 32 x 384 contiguous floats), registers -> LDS (plane-padded)
+    auto slab_load = [&](int S) {
+        const int t0 = S * LS_SLAB, cnt = min(LS_SLAB, T - t0);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int e = (i * LS_THREADS + tid) * 4;                  // element of the 32 x 384 slab
+            pre[i] = e < cnt * LS_STASH ? *(const float4 *)(sb + (size_t)t0 * LS_STASH + e) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-    }
-    float *pb = part + (size_t)b * LS_NPARAM;
-    pb[j * 2] = dwi0;
-    pb[j * 2 + 1] = dwi1;
+        if (tid < LS_H) pre_c = t0 > 0 ? sb[(size_t)(t0 - 1) * LS_STASH + 256 + tid] : c_init[(size_t)b * LS_H + tid];
+        if (tid >= 64 && tid < 64 + LS_SLAB) {
+            const int t = t0 + tid - 64;
+            if (t < T) {
+                const float yv = yb[t], e = yv - wb[t];
+                pre_dzy = loss_scale * (e > 0.0f ? 1.0f : (e < 0.0f ? -1.0f : 0.0f)) * (1.0f - yv * yv);
+            } else
+                pre_dzy = 0.0f;
+        }
+    };
+    auto slab_store = [&](float *dst) {
 #pragma unroll
-    for (int k = 0; k < LS_H; ++k) pb[512 + j * LS_H + k] = dW[k];
-    pb[512 + 16384 + j] = db;
-    pb[512 + 16384 + 256 + j] = db;
-    if (j < LS_H) {
-        pb[512 + 16384 + 512 + u] = dfcw;
-        if (u == 0) pb[LS_NPARAM - 1] = dfcb;
+        for (int i = 0; i < 6; ++i) {
+            const int e = (i * LS_THREADS + tid) * 4, srow = e / LS_STASH, j = e % LS_STASH;
+            *(float4 *)(dst + (srow + 1) * LS_ROWP + (j >> 6) * LS_PP + (j & 63)) = pre[i];
+        }
+        if (tid < LS_H) dst[4 * LS_PP + tid] = pre_c;                  // row -1, c plane
+        if (tid >= 64 && tid < 64 + LS_SLAB) dst[(LS_SLAB + 1) * LS_ROWP + tid - 64] = pre_dzy;
+    };
+
+    for (int i = tid; i < 512; i += LS_THREADS) dgl[i] = 0.0f;        // dh from "step T" is zero
+    slab_load(n_slabs - 1);
+    slab_store((n_slabs - 1) & 1 ? slab1 : slab0);
+    __syncthreads();
+
+    float dc_next = 0.0f;
+    int par = 0;                                                       // dgl buffer read by the current step
+    for (int S = n_slabs - 1; S >= 0; --S) {
+        const int t0 = S * LS_SLAB, cnt = min(LS_SLAB, T - t0);
+        const float *sl = (S & 1 ? slab1 : slab0) + LS_ROWP;           // row 0 of the slab
+        const float *dzl = (S & 1 ? slab1 : slab0) + (LS_SLAB + 1) * LS_ROWP;
+        if (S > 0) slab_load(S - 1);
+        // raw stash values of the first step processed (the loop below prefetches one step ahead)
+        const float *r0 = sl + (cnt - 1) * LS_ROWP;
+        float n_a = r0[off_a], n_p = r0[off_p], n_f = r0[off_f], n_o = r0[off_o], n_c = r0[off_c], n_z = dzl[cnt - 1];
+        for (int s = cnt - 1; s >= 0; --s) {
+            // (1) the 16 gate gradients of step t+1 this lane multiplies
+            const float *dr = dgl + par * 256 + dg_rd;
+            const float4 g0 = *(const float4 *)dr, g1 = *(const float4 *)(dr + 64), g2 = *(const float4 *)(dr + 128),
+                         g3 = *(const float4 *)(dr + 192);
+            // (2) while they arrive: the local derivatives of step t from the values prefetched last step
+            const float a = n_a, pp = n_p, f = n_f, o = n_o, dzy = n_z;
+            const float tc = ls_tanh(n_c);
+            const float kc = o * fmaf(-tc, tc, 1.0f);                  // d h / d c = o (1 - tanh^2 c)
+            const float der = fmaf(a, beta - a, alpha);
+            const float kq = der * (q == 3 ? tc : pp);                 // i: g i(1-i); f: c_prev f(1-f); g: i (1-g^2); o: tanh(c) o(1-o)
+            // (3) prefetch the raw values of step t-1 (row -1 of the slab is never used as a step)
+            {   // unconditional (s = 0 re-reads row 0): the compiler can then count these reads behind the four above
+                const int sp = s > 0 ? s - 1 : 0;
+                const float *rn = sl + sp * LS_ROWP;
+                n_a = rn[off_a]; n_p = rn[off_p]; n_f = rn[off_f]; n_o = rn[off_o]; n_c = rn[off_c]; n_z = dzl[sp];
+            }
+            // (4) dh_prev[k] = sum_r W[r][k] dg[r] for the unit pair: 16 rows per lane, all-reduce over the 16 row groups
+            ls_f2 acc = {0.0f, 0.0f};
+            LS_PK16(acc, wp, g0, g1, g2, g3);
+            float da = acc.x, db = acc.y;
+            da += ls_dpp<0xB1>(da); db += ls_dpp<0xB1>(db);            // quad_perm [1,0,3,2]
+            da += ls_dpp<0x4E>(da); db += ls_dpp<0x4E>(db);            // quad_perm [2,3,0,1]
+            da += ls_dpp<0x141>(da); db += ls_dpp<0x141>(db);          // row_half_mirror
+            da += ls_dpp<0x140>(da); db += ls_dpp<0x140>(db);          // row_mirror
+            const float dhn = second ? db : da;
+            // (5) element-wise backward of step t
+            const float dh = fmaf(dzy, fcw, dhn);
+            const float dc = fmaf(dh, kc, dc_next);
+            const float dg = (q == 3 ? dh : dc) * kq;
+            dc_next = dc * f;
+            *(owner ? dgl + (par ^ 1) * 256 + dg_wr : dummy + tid) = dg;
+            if (owner) dgb[(size_t)(t0 + s) * 256 + q * LS_H + k] = dg;
+            par ^= 1;
+            if (S > 0 && s == cnt / 2) slab_store((S - 1) & 1 ? slab1 : slab0);   // the other buffer is idle
+            ls_barrier();
+        }
     }
 }
 
+// ---- weight gradients of the chunk: one GEMM on the matrix cores -----------------------------------
+// part row (b * n_split + ks), state-dict order:
+//   [lstm.weight_ih_l0 (256,2) | lstm.weight_hh_l0 (256,64) | lstm.bias_ih_l0 | lstm.bias_hh_l0 | fc.weight | fc.bias]
+#define WG_TB 32            // steps per staged block
+#define WG_DP 260           // LDS row pitch of the dg block (floats; 260 = 256 + 4 keeps rows 16-byte aligned)
+#define WG_HP 68            // LDS row pitch of the h block
+__global__ __launch_bounds__(256) void lstm_wgrad_kernel(const float *__restrict__ x, long long xs,
+                                                         const float *__restrict__ lfo, long long ls,
+                                                         const float *__restrict__ y, long long ys,
+                                                         const float *__restrict__ wet, long long ws,
+                                                         const float *__restrict__ stash,
+                                                         const float *__restrict__ dgate,
+                                                         const float *__restrict__ h_init, float loss_scale,
+                                                         float *__restrict__ part, int T, int n_split)
+{
+    // blocks of 32 steps are staged through LDS with 16-byte loads (double buffered: the next block is in
+    // flight in registers while the 64 MFMAs per wave of the current one run)
+    __shared__ __attribute__((aligned(16))) float dgs[2][WG_TB * WG_DP];
+    __shared__ __attribute__((aligned(16))) float hps[2][WG_TB * WG_HP];
+    __shared__ float xls[2][WG_TB][2];
+    __shared__ float red[4][LS_H + 1];
+    const int b = blockIdx.x, ks = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int c32 = lane & 31, tpar = lane >> 5;
+    int t_per = (T + n_split - 1) / n_split;
+    t_per = (t_per + WG_TB - 1) / WG_TB * WG_TB;
+    const int t_beg = ks * t_per, t_end = min(T, t_beg + t_per);
+    const float *xb = x + (size_t)b * xs, *lb = lfo + (size_t)b * ls, *yb = y + (size_t)b * ys, *wb = wet + (size_t)b * ws;
+    const float *sb = stash + (size_t)b * T * LS_STASH;
+    const float *dgb = dgate + (size_t)b * T * 256;
+    const float *h0 = h_init + (size_t)b * LS_H;
+    float *pb = part + ((size_t)b * n_split + ks) * LS_NPARAM;
+
+    floatx16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    float dwi0[2] = {0.f, 0.f}, dwi1[2] = {0.f, 0.f}, db[2] = {0.f, 0.f};
+    const int r0 = wv * 64 + c32;                      // gate rows r0 and r0 + 32 of this lane's A fragments
+
+    float4 pdg[8], php[2];
+    float pxl = 0.0f;
+    auto fetch = [&](int t0) {                         // block [t0, t0 + 32) -> registers (zeros past t_end)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int e = (i * 256 + tid) * 4, tt = t0 + (e >> 8);
+            pdg[i] = tt < t_end ? *(const float4 *)(dgb + (size_t)tt * 256 + (e & 255)) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int e = (i * 256 + tid) * 4, tt = t0 + (e >> 6);       // h_{tt-1}: the state entering step tt
+            const float *hp = tt > 0 ? sb + (size_t)(tt - 1) * LS_STASH + 320 : h0;
+            php[i] = tt < t_end ? *(const float4 *)(hp + (e & 63)) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (tid < 2 * WG_TB) {
+            const int tt = t0 + (tid >> 1);
+            pxl = tt < t_end ? (tid & 1 ? xb[tt] : lb[tt]) : 0.0f;
+        }
+    };
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int e = (i * 256 + tid) * 4;
+            *(float4 *)(&dgs[buf][(e >> 8) * WG_DP + (e & 255)]) = pdg[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int e = (i * 256 + tid) * 4;
+            *(float4 *)(&hps[buf][(e >> 6) * WG_HP + (e & 63)]) = php[i];
+        }
+        if (tid < 2 * WG_TB) xls[buf][tid >> 1][tid & 1] = pxl;
+    };
+    if (t_beg < t_end) {
+        fetch(t_beg);
+        stage(0);
+    }
+    __syncthreads();
+    int buf = 0;
+    // A[i = gate row][k = step] = dg, B[k = step][j = hidden unit] = h_{t-1}: D += A B over the steps, 2 per MFMA
+    for (int t0 = t_beg; t0 < t_end; t0 += WG_TB) {
+        const bool more = t0 + WG_TB < t_end;
+        if (more) fetch(t0 + WG_TB);
+#pragma unroll 4
+        for (int kk = 0; kk < WG_TB / 2; ++kk) {
+            const int row = 2 * kk + tpar;
+            const float a0 = dgs[buf][row * WG_DP + r0], a1 = dgs[buf][row * WG_DP + r0 + 32];
+            const float b0 = hps[buf][row * WG_HP + c32], b1 = hps[buf][row * WG_HP + 32 + c32];
+            const float li = xls[buf][row][0], xi = xls[buf][row][1];
+            acc[0][0] = mfma32(a0, b0, acc[0][0]);
+            acc[0][1] = mfma32(a0, b1, acc[0][1]);
+            acc[1][0] = mfma32(a1, b0, acc[1][0]);
+            acc[1][1] = mfma32(a1, b1, acc[1][1]);
+            dwi0[0] = fmaf(a0, li, dwi0[0]); dwi1[0] = fmaf(a0, xi, dwi1[0]); db[0] += a0;
+            dwi0[1] = fmaf(a1, li, dwi0[1]); dwi1[1] = fmaf(a1, xi, dwi1[1]); db[1] += a1;
+        }
+        if (more) stage(buf ^ 1);                      // the other buffer was last read one block ago
+        __syncthreads();
+        buf ^= 1;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                pb[512 + (wv * 64 + i * 32 + mfma_row(r, lane)) * LS_H + j * 32 + c32] = acc[i][j][r];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const float s0 = dwi0[i] + __shfl_xor(dwi0[i], 32, 64), s1 = dwi1[i] + __shfl_xor(dwi1[i], 32, 64);
+        const float sbias = db[i] + __shfl_xor(db[i], 32, 64);
+        if (tpar == 0) {
+            const int r = r0 + 32 * i;
+            pb[r * 2] = s0;
+            pb[r * 2 + 1] = s1;
+            pb[512 + 16384 + r] = sbias;
+            pb[512 + 16384 + 256 + r] = sbias;
+        }
+    }
+    // fc: d fc_w[u] = sum_t dzy_t h_t[u], d fc_b = sum_t dzy_t; wave wv takes every 4th step
+    {
+        float dfw = 0.0f, dfb = 0.0f;
+        for (int t = t_beg + wv; t < t_end; t += 4) {
+            const float yv = yb[t], e = yv - wb[t];
+            const float dzy = loss_scale * (e > 0.0f ? 1.0f : (e < 0.0f ? -1.0f : 0.0f)) * (1.0f - yv * yv);
+            dfw = fmaf(dzy, sb[(size_t)t * LS_STASH + 320 + lane], dfw);
+            dfb += dzy;
+        }
+        red[wv][lane] = dfw;
+        if (lane == 0) red[wv][LS_H] = dfb;
+        __syncthreads();
+        if (tid <= LS_H) pb[512 + 16384 + 512 + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+    }
+}
+
+// dgate_ws: workspace (B, T, 256) floats; part: (B * n_split, 17473) partial gradient rows, to be summed with
+// mx_reduce_rows(part, B * n_split, 17473, ...); n_split in {1, 2, 4}: workgroups per clip of the weight-gradient GEMM.
 MX_EXPORT int mx_lstm_bwd_l1(const float *x, int64_t x_stride, const float *lfo, int64_t lfo_stride, const float *y,
                              int64_t y_stride, const float *wet, int64_t wet_stride, const float *stash,
                              const float *w_hh, const float *fc_w, const float *h_init, const float *c_init,
-                             float loss_scale, float *part, int64_t B, int64_t T, void *stream)
+                             float loss_scale, float *dgate_ws, float *part, int32_t n_split, int64_t B, int64_t T,
+                             void *stream)
 {
-    if (!x || !lfo || !y || !wet || !stash || !w_hh || !fc_w || !h_init || !c_init || !part || B <= 0 || T <= 0)
+    if (!x || !lfo || !y || !wet || !stash || !w_hh || !fc_w || !h_init || !c_init || !dgate_ws || !part || B <= 0 ||
+        T <= 0 || n_split < 1 || n_split > 4)
         return MX_ERR_ARG;
-    hipLaunchKernelGGL(lstm_bwd_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, x, (long long)x_stride,
-                       lfo, (long long)lfo_stride, y, (long long)y_stride, wet, (long long)wet_stride, stash, w_hh,
-                       fc_w, h_init, c_init, loss_scale, part, (int)T);
+    if (T >= (1ll << 30)) return MX_ERR_UNSUPPORTED;
+    const size_t lds = (size_t)(2 * ((LS_SLAB + 1) * LS_ROWP + LS_SLAB) + 512 + LS_THREADS) * sizeof(float);
+    static bool attr_set[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+        (void)hipFuncSetAttribute((const void *)lstm_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set[dev] = true;
+    }
+    hipLaunchKernelGGL(lstm_bwd_kernel, dim3((unsigned)B), dim3(LS_THREADS), lds, (hipStream_t)stream, y,
+                       (long long)y_stride, wet, (long long)wet_stride, stash, w_hh, fc_w, c_init, loss_scale, dgate_ws,
+                       (int)T);
+    hipLaunchKernelGGL(lstm_wgrad_kernel, dim3((unsigned)B, (unsigned)n_split), dim3(256), 0, (hipStream_t)stream, x,
+                       (long long)x_stride, lfo, (long long)lfo_stride, y, (long long)y_stride, wet, (long long)wet_stride,
+                       stash, dgate_ws, h_init, loss_scale, part, (int)T, (int)n_split);
     return mx_launch_status();
 }
