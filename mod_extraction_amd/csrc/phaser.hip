@@ -3,12 +3,18 @@
 // third-party source absent from the reference tree: PARITY UNPINNED, checked against
 // oracle/csrc/oracle_ref.c:orc_phaser, which restates the published JUCE algorithm).
 //
-// One wavefront per clip (16 clips per workgroup).  The recurrence (in - lastOut -> 6 first-order TPT all-pass stages ->
-// out; lastOut = out * feedback) is strictly serial per sample, so the wave splits the work by
-// kind: per block of 256 samples the 64 lanes evaluate the 64 LFO / cut-off updates in parallel
-// (sin, pow, fp64 tan -> G = g / (1 + g), one per lane), samples are loaded/stored 4 per lane
-// coalesced (lane registers, broadcast with v_readlane), and only the 256-sample dependent chain
-// runs wave-uniformly.
+// One wavefront per clip.  The recurrence (in - lastOut -> 6 first-order TPT all-pass stages -> out;
+// lastOut = out * feedback) is strictly serial per sample.  Per block of 256 samples the 64 lanes evaluate the
+// 64 LFO / cut-off updates in parallel (sin, pow, fp64 tan -> G = g / (1 + g), one per lane); the samples
+// themselves run as a LINEAR STATE-SPACE step on all 64 lanes (phaser_mat_kernel, the default):
+//     z = (s0..s5, lastOut, in)  ->  (s0'..s5', lastOut', y) = A(G) z,     A: 8 x 8, constant for 4 samples,
+// one matrix entry per lane (lane = 8 row + col), a step = one FMA + a DPP all-reduce over the 8 columns; the
+// next step uses the TRANSPOSED lane layout (one FMA + an all-reduce over the 8 rows: row_ror:8 and two
+// v_permlane swaps), so the state vector never has to be transposed back: ~12 instructions per sample on a
+// 6-deep dependent chain, against ~35 wave-uniform instructions (8 deep) of the scalar form.  The entries of
+// A are products of a per-update table (powers of 2G-1 etc., written to LDS by the lane that owns the update)
+// picked by per-lane static indices.  Algebraically identical to JUCE's stage order, rounding differs
+// (<= 1e-6 on audio); exact_order != 0 keeps the scalar kernel in JUCE's operation order for bit tests.
 // sin / pow / log10 are evaluated in fp64 and rounded once, which reproduces the host libm's (correctly
 // rounded) float results; the LFO phase accumulator is advanced sequentially in fp32 (as JUCE does) to stay bit-faithful.
 // `lead` samples are processed (filter warm-up, LFO phase) before the N output samples: the
@@ -22,7 +28,6 @@
                           // that the 1-workgroup-per-CU matrix kernels of the train step keep the other CUs
 #endif
 
-template <bool FAST>
 __global__ __launch_bounds__(64 * PH_WPB) void phaser_kernel(const float *__restrict__ x, long long x_stride,
                                                     const float *__restrict__ rate,
                                                     const float *__restrict__ depth,
@@ -87,40 +92,12 @@ __global__ __launch_bounds__(64 * PH_WPB) void phaser_kernel(const float *__rest
         // (4) the dependent chain, wave-uniform; inputs and coefficients are broadcast from lane
         //     registers (v_readlane) so that no LDS round trip sits between two samples
         const int cnt = min(PH_BLOCK, total - n0);
-        // FAST: the same all-pass stage written as out = (2G-1) x + (2-2G) s, s' = 2G x + (1-2G) s: one FMA
-        // per stage on the sample-to-sample critical path instead of five dependent operations (4-5x
-        // shorter chain).  Algebraically identical to the JUCE order, rounding differs (<= 1e-6 on audio).
-        const float c1r = 2.0f * Greg - 1.0f, c2r = 2.0f - 2.0f * Greg, c3r = 2.0f * Greg, c4r = 1.0f - 2.0f * Greg;
-        float fc1 = 0.f, fc2 = 0.f, fc3 = 0.f, fc4 = 0.f;
 #pragma unroll
         for (int j = 0; j < PH_BLOCK / 64; ++j) {
             const int lim = min(64, cnt - j * 64);
             for (int li = 0; li < lim; ++li) {
                 const float in = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xr[j]), li));
                 float out = __fsub_rn(in, last);
-                if (FAST) {
-                    // coefficients change every 4 samples (one cut-off update): re-broadcast only then
-                    if ((li & 3) == 0) {
-                        const int src = (j * 64 + li) >> 2;
-                        fc1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c1r), src));
-                        fc2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c2r), src));
-                        fc3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c3r), src));
-                        fc4 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c4r), src));
-                    }
-#define PH_FSTAGE(S)                              \
-    {                                             \
-        const float xin = out;                    \
-        out = fmaf(fc1, xin, fc2 * S);            \
-        S = fmaf(fc3, xin, fc4 * S);              \
-    }
-                    PH_FSTAGE(s0) PH_FSTAGE(s1) PH_FSTAGE(s2) PH_FSTAGE(s3) PH_FSTAGE(s4) PH_FSTAGE(s5)
-#undef PH_FSTAGE
-                    last = __fmul_rn(out, fb);
-                    float m = __fadd_rn(__fmul_rn(out, wet_g), __fmul_rn(in, dry_g));
-                    m = m < -1.0f ? -1.0f : (m > 1.0f ? 1.0f : m);
-                    yr[j] = lane == li ? m : yr[j];
-                    continue;
-                }
                 const float G = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Greg), (j * 64 + li) >> 2));
                 float v, yk;
 #define PH_STAGE(S)                                   \
@@ -148,12 +125,175 @@ __global__ __launch_bounds__(64 * PH_WPB) void phaser_kernel(const float *__rest
     }
 }
 
+// ---- the default kernel: 8 x 8 state-space step on 64 lanes (see the header) ------------------------------
+#define PM_TAB 20                 // table row pitch (floats): P[0..6] = (2G-1)^e, then the 11 scale factors below
+#define PM_LDS (256 + 256 + 64 * PM_TAB + 320)     // floats per wave: x block, y block, table, write sink
+
+template <int CTRL> __device__ __forceinline__ float ph_dpp(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+// table slots of the scale factor S and the exponent e of matrix entry A[k][j] = S (2G-1)^e
+// rows k: 0..5 = all-pass states, 6 = lastOut, 7 = output; columns j: 0..5 states, 6 = lastOut, 7 = input sample
+__device__ __forceinline__ void ph_entry(int k, int j, int &s_idx, int &p_idx)
+{
+    if (k <= 5) {
+        if (j < k) { s_idx = 9; p_idx = k - 1 - j; }            //  c3 c2 c1^(k-1-j)
+        else if (j == k) { s_idx = 8; p_idx = 0; }              //  c4
+        else if (j <= 5) { s_idx = 7; p_idx = 0; }              //  0
+        else if (j == 6) { s_idx = 11; p_idx = k; }             // -c3 c1^k
+        else { s_idx = 10; p_idx = k; }                         //  c3 c1^k
+    } else {
+        const int base = k == 6 ? 12 : 15;                      // feedback row / wet row
+        if (j <= 5) { s_idx = base; p_idx = 5 - j; }            //  g c2 c1^(5-j)
+        else if (j == 6) { s_idx = base + 1; p_idx = 6; }       // -g c1^6
+        else { s_idx = base + 2; p_idx = 6; }                   //  g c1^6  (+ dry on the output row)
+    }
+}
+
+__global__ __launch_bounds__(64 * PH_WPB) void phaser_mat_kernel(const float *__restrict__ x, long long x_stride,
+                                                                 const float *__restrict__ rate,
+                                                                 const float *__restrict__ depth,
+                                                                 const float *__restrict__ centre,
+                                                                 const float *__restrict__ feedback,
+                                                                 const float *__restrict__ mix,
+                                                                 const int *__restrict__ lead_arr,
+                                                                 const int *__restrict__ rows, int n_items, int N,
+                                                                 double sr, float *__restrict__ y, long long y_stride,
+                                                                 float *__restrict__ dry_out)
+{
+    __shared__ __attribute__((aligned(16))) float lds_all[PH_WPB * PM_LDS];
+    const int lane = threadIdx.x & 63;
+    const int item = blockIdx.x * PH_WPB + (threadIdx.x >> 6);
+    if (item >= n_items) return;                        // whole wave exits; waves never synchronise with each other
+    float *xbuf = lds_all + (threadIdx.x >> 6) * PM_LDS, *ybuf = xbuf + 256, *tab = ybuf + 256, *sink = tab + 64 * PM_TAB;
+    const int b = rows ? rows[item] : item;
+    const int lead = lead_arr ? lead_arr[b] : 0;
+    const int total = lead + N;
+    const float *xb = x + (size_t)b * x_stride;
+    float *yb = y + (size_t)b * y_stride;
+    float *db = dry_out ? dry_out + (size_t)b * y_stride : nullptr;
+
+    const float two_pi = 6.283185307179586476925286766559f;
+    const float pi_f = 3.14159265358979323846f;
+    const float fmax_hz = (float)fmin(20000.0, 0.49 * sr);
+    const float log_min = (float)log10(20.0), log_max = (float)log10((double)fmax_hz);
+    const float inc = __fmul_rn(__fdiv_rn(two_pi, (float)(sr / 4.0)), rate[b]);
+    const float norm_centre = __fdiv_rn(__fsub_rn((float)log10((double)centre[b]), log_min), __fsub_rn(log_max, log_min));
+    const float osc_vol = __fmul_rn(depth[b], 0.5f);
+    const float fb = feedback[b];
+    const float wet_g = mix[b], dry_g = __fsub_rn(1.0f, mix[b]);
+
+    // lane = 8 r + c.  Layout 1 (even samples): the lane holds z[c] and entry A[r][c]; layout 2 (odd samples): it
+    // holds z[r] and entry A[c][r].  The input column / row (index 7) enters as a separate product (inj * sample).
+    const int r = lane >> 3, c = lane & 7;
+    int s1, p1, s2, p2;
+    ph_entry(r, c, s1, p1);
+    ph_entry(c, r, s2, p2);
+    const float dry_add = lane == 63 ? dry_g : 0.0f;            // A[7][7] = wet c1^6 + dry
+    const float keep1 = c == 7 ? 0.0f : 1.0f, keep2 = r == 7 ? 0.0f : 1.0f;
+    // the output row lands in lanes r == 7 (layout 1) / c == 7 (layout 2): lanes 56 and 7 write it, the others a sink
+    float *w1 = lane == 56 ? ybuf : sink + lane, *w2 = lane == 7 ? ybuf : sink + lane;
+
+    float phase = 0.0f;
+    float z = 0.0f;                                             // state vector, layout 1
+
+    for (int n0 = 0; n0 < total; n0 += PH_BLOCK) {
+        // (1) coalesced load of 256 input samples into LDS
+#pragma unroll
+        for (int j = 0; j < PH_BLOCK / 64; ++j) {
+            const int n = n0 + j * 64 + lane;
+            xbuf[j * 64 + lane] = n < total ? xb[n] : 0.0f;
+        }
+        // (2) sequential fp32 phase accumulation; lane k keeps the phase of update k
+        float my_phase = 0.0f;
+        for (int k = 0; k < PH_BLOCK / 4; ++k) {
+            if (lane == k) my_phase = phase;
+            phase = __fadd_rn(phase, inc);
+            while (phase >= two_pi) phase = __fsub_rn(phase, two_pi);
+        }
+        // (3) one cut-off update per lane -> its row of the coefficient table
+        {
+            float osc = (float)sin((double)__fsub_rn(my_phase, pi_f));
+            float lfo = __fadd_rn(__fmul_rn(osc, osc_vol), norm_centre);
+            lfo = lfo < 0.0f ? 0.0f : (lfo > 1.0f ? 1.0f : lfo);
+            float fc = (float)pow(10.0, (double)__fadd_rn(__fmul_rn(lfo, __fsub_rn(log_max, log_min)), log_min));
+            float g = (float)tan(3.14159265358979323846 * (double)fc / sr);
+            const float G = __fdiv_rn(g, __fadd_rn(1.0f, g));
+            // all-pass stage: out = c1 in + c2 s, s' = c3 in + c4 s
+            const float c1 = 2.0f * G - 1.0f, c2 = 2.0f - 2.0f * G, c3 = 2.0f * G, c4 = 1.0f - 2.0f * G;
+            const float q2 = c1 * c1, q3 = q2 * c1, q4 = q2 * q2, q5 = q4 * c1, q6 = q4 * q2;
+            float4 *row = (float4 *)(tab + lane * PM_TAB);
+            row[0] = make_float4(1.0f, c1, q2, q3);
+            row[1] = make_float4(q4, q5, q6, 0.0f);
+            row[2] = make_float4(c4, c3 * c2, c3, -c3);
+            row[3] = make_float4(fb * c2, -fb, fb, wet_g * c2);
+            row[4] = make_float4(-wet_g, wet_g, 0.0f, 0.0f);
+        }
+        __builtin_amdgcn_wave_barrier();                        // LDS operations of one wave complete in order
+        // (4) the dependent chain: 64 updates x 4 samples
+        // (the table entries and the 4 samples of update k + 1 are read while update k runs)
+        float t_s1 = tab[s1], t_p1 = tab[p1], t_s2 = tab[s2], t_p2 = tab[p2];
+        float4 t_x = *(const float4 *)xbuf;
+        for (int k = 0; k < PH_BLOCK / 4; ++k) {
+            const float e1 = fmaf(t_s1, t_p1, dry_add), e2 = fmaf(t_s2, t_p2, dry_add);
+            const float a1 = e1 * keep1, i1 = e1 - a1, a2 = e2 * keep2, i2 = e2 - a2;   // entry / input weight
+            const float4 xin = t_x;
+            {
+                const int kn = k + 1 < PH_BLOCK / 4 ? k + 1 : k;
+                const float *tr = tab + kn * PM_TAB;
+                t_s1 = tr[s1]; t_p1 = tr[p1]; t_s2 = tr[s2]; t_p2 = tr[p2];
+                t_x = *(const float4 *)(xbuf + 4 * kn);
+            }
+            float *o1 = w1 + 4 * k, *o2 = w2 + 4 * k;
+#define PH_STEP1(XV, SLOT)                                                                         \
+    {                                                                                              \
+        float p = fmaf(a1, z, i1 * XV);                                                            \
+        p += ph_dpp<0xB1>(p);               /* quad_perm [1,0,3,2] */                              \
+        p += ph_dpp<0x4E>(p);               /* quad_perm [2,3,0,1] */                              \
+        p += ph_dpp<0x141>(p);              /* row_half_mirror: sum over the 8 columns */          \
+        o1[SLOT] = p;                                                                              \
+        z = p;                                                                                     \
+    }
+#define PH_STEP2(XV, SLOT)                                                                         \
+    {                                                                                              \
+        float p = fmaf(a2, z, i2 * XV);                                                            \
+        p += ph_dpp<0x128>(p);              /* row_ror:8 */                                        \
+        auto sa = __builtin_amdgcn_permlane16_swap(__float_as_int(p), __float_as_int(p), false, false); \
+        p = __int_as_float(sa[0]) + __int_as_float(sa[1]);                                         \
+        auto sb_ = __builtin_amdgcn_permlane32_swap(__float_as_int(p), __float_as_int(p), false, false); \
+        p = __int_as_float(sb_[0]) + __int_as_float(sb_[1]);   /* sum over the 8 rows */           \
+        o2[SLOT] = p;                                                                              \
+        z = p;                                                                                     \
+    }
+            PH_STEP1(xin.x, 0)
+            PH_STEP2(xin.y, 1)
+            PH_STEP1(xin.z, 2)
+            PH_STEP2(xin.w, 3)
+#undef PH_STEP1
+#undef PH_STEP2
+        }
+        __builtin_amdgcn_wave_barrier();
+        // (5) clip + coalesced store of the samples that fall inside the output window
+#pragma unroll
+        for (int j = 0; j < PH_BLOCK / 64; ++j) {
+            const int n = n0 + j * 64 + lane;
+            if (n >= lead && n < total) {
+                const float m = ybuf[j * 64 + lane];
+                yb[n - lead] = m < -1.0f ? -1.0f : (m > 1.0f ? 1.0f : m);
+                if (db) db[n - lead] = xbuf[j * 64 + lane];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // x: source audio, row b at x + b*x_stride, at least lead[b] + N samples; rate, depth, centre,
 // feedback, mix: (B,) fp32; lead: (B,) int32 warm-up samples (NULL = 0); rows/n_rows: optional
 // subset of clip indices.  y: row b at y + b*y_stride, N samples = processed[lead : lead+N];
 // dry_out (optional, same stride as y): the matching crop of the source.
 // exact_order != 0: evaluate every all-pass stage in JUCE's operation order (v = G (x - s); y = v + s;
-// s = v + y; out = 2 y - x); 0: the algebraically identical FMA form with a 4-5x shorter dependency chain.
+// s = v + y; out = 2 y - x) on the scalar kernel; 0: the algebraically identical 8 x 8 state-space step on 64 lanes.
 MX_EXPORT int mx_phaser_fwd(const float *x, int64_t x_stride, const float *rate, const float *depth,
                             const float *centre, const float *feedback, const float *mix, const int32_t *lead,
                             const int32_t *rows, int64_t n_rows, int64_t B, int64_t N, double sr, int32_t exact_order,
@@ -163,13 +303,12 @@ MX_EXPORT int mx_phaser_fwd(const float *x, int64_t x_stride, const float *rate,
     if (N >= (1ll << 30)) return MX_ERR_UNSUPPORTED;
     const int64_t items = rows ? n_rows : B;
     if (items <= 0) return MX_OK;
+    const dim3 grid((unsigned)((items + PH_WPB - 1) / PH_WPB)), block(64 * PH_WPB);
     if (exact_order)
-        hipLaunchKernelGGL((phaser_kernel<false>), dim3((unsigned)((items + PH_WPB - 1) / PH_WPB)), dim3(64 * PH_WPB), 0,
-                           (hipStream_t)stream, x, (long long)x_stride, rate, depth, centre, feedback, mix, lead, rows,
-                           (int)items, (int)N, (float)sr, sr, y, (long long)y_stride, dry_out);
+        hipLaunchKernelGGL(phaser_kernel, grid, block, 0, (hipStream_t)stream, x, (long long)x_stride, rate, depth, centre,
+                           feedback, mix, lead, rows, (int)items, (int)N, (float)sr, sr, y, (long long)y_stride, dry_out);
     else
-        hipLaunchKernelGGL((phaser_kernel<true>), dim3((unsigned)((items + PH_WPB - 1) / PH_WPB)), dim3(64 * PH_WPB), 0,
-                           (hipStream_t)stream, x, (long long)x_stride, rate, depth, centre, feedback, mix, lead, rows,
-                           (int)items, (int)N, (float)sr, sr, y, (long long)y_stride, dry_out);
+        hipLaunchKernelGGL(phaser_mat_kernel, grid, block, 0, (hipStream_t)stream, x, (long long)x_stride, rate, depth,
+                           centre, feedback, mix, lead, rows, (int)items, (int)N, sr, y, (long long)y_stride, dry_out);
     return mx_launch_status();
 }

@@ -91,6 +91,10 @@ def config5(B=256, N=176400):
 
 
 if __name__ == "__main__":
-    print(json.dumps({"effects_bs256": effects()}))
-    print(json.dumps({"config4_tbptt": config4()}))
-    print(json.dumps({"config5_flanger_mrstft": config5()}))
+    which = sys.argv[1:] or ["effects", "config4", "config5"]
+    if "effects" in which:
+        print(json.dumps({"effects_bs256": effects()}))
+    if "config4" in which:
+        print(json.dumps({"config4_tbptt": config4()}))
+    if "config5" in which:
+        print(json.dumps({"config5_flanger_mrstft": config5()}))
