@@ -58,14 +58,21 @@ class SyntheticFxBatcher:
     ``kinds`` lists the effect of each slot of the interleave, clip ``i`` gets ``kinds[i % len(kinds)]``
     (datasets.py:79-83): "flanger", "chorus" (fx.py with 1 ms / 30 ms base delay) or "phaser".
     Host RNG: ``torch`` global generator and numpy global RNG (scipy ``loguniform``), as in the
-    reference; draws are vectorised per batch (one call per parameter).
+    reference.  ``rng_order="batch"`` (default) draws each parameter once per batch (one vectorised call);
+    ``rng_order="reference"`` consumes the host RNG streams in the reference's own order -- per item
+    rate / phase / shape (datasets.py:367-372) resp. rate, depth, centre, feedback, mix, crop offset for a phaser
+    item (datasets.py:429-431,460-465,444), then the five (B,) effect draws of
+    ``FlangerCPUDataModule.on_before_batch_transfer`` (data_modules.py:421-445) -- so a seeded run reproduces the
+    reference's parameter stream value for value (tests/test_param_stream.py, golden from the real ``util``).
     """
 
     def __init__(self, batch_size: int, n_samples: int, sr: float, kinds: Sequence[str], device: torch.device,
                  flanger_fx: Optional[Dict] = None, chorus_fx: Optional[Dict] = None,
                  phaser_fx: Optional[Dict] = None, mod_sig: Optional[Dict] = None, audio_seed: int = 43,
                  peak_db: float = -1.0, fixed_lead: Optional[int] = None, overlap: bool = False,
-                 chunk_source: Optional[Any] = None) -> None:
+                 chunk_source: Optional[Any] = None, rng_order: str = "batch") -> None:
+        assert rng_order in ("batch", "reference")
+        self.rng_order = rng_order
         self.B, self.N, self.sr, self.device = batch_size, n_samples, float(sr), device
         self.chunk_source = chunk_source                             # datasets.FileChunkSource or None (synthetic)
         self.kinds = [kinds[i % len(kinds)] for i in range(batch_size)]
@@ -125,13 +132,52 @@ class SyntheticFxBatcher:
         """one vectorised draw per effect kind, merged by slot"""
         out = torch.zeros(self.B)
         for kid, name in enumerate(("flanger", "chorus")):
-            if name in per_kind:
+            if name in per_kind and bool((self.kind_id == kid).any()):      # no draw for a kind the batch lacks
                 lo, hi = per_kind[name]
                 v = self._uniform(lo, hi)
                 out = torch.where(self.kind_id == kid, v, out)
         return out
 
+    def _sample_params_reference_order(self) -> Dict[str, Any]:
+        """The reference's RNG consumption order (see the class docstring)."""
+        B = self.B
+        rate, phase, shapes = torch.zeros(B, dtype=torch.float64), torch.zeros(B, dtype=torch.float64), []
+        ph = {k: torch.zeros(B, dtype=torch.float64) for k in ("depth", "centre", "feedback", "mix")}
+        lead = torch.zeros(B, dtype=torch.int64)
+        rate_n = torch.zeros(B, dtype=torch.int64)
+        for i, kind in enumerate(self.kinds):
+            if kind == "phaser":
+                rate[i] = util.sample_log_uniform(*self.ph["rate_hz"])                      # datasets.py:429-432
+                rate_n[i] = int((self.sr / float(rate[i])) + 0.5)                           # datasets.py:433
+                ph["depth"][i] = util.sample_uniform(*self.ph["depth"])                     # datasets.py:460-465
+                ph["centre"][i] = util.sample_log_uniform(*self.ph["centre_frequency_hz"])
+                ph["feedback"][i] = util.sample_uniform(*self.ph["feedback"])
+                ph["mix"][i] = util.sample_uniform(*self.ph["mix"])
+                lead[i] = util.randint(0, int(rate_n[i]) + 1) if self.fixed_lead is None else int(self.fixed_lead)
+                phase[i] = math.pi / 2                                                       # datasets.py:442
+                shapes.append("cos")
+            else:
+                rate[i] = util.sample_log_uniform(*self.ms["rate_hz"])                      # datasets.py:367-372
+                phase[i] = util.sample_uniform(*self.ms["phase"])
+                shapes.append(util.choice(list(self.ms["shapes"])))
+        is_ph = self.kind_id == 2
+        p: Dict[str, Any] = {}
+        for name in ("feedback", "min_delay_width", "width", "depth", "mix"):               # data_modules.py:421-445
+            p[name] = self._choose({"flanger": self.fl[name], "chorus": self.ch[name]}) if self.has_fx else torch.zeros(B)
+        centre = torch.full((B,), 440.0)
+        if self.has_ph:
+            p["depth"] = torch.where(is_ph, ph["depth"].float(), p["depth"])
+            p["feedback"] = torch.where(is_ph, ph["feedback"].float(), p["feedback"])
+            p["mix"] = torch.where(is_ph, ph["mix"].float(), p["mix"])
+            centre = torch.where(is_ph, ph["centre"].float(), centre)
+            p["proc_extra"] = rate_n
+        p.update(rate_hz=rate.float(), phase=phase.float(), shape=shapes, exp=torch.full((B,), float(self.ms["exp"])),
+                 centre_frequency_hz=centre, lead=lead.to(torch.int32))
+        return p
+
     def sample_params(self) -> Dict[str, Any]:
+        if self.rng_order == "reference":
+            return self._sample_params_reference_order()
         B = self.B
         rate = util.sample_log_uniform(*self.ms["rate_hz"], n=B).float()
         phase = self._uniform(*self.ms["phase"])
@@ -246,8 +292,9 @@ class _SyntheticDataModule:
 
     def __init__(self, batch_size: int, n_samples: int = 88200, sr: float = 44100,
                  train_num_examples_per_epoch: int = 8000, val_num_examples_per_epoch: int = 2000,
-                 fx_config: Optional[Dict[str, Any]] = None, **ignored: Any) -> None:
+                 fx_config: Optional[Dict[str, Any]] = None, rng_order: str = "batch", **ignored: Any) -> None:
         self.batch_size, self.n_samples, self.sr = batch_size, n_samples, sr
+        self.rng_order = rng_order
         self.train_num_examples_per_epoch = train_num_examples_per_epoch
         self.val_num_examples_per_epoch = val_num_examples_per_epoch
         self.fx_config = fx_config or {}
@@ -274,7 +321,7 @@ class _SyntheticDataModule:
         fl = self.fx_config.get("flanger")
         common = dict(flanger_fx=fl, chorus_fx=fl if "chorus" in self.kinds and fl else None,
                       phaser_fx=self.fx_config.get("pedalboard_phaser"), mod_sig=self.fx_config.get("mod_sig"),
-                      audio_seed=seed + rank)
+                      audio_seed=seed + rank, rng_order=self.rng_order)
         self._batcher = SyntheticFxBatcher(self.batch_size, self.n_samples, self.sr, self.kinds, device,
                                            chunk_source=self._chunk_source("train"), **common)
         val_src = self._chunk_source("val")

@@ -24,6 +24,7 @@ def apply_tremolo(x: T, mod_sig: T, mix: Param = 1.0) -> T:
         mod_sig = mod_sig.unsqueeze(1).expand(-1, x.size(1), -1)
     if isinstance(mix, T):
         assert mix.size(0) == x.size(0)
+    assert 0.0 <= mix <= 1.0                    # fx.py:21 (a tensor mix must therefore hold one element)
     return ((1.0 - mix) * x) + (mix * mod_sig * x)
 
 

@@ -109,10 +109,14 @@ def make_rand_mod_signal(batch_size: int, n_samples: int, sr: float, freq_min: f
     if shapes is None:
         shapes = ["cos", "tri", "rect_cos", "inv_rect_cos", "saw", "rsaw"]
     freqs, phases, shape_ids = [], [], []
+    # ground-truth rows are perturbed with the reference's own fp32 tensor arithmetic (0-dim CPU tensors, in-place
+    # add / multiply, then the wrap / clip), on private copies: the reference mutates the caller's fx_params here
+    phase_gt = None if phase_gt is None else phase_gt.detach().to("cpu", torch.float32).clone()
+    freq_gt = None if freq_gt is None else freq_gt.detach().to("cpu", torch.float32).clone()
     for idx in range(batch_size):
         if phase_gt is not None:
             assert phase_gt.size(0) == batch_size
-            phase = float(phase_gt[idx])
+            phase = phase_gt[idx]
             if phase_error > 0:
                 phase += util.sample_uniform(-1.0, 1.0) * math.pi * phase_error
                 phase = (phase + (2 * math.pi)) % (2 * math.pi)
@@ -120,14 +124,14 @@ def make_rand_mod_signal(batch_size: int, n_samples: int, sr: float, freq_min: f
             phase = util.sample_uniform(0.0, 2 * math.pi)
         if freq_gt is not None:
             assert freq_gt.size(0) == batch_size
-            freq = float(freq_gt[idx])
+            freq = freq_gt[idx]
             if freq_error > 0:
                 freq *= util.sample_uniform(1.0 - freq_error, 1.0 + freq_error)
-                freq = min(max(freq, freq_min), freq_max)
+                freq = torch.clip(freq, freq_min, freq_max)
         else:
             freq = util.sample_uniform(freq_min, freq_max)
         shape = shapes_gt[idx] if shapes_gt is not None else util.choice(shapes)
-        freqs.append(freq); phases.append(phase); shape_ids.append(SHAPE_IDS[shape])
+        freqs.append(float(freq)); phases.append(float(phase)); shape_ids.append(SHAPE_IDS[shape])
     dev = _device(device)
     return make_mod_signals(n_samples, sr, torch.tensor(freqs, dtype=torch.float32, device=dev),
                             torch.tensor(phases, dtype=torch.float32, device=dev),

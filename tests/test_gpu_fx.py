@@ -171,3 +171,49 @@ def test_flanger_rejects_bad_params(dev):
         fl(x, m, feedback=1.0)                      # feedback must be < 1 strictly (fx.py:86)
     with pytest.raises(AssertionError):
         fl(x, m, mix=torch.tensor([0.5, 1.5], device=dev))
+
+
+def test_rand_mod_signal_and_random_lfo_vs_reference_golden(golden_dir, dev):
+    """a13: make_rand_mod_signal / RandomLFO (modulations.py:60-101, models.py:19-69) on the device against rows from the
+    real reference under the same host RNG seeds: phase-only shapes (tri, saw, rsaw) bit-exact, cosine shapes 1e-5."""
+    from mod_extraction_amd import models, modulations
+    g = np.load(os.path.join(golden_dir, "rand_lfo_tremolo.npz"))
+    shapes = ["cos", "rect_cos", "inv_rect_cos", "tri", "saw", "rsaw"]
+    shapes_gt = [shapes[i] for i in g["gt_shape"]]
+    phase_gt, freq_gt = torch.from_numpy(g["gt_phase"].copy()).to(dev), torch.from_numpy(g["gt_freq"].copy()).to(dev)
+
+    def check(y, want, exact_rows=()):
+        y = y.cpu().numpy()
+        assert y.shape == want.shape
+        assert np.abs(y - want).max() <= 1e-5
+        for i in exact_rows:
+            assert np.array_equal(y[i], want[i]), i
+
+    torch.manual_seed(7); np.random.seed(7)
+    check(modulations.make_rand_mod_signal(6, 345, 172.5, 0.5, 3.0, device=dev), g["rand_a"])
+    torch.manual_seed(8); np.random.seed(8)
+    check(modulations.make_rand_mod_signal(6, 345, 172.5, 0.5, 3.0, shapes_gt, None, phase_gt, 0.5, freq_gt, 0.25,
+                                           device=dev), g["rand_b"], exact_rows=(1, 4, 5))
+    assert torch.equal(phase_gt.cpu(), torch.from_numpy(g["gt_phase"]))        # the caller's tensors are left alone
+    check(modulations.make_rand_mod_signal(6, 345, 172.5, 0.5, 3.0, shapes_gt, None, phase_gt, 0.0, freq_gt, 0.0,
+                                           device=dev), g["rand_c"], exact_rows=(1, 4, 5))
+    torch.manual_seed(9); np.random.seed(9)
+    check(modulations.make_rand_mod_signal(6, 345, 172.5, 0.5, 3.0, None, ["tri", "saw"], None, 0.5, freq_gt, 0.1,
+                                           device=dev), g["rand_d"], exact_rows=range(6))
+    # the nn.Module wrapper of configs/models/baseline_rand_lfo.yml
+    lfo = models.RandomLFO(345, 172.5, use_shape_gt=True, use_phase_gt=True, use_freq_gt=True, phase_error=0.5,
+                           freq_error=0.25)
+    torch.manual_seed(8); np.random.seed(8)
+    out = lfo(6, {"shape": shapes_gt, "phase": phase_gt, "rate_hz": freq_gt})
+    assert out.shape == (6, 1, 345)
+    check(out[:, 0], g["rand_b"], exact_rows=(1, 4, 5))
+
+
+def test_apply_tremolo_vs_reference_golden(golden_dir, dev):
+    """a4: fx.apply_tremolo (fx.py:13-22) on device tensors, bit-identical to the reference's CPU result."""
+    from mod_extraction_amd import fx
+    g = np.load(os.path.join(golden_dir, "rand_lfo_tremolo.npz"))
+    x, mod = torch.from_numpy(g["trem_x"]).to(dev), torch.from_numpy(g["trem_mod"]).to(dev)
+    assert np.array_equal(fx.apply_tremolo(x, mod, 0.7).cpu().numpy(), g["trem_y_07"])
+    assert np.array_equal(fx.apply_tremolo(x, mod.unsqueeze(1).expand(-1, 2, -1), 1.0).cpu().numpy(), g["trem_y_10"])
+    assert np.array_equal(fx.apply_tremolo(x, mod, 0.0).cpu().numpy(), g["trem_y_00"])
