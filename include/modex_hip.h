@@ -31,6 +31,11 @@ extern "C" {
 
 /* ABI version, bumped on any signature change. */
 int mx_abi_version(void);
+/* Measurement aid (bench.py, SURVEY.md section 8d "measured serial floor"): mode != 0 makes the sample-recurrent
+ * kernels (mx_flanger_fwd, mx_phaser_fwd, mx_lstm_fwd, mx_lstm_bwd_l1) run their dependent chain without any
+ * global-memory traffic inside the loop; their outputs are then meaningless.  Process-wide; 0 restores normal
+ * operation.  No reference counterpart. */
+int mx_set_probe_mode(int32_t mode);
 
 /* ---- K1: LFO synthesis -- mod_extraction/modulations.py:16-57 (make_mod_signal) -------------
  * One row per LFO.  freq, phase, exp: (B,) float32; shape: (B,) int32 in

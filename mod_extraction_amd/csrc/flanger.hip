@@ -34,7 +34,7 @@ __global__ __launch_bounds__(64) void flanger_kernel(
     const float *__restrict__ mix, const float *__restrict__ one_minus_mix,
     const int *__restrict__ max_delay, const int *__restrict__ rows, int N, int lfo_off,
     float *__restrict__ y, long long y_stride, float *__restrict__ mod_up, long long *__restrict__ dbg_prev,
-    float *__restrict__ dbg_frac)
+    float *__restrict__ dbg_frac, int probe)
 {
     extern __shared__ float buf[];           // [M delay line | n_mod LFO row (when resampled in-kernel)]
     const int lane = threadIdx.x;
@@ -59,8 +59,8 @@ __global__ __launch_bounds__(64) void flanger_kernel(
 #pragma unroll
     for (int j = 0; j < FL_V; ++j) {
         int n = j * 64 + lane;
-        xr[j] = n < N ? xb[n] : 0.0f;
-        if (!resample) mr[j] = n < N ? mb[n] : 0.0f;
+        xr[j] = n < N && !probe ? xb[n] : 0.25f;
+        if (!resample) mr[j] = n < N && !probe ? mb[n] : 0.5f;
     }
 
     for (int c0 = 0; c0 < N; c0 += FL_CHUNK) {
@@ -110,8 +110,8 @@ __global__ __launch_bounds__(64) void flanger_kernel(
 #pragma unroll
         for (int j = 0; j < FL_V; ++j) {
             int n = c0 + FL_CHUNK + j * 64 + lane;
-            xn[j] = n < N ? xb[n] : 0.0f;
-            if (!resample) mn[j] = n < N ? mb[n] : 0.0f;
+            xn[j] = n < N && !probe ? xb[n] : 0.25f;
+            if (!resample) mn[j] = n < N && !probe ? mb[n] : 0.5f;
         }
 
         float o[FL_V];
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(64) void flanger_kernel(
 #pragma unroll
         for (int j = 0; j < FL_V; ++j) {
             const int n = c0 + j * 64 + lane;
-            if (n < N) {
+            if (n < N && (!probe || n + FL_CHUNK >= N)) {     // probe: only the last chunk is stored (keeps the chain live)
                 float v = __fadd_rn(__fmul_rn(omm, s[j].x), __fmul_rn(mx, o[j]));   // fx.py:117
                 yb[n] = fminf(fmaxf(v, -1.0f), 1.0f);                              // fx.py:118
             }
@@ -179,11 +179,13 @@ MX_EXPORT int mx_flanger_fwd(const float *x, int64_t x_stride, const float *mod,
     if (max_delay_max > FL_MAX_M || N >= (1ll << 30)) return MX_ERR_UNSUPPORTED;
     const int64_t items = rows ? n_rows : B;
     if (items <= 0) return MX_OK;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[64] = {};                       // per device: one process may drive several GPUs
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
         (void)hipFuncSetAttribute((const void *)flanger_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                             FL_MAX_M * sizeof(float));
-        attr_set = true;
+        if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
     // LDS: delay line (max over the batch) + the LFO row when it is resampled in-kernel (n_mod < N)
     const int lfo_off = max_delay_max;
@@ -193,6 +195,6 @@ MX_EXPORT int mx_flanger_fwd(const float *x, int64_t x_stride, const float *mod,
     hipLaunchKernelGGL(flanger_kernel, dim3((unsigned)items), dim3(64), lds, (hipStream_t)stream, x, (long long)x_stride, mod,
                        (int)n_mod, interp_scale_host(n_mod, N), lfo_scale, min_delay, feedback, depth,
                        mix, one_minus_mix, max_delay, rows, (int)N, lfo_off, y, (long long)y_stride, mod_up, (long long *)dbg_prev,
-                       dbg_frac);
+                       dbg_frac, g_mx_probe);
     return mx_launch_status();
 }

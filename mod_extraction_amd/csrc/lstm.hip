@@ -115,7 +115,7 @@ __global__ __launch_bounds__(LS_THREADS) void lstm_fwd_kernel(const float *__res
                                                               const float *__restrict__ fc_w,
                                                               const float *__restrict__ fc_b, float *__restrict__ h_io,
                                                               float *__restrict__ c_io, float *__restrict__ y,
-                                                              long long ys, float *__restrict__ stash, int T)
+                                                              long long ys, float *__restrict__ stash, int T, int probe)
 {
     __shared__ __attribute__((aligned(16))) float hist[(LS_TB + 1) * LS_HP];   // row 0 = state entering the block
     __shared__ __attribute__((aligned(16))) float2 xl[LS_TB];                   // (lfo, x) of the block
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(LS_THREADS) void lstm_fwd_kernel(const float *__res
         const int cnt = min(LS_TB, T - t0);
         __syncthreads();                            // the previous block's y pass is done with hist / xl
         if (t0 > 0 && tid < LS_H) hist[tid] = hist[LS_TB * LS_HP + tid];
-        if (tid < cnt) xl[tid] = make_float2(lb[t0 + tid], xb[t0 + tid]);
+        if (tid < cnt) xl[tid] = probe ? make_float2(0.5f, 0.25f) : make_float2(lb[t0 + tid], xb[t0 + tid]);
         __syncthreads();
         const float *hr = hist + 16 * kq;
         float *hwp = hw;
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(LS_THREADS) void lstm_fwd_kernel(const float *__res
             const float hv = go * ((LS_ABL & 2) ? c * 0.5f : ls_tanh(c));
             LS_STAMP(2)                                         // reduce, activation, exchange, cell update
             if (!(LS_ABL & 8)) *hwp = hv;
-            if (sb && !(LS_ABL & 32)) {
+            if (sb && !probe && !(LS_ABL & 32)) {
                 *st = st_c ? c : (st_h ? hv : a);
                 st += LS_STASH;
             }
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(LS_THREADS) void lstm_fwd_kernel(const float *__res
                 acc = fmaf(fc_w[k + 2], h4.z, acc);
                 acc = fmaf(fc_w[k + 3], h4.w, acc);
             }
-            yb[t0 + tid] = tanhf(acc + xl[tid].y);
+            if (!probe || t0 + cnt >= T) yb[t0 + tid] = tanhf(acc + xl[tid].y);
         }
         if (t0 + cnt >= T) {
             if (tid < LS_H) h_io[(size_t)b * LS_H + tid] = hist[cnt * LS_HP + tid];
@@ -231,7 +231,7 @@ MX_EXPORT int mx_lstm_fwd(const float *x, int64_t x_stride, const float *lfo, in
     if (T >= (1ll << 30)) return MX_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(lstm_fwd_kernel, dim3((unsigned)B), dim3(LS_THREADS), 0, (hipStream_t)stream, x,
                        (long long)x_stride, lfo, (long long)lfo_stride, w_ih, w_hh, b_ih, b_hh, fc_w, fc_b, h_io, c_io,
-                       y, (long long)y_stride, stash, (int)T);
+                       y, (long long)y_stride, stash, (int)T, g_mx_probe);
     return mx_launch_status();
 }
 
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(LS_THREADS) void lstm_bwd_kernel(const float *__res
                                                               const float *__restrict__ w_hh,
                                                               const float *__restrict__ fc_w,
                                                               const float *__restrict__ c_init, float loss_scale,
-                                                              float *__restrict__ dgate, int T)
+                                                              float *__restrict__ dgate, int T, int probe)
 {
     // slab buffer = [row -1 (only its c plane: c of the step before the slab)] [32 rows of 6 planes] ; dzy (32)
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -284,6 +284,13 @@ __global__ __launch_bounds__(LS_THREADS) void lstm_bwd_kernel(const float *__res
     // slab S -> registers (global, coalesced: 32 x 384 contiguous floats), registers -> LDS (plane-padded)
     auto slab_load = [&](int S) {
         const int t0 = S * LS_SLAB, cnt = min(LS_SLAB, T - t0);
+        if (probe) {                                   // serial-floor measurement: no global traffic, constant values
+#pragma unroll
+            for (int i = 0; i < 6; ++i) pre[i] = make_float4(0.5f, 0.5f, 0.5f, 0.5f);
+            pre_c = 0.5f;
+            pre_dzy = 1e-3f;
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             const int e = (i * LS_THREADS + tid) * 4;                  // element of the 32 x 384 slab
@@ -356,7 +363,7 @@ __global__ __launch_bounds__(LS_THREADS) void lstm_bwd_kernel(const float *__res
             const float dg = (q == 3 ? dh : dc) * kq;
             dc_next = dc * f;
             *(owner ? dgl + (par ^ 1) * 256 + dg_wr : dummy + tid) = dg;
-            if (owner) dgb[(size_t)(t0 + s) * 256 + q * LS_H + k] = dg;
+            if (owner && (!probe || t0 + s == 0)) dgb[(size_t)(t0 + s) * 256 + q * LS_H + k] = dg;
             par ^= 1;
             if (S > 0 && s == cnt / 2) slab_store((S - 1) & 1 ? slab1 : slab0);   // the other buffer is idle
             ls_barrier();
@@ -522,7 +529,7 @@ MX_EXPORT int mx_lstm_bwd_l1(const float *x, int64_t x_stride, const float *lfo,
     }
     hipLaunchKernelGGL(lstm_bwd_kernel, dim3((unsigned)B), dim3(LS_THREADS), lds, (hipStream_t)stream, y,
                        (long long)y_stride, wet, (long long)wet_stride, stash, w_hh, fc_w, c_init, loss_scale, dgate_ws,
-                       (int)T);
+                       (int)T, g_mx_probe);
     hipLaunchKernelGGL(lstm_wgrad_kernel, dim3((unsigned)B, (unsigned)n_split), dim3(256), 0, (hipStream_t)stream, x,
                        (long long)x_stride, lfo, (long long)lfo_stride, y, (long long)y_stride, wet, (long long)wet_stride,
                        stash, dgate_ws, h_init, loss_scale, part, (int)T, (int)n_split);

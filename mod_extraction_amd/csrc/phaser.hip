@@ -160,7 +160,7 @@ __global__ __launch_bounds__(64 * PH_WPB) void phaser_mat_kernel(const float *__
                                                                  const int *__restrict__ lead_arr,
                                                                  const int *__restrict__ rows, int n_items, int N,
                                                                  double sr, float *__restrict__ y, long long y_stride,
-                                                                 float *__restrict__ dry_out)
+                                                                 float *__restrict__ dry_out, int probe)
 {
     __shared__ __attribute__((aligned(16))) float lds_all[PH_WPB * PM_LDS];
     const int lane = threadIdx.x & 63;
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(64 * PH_WPB) void phaser_mat_kernel(const float *__
 #pragma unroll
         for (int j = 0; j < PH_BLOCK / 64; ++j) {
             const int n = n0 + j * 64 + lane;
-            xbuf[j * 64 + lane] = n < total ? xb[n] : 0.0f;
+            xbuf[j * 64 + lane] = probe ? 0.25f : (n < total ? xb[n] : 0.0f);
         }
         // (2) sequential fp32 phase accumulation; lane k keeps the phase of update k
         float my_phase = 0.0f;
@@ -278,7 +278,7 @@ __global__ __launch_bounds__(64 * PH_WPB) void phaser_mat_kernel(const float *__
 #pragma unroll
         for (int j = 0; j < PH_BLOCK / 64; ++j) {
             const int n = n0 + j * 64 + lane;
-            if (n >= lead && n < total) {
+            if (n >= lead && n < total && (!probe || n + PH_BLOCK >= total)) {
                 const float m = ybuf[j * 64 + lane];
                 yb[n - lead] = m < -1.0f ? -1.0f : (m > 1.0f ? 1.0f : m);
                 if (db) db[n - lead] = xbuf[j * 64 + lane];
@@ -309,6 +309,6 @@ MX_EXPORT int mx_phaser_fwd(const float *x, int64_t x_stride, const float *rate,
                            feedback, mix, lead, rows, (int)items, (int)N, (float)sr, sr, y, (long long)y_stride, dry_out);
     else
         hipLaunchKernelGGL(phaser_mat_kernel, grid, block, 0, (hipStream_t)stream, x, (long long)x_stride, rate, depth,
-                           centre, feedback, mix, lead, rows, (int)items, (int)N, sr, y, (long long)y_stride, dry_out);
+                           centre, feedback, mix, lead, rows, (int)items, (int)N, sr, y, (long long)y_stride, dry_out, g_mx_probe);
     return mx_launch_status();
 }

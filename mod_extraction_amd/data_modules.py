@@ -123,6 +123,10 @@ class SyntheticFxBatcher:
         self._side = torch.cuda.Stream(device=device) if self.overlap else None
         self._pending = None
         self._slot = 0
+        # optional work on each freshly rendered batch that does not depend on the trainable weights (the frozen LFO
+        # extractor of the effect-modelling step): with overlap it runs one batch ahead on the side stream too
+        self.ahead_fn = None
+        self.last_ahead = None
 
     # ---- host-side parameter draws -------------------------------------------------------------
     def _uniform(self, lo: float, hi: float) -> T:
@@ -264,21 +268,37 @@ class SyntheticFxBatcher:
         self._side.wait_stream(main)            # the idle set was last read two steps ago; also orders the RNG state
         with torch.cuda.stream(self._side), torch.no_grad():
             batch = self.render(self.sample_params())
+            extra = self.ahead_fn(batch) if self.ahead_fn is not None else None
             ev = torch.cuda.Event()
             ev.record(self._side)
-        self._pending = (batch, ev)
+        self._pending = (batch, extra, ev)
+
+    @staticmethod
+    def _tensors(obj):
+        if isinstance(obj, torch.Tensor):
+            yield obj
+        elif isinstance(obj, dict):
+            for v in obj.values():
+                yield from SyntheticFxBatcher._tensors(v)
+        elif isinstance(obj, (list, tuple)):
+            for v in obj:
+                yield from SyntheticFxBatcher._tensors(v)
 
     def next_batch(self) -> Tuple[T, T, T, Dict[str, Any]]:
         if not self.overlap:
             with torch.no_grad():
-                return self.render(self.sample_params())
+                batch = self.render(self.sample_params())
+                self.last_ahead = self.ahead_fn(batch) if self.ahead_fn is not None else None
+                return batch
         if self._pending is None:
             self._launch_ahead()
-        batch, ev = self._pending
+        batch, extra, ev = self._pending
+        self.last_ahead = extra
         main = torch.cuda.current_stream(self.device)
         main.wait_event(ev)
-        for t in (batch[2], *[v for v in batch[3].values() if isinstance(v, torch.Tensor)]):
-            t.record_stream(main)               # allocated on the side stream, consumed on the main stream
+        for t in (batch[2], *self._tensors(batch[3]), *self._tensors(extra)):
+            if t.is_cuda:
+                t.record_stream(main)           # allocated on the side stream, consumed on the main stream
         self._launch_ahead()                    # overlaps with the train step the caller is about to enqueue
         return batch
 
@@ -292,9 +312,12 @@ class _SyntheticDataModule:
 
     def __init__(self, batch_size: int, n_samples: int = 88200, sr: float = 44100,
                  train_num_examples_per_epoch: int = 8000, val_num_examples_per_epoch: int = 2000,
-                 fx_config: Optional[Dict[str, Any]] = None, rng_order: str = "batch", **ignored: Any) -> None:
+                 fx_config: Optional[Dict[str, Any]] = None, rng_order: str = "batch", overlap: bool = True,
+                 **ignored: Any) -> None:
         self.batch_size, self.n_samples, self.sr = batch_size, n_samples, sr
         self.rng_order = rng_order
+        self.overlap = overlap              # render (and prefetch work, see set_ahead_fn) one batch ahead on a side stream
+        self._ahead_fn = None
         self.train_num_examples_per_epoch = train_num_examples_per_epoch
         self.val_num_examples_per_epoch = val_num_examples_per_epoch
         self.fx_config = fx_config or {}
@@ -323,11 +346,26 @@ class _SyntheticDataModule:
                       phaser_fx=self.fx_config.get("pedalboard_phaser"), mod_sig=self.fx_config.get("mod_sig"),
                       audio_seed=seed + rank, rng_order=self.rng_order)
         self._batcher = SyntheticFxBatcher(self.batch_size, self.n_samples, self.sr, self.kinds, device,
-                                           chunk_source=self._chunk_source("train"), **common)
+                                           chunk_source=self._chunk_source("train"), overlap=self.overlap, **common)
+        self._batcher.ahead_fn = self._ahead_fn
         val_src = self._chunk_source("val")
         if val_src is not None:
             self._val_batcher = SyntheticFxBatcher(self.batch_size, self.n_samples, self.sr, self.kinds, device,
                                                    chunk_source=val_src, **common)
+
+    def set_ahead_fn(self, fn) -> None:
+        """``fn(batch)`` is evaluated on every TRAINING batch right after it is rendered -- one batch ahead on the side
+        stream when ``overlap`` is on; ``take_ahead()`` returns its result for the batch handed out last."""
+        self._ahead_fn = fn
+        if self._batcher is not None:
+            self._batcher.ahead_fn = fn
+
+    def take_ahead(self):
+        b = self._batcher
+        if b is None:
+            return None
+        out, b.last_ahead = b.last_ahead, None
+        return out
 
     def train_steps_per_epoch(self) -> int:
         return max(1, self.train_num_examples_per_epoch // self.batch_size)
@@ -393,6 +431,13 @@ class RandomAudioChunkDryWetDataModule(_SyntheticDataModule):
         self._device = device
         if self._pairs["train"] is None:
             super().setup(device, rank, seed)
+
+    def set_ahead_fn(self, fn) -> None:
+        # the step sees (dry, wet, None, None): prefetch on exactly that tuple
+        super().set_ahead_fn(None if fn is None else (lambda b: fn((b[0], b[1], None, None))))
+
+    def take_ahead(self):
+        return super().take_ahead() if self._pairs.get("train") is None else None
 
     def _pair_batch(self, ds):
         dry = torch.empty((self.batch_size, 1, self.n_samples), dtype=torch.float32)

@@ -271,12 +271,24 @@ class TBPTTLFOEffectModeling(BaseLightingModule):
         lfo_sr = linear_interpolate_last_dim(mod_sig_hat, dry.size(-1), align_corners=True).unsqueeze(1)
         return dry, wet, mod_sig_hat, mod_sig, lfo_sr
 
-    def common_step(self, batch, is_training: bool, optimizer=None, world_size: int = 1):
+    PREP_NONE = "no valid LFO"          # prefetched marker: prepare() ran and found nothing to train on
+
+    def prepare_ahead(self, batch):
+        """``prepare`` for a data module's ``set_ahead_fn``: everything before the LSTM loop depends only on the batch
+        and on the FROZEN extractor, so it can run one batch ahead on the side stream (the reference gets the same
+        overlap from its DataLoader workers for the rendering; the extractor forward is prefetched on top)."""
+        out = self.prepare(batch)
+        return self.PREP_NONE if out is None else out
+
+    def common_step(self, batch, is_training: bool, optimizer=None, world_size: int = 1, prep=None):
         """lightning.py:302-419."""
         from .effect_losses import effect_loss_terms
         from .trainer import allreduce_flat_grad
         prefix = "train" if is_training else "val"
-        prep = self.prepare(batch)
+        if prep is None:
+            prep = self.prepare(batch)
+        elif isinstance(prep, str):
+            prep = None
         n_chunks_max = (batch[0].size(-1) - self.warmup_n_samples) // self.step_n_samples
         if prep is None:
             if is_training and world_size > 1:          # stay in lock-step with the other ranks
@@ -330,9 +342,9 @@ class TBPTTLFOEffectModeling(BaseLightingModule):
             data_dict["mod_sig"] = mod_sig
         return loss, data_dict, batch[3]
 
-    def training_step(self, batch, batch_idx: int = 0, optimizer=None, world_size: int = 1):
+    def training_step(self, batch, batch_idx: int = 0, optimizer=None, world_size: int = 1, prep=None):
         assert optimizer is not None, "manual optimisation: pass the FlatAdamW optimizer"
-        result = self.common_step(batch, is_training=True, optimizer=optimizer, world_size=world_size)
+        result = self.common_step(batch, is_training=True, optimizer=optimizer, world_size=world_size, prep=prep)
         return None if result is None else result[0]
 
     def validation_step(self, batch, batch_idx: int = 0):

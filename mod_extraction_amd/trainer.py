@@ -135,6 +135,9 @@ class Trainer:
         manual = getattr(module, "automatic_optimization", True) is False
         if self.num_sanity_val_steps:
             self.validate(module, datamodule, self.num_sanity_val_steps)
+        prefetch = manual and hasattr(module, "prepare_ahead") and hasattr(datamodule, "set_ahead_fn")
+        if prefetch:
+            datamodule.set_ahead_fn(module.prepare_ahead)        # frozen-extractor forward one batch ahead (side stream)
         for epoch in range(self.start_epoch, self.max_epochs):
             module.train()
             module.logged.clear()
@@ -143,7 +146,8 @@ class Trainer:
             for i in range(n):
                 batch = datamodule.train_batch()
                 if manual:
-                    module.training_step(batch, i, optimizer=optimizer, world_size=self.env["world_size"])
+                    kw = {"prep": datamodule.take_ahead()} if prefetch else {}
+                    module.training_step(batch, i, optimizer=optimizer, world_size=self.env["world_size"], **kw)
                 else:
                     self.train_step(module, optimizer, batch)
             metrics = reduce_metrics(module.logged, self.env["world_size"], metric_names(module, "train"))

@@ -2,6 +2,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -DLS_DIAG -I include -I mod_extraction_amd/csrc \
 //         tools/probe/lstm_probe.hip -o tools/probe/_bin/lstm_probe
 #include "../../mod_extraction_amd/csrc/lstm.hip"
+int g_mx_probe = 0;
 #include <cstdio>
 #include <vector>
 int main()
