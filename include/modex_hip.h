@@ -274,6 +274,31 @@ int mx_lstm_bwd_l1(const float *x, int64_t x_stride, const float *lfo, int64_t l
                    float loss_scale, float *dgate_ws, float *part, int32_t n_split, int64_t B, int64_t T,
                    void *stream);
 
+/* ---- TCN extractors -- mod_extraction/tcn.py:106-302 (TCNBlock / TCN) under models.py:72-125,218-289
+ * (SpectralTCN / SpectralDSTCN).  Activations: (B, C, 352) fp32 planes with T <= 352 valid columns.
+ * mx_sgemm_f32: general fp32 GEMM on the matrix cores (exact fp32), element strides for every operand:
+ *   C[m c_rs + n c_cs] (+)= sum_k A[m a_rs + k a_cs] B[k b_rs + n b_cs], n_batch batches a_bs / b_bs apart;
+ *   batches_per_group consecutive batches are summed inside the kernel, group g writes C + g c_bs.
+ * mx_tcn_im2col: col[(ci ksz + k)][b To + t'] = xhat[b][ci][t' stride + (k - ksz/2) dilation] (0 outside [0,T));
+ *   xhat = (x - stats[2b]) stats[2b+1] (LayerNorm([C,T]) statistics from mx_plane_stats(x, NULL, B, 1, C, T)) or x.
+ * mx_tcn_col2im: the transposed gather (gradient w.r.t. xhat).
+ * mx_tcn_act_fwd: z += bias (kept: PReLU input); y = PReLU(z) + res.  mx_tcn_act_bwd: dz = dy PReLU'(zb);
+ *   part (B*C, 2) = row sums of dz and of dy zb [zb <= 0] (bias / slope gradients after mx_reduce_rows).
+ * mx_tcn_ln_bwd: dx = rstd (dxhat - mean(dxhat) - xhat mean(dxhat xhat)) + add, per clip. */
+int mx_sgemm_f32(const float *a, int64_t a_rs, int64_t a_cs, int64_t a_bs, const float *b, int64_t b_rs, int64_t b_cs,
+                 int64_t b_bs, float *c, int64_t c_rs, int64_t c_cs, int64_t c_bs, int64_t M, int64_t N, int64_t K,
+                 int64_t n_batch, int64_t batches_per_group, int32_t accumulate, void *stream);
+int mx_tcn_im2col(const float *x, const float *stats, int64_t B, int64_t C, int64_t T, int64_t To, int64_t ksz,
+                  int64_t dilation, int64_t stride, float *col, void *stream);
+int mx_tcn_col2im(const float *dcol, int64_t B, int64_t C, int64_t T, int64_t To, int64_t ksz, int64_t dilation,
+                  int64_t stride, float *dx, void *stream);
+int mx_tcn_act_fwd(float *z, const float *bias, const float *slope, const float *res, int64_t B, int64_t C, int64_t T,
+                   float *y, void *stream);
+int mx_tcn_act_bwd(const float *dy, const float *zb, const float *slope, int64_t B, int64_t C, int64_t T, float *dz,
+                   float *part, void *stream);
+int mx_tcn_ln_bwd(const float *x, const float *dxhat, const float *stats, const float *add, int64_t B, int64_t C,
+                  int64_t T, float *dx, void *stream);
+
 /* ---- effect-model losses -- mod_extraction/losses.py:14-67 (ESR, DC) and nn.L1Loss:
  * part (B,4) = per-clip sums of |y - y_hat|, (y - y_hat)^2, y^2, (y - y_hat). */
 int mx_effect_loss_sums(const float *y_hat, int64_t y_hat_stride, const float *y, int64_t y_stride, int64_t B,

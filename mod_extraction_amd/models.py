@@ -9,6 +9,7 @@ and state-dict keys; every forward/backward runs hand-written HIP kernels throug
   (they give the reference's state-dict keys and default initialisation); they are never called.
 * ``LSTMEffectModel`` / ``HiddenStateModel`` (models.py:292-339) and ``RandomLFO`` (models.py:19-69).
 """
+import logging
 import math
 import os
 from typing import Dict, List, Optional, Sequence, Tuple
@@ -17,6 +18,8 @@ import torch
 from torch import Tensor as T, nn
 
 from . import _hip
+
+log = logging.getLogger(__name__)
 
 import os as _os
 
@@ -506,6 +509,118 @@ class RandomLFO(nn.Module):
             freq_gt = fx_params["rate_hz"]
         return make_rand_mod_signal(batch_size, self.n_samples, self.sr, self.freq_min, self.freq_max, shapes_gt,
                                     self.shapes, phase_gt, self.phase_error, freq_gt, self.freq_error).unsqueeze(1)
+
+
+class SpectrogramHIP(nn.Module):
+    """State-dict compatible stand-in for ``torchaudio.transforms.Spectrogram(n_fft, hop_length=hop, normalized=False)``
+    (key ``window``; power 2, centre + reflect padding) of SpectralTCN / SpectralDSTCN (models.py:99,252): the log-mel
+    kernel with an identity filter bank -- band m = bin m, weight 1.0 -- returns log(clip(|STFT|^2, eps)) exactly."""
+
+    def __init__(self, n_fft: int, hop_length: int) -> None:
+        super().__init__()
+        if n_fft != 1024:
+            raise NotImplementedError("mx_logmel_fwd is built for n_fft = 1024")
+        self.n_fft, self.hop_length, self.n_bins = n_fft, hop_length, n_fft // 2 + 1
+        self.register_buffer("window", torch.hann_window(n_fft))
+        k = torch.arange(n_fft, dtype=torch.float64) * (-2.0 * math.pi / n_fft)
+        self.register_buffer("twiddle", torch.stack([torch.cos(k), torch.sin(k)], dim=1).float(), persistent=False)
+        self.register_buffer("eye", torch.eye(self.n_bins), persistent=False)
+        self.register_buffer("band_lo", torch.arange(self.n_bins, dtype=torch.int32), persistent=False)
+        self.register_buffer("band_hi", torch.arange(1, self.n_bins + 1, dtype=torch.int32), persistent=False)
+
+    def log_power(self, x: T, n_frames: int, eps: float) -> T:
+        """x (B, 1, N) -> (B, n_fft/2 + 1, 352) planes = log(clip(power, eps)), columns >= n_frames zero"""
+        assert x.ndim == 3 and x.size(1) == 1
+        B, _, N = x.shape
+        xc = x.contiguous().float()
+        out = torch.empty((B, self.n_bins, PITCH), device=x.device, dtype=torch.float32)
+        _hip.call("mx_logmel_fwd", _hip.ptr(xc), B, N, _hip.ptr(self.window), _hip.ptr(self.twiddle), _hip.ptr(self.eye),
+                  _hip.ptr(self.band_lo), _hip.ptr(self.band_hi), self.n_fft, self.hop_length, self.n_bins, n_frames, PITCH,
+                  float(eps), 0, 0, 0, 0, _hip.ptr(out), _hip.stream())
+        return out
+
+
+class SpectralTCN(nn.Module):
+    """models.py:72-125: log power spectrogram (513 bins) -> 5-block dilated TCN over time (LayerNorm, 13 taps, PReLU,
+    1x1 residual) -> Conv1d(96 -> latent_dim, 1) -> sigmoid; (B, 1, N) -> (B, latent_dim, frames).  The front end and the
+    TCN stack run in HIP kernels (``tcn.py``); the 1x1 head is a library matmul."""
+
+    def __init__(self, n_samples: int = 88200, n_fft: int = 1024, hop_len: int = 256, kernel_size: int = 13,
+                 out_channels: Optional[List[int]] = None, dilations: Optional[List[int]] = None, latent_dim: int = 1,
+                 use_ln: bool = True, use_res: bool = True, eps: float = 1e-7) -> None:
+        super().__init__()
+        from .tcn import TCN
+        self.n_fft, self.hop_len, self.kernel_size, self.latent_dim = n_fft, hop_len, kernel_size, latent_dim
+        self.use_ln, self.use_res, self.eps = use_ln, use_res, eps
+        if out_channels is None:
+            out_channels = [96] * 5
+        self.out_channels = out_channels
+        if dilations is None:
+            dilations = [2 ** idx for idx in range(len(out_channels))]
+        self.dilations = dilations
+        self.spectrogram = SpectrogramHIP(n_fft, hop_len)
+        self.n_frames = n_samples // hop_len + 1
+        self.tcn = TCN(out_channels, dilations, n_fft // 2 + 1, kernel_size, padding=None, use_ln=use_ln,
+                       temporal_dims=[self.n_frames] * len(out_channels), use_res=use_res, is_causal=False)
+        self.receptive_field = self.tcn.calc_receptive_field()
+        log.info(f"Receptive field = {self.receptive_field} samples")
+        self.output = nn.Conv1d(out_channels[-1], self.latent_dim, kernel_size=(1,))
+
+    def features(self, x: T) -> T:
+        assert x.ndim == 3
+        n_frames = x.size(-1) // self.hop_len + 1
+        with torch.no_grad():
+            spec = self.spectrogram.log_power(x, n_frames, self.eps)
+        y, t_out = self.tcn.forward_planes(spec, n_frames)
+        return y[:, :, :t_out]
+
+    def forward(self, x: T) -> T:
+        f = self.features(x)
+        w = self.output.weight.view(self.latent_dim, -1)
+        return torch.sigmoid(torch.matmul(w, f) + self.output.bias.view(1, -1, 1))
+
+
+class SpectralDSTCN(nn.Module):
+    """models.py:218-289: the strided (down-sampling) variant: TCN with stride 2 per block -> mean over time ->
+    Linear(96, 48) -> PReLU -> Linear(48, latent_dim) -> sigmoid; (B, 1, N) -> (B, latent_dim)."""
+
+    def __init__(self, n_samples: int = 88200, n_fft: int = 1024, hop_len: int = 256, kernel_size: int = 13,
+                 out_channels: Optional[List[int]] = None, dilations: Optional[List[int]] = None,
+                 strides: Optional[List[int]] = None, n_fc_units: int = 48, latent_dim: int = 2, use_ln: bool = True,
+                 use_res: bool = True, eps: float = 1e-7) -> None:
+        super().__init__()
+        from .tcn import TCN
+        self.n_fft, self.hop_len, self.kernel_size, self.n_fc_units, self.latent_dim = n_fft, hop_len, kernel_size, n_fc_units, latent_dim
+        self.use_ln, self.use_res, self.eps = use_ln, use_res, eps
+        if out_channels is None:
+            out_channels = [96] * 5
+        self.out_channels = out_channels
+        if dilations is None:
+            dilations = [2 ** idx for idx in range(len(out_channels))]
+        self.dilations = dilations
+        if strides is None:
+            strides = [2] * len(out_channels)
+        self.strides = strides
+        self.spectrogram = SpectrogramHIP(n_fft, hop_len)
+        self.n_frames = n_samples // hop_len + 1
+        temporal_dims, cur = [self.n_frames], self.n_frames
+        for stride in strides[:-1]:
+            cur = math.ceil(cur / stride)
+            temporal_dims.append(cur)
+        self.tcn = TCN(out_channels, dilations, n_fft // 2 + 1, kernel_size, strides, padding=None, use_ln=use_ln,
+                       temporal_dims=temporal_dims, use_res=use_res, is_causal=False)
+        self.fc = nn.Linear(out_channels[-1], self.n_fc_units)
+        self.fc_act = nn.PReLU(self.n_fc_units)
+        self.output = nn.Linear(self.n_fc_units, self.latent_dim)
+
+    def forward(self, x: T) -> T:
+        assert x.ndim == 3
+        n_frames = x.size(-1) // self.hop_len + 1
+        with torch.no_grad():
+            spec = self.spectrogram.log_power(x, n_frames, self.eps)
+        y, t_out = self.tcn.forward_planes(spec, n_frames)
+        f = y[:, :, :t_out].mean(dim=-1)
+        return torch.sigmoid(self.output(self.fc_act(self.fc(f))))
 
 
 class HiddenStateModel(nn.Module):

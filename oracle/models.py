@@ -174,3 +174,66 @@ def forward_routed(ref: "Spectral2DCNN", x: T, masks, tap: dict, W: int, tie_tol
             h = m(h)
     latent = h.mean(dim=-2)
     return torch.sigmoid(ref.output(latent)), latent, n_kinks
+
+
+# ---- f4: the TCN extractors (models.py:72-125, 218-289) --------------------------------------------------------
+class _PowerSpectrogram(nn.Module):
+    """torchaudio.transforms.Spectrogram(n_fft, hop_length=hop, normalized=False): power 2, periodic hann, centre +
+    reflect padding (third-party, restated through torch.stft; its ``window`` buffer keeps the state-dict key)."""
+
+    def __init__(self, n_fft: int, hop: int) -> None:
+        super().__init__()
+        self.n_fft, self.hop = n_fft, hop
+        self.register_buffer("window", torch.hann_window(n_fft))
+
+    def forward(self, x: T) -> T:
+        s = torch.stft(x.reshape(-1, x.size(-1)), self.n_fft, self.hop, self.n_fft, self.window, center=True,
+                       pad_mode="reflect", normalized=False, return_complex=True)
+        return (s.real ** 2 + s.imag ** 2).view(x.shape[:-1] + s.shape[-2:])
+
+
+class SpectralTCN(nn.Module):
+    def __init__(self, n_samples: int = 88200, n_fft: int = 1024, hop_len: int = 256, kernel_size: int = 13,
+                 out_channels=None, dilations=None, latent_dim: int = 1, use_ln: bool = True, use_res: bool = True,
+                 eps: float = 1e-7) -> None:
+        super().__init__()
+        from .tcn import TCN
+        out_channels = out_channels or [96] * 5
+        dilations = dilations or [2 ** i for i in range(len(out_channels))]
+        self.eps = eps
+        self.spectrogram = _PowerSpectrogram(n_fft, hop_len)
+        n_frames = n_samples // hop_len + 1
+        self.tcn = TCN(out_channels, dilations, n_fft // 2 + 1, kernel_size, None, use_ln, [n_frames] * len(out_channels),
+                       True, use_res)
+        self.output = nn.Conv1d(out_channels[-1], latent_dim, kernel_size=(1,))
+
+    def forward(self, x: T) -> T:
+        x = torch.log(torch.clip(self.spectrogram(x).squeeze(1), min=self.eps))      # models.py:118-121
+        return torch.sigmoid(self.output(self.tcn(x)))
+
+
+class SpectralDSTCN(nn.Module):
+    def __init__(self, n_samples: int = 88200, n_fft: int = 1024, hop_len: int = 256, kernel_size: int = 13,
+                 out_channels=None, dilations=None, strides=None, n_fc_units: int = 48, latent_dim: int = 2,
+                 use_ln: bool = True, use_res: bool = True, eps: float = 1e-7) -> None:
+        super().__init__()
+        import math
+        from .tcn import TCN
+        out_channels = out_channels or [96] * 5
+        dilations = dilations or [2 ** i for i in range(len(out_channels))]
+        strides = strides or [2] * len(out_channels)
+        self.eps = eps
+        self.spectrogram = _PowerSpectrogram(n_fft, hop_len)
+        dims, cur = [n_samples // hop_len + 1], n_samples // hop_len + 1
+        for s in strides[:-1]:                                                       # models.py:255-260
+            cur = math.ceil(cur / s)
+            dims.append(cur)
+        self.tcn = TCN(out_channels, dilations, n_fft // 2 + 1, kernel_size, strides, use_ln, dims, True, use_res)
+        self.fc = nn.Linear(out_channels[-1], n_fc_units)
+        self.fc_act = nn.PReLU(n_fc_units)
+        self.output = nn.Linear(n_fc_units, latent_dim)
+
+    def forward(self, x: T) -> T:
+        x = torch.log(torch.clip(self.spectrogram(x).squeeze(1), min=self.eps))
+        x = self.tcn(x).mean(dim=-1)                                                 # models.py:282-283
+        return torch.sigmoid(self.output(self.fc_act(self.fc(x))))
