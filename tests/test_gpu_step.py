@@ -178,3 +178,50 @@ def test_file_backed_batch_matches_disk_and_oracle(dev, tmp_path):
     assert torch.equal(dry.cpu(), d_r)
     assert torch.equal(wet.cpu()[fx_rows], w_r[fx_rows])
     assert float((wet.cpu()[ph_rows] - w_r[ph_rows]).abs().max()) < 1e-5
+
+
+def test_train_step_through_the_rccl_init_path_world_size_1(dev):
+    """torch.distributed over backend "nccl" (= RCCL on ROCm) with ONE rank: process-group initialisation, the flat
+    gradient all-reduce and the metric reduction run through RCCL before the driver's multi-GPU launch does.  The step
+    must be bit-identical to the same step without a process group (a 1-rank sum all-reduce is the identity)."""
+    import socket
+    import torch.distributed as dist
+    from mod_extraction_amd import data_modules, lightning, models, optim, trainer
+
+    def run(with_pg):
+        torch.manual_seed(3); np.random.seed(3)
+        cfg = dict(in_ch=2, n_samples=22272, sr=44100, n_fft=1024, hop_len=256, n_mels=64, kernel_size=(5, 13),
+                   out_channels=[64] * 6, temp_dilations=[1, 1, 2, 4, 8, 16], pool_size=(2, 1), latent_dim=1,
+                   freq_mask_amount=0.25, time_mask_amount=0.25, use_ln=True)
+        module = lightning.LFOExtraction(models.Spectral2DCNN(**cfg), sr=44100, model_smooth_n_frames=0,
+                                         loss_dict={"l1": 1.0, "fdl1": 5.0, "sdl1": 10.0, "mse": 0.0}).to(dev).train()
+        opt = optim.FlatAdamW(module.parameters(), lr=1e-4, betas=(0.8, 0.99))
+        bt = data_modules.SyntheticFxBatcher(6, 22272, 44100, ("flanger", "chorus", "phaser"), dev, audio_seed=9)
+        losses = []
+        for _ in range(2):
+            opt.zero_grad()
+            loss = module.training_step(bt.next_batch(), 0)
+            loss.backward()
+            if with_pg:
+                dist.all_reduce(opt.flat_grad, op=dist.ReduceOp.SUM)         # ... on a 1-rank group: the identity
+                scale = 1.0
+            else:
+                scale = trainer.allreduce_flat_grad(opt.flat_grad, 1)
+            opt.step(grad_scale=scale)
+            losses.append(float(loss.detach()))
+        # world_size > 1 makes reduce_metrics all-reduce its (sum, count) table: on a 1-rank group the means are unchanged
+        metrics = trainer.reduce_metrics(module.logged, 2 if with_pg else 1, trainer.metric_names(module, "train"))
+        return losses, opt.flat_param.clone(), metrics
+
+    base = run(False)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        assert dist.get_backend() == "nccl"
+        with_pg = run(True)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+    assert base[0] == with_pg[0] and torch.equal(base[1], with_pg[1])
+    assert base[2] == with_pg[2] and set(base[2]) == {"train/l1", "train/fdl1", "train/sdl1", "train/mse", "train/loss"}
