@@ -256,12 +256,13 @@ int mx_check_mod_sig(const float *x, int64_t rows, int64_t n, int32_t min_top, i
  * + x -> tanh, input order (lfo, audio)) and its truncated BPTT, lightning.py:355-384.
  * x, lfo, y: B rows of T samples with row strides (chunks are views into (B,1,n) tensors).
  * Parameters in torch layout: w_ih (256,2), w_hh (256,64), b_ih (256), b_hh (256), fc_w (64), fc_b (1).
- * h_io, c_io (B,64): initial state in, final state out.  stash (B,T,384) = per-step (i,f,g,o,c,h) for
- * the backward, or NULL. */
+ * h_in, c_in (B,64): state entering the chunk (read only); h_out, c_out (B,64): state leaving it (may alias the
+ * inputs when no backward follows: HiddenStateModel.update_hidden, models.py:298-301).  stash (B,T,384) = per-step
+ * (i,f,g,o,c,h) for the backward, or NULL. */
 int mx_lstm_fwd(const float *x, int64_t x_stride, const float *lfo, int64_t lfo_stride, const float *w_ih,
                 const float *w_hh, const float *b_ih, const float *b_hh, const float *fc_w, const float *fc_b,
-                float *h_io, float *c_io, float *y, int64_t y_stride, float *stash, int64_t B, int64_t T,
-                void *stream);
+                const float *h_in, const float *c_in, float *h_out, float *c_out, float *y, int64_t y_stride,
+                float *stash, int64_t B, int64_t T, void *stream);
 /* BPTT of one chunk with nn.L1Loss fused: loss = loss_scale * sum |y - wet| (loss_scale = w/(B*T)).
  * h_init, c_init (B,64): state at the chunk start (detached, lightning.py:383).  Two launches: the serial
  * recurrence writes the gate gradients to the workspace dgate_ws (B,T,256); a GEMM on the matrix cores

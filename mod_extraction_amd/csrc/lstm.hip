@@ -113,8 +113,10 @@ __global__ __launch_bounds__(LS_THREADS) void lstm_fwd_kernel(const float *__res
                                                               const float *__restrict__ b_ih,
                                                               const float *__restrict__ b_hh,
                                                               const float *__restrict__ fc_w,
-                                                              const float *__restrict__ fc_b, float *__restrict__ h_io,
-                                                              float *__restrict__ c_io, float *__restrict__ y,
+                                                              const float *__restrict__ fc_b,
+                                                              const float *__restrict__ h_in,
+                                                              const float *__restrict__ c_in, float *__restrict__ h_out,
+                                                              float *__restrict__ c_out, float *__restrict__ y,
                                                               long long ys, float *__restrict__ stash, int T, int probe)
 {
     __shared__ __attribute__((aligned(16))) float hist[(LS_TB + 1) * LS_HP];   // row 0 = state entering the block
@@ -135,8 +137,8 @@ __global__ __launch_bounds__(LS_THREADS) void lstm_fwd_kernel(const float *__res
     const float s = q == 2 ? 2.0f : 1.0f, nsl2e = -s * 1.4426950408889634f, oms = 1.0f - s;
     const bool odd = kq & 1;
     const float fcb = fc_b[0];
-    float c = c_io[(size_t)b * LS_H + u];
-    if (tid < LS_H) hist[tid] = h_io[(size_t)b * LS_H + tid];
+    float c = c_in[(size_t)b * LS_H + u];
+    if (tid < LS_H) hist[tid] = h_in[(size_t)b * LS_H + tid];
     const float *xb = x + (size_t)b * xs, *lb = lfo + (size_t)b * ls;
     float *yb = y + (size_t)b * ys;
     float *sb = stash ? stash + (size_t)b * T * LS_STASH : nullptr;
@@ -211,27 +213,29 @@ __global__ __launch_bounds__(LS_THREADS) void lstm_fwd_kernel(const float *__res
             if (!probe || t0 + cnt >= T) yb[t0 + tid] = tanhf(acc + xl[tid].y);
         }
         if (t0 + cnt >= T) {
-            if (tid < LS_H) h_io[(size_t)b * LS_H + tid] = hist[cnt * LS_HP + tid];
-            if (valid && kq == 0) c_io[(size_t)b * LS_H + u] = c;
+            if (tid < LS_H) h_out[(size_t)b * LS_H + tid] = hist[cnt * LS_HP + tid];
+            if (valid && kq == 0) c_out[(size_t)b * LS_H + u] = c;
         }
     }
 }
 
 // x (B rows, stride xs) audio, lfo (B rows, stride ls), T samples each; parameters in torch layout:
-// w_ih (256,2), w_hh (256,64), b_ih (256), b_hh (256), fc_w (64), fc_b (1); h_io / c_io (B,64) are
-// read as the initial state and overwritten with the final state; y (B rows, stride ys);
-// stash (B, T, 384) or NULL when no backward follows.
+// w_ih (256,2), w_hh (256,64), b_ih (256), b_hh (256), fc_w (64), fc_b (1); h_in / c_in (B,64): the state
+// entering the chunk (read only: the BPTT of the chunk needs it again), h_out / c_out (B,64): the state leaving it
+// (may alias h_in / c_in when no backward follows); y (B rows, stride ys); stash (B, T, 384) or NULL when no
+// backward follows.
 MX_EXPORT int mx_lstm_fwd(const float *x, int64_t x_stride, const float *lfo, int64_t lfo_stride, const float *w_ih,
                           const float *w_hh, const float *b_ih, const float *b_hh, const float *fc_w,
-                          const float *fc_b, float *h_io, float *c_io, float *y, int64_t y_stride, float *stash,
-                          int64_t B, int64_t T, void *stream)
+                          const float *fc_b, const float *h_in, const float *c_in, float *h_out, float *c_out, float *y,
+                          int64_t y_stride, float *stash, int64_t B, int64_t T, void *stream)
 {
-    if (!x || !lfo || !w_ih || !w_hh || !b_ih || !b_hh || !fc_w || !fc_b || !h_io || !c_io || !y || B <= 0 || T <= 0)
+    if (!x || !lfo || !w_ih || !w_hh || !b_ih || !b_hh || !fc_w || !fc_b || !h_in || !c_in || !h_out || !c_out || !y ||
+        B <= 0 || T <= 0)
         return MX_ERR_ARG;
     if (T >= (1ll << 30)) return MX_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(lstm_fwd_kernel, dim3((unsigned)B), dim3(LS_THREADS), 0, (hipStream_t)stream, x,
-                       (long long)x_stride, lfo, (long long)lfo_stride, w_ih, w_hh, b_ih, b_hh, fc_w, fc_b, h_io, c_io,
-                       y, (long long)y_stride, stash, (int)T, g_mx_probe);
+                       (long long)x_stride, lfo, (long long)lfo_stride, w_ih, w_hh, b_ih, b_hh, fc_w, fc_b, h_in, c_in,
+                       h_out, c_out, y, (long long)y_stride, stash, (int)T, g_mx_probe);
     return mx_launch_status();
 }
 

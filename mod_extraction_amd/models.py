@@ -677,26 +677,32 @@ class LSTMEffectModel(HiddenStateModel):
     def _state(self, B: int, device) -> Tuple[T, T]:
         if self.is_hidden_init:
             h, c = self.hidden
-            return h.reshape(B, 64).clone(), c.reshape(B, 64).clone()
+            return h.reshape(B, 64), c.reshape(B, 64)
         return (torch.zeros((B, 64), device=device, dtype=torch.float32),
                 torch.zeros((B, 64), device=device, dtype=torch.float32))
+
+    def detach_hidden(self) -> None:
+        """models.py:303-305 clones the detached state; the state tensors here never carry a graph and the kernels never
+        write to a state they were given as input (``mx_lstm_fwd`` writes the new state to fresh buffers), so there is
+        nothing to copy."""
 
     def run_chunk(self, x: T, latent: T, stash: Optional[T] = None) -> Tuple[T, T, T]:
         """Forward one chunk without autograd.  Returns (y (B,1,T), h_start, c_start); updates the hidden
         state.  ``stash`` (B,T,384) receives the per-step activations when a BPTT step follows."""
         assert x.ndim == 3 and latent.shape == (x.size(0), self.latent_dim, x.size(-1))
         B, _, Tn = x.shape
-        h, c = self._state(B, x.device)
-        h0, c0 = h.clone(), c.clone()
+        h0, c0 = self._state(B, x.device)
+        h1 = torch.empty((B, 64), device=x.device, dtype=torch.float32)
+        c1 = torch.empty((B, 64), device=x.device, dtype=torch.float32)
         y = torch.empty((B, 1, Tn), device=x.device, dtype=torch.float32)
         xp, xs = _rows(x)
         lp, ls = _rows(latent)
         yp, ys = _rows(y)
         w = [p.detach().contiguous() for p in self._params()]
         _hip.call("mx_lstm_fwd", xp, xs, lp, ls, _hip.ptr(w[0]), _hip.ptr(w[1]), _hip.ptr(w[2]), _hip.ptr(w[3]),
-                  _hip.ptr(w[4]), _hip.ptr(w[5]), _hip.ptr(h), _hip.ptr(c), yp, ys, _hip.ptr(stash), B, Tn,
-                  _hip.stream())
-        self.update_hidden((h.view(1, B, 64), c.view(1, B, 64)))
+                  _hip.ptr(w[4]), _hip.ptr(w[5]), _hip.ptr(h0.contiguous()), _hip.ptr(c0.contiguous()), _hip.ptr(h1), _hip.ptr(c1),
+                  yp, ys, _hip.ptr(stash), B, Tn, _hip.stream())
+        self.update_hidden((h1.view(1, B, 64), c1.view(1, B, 64)))
         return y, h0, c0
 
     def bptt_l1_chunk(self, x: T, latent: T, y: T, wet: T, stash: T, h0: T, c0: T, loss_scale: float,

@@ -26,7 +26,7 @@ int main()
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int stash = 0; stash < 2; ++stash) {
         hipEventRecord(e0);
-        for (int rep = 0; rep < 10; ++rep) mx_lstm_fwd(dx, T, dl, T, dwi, dw, db, db, dfc, dfb, dh, dc, dy, T, stash ? dst : nullptr, B, T, nullptr);
+        for (int rep = 0; rep < 10; ++rep) mx_lstm_fwd(dx, T, dl, T, dwi, dw, db, db, dfc, dfb, dh, dc, dh, dc, dy, T, stash ? dst : nullptr, B, T, nullptr);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         printf("LS_ABL=%d stash=%d: %.1f ns per step\n", LS_ABL, stash, ms / 10 * 1e6 / T);

@@ -1,19 +1,28 @@
+# rocprofv3 summaries of one round (run on the GPU box through gpurun):  bash tools/profile_round.sh r02
+# kernel statistics of every BASELINE config (bench.py --config 2..5) + the PMC passes of the headline roofline kernel.
 export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r01
+R=${1:-r02}
+O=gpurun_out/$R
 rm -rf $O; mkdir -p $O
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_b256_under_rocprof.json 2> $O/stats.err
-cp $(find $O/stats -name "*kernel_stats.csv" | head -1) $O/bench_b256_kernel_stats.csv
+stats() { c=$1; steps=$2
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c$c -- python3 bench.py --config $c --steps $steps --warmup 1 --no-cpu-baseline --no-fp32-leg > $O/bench_c${c}_under_rocprof.json 2> $O/stats_c$c.err
+  cp $(find $O/stats_c$c -name "*kernel_stats.csv" | head -1) $O/bench_c${c}_kernel_stats.csv
+  rm -rf $O/stats_c$c
+}
+stats 3 5; stats 2 10; stats 4 2; stats 5 5
 run_pmc() { n=$1; shift
-  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $O/pmc_$n -- python3 bench.py --steps 2 --warmup 1 --batch 64 --no-cpu-baseline > $O/pmc_$n.log 2>&1
+  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $O/pmc_$n -- python3 bench.py --steps 2 --warmup 1 --batch 64 --no-cpu-baseline --no-fp32-leg > $O/pmc_$n.log 2>&1
 }
 run_pmc sq SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE
 python tools/pmc_summary.py $O/pmc_sq > $O/pmc_b64_sq.txt
 python tools/pmc_clock.py $O/pmc_sq f16x3 > $O/pmc_b64_clock_f16x3.txt
-run_pmc lds SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VALU
-python tools/pmc_summary.py $O/pmc_lds > $O/pmc_b64_lds.txt
 run_pmc fetch FETCH_SIZE
 python tools/pmc_summary.py $O/pmc_fetch > $O/pmc_b64_fetch.txt
 run_pmc write WRITE_SIZE
 python tools/pmc_summary.py $O/pmc_write > $O/pmc_b64_write.txt
-rm -rf $O/stats $O/pmc_sq $O/pmc_lds $O/pmc_fetch $O/pmc_write $O/*.log $O/stats.err
+# the sample-recurrent kernels of config 4 (LSTM forward / backward): issue and LDS counters
+rocprofv3 --kernel-trace --pmc SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_lstm -- python3 tools/bench_lstm.py > $O/pmc_lstm.log 2>&1
+python tools/pmc_summary.py $O/pmc_lstm lstm > $O/pmc_lstm_sq.txt
+rm -rf $O/pmc_sq $O/pmc_fetch $O/pmc_write $O/pmc_lstm $O/*.log $O/*.err
+ls -la $O
