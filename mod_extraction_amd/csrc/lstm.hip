@@ -32,6 +32,7 @@
 // tanh(x) = 2 sigmoid(2x) - 1 (absolute error ~1e-7, the recurrent path carries 1e-5 parity, tests/test_gpu_lstm.py).
 // Algorithmic HBM traffic: 12 B/sample I/O + 1536 B/sample stash (written, read once) + 1024 B/sample dg.
 #include "conv_common.h"
+#include <stdlib.h>
 
 #define LS_H 64
 #define LS_STASH 384        // floats per time step: gates 256 (i, f, g, o) + c 64 + h 64
@@ -106,7 +107,8 @@ __device__ __forceinline__ void ls_barrier()      // LDS-only: outstanding globa
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-__global__ __launch_bounds__(LS_THREADS) void lstm_fwd_kernel(const float *__restrict__ x, long long xs,
+template <int KQ>     // k-split of a gate row over lanes: 4 (512 threads, 16 k per lane) or 2 (256 threads, 32 k per lane)
+__global__ __launch_bounds__(128 * KQ) void lstm_fwd_kernel(const float *__restrict__ x, long long xs,
                                                               const float *__restrict__ lfo, long long ls,
                                                               const float *__restrict__ w_ih,
                                                               const float *__restrict__ w_hh,
@@ -123,12 +125,13 @@ __global__ __launch_bounds__(LS_THREADS) void lstm_fwd_kernel(const float *__res
     __shared__ __attribute__((aligned(16))) float2 xl[LS_TB];                   // (lfo, x) of the block
     __shared__ float dummy[LS_THREADS];                                          // sink of the lanes that hold no h
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int kq = lane & 3, gp = (lane >> 2) & 1, u = wv * 8 + (lane >> 3);
+    constexpr int KPL = LS_H / KQ;                  // k values per lane
+    const int kq = lane & (KQ - 1), gp = (lane / KQ) & 1, u = wv * (32 / KQ) + lane / (2 * KQ);
     const int q = 2 * gp + (kq & 1);                // the gate this lane activates (lanes kq >= 2 duplicate kq - 2)
     const int ra = (2 * gp) * LS_H + u, rb = (2 * gp + 1) * LS_H + u;
-    ls_f2 wp[16];
+    ls_f2 wp[KPL];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) wp[j] = (ls_f2){w_hh[ra * LS_H + 16 * kq + j], w_hh[rb * LS_H + 16 * kq + j]};
+    for (int j = 0; j < KPL; ++j) wp[j] = (ls_f2){w_hh[ra * LS_H + KPL * kq + j], w_hh[rb * LS_H + KPL * kq + j]};
     // the input term and both biases enter through the kq = 0 quarter only (input order (lfo, audio): models.py:328)
     const bool k0 = kq == 0;
     const ls_f2 wi0 = k0 ? (ls_f2){w_ih[ra * 2], w_ih[rb * 2]} : (ls_f2){0.f, 0.f};
@@ -142,13 +145,17 @@ __global__ __launch_bounds__(LS_THREADS) void lstm_fwd_kernel(const float *__res
     const float *xb = x + (size_t)b * xs, *lb = lfo + (size_t)b * ls;
     float *yb = y + (size_t)b * ys;
     float *sb = stash ? stash + (size_t)b * T * LS_STASH : nullptr;
-    // quads gp = 0 see (i, f) in their own lanes and (o, g) mirrored: they carry c and h; quads gp = 1 compute junk
-    const bool valid = gp == 0;
-    float *hw = valid ? hist + LS_HP + u : dummy + tid;          // where this lane's h goes (row 1 = step 0)
-    const int hw_step = valid ? LS_HP : 0;
-    // stash slot of this lane: its gate activation; the spare lanes kq = 2, 3 of the valid quads store c and h
-    const bool st_c = valid && kq == 2, st_h = valid && kq == 3;
-    const int st_off = st_c ? 256 + u : (st_h ? 320 + u : q * LS_H + u);
+    // KQ = 4: quads gp = 0 see (i, f) in their own lanes and (o, g) mirrored: they carry c and h; quads gp = 1 compute
+    // junk.  KQ = 2: a quad holds i, f, g, o of one unit: every lane carries c and h.
+    const bool valid = KQ == 2 || gp == 0;
+    const bool writer = valid && (KQ == 2 ? (lane & 3) == 0 : true);
+    float *hw = writer ? hist + LS_HP + u : dummy + tid;         // where this lane's h goes (row 1 = step 0)
+    const int hw_step = writer ? LS_HP : 0;
+    // stash slot of this lane: its gate activation; KQ = 4: the spare lanes kq = 2, 3 of the valid quads store c and h
+    // in the same instruction; KQ = 2: lanes 0 / 1 of the quad store them with a second instruction
+    const bool st_c = KQ == 4 ? valid && kq == 2 : (lane & 3) == 0, st_h = KQ == 4 ? valid && kq == 3 : (lane & 3) == 1;
+    const int st_off = KQ == 4 ? (st_c ? 256 + u : (st_h ? 320 + u : q * LS_H + u)) : q * LS_H + u;
+    const int st_off2 = st_c ? 256 + u : (st_h ? 320 + u : q * LS_H + u);
 
     for (int t0 = 0; t0 < T; t0 += LS_TB) {
         const int cnt = min(LS_TB, T - t0);
@@ -156,7 +163,7 @@ __global__ __launch_bounds__(LS_THREADS) void lstm_fwd_kernel(const float *__res
         if (t0 > 0 && tid < LS_H) hist[tid] = hist[LS_TB * LS_HP + tid];
         if (tid < cnt) xl[tid] = probe ? make_float2(0.5f, 0.25f) : make_float2(lb[t0 + tid], xb[t0 + tid]);
         __syncthreads();
-        const float *hr = hist + 16 * kq;
+        const float *hr = hist + KPL * kq;
         float *hwp = hw;
         LS_DIAG_INIT
         float *st = sb + (size_t)t0 * LS_STASH + st_off;       // dereferenced only when sb != NULL (wave-uniform test)
@@ -168,27 +175,46 @@ __global__ __launch_bounds__(LS_THREADS) void lstm_fwd_kernel(const float *__res
                 h0 = *(const float4 *)hr; h1 = *(const float4 *)(hr + 4); h2 = *(const float4 *)(hr + 8);
                 h3 = *(const float4 *)(hr + 12);
             }
+            float4 h4, h5, h6, h7;
+            if (KQ == 2) {
+                h4 = *(const float4 *)(hr + 16); h5 = *(const float4 *)(hr + 20); h6 = *(const float4 *)(hr + 24);
+                h7 = *(const float4 *)(hr + 28);
+            }
             const float2 in = xl[tt];
             LS_STAMP(0)                                         // LDS reads landed
             ls_f2 acc = wi1 * in.y + (wi0 * in.x + bias);
             if (!(LS_ABL & 16)) {
                 LS_PK16(acc, wp, h0, h1, h2, h3);
+                if (KQ == 2) {
+                    const ls_f2 *wq = wp + (KQ == 2 ? 16 : 0);
+                    LS_PK16(acc, wq, h4, h5, h6, h7);
+                }
             } else {
                 acc += (ls_f2){h0.x, h3.w};
             }
             float pa = acc.x, pb = acc.y;
             LS_STAMP(1)                                         // packed FMAs
             pa += ls_dpp<0xB1>(pa); pb += ls_dpp<0xB1>(pb);     // quad_perm [1,0,3,2]
-            pa += ls_dpp<0x4E>(pa); pb += ls_dpp<0x4E>(pb);     // quad_perm [2,3,0,1]: all four quarters
+            if (KQ == 4) { pa += ls_dpp<0x4E>(pa); pb += ls_dpp<0x4E>(pb); }   // quad_perm [2,3,0,1]: all four quarters
             const float a = (LS_ABL & 2) ? (odd ? pb : pa) * 0.01f : ls_act(odd ? pb : pa, nsl2e, s, oms);
-            const float m = ls_dpp<0x141>(a);                   // row_half_mirror: the other gate pair of the unit
-            const float gi = ls_dpp<0x00>(a), gf = ls_dpp<0x55>(a), gg = ls_dpp<0x55>(m), go = ls_dpp<0x00>(m);
+            float gi, gf, gg, go;
+            if (KQ == 4) {
+                const float m = ls_dpp<0x141>(a);               // row_half_mirror: the other gate pair of the unit
+                gi = ls_dpp<0x00>(a); gf = ls_dpp<0x55>(a); gg = ls_dpp<0x55>(m); go = ls_dpp<0x00>(m);
+            } else {
+                gi = ls_dpp<0x00>(a); gf = ls_dpp<0x55>(a); gg = ls_dpp<0xAA>(a); go = ls_dpp<0xFF>(a);
+            }
             c = fmaf(gf, c, gi * gg);
             const float hv = go * ((LS_ABL & 2) ? c * 0.5f : ls_tanh(c));
             LS_STAMP(2)                                         // reduce, activation, exchange, cell update
             if (!(LS_ABL & 8)) *hwp = hv;
             if (sb && !probe && !(LS_ABL & 32)) {
-                *st = st_c ? c : (st_h ? hv : a);
+                if (KQ == 4) {
+                    *st = st_c ? c : (st_h ? hv : a);
+                } else {
+                    *st = a;
+                    st[st_off2 - st_off] = st_c ? c : (st_h ? hv : a);
+                }
                 st += LS_STASH;
             }
             hr += LS_HP;
@@ -214,7 +240,7 @@ __global__ __launch_bounds__(LS_THREADS) void lstm_fwd_kernel(const float *__res
         }
         if (t0 + cnt >= T) {
             if (tid < LS_H) h_out[(size_t)b * LS_H + tid] = hist[cnt * LS_HP + tid];
-            if (valid && kq == 0) c_out[(size_t)b * LS_H + u] = c;
+            if (writer && kq == 0) c_out[(size_t)b * LS_H + u] = c;
         }
     }
 }
@@ -233,9 +259,19 @@ MX_EXPORT int mx_lstm_fwd(const float *x, int64_t x_stride, const float *lfo, in
         B <= 0 || T <= 0)
         return MX_ERR_ARG;
     if (T >= (1ll << 30)) return MX_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(lstm_fwd_kernel, dim3((unsigned)B), dim3(LS_THREADS), 0, (hipStream_t)stream, x,
-                       (long long)x_stride, lfo, (long long)lfo_stride, w_ih, w_hh, b_ih, b_hh, fc_w, fc_b, h_in, c_in,
-                       h_out, c_out, y, (long long)y_stride, stash, (int)T, g_mx_probe);
+    // 8 waves (16 k per lane) when the BPTT stash is written -- its spare lanes carry c and h in the one store -- and
+    // 4 waves (32 k per lane, no idle lanes in the cell update) for inference / warm-up: measured 0.349 vs 0.343 ms with
+    // the stash and 0.343 vs 0.322 ms without, per 128 clips x 1024 steps.  MODEX_LSTM_KQ = 2 | 4 forces one (experiments).
+    static const int kq_env = getenv("MODEX_LSTM_KQ") ? atoi(getenv("MODEX_LSTM_KQ")) : 0;
+    const int kq = kq_env ? kq_env : (stash ? 4 : 2);
+    if (kq == 2)
+        hipLaunchKernelGGL(lstm_fwd_kernel<2>, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, x,
+                           (long long)x_stride, lfo, (long long)lfo_stride, w_ih, w_hh, b_ih, b_hh, fc_w, fc_b, h_in, c_in,
+                           h_out, c_out, y, (long long)y_stride, stash, (int)T, g_mx_probe);
+    else
+        hipLaunchKernelGGL(lstm_fwd_kernel<4>, dim3((unsigned)B), dim3(512), 0, (hipStream_t)stream, x,
+                           (long long)x_stride, lfo, (long long)lfo_stride, w_ih, w_hh, b_ih, b_hh, fc_w, fc_b, h_in, c_in,
+                           h_out, c_out, y, (long long)y_stride, stash, (int)T, g_mx_probe);
     return mx_launch_status();
 }
 
