@@ -408,18 +408,18 @@ def run_config4(args, env):
             _hip.call("mx_set_probe_mode", 0)
     em.clear_hidden()
     fwd_bytes = B * S * (12.0 + 1536.0)
-    bwd_bytes = B * S * (1536.0 + 8.0 + 1024.0 + 1024.0 + 256.0 + 8.0)
+    bwd_bytes = B * S * (1536.0 + 16.0) + B * 17473 * 4.0
     note = ("one 512-thread workgroup per clip; a launch lasts T = 1024 x (latency of one step): LDS exchange of h / dg + "
             "barrier + the dependent FMA / activation chain (csrc/lstm.hip)")
     kernels = {
         "lstm_fwd_kernel": hbm_block(f"lstm_fwd_kernel ({B} clips x {S} steps, models.py:325-339)", fwd_bytes,
                                      iso[0]["mx_lstm_fwd"], iso[1]["mx_lstm_fwd"],
                                      note="12 B/sample I/O + 1536 B/sample BPTT stash written; " + note),
-        "lstm_bwd_l1 (serial kernel + weight-gradient GEMM)": hbm_block(
-            f"lstm_bwd_kernel + lstm_wgrad_kernel ({B} clips x {S} steps, lightning.py:355-384)", bwd_bytes,
+        "lstm_bwd_kernel": hbm_block(
+            f"lstm_bwd_kernel ({B} clips x {S} steps, BPTT + L1 + weight gradients, lightning.py:355-384)", bwd_bytes,
             iso[0]["mx_lstm_bwd_l1"], iso[1]["mx_lstm_bwd_l1"],
-            note="stash read once, gate gradients written and read once, h re-read by the GEMM; the probe launch still runs "
-                 "the (HBM-fed) weight-gradient GEMM, so its floor is an upper bound; " + note),
+            note="stash read once (1536 B/sample) + x, lfo, y, wet (16 B/sample) + one gradient row per clip; the weight "
+                 "gradients accumulate on the matrix pipes inside the recurrence (fp32 MFMA, operands from LDS); " + note),
     }
     live = {k: mean(v) for k, v in timings.items()}
     per_batch = {k: round(sum(v) / args.steps, 3) for k, v in timings.items()}

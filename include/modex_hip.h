@@ -264,16 +264,13 @@ int mx_lstm_fwd(const float *x, int64_t x_stride, const float *lfo, int64_t lfo_
                 const float *h_in, const float *c_in, float *h_out, float *c_out, float *y, int64_t y_stride,
                 float *stash, int64_t B, int64_t T, void *stream);
 /* BPTT of one chunk with nn.L1Loss fused: loss = loss_scale * sum |y - wet| (loss_scale = w/(B*T)).
- * h_init, c_init (B,64): state at the chunk start (detached, lightning.py:383).  Two launches: the serial
- * recurrence writes the gate gradients to the workspace dgate_ws (B,T,256); a GEMM on the matrix cores
- * (K = T split over n_split in {1,2,4} workgroups per clip) turns them into part (B*n_split,17473):
- * partial gradient rows in state-dict order [weight_ih | weight_hh | bias_ih | bias_hh | fc.weight |
- * fc.bias]; sum them with mx_reduce_rows(part, B*n_split, 17473, ...). */
+ * h_init, c_init (B,64): state at the chunk start (detached, lightning.py:383).  part (B,17473):
+ * per-clip gradient rows in state-dict order [weight_ih | weight_hh | bias_ih | bias_hh | fc.weight |
+ * fc.bias]; sum them with mx_reduce_rows. */
 int mx_lstm_bwd_l1(const float *x, int64_t x_stride, const float *lfo, int64_t lfo_stride, const float *y,
                    int64_t y_stride, const float *wet, int64_t wet_stride, const float *stash,
                    const float *w_hh, const float *fc_w, const float *h_init, const float *c_init,
-                   float loss_scale, float *dgate_ws, float *part, int32_t n_split, int64_t B, int64_t T,
-                   void *stream);
+                   float loss_scale, float *part, int64_t B, int64_t T, void *stream);
 
 /* ---- TCN extractors -- mod_extraction/tcn.py:106-302 (TCNBlock / TCN) under models.py:72-125,218-289
  * (SpectralTCN / SpectralDSTCN).  Activations: (B, C, 352) fp32 planes with T <= 352 valid columns.

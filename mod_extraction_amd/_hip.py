@@ -60,8 +60,7 @@ SIGNATURES = {
     "mx_stretch_corners": [_P, _I64, _I64, _I64, _P, _P],
     "mx_check_mod_sig": [_P, _I64, _I64, _I32, _I32, _I32, _I32, _I32, _P, _P],
     "mx_lstm_fwd": [_P, _I64, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _I64, _I64, _P],
-    "mx_lstm_bwd_l1": [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _P, _P, _P, _P, _F32, _P, _P, _I32, _I64, _I64,
-                       _P],
+    "mx_lstm_bwd_l1": [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _P, _P, _P, _P, _F32, _P, _I64, _I64, _P],
     "mx_sgemm_f32": [_P, _I64, _I64, _I64, _P, _I64, _I64, _I64, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I32, _P],
     "mx_tcn_im2col": [_P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _P, _P],
     "mx_tcn_col2im": [_P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _P, _P],

@@ -22,15 +22,16 @@
 //            as 16 v_pk_fma_f32 (two units per packed FMA), an all-reduce over the 16 groups by four DPP adds per
 //            unit, and the element-wise gate derivatives computed by the lanes rg < 8 (one (unit, gate) each) from a
 //            slab of the forward stash that is staged through LDS 32 steps at a time (coalesced, double buffered).
-//            The gate gradients dg (B, T, 256) are written out ...
-//  wgrad     ... and the weight gradients, which do not feed the recurrence, are one GEMM per chunk on the
-//            matrix cores afterwards: dW_hh = sum_t dg_t (x) h_{t-1} with v_mfma_f32_32x32x2_f32 (exact fp32),
-//            K = T split over the workgroups; dW_ih / biases / fc ride along on the VALU.
-// Per-workgroup partial rows (state-dict order) are summed by mx_reduce_rows (deterministic, no atomics).
+//            The weight gradients do not feed the recurrence: dW_hh = sum_t dg_t (x) h_{t-1} accumulates in the SAME
+//            kernel on the matrix pipes, which the recurrence leaves idle -- two v_mfma_f32_32x32x2_f32 (exact fp32) per
+//            wave every second step, on the gate gradients of steps t+1, t+2 that sit in LDS anyway (three rotating
+//            buffers) and the h rows of the stash slab; dW_ih / biases ride along on the A fragment, fc on the unit
+//            lanes.  (First version: gate gradients written to HBM and a separate GEMM kernel per chunk, 0.10-0.14 ms.)
+// One gradient row per clip (state-dict order) is summed over the batch by mx_reduce_rows (deterministic, no atomics).
 //
 // Activations use v_exp_f32 / v_rcp_f32 (1 ulp each): sigmoid(x) = 1 / (1 + 2^(-x log2 e)),
 // tanh(x) = 2 sigmoid(2x) - 1 (absolute error ~1e-7, the recurrent path carries 1e-5 parity, tests/test_gpu_lstm.py).
-// Algorithmic HBM traffic: 12 B/sample I/O + 1536 B/sample stash (written, read once) + 1024 B/sample dg.
+// Algorithmic HBM traffic: 12 B/sample I/O + 1536 B/sample stash (written, read once).
 #include "conv_common.h"
 #include <stdlib.h>
 
@@ -43,6 +44,7 @@
 #define LS_SLAB 32          // steps per stash slab (backward)
 #define LS_PP 72            // plane pitch inside a slab row (64 + 8: the four gate planes land on different banks)
 #define LS_ROWP (6 * LS_PP) // slab row pitch (floats)
+#define LS_SLAB_FLOATS ((LS_SLAB + 2) * LS_ROWP + LS_SLAB + 72)   // rows -1 .. 32, dzy, (lfo, x) of 36 steps
 
 typedef float ls_f2 __attribute__((ext_vector_type(2)));
 // acc(2) += W[j](2) * v[j] for j = 0..15: 16 packed FMAs in ONE asm block (the compiler pads an s_nop after every
@@ -283,20 +285,24 @@ __device__ __forceinline__ int ls_dg_slot(int r)   // LDS slot of gate row r: [1
     return ((r & 15) >> 2) * 64 + (r >> 4) * 4 + (r & 3);
 }
 
-__global__ __launch_bounds__(LS_THREADS) void lstm_bwd_kernel(const float *__restrict__ y, long long ys,
+__global__ __launch_bounds__(LS_THREADS) void lstm_bwd_kernel(const float *__restrict__ x, long long xs,
+                                                              const float *__restrict__ lfo, long long ls,
+                                                              const float *__restrict__ y, long long ys,
                                                               const float *__restrict__ wet, long long ws,
                                                               const float *__restrict__ stash,
                                                               const float *__restrict__ w_hh,
                                                               const float *__restrict__ fc_w,
+                                                              const float *__restrict__ h_init,
                                                               const float *__restrict__ c_init, float loss_scale,
-                                                              float *__restrict__ dgate, int T, int probe)
+                                                              float *__restrict__ part, int T, int probe)
 {
-    // slab buffer = [row -1 (only its c plane: c of the step before the slab)] [32 rows of 6 planes] ; dzy (32)
+    // slab buffer = [row -1 (only its c plane: c of the step before the slab)] [32 rows of 6 planes] [row 32 (only its h
+    // plane: h of the step after the slab)] ; dzy (32) ; lfo (36) ; x (36) of steps t0 .. t0 + 33
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int slab_floats = (LS_SLAB + 1) * LS_ROWP + LS_SLAB;
+    const int slab_floats = LS_SLAB_FLOATS;
     float *slab0 = smem, *slab1 = smem + slab_floats;
-    float *dgl = smem + 2 * slab_floats;                       // 2 x 256 gate gradients (double buffer)
-    float *dummy = dgl + 512;                                  // sink of the lanes that hold no gate gradient
+    float *dgl = smem + 2 * slab_floats;                       // 3 x 256 gate gradients: dg(t+1), dg(t+2), and the one being written
+    float *dummy = dgl + 768;                                  // sink of the lanes that hold no gate gradient
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int rg = lane & 15, kp = wv * 4 + (lane >> 4);       // 16 gate rows 16 rg .. 16 rg + 15, hidden units 2 kp, 2 kp + 1
     const int e = rg & 7, q = e & 3, k = 2 * kp + (e >> 2);    // the (unit, gate) this lane differentiates (rg >= 8: duplicate)
@@ -316,11 +322,21 @@ __global__ __launch_bounds__(LS_THREADS) void lstm_bwd_kernel(const float *__res
     const int dg_wr = ls_dg_slot(q * LS_H + k);
     const float *yb = y + (size_t)b * ys, *wb = wet + (size_t)b * ws;
     const float *sb = stash + (size_t)b * T * LS_STASH;
-    float *dgb = dgate + (size_t)b * T * 256;
+    const float *xb = x + (size_t)b * xs, *lb = lfo + (size_t)b * ls;
+    // weight gradients (they do not feed the recurrence): dW_hh = sum_t dg_t (x) h_{t-1} accumulates on the otherwise idle
+    // matrix pipes, two fp32 MFMAs per wave every second step on the steps (t+1, t+2) whose gate gradients are in LDS;
+    // wave wv owns gate rows 32 wv .. 32 wv + 31.  dW_ih / biases ride along on the A fragment, fc on the unit lanes.
+    const int c32 = lane & 31, tpar = lane >> 5;
+    const int a_slot = ls_dg_slot(32 * wv + c32);
+    floatx16 wacc0, wacc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) wacc0[r] = wacc1[r] = 0.0f;
+    float dwi0 = 0.0f, dwi1 = 0.0f, dbs = 0.0f, dfw = 0.0f, dfb = 0.0f;
+    const int off_h = 5 * LS_PP + k;
 
     const int n_slabs = (T + LS_SLAB - 1) / LS_SLAB;
     float4 pre[6];
-    float pre_c = 0.0f, pre_dzy = 0.0f;
+    float pre_c = 0.0f, pre_dzy = 0.0f, pre_h32 = 0.0f, pre_xl = 0.0f;
     // slab S -> registers (global, coalesced: 32 x 384 contiguous floats), registers -> LDS (plane-padded)
     auto slab_load = [&](int S) {
         const int t0 = S * LS_SLAB, cnt = min(LS_SLAB, T - t0);
@@ -329,6 +345,8 @@ __global__ __launch_bounds__(LS_THREADS) void lstm_bwd_kernel(const float *__res
             for (int i = 0; i < 6; ++i) pre[i] = make_float4(0.5f, 0.5f, 0.5f, 0.5f);
             pre_c = 0.5f;
             pre_dzy = 1e-3f;
+            pre_h32 = 0.5f;
+            pre_xl = 0.25f;
             return;
         }
 #pragma unroll
@@ -345,6 +363,11 @@ __global__ __launch_bounds__(LS_THREADS) void lstm_bwd_kernel(const float *__res
             } else
                 pre_dzy = 0.0f;
         }
+        if (tid >= 96 && tid < 96 + LS_H) pre_h32 = t0 + LS_SLAB < T ? sb[(size_t)(t0 + LS_SLAB) * LS_STASH + 320 + tid - 96] : 0.0f;
+        if (tid >= 160 && tid < 160 + 72) {                            // lfo of steps t0 .. t0 + 35, then x of the same steps
+            const int i = tid - 160, t = t0 + (i < 36 ? i : i - 36);
+            pre_xl = t < T ? (i < 36 ? lb[t] : xb[t]) : 0.0f;
+        }
     };
     auto slab_store = [&](float *dst) {
 #pragma unroll
@@ -353,31 +376,49 @@ __global__ __launch_bounds__(LS_THREADS) void lstm_bwd_kernel(const float *__res
             *(float4 *)(dst + (srow + 1) * LS_ROWP + (j >> 6) * LS_PP + (j & 63)) = pre[i];
         }
         if (tid < LS_H) dst[4 * LS_PP + tid] = pre_c;                  // row -1, c plane
-        if (tid >= 64 && tid < 64 + LS_SLAB) dst[(LS_SLAB + 1) * LS_ROWP + tid - 64] = pre_dzy;
+        if (tid >= 64 && tid < 64 + LS_SLAB) dst[(LS_SLAB + 2) * LS_ROWP + tid - 64] = pre_dzy;
+        if (tid >= 96 && tid < 96 + LS_H) dst[(LS_SLAB + 1) * LS_ROWP + 5 * LS_PP + tid - 96] = pre_h32;   // row 32, h plane
+        if (tid >= 160 && tid < 160 + 72) dst[(LS_SLAB + 2) * LS_ROWP + LS_SLAB + tid - 160] = pre_xl;
     };
 
-    for (int i = tid; i < 512; i += LS_THREADS) dgl[i] = 0.0f;        // dh from "step T" is zero
+    for (int i = tid; i < 768; i += LS_THREADS) dgl[i] = 0.0f;        // dh from "step T" is zero
     slab_load(n_slabs - 1);
     slab_store((n_slabs - 1) & 1 ? slab1 : slab0);
     __syncthreads();
 
     float dc_next = 0.0f;
-    int par = 0;                                                       // dgl buffer read by the current step
+    int b_cur = 0, b_prev = 1, b_wr = 2;                               // dgl buffers: dg(t+1), dg(t+2), written by this step
     for (int S = n_slabs - 1; S >= 0; --S) {
         const int t0 = S * LS_SLAB, cnt = min(LS_SLAB, T - t0);
         const float *sl = (S & 1 ? slab1 : slab0) + LS_ROWP;           // row 0 of the slab
-        const float *dzl = (S & 1 ? slab1 : slab0) + (LS_SLAB + 1) * LS_ROWP;
+        const float *dzl = (S & 1 ? slab1 : slab0) + (LS_SLAB + 2) * LS_ROWP;
+        const float *xll = dzl + LS_SLAB;                              // lfo[t0 + i] at i, x[t0 + i] at 36 + i
         if (S > 0) slab_load(S - 1);
         // raw stash values of the first step processed (the loop below prefetches one step ahead)
         const float *r0 = sl + (cnt - 1) * LS_ROWP;
         float n_a = r0[off_a], n_p = r0[off_p], n_f = r0[off_f], n_o = r0[off_o], n_c = r0[off_c], n_z = dzl[cnt - 1];
+        float n_h = r0[off_h];
         for (int s = cnt - 1; s >= 0; --s) {
+            // (0) every second step: gate gradients of steps t+1, t+2 (x) the states entering them -> dW_hh, dW_ih, db
+            if ((T - 1 - (t0 + s)) & 1) {
+                const float av = dgl[(tpar ? b_prev : b_cur) * 256 + a_slot];
+                const float *hrow = sl + (s + tpar) * LS_ROWP + 5 * LS_PP;      // h_t (tpar 0) / h_{t+1} (tpar 1); row 32 exists
+                const float bv0 = hrow[c32], bv1 = hrow[32 + c32];
+                const float li = xll[s + 1 + tpar], xi = xll[36 + s + 1 + tpar];
+                wacc0 = mfma32(av, bv0, wacc0);
+                wacc1 = mfma32(av, bv1, wacc1);
+                dwi0 = fmaf(av, li, dwi0);
+                dwi1 = fmaf(av, xi, dwi1);
+                dbs += av;
+            }
             // (1) the 16 gate gradients of step t+1 this lane multiplies
-            const float *dr = dgl + par * 256 + dg_rd;
+            const float *dr = dgl + b_cur * 256 + dg_rd;
             const float4 g0 = *(const float4 *)dr, g1 = *(const float4 *)(dr + 64), g2 = *(const float4 *)(dr + 128),
                          g3 = *(const float4 *)(dr + 192);
             // (2) while they arrive: the local derivatives of step t from the values prefetched last step
             const float a = n_a, pp = n_p, f = n_f, o = n_o, dzy = n_z;
+            dfw = fmaf(dzy, n_h, dfw);                                 // d fc.weight[k] = sum_t dzy_t h_t[k]
+            dfb += dzy;
             const float tc = ls_tanh(n_c);
             const float kc = o * fmaf(-tc, tc, 1.0f);                  // d h / d c = o (1 - tanh^2 c)
             const float der = fmaf(a, beta - a, alpha);
@@ -387,6 +428,7 @@ __global__ __launch_bounds__(LS_THREADS) void lstm_bwd_kernel(const float *__res
                 const int sp = s > 0 ? s - 1 : 0;
                 const float *rn = sl + sp * LS_ROWP;
                 n_a = rn[off_a]; n_p = rn[off_p]; n_f = rn[off_f]; n_o = rn[off_o]; n_c = rn[off_c]; n_z = dzl[sp];
+                n_h = rn[off_h];
             }
             // (4) dh_prev[k] = sum_r W[r][k] dg[r] for the unit pair: 16 rows per lane, all-reduce over the 16 row groups
             ls_f2 acc = {0.0f, 0.0f};
@@ -402,176 +444,72 @@ __global__ __launch_bounds__(LS_THREADS) void lstm_bwd_kernel(const float *__res
             const float dc = fmaf(dh, kc, dc_next);
             const float dg = (q == 3 ? dh : dc) * kq;
             dc_next = dc * f;
-            *(owner ? dgl + (par ^ 1) * 256 + dg_wr : dummy + tid) = dg;
-            if (owner && (!probe || t0 + s == 0)) dgb[(size_t)(t0 + s) * 256 + q * LS_H + k] = dg;
-            par ^= 1;
+            *(owner ? dgl + b_wr * 256 + dg_wr : dummy + tid) = dg;
+            {
+                const int t_ = b_prev;                                 // rotate: the buffer of dg(t+2) is free after this step
+                b_prev = b_cur;
+                b_cur = b_wr;
+                b_wr = t_;
+            }
             if (S > 0 && s == cnt / 2) slab_store((S - 1) & 1 ? slab1 : slab0);   // the other buffer is idle
             ls_barrier();
         }
     }
-}
-
-// ---- weight gradients of the chunk: one GEMM on the matrix cores -----------------------------------
-// part row (b * n_split + ks), state-dict order:
-//   [lstm.weight_ih_l0 (256,2) | lstm.weight_hh_l0 (256,64) | lstm.bias_ih_l0 | lstm.bias_hh_l0 | fc.weight | fc.bias]
-#define WG_TB 32            // steps per staged block
-#define WG_DP 260           // LDS row pitch of the dg block (floats; 260 = 256 + 4 keeps rows 16-byte aligned)
-#define WG_HP 68            // LDS row pitch of the h block
-__global__ __launch_bounds__(256) void lstm_wgrad_kernel(const float *__restrict__ x, long long xs,
-                                                         const float *__restrict__ lfo, long long ls,
-                                                         const float *__restrict__ y, long long ys,
-                                                         const float *__restrict__ wet, long long ws,
-                                                         const float *__restrict__ stash,
-                                                         const float *__restrict__ dgate,
-                                                         const float *__restrict__ h_init, float loss_scale,
-                                                         float *__restrict__ part, int T, int n_split)
-{
-    // blocks of 32 steps are staged through LDS with 16-byte loads (double buffered: the next block is in
-    // flight in registers while the 64 MFMAs per wave of the current one run)
-    __shared__ __attribute__((aligned(16))) float dgs[2][WG_TB * WG_DP];
-    __shared__ __attribute__((aligned(16))) float hps[2][WG_TB * WG_HP];
-    __shared__ float xls[2][WG_TB][2];
-    __shared__ float red[4][LS_H + 1];
-    const int b = blockIdx.x, ks = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int c32 = lane & 31, tpar = lane >> 5;
-    int t_per = (T + n_split - 1) / n_split;
-    t_per = (t_per + WG_TB - 1) / WG_TB * WG_TB;
-    const int t_beg = ks * t_per, t_end = min(T, t_beg + t_per);
-    const float *xb = x + (size_t)b * xs, *lb = lfo + (size_t)b * ls, *yb = y + (size_t)b * ys, *wb = wet + (size_t)b * ws;
-    const float *sb = stash + (size_t)b * T * LS_STASH;
-    const float *dgb = dgate + (size_t)b * T * 256;
-    const float *h0 = h_init + (size_t)b * LS_H;
-    float *pb = part + ((size_t)b * n_split + ks) * LS_NPARAM;
-
-    floatx16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-    float dwi0[2] = {0.f, 0.f}, dwi1[2] = {0.f, 0.f}, db[2] = {0.f, 0.f};
-    const int r0 = wv * 64 + c32;                      // gate rows r0 and r0 + 32 of this lane's A fragments
-
-    float4 pdg[8], php[2];
-    float pxl = 0.0f;
-    auto fetch = [&](int t0) {                         // block [t0, t0 + 32) -> registers (zeros past t_end)
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int e = (i * 256 + tid) * 4, tt = t0 + (e >> 8);
-            pdg[i] = tt < t_end ? *(const float4 *)(dgb + (size_t)tt * 256 + (e & 255)) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int e = (i * 256 + tid) * 4, tt = t0 + (e >> 6);       // h_{tt-1}: the state entering step tt
-            const float *hp = tt > 0 ? sb + (size_t)(tt - 1) * LS_STASH + 320 : h0;
-            php[i] = tt < t_end ? *(const float4 *)(hp + (e & 63)) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        if (tid < 2 * WG_TB) {
-            const int tt = t0 + (tid >> 1);
-            pxl = tt < t_end ? (tid & 1 ? xb[tt] : lb[tt]) : 0.0f;
-        }
-    };
-    auto stage = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int e = (i * 256 + tid) * 4;
-            *(float4 *)(&dgs[buf][(e >> 8) * WG_DP + (e & 255)]) = pdg[i];
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int e = (i * 256 + tid) * 4;
-            *(float4 *)(&hps[buf][(e >> 6) * WG_HP + (e & 63)]) = php[i];
-        }
-        if (tid < 2 * WG_TB) xls[buf][tid >> 1][tid & 1] = pxl;
-    };
-    if (t_beg < t_end) {
-        fetch(t_beg);
-        stage(0);
-    }
-    __syncthreads();
-    int buf = 0;
-    // A[i = gate row][k = step] = dg, B[k = step][j = hidden unit] = h_{t-1}: D += A B over the steps, 2 per MFMA
-    for (int t0 = t_beg; t0 < t_end; t0 += WG_TB) {
-        const bool more = t0 + WG_TB < t_end;
-        if (more) fetch(t0 + WG_TB);
-#pragma unroll 4
-        for (int kk = 0; kk < WG_TB / 2; ++kk) {
-            const int row = 2 * kk + tpar;
-            const float a0 = dgs[buf][row * WG_DP + r0], a1 = dgs[buf][row * WG_DP + r0 + 32];
-            const float b0 = hps[buf][row * WG_HP + c32], b1 = hps[buf][row * WG_HP + 32 + c32];
-            const float li = xls[buf][row][0], xi = xls[buf][row][1];
-            acc[0][0] = mfma32(a0, b0, acc[0][0]);
-            acc[0][1] = mfma32(a0, b1, acc[0][1]);
-            acc[1][0] = mfma32(a1, b0, acc[1][0]);
-            acc[1][1] = mfma32(a1, b1, acc[1][1]);
-            dwi0[0] = fmaf(a0, li, dwi0[0]); dwi1[0] = fmaf(a0, xi, dwi1[0]); db[0] += a0;
-            dwi0[1] = fmaf(a1, li, dwi0[1]); dwi1[1] = fmaf(a1, xi, dwi1[1]); db[1] += a1;
-        }
-        if (more) stage(buf ^ 1);                      // the other buffer was last read one block ago
-        __syncthreads();
-        buf ^= 1;
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                pb[512 + (wv * 64 + i * 32 + mfma_row(r, lane)) * LS_H + j * 32 + c32] = acc[i][j][r];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const float s0 = dwi0[i] + __shfl_xor(dwi0[i], 32, 64), s1 = dwi1[i] + __shfl_xor(dwi1[i], 32, 64);
-        const float sbias = db[i] + __shfl_xor(db[i], 32, 64);
-        if (tpar == 0) {
-            const int r = r0 + 32 * i;
-            pb[r * 2] = s0;
-            pb[r * 2 + 1] = s1;
-            pb[512 + 16384 + r] = sbias;
-            pb[512 + 16384 + 256 + r] = sbias;
-        }
-    }
-    // fc: d fc_w[u] = sum_t dzy_t h_t[u], d fc_b = sum_t dzy_t; wave wv takes every 4th step
+    // the steps the pairing above left over: dg(0) (x) h_init always, dg(1) (x) h_0 when T is odd
     {
-        float dfw = 0.0f, dfb = 0.0f;
-        for (int t = t_beg + wv; t < t_end; t += 4) {
-            const float yv = yb[t], e = yv - wb[t];
-            const float dzy = loss_scale * (e > 0.0f ? 1.0f : (e < 0.0f ? -1.0f : 0.0f)) * (1.0f - yv * yv);
-            dfw = fmaf(dzy, sb[(size_t)t * LS_STASH + 320 + lane], dfw);
-            dfb += dzy;
-        }
-        red[wv][lane] = dfw;
-        if (lane == 0) red[wv][LS_H] = dfb;
-        __syncthreads();
-        if (tid <= LS_H) pb[512 + 16384 + 512 + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+        const float av = tpar == 0 ? dgl[b_cur * 256 + a_slot] : ((T & 1) ? dgl[b_prev * 256 + a_slot] : 0.0f);
+        const float *hrow = tpar == 0 ? h_init + (size_t)b * LS_H : slab0 + LS_ROWP + 5 * LS_PP;     // slab 0, row 0, h plane
+        const float bv0 = hrow[c32], bv1 = hrow[32 + c32];
+        const float li = tpar < T ? (probe ? 0.5f : lb[tpar]) : 0.0f, xi = tpar < T ? (probe ? 0.25f : xb[tpar]) : 0.0f;
+        wacc0 = mfma32(av, bv0, wacc0);
+        wacc1 = mfma32(av, bv1, wacc1);
+        dwi0 = fmaf(av, li, dwi0);
+        dwi1 = fmaf(av, xi, dwi1);
+        dbs += av;
     }
+    // one gradient row per clip, state-dict order:
+    //   [lstm.weight_ih_l0 (256,2) | lstm.weight_hh_l0 (256,64) | lstm.bias_ih_l0 | lstm.bias_hh_l0 | fc.weight | fc.bias]
+    float *pb = part + (size_t)b * LS_NPARAM;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = 32 * wv + mfma_row(r, lane);
+        pb[512 + row * LS_H + c32] = wacc0[r];
+        pb[512 + row * LS_H + 32 + c32] = wacc1[r];
+    }
+    {
+        const float s0 = dwi0 + __shfl_xor(dwi0, 32, 64), s1 = dwi1 + __shfl_xor(dwi1, 32, 64);
+        const float sbias = dbs + __shfl_xor(dbs, 32, 64);
+        if (tpar == 0) {
+            const int row = 32 * wv + c32;
+            pb[row * 2] = s0;
+            pb[row * 2 + 1] = s1;
+            pb[512 + 16384 + row] = sbias;
+            pb[512 + 16384 + 256 + row] = sbias;
+        }
+    }
+    if (rg == 0 || rg == 4) pb[512 + 16384 + 512 + k] = dfw;          // lanes e = 0 / 4 hold units 2 kp / 2 kp + 1
+    if (tid == 0) pb[LS_NPARAM - 1] = dfb;
 }
 
-// dgate_ws: workspace (B, T, 256) floats; part: (B * n_split, 17473) partial gradient rows, to be summed with
-// mx_reduce_rows(part, B * n_split, 17473, ...); n_split in {1, 2, 4}: workgroups per clip of the weight-gradient GEMM.
+// part: (B, 17473) gradient rows, one per clip, to be summed with mx_reduce_rows(part, B, 17473, ...).
 MX_EXPORT int mx_lstm_bwd_l1(const float *x, int64_t x_stride, const float *lfo, int64_t lfo_stride, const float *y,
                              int64_t y_stride, const float *wet, int64_t wet_stride, const float *stash,
                              const float *w_hh, const float *fc_w, const float *h_init, const float *c_init,
-                             float loss_scale, float *dgate_ws, float *part, int32_t n_split, int64_t B, int64_t T,
-                             void *stream)
+                             float loss_scale, float *part, int64_t B, int64_t T, void *stream)
 {
-    if (!x || !lfo || !y || !wet || !stash || !w_hh || !fc_w || !h_init || !c_init || !dgate_ws || !part || B <= 0 ||
-        T <= 0 || n_split < 1 || n_split > 4)
+    if (!x || !lfo || !y || !wet || !stash || !w_hh || !fc_w || !h_init || !c_init || !part || B <= 0 || T <= 0)
         return MX_ERR_ARG;
     if (T >= (1ll << 30)) return MX_ERR_UNSUPPORTED;
-    const size_t lds = (size_t)(2 * ((LS_SLAB + 1) * LS_ROWP + LS_SLAB) + 512 + LS_THREADS) * sizeof(float);
+    const size_t lds = (size_t)(2 * LS_SLAB_FLOATS + 768 + LS_THREADS) * sizeof(float);
     static bool attr_set[64] = {};
     int dev = 0;
     (void)hipGetDevice(&dev);
-    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
         (void)hipFuncSetAttribute((const void *)lstm_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set[dev] = true;
+        if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
-    hipLaunchKernelGGL(lstm_bwd_kernel, dim3((unsigned)B), dim3(LS_THREADS), lds, (hipStream_t)stream, y,
-                       (long long)y_stride, wet, (long long)wet_stride, stash, w_hh, fc_w, c_init, loss_scale, dgate_ws,
-                       (int)T, g_mx_probe);
-    hipLaunchKernelGGL(lstm_wgrad_kernel, dim3((unsigned)B, (unsigned)n_split), dim3(256), 0, (hipStream_t)stream, x,
+    hipLaunchKernelGGL(lstm_bwd_kernel, dim3((unsigned)B), dim3(LS_THREADS), lds, (hipStream_t)stream, x,
                        (long long)x_stride, lfo, (long long)lfo_stride, y, (long long)y_stride, wet, (long long)wet_stride,
-                       stash, dgate_ws, h_init, loss_scale, part, (int)T, (int)n_split);
+                       stash, w_hh, fc_w, h_init, c_init, loss_scale, part, (int)T, g_mx_probe);
     return mx_launch_status();
 }

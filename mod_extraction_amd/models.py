@@ -710,18 +710,15 @@ class LSTMEffectModel(HiddenStateModel):
         """BPTT of one chunk with the L1 loss fused; the summed parameter gradient (17473,) in
         state-dict order is written to ``grad_out``."""
         B, _, Tn = x.shape
-        n_split = 4 if B <= 64 else (2 if B <= 128 else 1)      # workgroups per clip of the weight-gradient GEMM
-        part = torch.empty((B * n_split, LSTM_NPARAM), device=x.device, dtype=torch.float32)
-        dgate = torch.empty((B, Tn, 256), device=x.device, dtype=torch.float32)
+        part = torch.empty((B, LSTM_NPARAM), device=x.device, dtype=torch.float32)
         xp, xs = _rows(x)
         lp, ls = _rows(latent)
         yp, ys = _rows(y)
         wp, ws = _rows(wet)
         _hip.call("mx_lstm_bwd_l1", xp, xs, lp, ls, yp, ys, wp, ws, _hip.ptr(stash),
                   _hip.ptr(self.lstm.weight_hh_l0.detach().contiguous()), _hip.ptr(self.fc.weight.detach().contiguous()),
-                  _hip.ptr(h0), _hip.ptr(c0), float(loss_scale), _hip.ptr(dgate), _hip.ptr(part), n_split, B, Tn,
-                  _hip.stream())
-        _hip.call("mx_reduce_rows", _hip.ptr(part), B * n_split, LSTM_NPARAM, 0, _hip.ptr(grad_out), _hip.stream())
+                  _hip.ptr(h0.contiguous()), _hip.ptr(c0.contiguous()), float(loss_scale), _hip.ptr(part), B, Tn, _hip.stream())
+        _hip.call("mx_reduce_rows", _hip.ptr(part), B, LSTM_NPARAM, 0, _hip.ptr(grad_out), _hip.stream())
 
     def forward(self, x: T, latent: T) -> T:
         """Inference / validation forward (no autograd graph; training goes through the fused TBPTT
