@@ -127,7 +127,6 @@ __global__ __launch_bounds__(64 * PH_WPB) void phaser_kernel(const float *__rest
 
 // ---- the default kernel: 8 x 8 state-space step on 64 lanes (see the header) ------------------------------
 #define PM_TAB 20                 // table row pitch (floats): P[0..6] = (2G-1)^e, then the 11 scale factors below
-#define PM_LDS (256 + 256 + 64 * PM_TAB + 320)     // floats per wave: x block, y block, table, write sink
 
 template <int CTRL> __device__ __forceinline__ float ph_dpp(float v)
 {
@@ -151,22 +150,33 @@ __device__ __forceinline__ void ph_entry(int k, int j, int &s_idx, int &p_idx)
     }
 }
 
-__global__ __launch_bounds__(64 * PH_WPB) void phaser_mat_kernel(const float *__restrict__ x, long long x_stride,
-                                                                 const float *__restrict__ rate,
-                                                                 const float *__restrict__ depth,
-                                                                 const float *__restrict__ centre,
-                                                                 const float *__restrict__ feedback,
-                                                                 const float *__restrict__ mix,
-                                                                 const int *__restrict__ lead_arr,
-                                                                 const int *__restrict__ rows, int n_items, int N,
-                                                                 double sr, float *__restrict__ y, long long y_stride,
-                                                                 float *__restrict__ dry_out, int probe)
+// One workgroup = one clip = TWO wavefronts.  The PRODUCER wave runs everything that does not depend on the filter
+// state one 64-sample sub-block ahead -- input load, the sequential fp32 phase accumulation, the 64 cut-off updates of
+// a 256-sample block and their table rows, and for every update the four per-lane factors (a1, i1, a2, i2) of the two
+// lane layouts, written to an LDS ring as one float4 per lane -- and stores the finished blocks (clip, coalesced).
+// The CONSUMER wave runs the dependent chain only: per update one ds_read_b128 of its factors, one broadcast read of
+// the 4 samples, and the 4 state-space steps (~9 instructions per sample; the single-wave version spent 15).
+// The two waves meet at one workgroup barrier per 64 samples.
+#define PM_SUB 16                 // cut-off updates (x 4 samples) per sub-block
+#define PM_RING (PM_SUB * 64 * 4) // floats per ring buffer
+#define PM2_LDS (2 * 256 + 2 * 256 + 2 * 64 * PM_TAB + 2 * PM_RING + 320)
+
+__global__ __launch_bounds__(128) void phaser_mat_kernel(const float *__restrict__ x, long long x_stride,
+                                                         const float *__restrict__ rate,
+                                                         const float *__restrict__ depth,
+                                                         const float *__restrict__ centre,
+                                                         const float *__restrict__ feedback,
+                                                         const float *__restrict__ mix,
+                                                         const int *__restrict__ lead_arr,
+                                                         const int *__restrict__ rows, int n_items, int N,
+                                                         double sr, float *__restrict__ y, long long y_stride,
+                                                         float *__restrict__ dry_out, int probe)
 {
-    __shared__ __attribute__((aligned(16))) float lds_all[PH_WPB * PM_LDS];
+    __shared__ __attribute__((aligned(16))) float lds_all[PM2_LDS];
     const int lane = threadIdx.x & 63;
-    const int item = blockIdx.x * PH_WPB + (threadIdx.x >> 6);
-    if (item >= n_items) return;                        // whole wave exits; waves never synchronise with each other
-    float *xbuf = lds_all + (threadIdx.x >> 6) * PM_LDS, *ybuf = xbuf + 256, *tab = ybuf + 256, *sink = tab + 64 * PM_TAB;
+    const bool producer = threadIdx.x >= 64;
+    const int item = blockIdx.x;
+    float *xbuf = lds_all, *ybuf = xbuf + 512, *tabs = ybuf + 512, *ring = tabs + 2 * 64 * PM_TAB, *sink = ring + 2 * PM_RING;
     const int b = rows ? rows[item] : item;
     const int lead = lead_arr ? lead_arr[b] : 0;
     const int total = lead + N;
@@ -192,60 +202,105 @@ __global__ __launch_bounds__(64 * PH_WPB) void phaser_mat_kernel(const float *__
     ph_entry(c, r, s2, p2);
     const float dry_add = lane == 63 ? dry_g : 0.0f;            // A[7][7] = wet c1^6 + dry
     const float keep1 = c == 7 ? 0.0f : 1.0f, keep2 = r == 7 ? 0.0f : 1.0f;
-    // the output row lands in lanes r == 7 (layout 1) / c == 7 (layout 2): lanes 56 and 7 write it, the others a sink
-    float *w1 = lane == 56 ? ybuf : sink + lane, *w2 = lane == 7 ? ybuf : sink + lane;
 
-    float phase = 0.0f;
-    float z = 0.0f;                                             // state vector, layout 1
-
-    for (int n0 = 0; n0 < total; n0 += PH_BLOCK) {
-        // (1) coalesced load of 256 input samples into LDS
-#pragma unroll
-        for (int j = 0; j < PH_BLOCK / 64; ++j) {
-            const int n = n0 + j * 64 + lane;
-            xbuf[j * 64 + lane] = probe ? 0.25f : (n < total ? xb[n] : 0.0f);
-        }
-        // (2) sequential fp32 phase accumulation; lane k keeps the phase of update k
-        float my_phase = 0.0f;
+    float phase = 0.0f;                                         // producer state
+    float z = 0.0f;                                             // consumer state: the state vector, layout 1
+    const int n_sub = ((total + PH_BLOCK - 1) / PH_BLOCK) * 4;  // whole 256-sample blocks
+    // The cut-off updates of a block (sequential fp32 phase accumulation, then per lane sin -> pow -> tan in fp64, the
+    // expensive part of the producer) are prepared ONE BLOCK AHEAD, a quarter per sub-block iteration, so that no
+    // iteration is much longer than the consumer's; two table buffers.
+    float my_phase = 0.0f, st_osc = 0.0f, st_fc = 0.0f;
+    auto prep_phase = [&]() {       // lane k keeps the phase of update k of the next block
         for (int k = 0; k < PH_BLOCK / 4; ++k) {
             if (lane == k) my_phase = phase;
             phase = __fadd_rn(phase, inc);
             while (phase >= two_pi) phase = __fsub_rn(phase, two_pi);
         }
-        // (3) one cut-off update per lane -> its row of the coefficient table
-        {
-            float osc = (float)sin((double)__fsub_rn(my_phase, pi_f));
-            float lfo = __fadd_rn(__fmul_rn(osc, osc_vol), norm_centre);
-            lfo = lfo < 0.0f ? 0.0f : (lfo > 1.0f ? 1.0f : lfo);
-            float fc = (float)pow(10.0, (double)__fadd_rn(__fmul_rn(lfo, __fsub_rn(log_max, log_min)), log_min));
-            float g = (float)tan(3.14159265358979323846 * (double)fc / sr);
-            const float G = __fdiv_rn(g, __fadd_rn(1.0f, g));
-            // all-pass stage: out = c1 in + c2 s, s' = c3 in + c4 s
-            const float c1 = 2.0f * G - 1.0f, c2 = 2.0f - 2.0f * G, c3 = 2.0f * G, c4 = 1.0f - 2.0f * G;
-            const float q2 = c1 * c1, q3 = q2 * c1, q4 = q2 * q2, q5 = q4 * c1, q6 = q4 * q2;
-            float4 *row = (float4 *)(tab + lane * PM_TAB);
-            row[0] = make_float4(1.0f, c1, q2, q3);
-            row[1] = make_float4(q4, q5, q6, 0.0f);
-            row[2] = make_float4(c4, c3 * c2, c3, -c3);
-            row[3] = make_float4(fb * c2, -fb, fb, wet_g * c2);
-            row[4] = make_float4(-wet_g, wet_g, 0.0f, 0.0f);
-        }
+    };
+    auto prep_sin = [&]() { st_osc = (float)sin((double)__fsub_rn(my_phase, pi_f)); };
+    auto prep_pow = [&]() {
+        float lfo = __fadd_rn(__fmul_rn(st_osc, osc_vol), norm_centre);
+        lfo = lfo < 0.0f ? 0.0f : (lfo > 1.0f ? 1.0f : lfo);
+        st_fc = (float)pow(10.0, (double)__fadd_rn(__fmul_rn(lfo, __fsub_rn(log_max, log_min)), log_min));
+    };
+    auto prep_table = [&](float *tab) {
+        float gg = (float)tan(3.14159265358979323846 * (double)st_fc / sr);
+        const float G = __fdiv_rn(gg, __fadd_rn(1.0f, gg));
+        // all-pass stage: out = c1 in + c2 s, s' = c3 in + c4 s
+        const float c1 = 2.0f * G - 1.0f, c2 = 2.0f - 2.0f * G, c3 = 2.0f * G, c4 = 1.0f - 2.0f * G;
+        const float q2 = c1 * c1, q3 = q2 * c1, q4 = q2 * q2, q5 = q4 * c1, q6 = q4 * q2;
+        float4 *row = (float4 *)(tab + lane * PM_TAB);
+        row[0] = make_float4(1.0f, c1, q2, q3);
+        row[1] = make_float4(q4, q5, q6, 0.0f);
+        row[2] = make_float4(c4, c3 * c2, c3, -c3);
+        row[3] = make_float4(fb * c2, -fb, fb, wet_g * c2);
+        row[4] = make_float4(-wet_g, wet_g, 0.0f, 0.0f);
         __builtin_amdgcn_wave_barrier();                        // LDS operations of one wave complete in order
-        // (4) the dependent chain: 64 updates x 4 samples
-        // (the table entries and the 4 samples of update k + 1 are read while update k runs)
-        float t_s1 = tab[s1], t_p1 = tab[p1], t_s2 = tab[s2], t_p2 = tab[p2];
-        float4 t_x = *(const float4 *)xbuf;
-        for (int k = 0; k < PH_BLOCK / 4; ++k) {
-            const float e1 = fmaf(t_s1, t_p1, dry_add), e2 = fmaf(t_s2, t_p2, dry_add);
-            const float a1 = e1 * keep1, i1 = e1 - a1, a2 = e2 * keep2, i2 = e2 - a2;   // entry / input weight
-            const float4 xin = t_x;
-            {
-                const int kn = k + 1 < PH_BLOCK / 4 ? k + 1 : k;
-                const float *tr = tab + kn * PM_TAB;
-                t_s1 = tr[s1]; t_p1 = tr[p1]; t_s2 = tr[s2]; t_p2 = tr[p2];
-                t_x = *(const float4 *)(xbuf + 4 * kn);
+    };
+    if (producer) {                                             // block 0
+        prep_phase(); prep_sin(); prep_pow(); prep_table(tabs);
+    }
+
+    for (int g = 0; g <= n_sub + 1; ++g) {
+        if (producer) {
+            // ---- store the block the consumer finished two iterations ago
+            if (g >= 2 && ((g - 2) & 3) == 3) {
+                const int nb = (g - 2) >> 2;
+                const float *yb_l = ybuf + (nb & 1) * 256, *xb_l = xbuf + (nb & 1) * 256;
+#pragma unroll
+                for (int j = 0; j < PH_BLOCK / 64; ++j) {
+                    const int n = nb * PH_BLOCK + j * 64 + lane;
+                    if (n >= lead && n < total && (!probe || n + PH_BLOCK >= total)) {
+                        const float m = yb_l[j * 64 + lane];
+                        yb[n - lead] = m < -1.0f ? -1.0f : (m > 1.0f ? 1.0f : m);
+                        if (db) db[n - lead] = xb_l[j * 64 + lane];
+                    }
+                }
             }
-            float *o1 = w1 + 4 * k, *o2 = w2 + 4 * k;
+            if (g < n_sub) {
+                const int nb = g >> 2, sub = g & 3;
+                if (sub == 0) {
+                    // (1) coalesced load of 256 input samples into LDS
+                    float *xl = xbuf + (nb & 1) * 256;
+#pragma unroll
+                    for (int j = 0; j < PH_BLOCK / 64; ++j) {
+                        const int n = nb * PH_BLOCK + j * 64 + lane;
+                        xl[j * 64 + lane] = probe ? 0.25f : (n < total ? xb[n] : 0.0f);
+                    }
+                }
+                // (2, 3) a quarter of the next block's cut-off updates
+                if (sub == 0) prep_phase();
+                else if (sub == 1) prep_sin();
+                else if (sub == 2) prep_pow();
+                else prep_table(tabs + ((nb + 1) & 1) * 64 * PM_TAB);
+                const float *tab = tabs + (nb & 1) * 64 * PM_TAB;
+                // (4) the per-lane factors of the 16 updates of this sub-block
+                float4 *rg = (float4 *)(ring + (g & 1) * PM_RING) + lane;
+#pragma unroll 4
+                for (int u = 0; u < PM_SUB; ++u) {
+                    const float *tr = tab + (sub * PM_SUB + u) * PM_TAB;
+                    const float e1 = fmaf(tr[s1], tr[p1], dry_add), e2 = fmaf(tr[s2], tr[p2], dry_add);
+                    const float a1 = e1 * keep1, a2 = e2 * keep2;
+                    rg[u * 64] = make_float4(a1, e1 - a1, a2, e2 - a2);      // entry / input weight of both layouts
+                }
+            }
+        } else if (g >= 1 && g - 1 < n_sub) {
+            // ---- the dependent chain of sub-block g - 1
+            const int gc = g - 1, nb = gc >> 2, sub = gc & 3;
+            const float4 *rg = (const float4 *)(ring + (gc & 1) * PM_RING) + lane;
+            const float *xl = xbuf + (nb & 1) * 256 + sub * 64;
+            float *yl = ybuf + (nb & 1) * 256 + sub * 64;
+            // the output row lands in lanes r == 7 (layout 1) / c == 7 (layout 2): lanes 56 and 7 write it, the others a sink
+            float *o1 = lane == 56 ? yl : sink + lane, *o2 = lane == 7 ? yl : sink + lane;
+            float4 cf = rg[0], xin = *(const float4 *)xl;
+            for (int u = 0; u < PM_SUB; ++u) {
+                const float a1 = cf.x, i1 = cf.y, a2 = cf.z, i2 = cf.w;
+                const float4 xv = xin;
+                {
+                    const int un = u + 1 < PM_SUB ? u + 1 : u;             // the next update's factors and samples
+                    cf = rg[un * 64];
+                    xin = *(const float4 *)(xl + 4 * un);
+                }
 #define PH_STEP1(XV, SLOT)                                                                         \
     {                                                                                              \
         float p = fmaf(a1, z, i1 * XV);                                                            \
@@ -266,25 +321,17 @@ __global__ __launch_bounds__(64 * PH_WPB) void phaser_mat_kernel(const float *__
         o2[SLOT] = p;                                                                              \
         z = p;                                                                                     \
     }
-            PH_STEP1(xin.x, 0)
-            PH_STEP2(xin.y, 1)
-            PH_STEP1(xin.z, 2)
-            PH_STEP2(xin.w, 3)
+                PH_STEP1(xv.x, 0)
+                PH_STEP2(xv.y, 1)
+                PH_STEP1(xv.z, 2)
+                PH_STEP2(xv.w, 3)
 #undef PH_STEP1
 #undef PH_STEP2
-        }
-        __builtin_amdgcn_wave_barrier();
-        // (5) clip + coalesced store of the samples that fall inside the output window
-#pragma unroll
-        for (int j = 0; j < PH_BLOCK / 64; ++j) {
-            const int n = n0 + j * 64 + lane;
-            if (n >= lead && n < total && (!probe || n + PH_BLOCK >= total)) {
-                const float m = ybuf[j * 64 + lane];
-                yb[n - lead] = m < -1.0f ? -1.0f : (m > 1.0f ? 1.0f : m);
-                if (db) db[n - lead] = xbuf[j * 64 + lane];
+                o1 += 4;
+                o2 += 4;
             }
         }
-        __builtin_amdgcn_wave_barrier();
+        __syncthreads();
     }
 }
 
@@ -308,7 +355,7 @@ MX_EXPORT int mx_phaser_fwd(const float *x, int64_t x_stride, const float *rate,
         hipLaunchKernelGGL(phaser_kernel, grid, block, 0, (hipStream_t)stream, x, (long long)x_stride, rate, depth, centre,
                            feedback, mix, lead, rows, (int)items, (int)N, (float)sr, sr, y, (long long)y_stride, dry_out);
     else
-        hipLaunchKernelGGL(phaser_mat_kernel, grid, block, 0, (hipStream_t)stream, x, (long long)x_stride, rate, depth,
+        hipLaunchKernelGGL(phaser_mat_kernel, dim3((unsigned)items), dim3(128), 0, (hipStream_t)stream, x, (long long)x_stride, rate, depth,
                            centre, feedback, mix, lead, rows, (int)items, (int)N, sr, y, (long long)y_stride, dry_out, g_mx_probe);
     return mx_launch_status();
 }

@@ -60,7 +60,11 @@ def reduce_metrics(logged: Dict[str, List[torch.Tensor]], world_size: int,
         names = sorted(logged.keys())
     if not names:
         return {}
-    dev = next((v[0].device for v in logged.values() if v), torch.device("cpu"))
+    dev = next((v[0].device for v in logged.values() if v), None)
+    if dev is None or (world_size > 1 and dist.get_backend() == "nccl" and dev.type != "cuda"):
+        # a rank that logged nothing still needs a tensor the backend can reduce (RCCL: on its GPU)
+        dev = torch.device("cuda", torch.cuda.current_device()) if world_size > 1 and dist.get_backend() == "nccl" \
+            else torch.device("cpu")
     sums = torch.zeros(2, len(names), dtype=torch.float64, device=dev)
     for i, n in enumerate(names):
         vals = [v.double().reshape(()) for v in logged.get(n, []) if v is not None]
