@@ -163,3 +163,37 @@ def test_streaming_effect_model_vs_reference_golden(golden_dir, dev):
         assert y.shape == (2, int(n))
         assert np.abs(y.cpu().numpy() - g[f"y{b}"]).max() < 1e-5, b
         assert float(em.prev_phase) == float(g[f"phase{b}"]), b            # carried LFO phase: bit-exact
+
+
+def test_tbptt_prefetched_prepare_is_bit_identical(dev):
+    """The effect-modelling trainer renders batch i+1 and runs the frozen extractor on it on a side stream while the LSTM
+    trains on batch i (data_modules.set_ahead_fn / lightning.prepare_ahead).  Same weights after two batches, bit for bit,
+    as with everything on the main stream."""
+    from mod_extraction_amd import data_modules, lightning as al, models as am, optim, trainer
+
+    def run(prefetch):
+        torch.manual_seed(12); np.random.seed(12)
+        cnn = am.Spectral2DCNN(in_ch=2, n_samples=22272, n_mels=64, out_channels=[64] * 6, temp_dilations=[1, 1, 2, 4, 8, 16],
+                               pool_size=(2, 1))
+        em = am.LSTMEffectModel()
+        mod = al.TBPTTLFOEffectModeling(1024, 1024, em, lfo_model=cnn, discard_invalid_lfos=False,
+                                        loss_dict={"l1": 1.0, "esr": 0.0, "dc": 0.0}).to(dev).train()
+        opt = optim.FlatAdamW([p for p in mod.parameters() if p.requires_grad], lr=1e-4, betas=(0.8, 0.99))
+        dm = data_modules.RandomAudioChunkDryWetDataModule(batch_size=4, n_samples=22272, sr=44100, train_num_examples_per_epoch=8,
+                                                           val_num_examples_per_epoch=4, overlap=prefetch)
+        dm.setup(dev, rank=0, seed=77)
+        if prefetch:
+            t = trainer.Trainer(max_epochs=1, log_fn=None, limit_val_batches=1)
+            hist = t.fit(mod, dm, opt)                                   # installs prepare_ahead, 2 train batches
+            loss = hist[0]["train/loss"]
+        else:
+            for i in range(2):
+                mod.training_step(dm.train_batch(), i, optimizer=opt, world_size=1)
+            loss = float(torch.stack(mod.logged["train/loss"]).mean())
+        return opt.flat_param.clone(), opt.step_count, loss
+
+    p0, n0, l0 = run(False)
+    p1, n1, l1 = run(True)
+    assert n0 == n1 == 2 * ((int((81 / 88) * 22272) - 1024) // 1024)
+    assert torch.equal(p0, p1)
+    assert abs(l0 - l1) < 1e-7
