@@ -376,6 +376,13 @@ def run_config4(args, env):
     # the batch render and the FROZEN extractor's forward run one batch ahead on the side stream
     bt.ahead_fn = lambda b: mod.prepare_ahead((b[0], b[1], None, None))
     n_chunks = (int((338 / 345) * N_SAMPLES) - W) // S
+    # the latency-bound recurrence and the prefetch work on disjoint XCDs (mod_extraction_amd/streams.py), as in Trainer.fit
+    from mod_extraction_amd import streams
+    part = None if (args.no_overlap or args.no_cu_partition) else streams.xcd_partition(device)
+    if part is not None:
+        bt.use_side_stream(part[1])
+        part[0].wait_stream(torch.cuda.current_stream(device))
+        torch.cuda.set_stream(part[0])
 
     def step():
         dry, wet, _, _ = bt.next_batch()
@@ -439,8 +446,9 @@ def run_config4(args, env):
                                f"@44.1 kHz per GPU, synthetic dry + this package's phaser render as the wet target",
                    "baseline_config": 4, "global_batch": world * B, "n_samples": N_SAMPLES, "parallelism": f"dp{world}",
                    "optimizer_steps_per_batch": n_chunks,
-                   "pipelining": "batch render + frozen extractor forward of batch i+1 on a side stream under the TBPTT loop of "
-                                 "batch i" if not args.no_overlap else "none"},
+                   "pipelining": ("batch render + frozen extractor forward of batch i+1 on a side stream under the TBPTT loop of "
+                                  "batch i" + ("; recurrence on 5 XCDs, prefetch work on the other 3 (CU-masked streams)" if part is not None
+                                               else "")) if not args.no_overlap else "none"},
         "roofline": kernels["lstm_fwd_kernel"],
         "kernels": kernels,
         "ms_per_batch_by_entry_point": per_batch,
@@ -564,6 +572,8 @@ def main():
     ap.add_argument("--no-fp32-leg", action="store_true", help="skip the 3 extra steps on the exact-fp32 convolutions")
     ap.add_argument("--conv-precision", choices=["f16x3", "f32"], default=None,
                     help="arithmetic of the 64->64 convolutions (default: the package default, f16x3)")
+    ap.add_argument("--no-cu-partition", action="store_true",
+                    help="config 4: let the dispatcher place the recurrence and the prefetch work on the same XCDs")
     ap.add_argument("--no-overlap", action="store_true",
                     help="render each batch on the main stream instead of one step ahead on a side stream")
     args = ap.parse_args()

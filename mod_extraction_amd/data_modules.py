@@ -259,6 +259,11 @@ class SyntheticFxBatcher:
         fx_params["shape"] = p["shape"]
         return self.audio[:, 0:1, :], self.audio[:, 1:2, :], mod, fx_params
 
+    def use_side_stream(self, stream) -> None:
+        """render ahead on ``stream`` (e.g. one confined to a few XCDs, streams.xcd_partition) instead of the private one"""
+        if self.overlap:
+            self._side = stream
+
     def _launch_ahead(self) -> None:
         """render the next batch on the side stream into the idle buffer set"""
         main = torch.cuda.current_stream(self.device)
@@ -359,6 +364,11 @@ class _SyntheticDataModule:
         self._ahead_fn = fn
         if self._batcher is not None:
             self._batcher.ahead_fn = fn
+
+    def use_side_stream(self, stream) -> None:
+        for b in (self._batcher, self._val_batcher):
+            if b is not None:
+                b.use_side_stream(stream)
 
     def take_ahead(self):
         b = self._batcher

@@ -140,8 +140,26 @@ class Trainer:
         if self.num_sanity_val_steps:
             self.validate(module, datamodule, self.num_sanity_val_steps)
         prefetch = manual and hasattr(module, "prepare_ahead") and hasattr(datamodule, "set_ahead_fn")
+        main = None
         if prefetch:
             datamodule.set_ahead_fn(module.prepare_ahead)        # frozen-extractor forward one batch ahead (side stream)
+            # the latency-bound recurrence and the prefetch work on disjoint XCDs (streams.py)
+            from . import streams
+            dev = next(module.parameters()).device
+            part = streams.xcd_partition(dev) if dev.type == "cuda" and hasattr(datamodule, "use_side_stream") else None
+            if part is not None:
+                main = part[0]
+                datamodule.use_side_stream(part[1])
+                main.wait_stream(torch.cuda.current_stream(dev))
+        if main is None:
+            self._fit_epochs(module, datamodule, optimizer, manual, prefetch)
+        else:
+            with torch.cuda.stream(main):
+                self._fit_epochs(module, datamodule, optimizer, manual, prefetch)
+            torch.cuda.current_stream(main.device).wait_stream(main)
+        return self.history
+
+    def _fit_epochs(self, module, datamodule, optimizer: FlatAdamW, manual: bool, prefetch: bool) -> None:
         for epoch in range(self.start_epoch, self.max_epochs):
             module.train()
             module.logged.clear()
