@@ -20,6 +20,10 @@
 #define MR_FR 8          // frames per workgroup in pass A
 
 struct cf { float re, im; };
+// LDS index of FFT element i.  Measured: padding one element per 16 (to spread the stride-4 / -16 / -64 scatter of the
+// first three Stockham passes over the banks) made the loss 6 % SLOWER -- the passes are VALU-issue bound, not LDS bound
+#define MR_PH(i) (i)
+#define MR_LEN(N) (N)
 __device__ __forceinline__ cf cmulf(cf a, cf b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
 __device__ __forceinline__ cf caddf(cf a, cf b) { return {a.re + b.re, a.im + b.im}; }
 __device__ __forceinline__ cf csubf(cf a, cf b) { return {a.re - b.re, a.im - b.im}; }
@@ -27,16 +31,16 @@ __device__ __forceinline__ cf csubf(cf a, cf b) { return {a.re - b.re, a.im - b.
 // In-LDS Stockham FFT of length N (512, 1024 or 2048) by 256 threads; tw = exp(-2 pi i m / 2048).
 // INV = true conjugates the twiddles (unnormalised inverse).  Returns the buffer holding the result.
 template <int N, bool INV>
-__device__ cf *fft_lds(cf *a, cf *b, const float2 *__restrict__ tw)
+__device__ cf *fft_lds(cf *a, cf *b, const float2 *tw)      // tw: the N-point table staged in LDS (stage_twiddles)
 {
-    constexpr int TWS = MR_MAXN / N;           // stride into the 2048-point twiddle table
+    constexpr int TWS = 1;
     cf *src = a, *dst = b;
     int Ns = 1;
     // radix-4 passes while 4*Ns <= N (and N/Ns divisible by 4)
     for (; Ns * 4 <= N && ((N / Ns) % 4) == 0; Ns *= 4) {
         for (int j = threadIdx.x; j < N / 4; j += 256) {
             const int k = j & (Ns - 1);
-            cf v0 = src[j], v1 = src[j + N / 4], v2 = src[j + N / 2], v3 = src[j + 3 * N / 4];
+            cf v0 = src[MR_PH(j)], v1 = src[MR_PH(j + N / 4)], v2 = src[MR_PH(j + N / 2)], v3 = src[MR_PH(j + 3 * N / 4)];
             if (Ns > 1) {
                 const int step = k * (N / (Ns * 4)) * TWS;
                 float2 w1 = tw[step], w2 = tw[2 * step], w3 = tw[3 * step];
@@ -48,10 +52,10 @@ __device__ cf *fft_lds(cf *a, cf *b, const float2 *__restrict__ tw)
             const cf a0 = caddf(v0, v2), a1 = csubf(v0, v2), a2 = caddf(v1, v3), d = csubf(v1, v3);
             const cf a3 = INV ? cf{-d.im, d.re} : cf{d.im, -d.re};      // (+/-) i * (v1 - v3)
             const int j0 = ((j - k) << 2) + k;
-            dst[j0] = caddf(a0, a2);
-            dst[j0 + Ns] = caddf(a1, a3);
-            dst[j0 + 2 * Ns] = csubf(a0, a2);
-            dst[j0 + 3 * Ns] = csubf(a1, a3);
+            dst[MR_PH(j0)] = caddf(a0, a2);
+            dst[MR_PH(j0 + Ns)] = caddf(a1, a3);
+            dst[MR_PH(j0 + 2 * Ns)] = csubf(a0, a2);
+            dst[MR_PH(j0 + 3 * Ns)] = csubf(a1, a3);
         }
         __syncthreads();
         cf *t = src; src = dst; dst = t;
@@ -59,18 +63,27 @@ __device__ cf *fft_lds(cf *a, cf *b, const float2 *__restrict__ tw)
     if (Ns < N) {                                // one radix-2 pass (Ns == N/2)
         for (int j = threadIdx.x; j < N / 2; j += 256) {
             const int k = j & (Ns - 1);
-            cf v0 = src[j], v1 = src[j + N / 2];
+            cf v0 = src[MR_PH(j)], v1 = src[MR_PH(j + N / 2)];
             float2 w = tw[k * (N / (Ns * 2)) * TWS];
             if (INV) w.y = -w.y;
             v1 = cmulf(v1, {w.x, w.y});
             const int j0 = ((j - k) << 1) + k;
-            dst[j0] = caddf(v0, v1);
-            dst[j0 + Ns] = csubf(v0, v1);
+            dst[MR_PH(j0)] = caddf(v0, v1);
+            dst[MR_PH(j0 + Ns)] = csubf(v0, v1);
         }
         __syncthreads();
         cf *t = src; src = dst; dst = t;
     }
     return src;
+}
+
+// tw_s[m] = exp(-2 pi i m / N) from the 2048-point table in global memory: three twiddle loads per butterfly came from
+// global memory (L1/L2 round trips in every pass) before the table was staged once per workgroup
+template <int N>
+__device__ __forceinline__ void stage_twiddles(float2 *tw_s, const float2 *__restrict__ tw)
+{
+    for (int m = threadIdx.x; m < N; m += 256) tw_s[m] = tw[m * (MR_MAXN / N)];
+    __syncthreads();
 }
 
 __device__ __forceinline__ int reflect_index(int s, int T)
@@ -88,7 +101,7 @@ __device__ __forceinline__ void load_frame(cf *buf, const float *xb, const float
     for (int n = threadIdx.x; n < N; n += 256) {
         const int s = reflect_index(f * hop + n - N / 2, T);
         const float w = win[n];
-        buf[n] = {xb[s] * w, yb[s] * w};
+        buf[MR_PH(n)] = {xb[s] * w, yb[s] * w};
     }
     __syncthreads();
 }
@@ -98,7 +111,7 @@ __device__ __forceinline__ void load_frame(cf *buf, const float *xb, const float
 template <int N>
 __device__ __forceinline__ void split_bins(const cf *Z, int k, cf &X, cf &Y)
 {
-    const cf z = Z[k], zc = Z[(N - k) & (N - 1)];
+    const cf z = Z[MR_PH(k)], zc = Z[MR_PH((N - k) & (N - 1))];
     X = {0.5f * (z.re + zc.re), 0.5f * (z.im - zc.im)};
     Y = {0.5f * (z.im + zc.im), -0.5f * (z.re - zc.re)};
 }
@@ -111,16 +124,18 @@ __global__ __launch_bounds__(256) void mr_stats_kernel(const float *__restrict__
                                                        const float2 *__restrict__ tw, int T, int hop, int n_frames,
                                                        float eps, double *__restrict__ part)
 {
-    __shared__ cf bufA[N], bufB[N];
+    __shared__ cf bufA[MR_LEN(N)], bufB[MR_LEN(N)];
+    __shared__ float2 tw_s[N];
     __shared__ double red[4][3];
     const int b = blockIdx.y;
     const float *xb = x + (size_t)b * xs, *yb = y + (size_t)b * ys;
+    stage_twiddles<N>(tw_s, tw);
     double s_d = 0.0, s_y = 0.0, s_l = 0.0;
     for (int fl = 0; fl < MR_FR; ++fl) {
         const int f = blockIdx.x * MR_FR + fl;
         if (f >= n_frames) break;                                      // block-uniform
         load_frame<N>(bufA, xb, yb, win, f, hop, T);
-        const cf *Z = fft_lds<N, false>(bufA, bufB, tw);
+        const cf *Z = fft_lds<N, false>(bufA, bufB, tw_s);
         for (int k = threadIdx.x; k <= N / 2; k += 256) {
             cf X, Y;
             split_bins<N>(Z, k, X, Y);
@@ -176,35 +191,42 @@ __global__ __launch_bounds__(256) void mr_grad_kernel(const float *__restrict__ 
                                                       float eps, const float *__restrict__ coef,
                                                       float *__restrict__ scratch)
 {
-    __shared__ cf bufA[N], bufB[N];
-    const int b = blockIdx.y, f = blockIdx.x;
+    __shared__ cf bufA[MR_LEN(N)], bufB[MR_LEN(N)];
+    __shared__ float2 tw_s[N];
+    const int b = blockIdx.y;
     const float *xb = x + (size_t)b * xs, *yb = y + (size_t)b * ys;
     const float c_sc = coef[0], c_log = coef[1];
-    load_frame<N>(bufA, xb, yb, win, f, hop, T);
-    cf *Z = fft_lds<N, false>(bufA, bufB, tw);
-    cf *G = (Z == bufA) ? bufB : bufA;
-    for (int k = threadIdx.x; k < N; k += 256) {
-        cf g = {0.0f, 0.0f};
-        if (k <= N / 2) {
-            cf X, Y;
-            split_bins<N>(Z, k, X, Y);
-            const float px = X.re * X.re + X.im * X.im;
-            const float xm = sqrtf(fmaxf(px, eps));
-            const float ym = sqrtf(fmaxf(Y.re * Y.re + Y.im * Y.im, eps));
-            if (px > eps) {                                             // clamp passes no gradient below eps
-                const float dl = logf(xm) - logf(ym);
-                const float dxm = c_sc * (xm - ym) + c_log * (dl > 0.0f ? 1.0f : (dl < 0.0f ? -1.0f : 0.0f)) / xm;
-                const float s = dxm / xm;
-                g = {s * X.re, s * X.im};                               // dL/dRe X, dL/dIm X
+    stage_twiddles<N>(tw_s, tw);
+    for (int fl = 0; fl < MR_FR; ++fl) {
+        const int f = blockIdx.x * MR_FR + fl;
+        if (f >= n_frames) break;                                      // block-uniform
+        load_frame<N>(bufA, xb, yb, win, f, hop, T);
+        cf *Z = fft_lds<N, false>(bufA, bufB, tw_s);
+        cf *G = (Z == bufA) ? bufB : bufA;
+        for (int k = threadIdx.x; k < N; k += 256) {
+            cf g = {0.0f, 0.0f};
+            if (k <= N / 2) {
+                cf X, Y;
+                split_bins<N>(Z, k, X, Y);
+                const float px = X.re * X.re + X.im * X.im;
+                const float xm = sqrtf(fmaxf(px, eps));
+                const float ym = sqrtf(fmaxf(Y.re * Y.re + Y.im * Y.im, eps));
+                if (px > eps) {                                             // clamp passes no gradient below eps
+                    const float dl = logf(xm) - logf(ym);
+                    const float dxm = c_sc * (xm - ym) + c_log * (dl > 0.0f ? 1.0f : (dl < 0.0f ? -1.0f : 0.0f)) / xm;
+                    const float s = dxm / xm;
+                    g = {s * X.re, s * X.im};                               // dL/dRe X, dL/dIm X
+                }
             }
+            G[MR_PH(k)] = g;
         }
-        G[k] = g;
+        __syncthreads();
+        // adjoint of the one-sided DFT: dx[n] = Re sum_{k<=N/2} G[k] e^{+2 pi i k n / N}
+        cf *gt = fft_lds<N, true>(G, Z, tw_s);
+        float *out = scratch + ((size_t)b * n_frames + f) * N;
+        for (int n = threadIdx.x; n < N; n += 256) out[n] = gt[MR_PH(n)].re * win[n];
+        __syncthreads();                                               // the next frame reuses both buffers
     }
-    __syncthreads();
-    // adjoint of the one-sided DFT: dx[n] = Re sum_{k<=N/2} G[k] e^{+2 pi i k n / N}
-    cf *gt = fft_lds<N, true>(G, Z, tw);
-    float *out = scratch + ((size_t)b * n_frames + f) * N;
-    for (int n = threadIdx.x; n < N; n += 256) out[n] = gt[n].re * win[n];
 }
 
 // ---- pass C -------------------------------------------------------------------------------------
@@ -257,7 +279,7 @@ static int run_resolution(const float *x, long long xs, const float *y, long lon
     hipLaunchKernelGGL(mr_finish_kernel, dim3(1), dim3(256), 0, st, part, groups * B, count, w_sc, w_log, res_scale,
                        terms, coef);
     if (dx) {
-        hipLaunchKernelGGL((mr_grad_kernel<N>), dim3(n_frames, B), dim3(256), 0, st, x, xs, y, ys, win, tw, T, hop,
+        hipLaunchKernelGGL((mr_grad_kernel<N>), dim3(groups, B), dim3(256), 0, st, x, xs, y, ys, win, tw, T, hop,
                            n_frames, eps, coef, scratch);
         hipLaunchKernelGGL((mr_fold_kernel<N>), dim3((T + 255) / 256, B), dim3(256), 0, st, scratch, T, hop, n_frames,
                            accumulate, dx, ds);
