@@ -6,83 +6,156 @@
 // frame, centre=True reflect padding, mag = sqrt(clamp(re^2 + im^2, eps)),
 // loss = mean over resolutions of [ ||Y - X||_F / ||Y||_F  +  mean |log X - log Y| ]).
 //
-// Three passes per resolution, all streaming (12 B/sample algorithmic: x, y in, grad out):
-//   A  stats : per frame, ONE complex FFT of x + i*y in LDS (radix-4 Stockham, + one radix-2 pass for
-//              512/2048) -> both spectra by Hermitian separation -> per-workgroup partial sums of
+// Three passes per resolution (12 B/sample algorithmic: x, y in, grad out):
+//   A  stats : per frame, ONE complex FFT of x + i*y (one frame per wavefront, register-staged radix-4 Stockham, see
+//              below) -> both spectra by Hermitian separation -> per-workgroup partial sums of
 //              (Ym - Xm)^2, Ym^2, |log Xm - log Ym|
-//   B  grad  : same FFT, per-bin dL/dX from the global norms, inverse FFT, window, store the frame's
-//              time-domain gradient to scratch (frames x n_fft)
+//   B  grad  : same FFT, per-bin dL/dX from the global norms evaluated by the lane that feeds the bin into the
+//              inverse FFT, window, store the frame's time-domain gradient to scratch (frames x n_fft)
 //   C  fold  : overlap-add as a GATHER (each sample sums the frames that cover it, incl. the reflect-
 //              padded positions) -> deterministic, no atomics
+// Measured per 256 clips x 4 s (all three resolutions, value + gradient): 19.2 ms (frame spread over 256 threads, an LDS
+// round trip and a __syncthreads per pass, twiddles from global memory) -> 14.9 (twiddles staged in LDS) -> 11.4 ms
+// (this file).  The FFT passes are VALU-issue bound: ~1 800 vector instructions per 1024-point frame.
 #include "common.h"
 
 #define MR_MAXN 2048
-#define MR_FR 8          // frames per workgroup in pass A
+#define MR_FPG 16        // frames per workgroup (passes A and B); the partial-sum workspace is sized for >= 8
 
 struct cf { float re, im; };
-// LDS index of FFT element i.  Measured: padding one element per 16 (to spread the stride-4 / -16 / -64 scatter of the
-// first three Stockham passes over the banks) made the loss 6 % SLOWER -- the passes are VALU-issue bound, not LDS bound
-#define MR_PH(i) (i)
-#define MR_LEN(N) (N)
 __device__ __forceinline__ cf cmulf(cf a, cf b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
 __device__ __forceinline__ cf caddf(cf a, cf b) { return {a.re + b.re, a.im + b.im}; }
 __device__ __forceinline__ cf csubf(cf a, cf b) { return {a.re - b.re, a.im - b.im}; }
 
-// In-LDS Stockham FFT of length N (512, 1024 or 2048) by 256 threads; tw = exp(-2 pi i m / 2048).
-// INV = true conjugates the twiddles (unnormalised inverse).  Returns the buffer holding the result.
-template <int N, bool INV>
-__device__ cf *fft_lds(cf *a, cf *b, const float2 *tw)      // tw: the N-point table staged in LDS (stage_twiddles)
+// ---- the FFT: one frame per wavefront (two per wavefront for N = 512), passes fused in registers -----------------
+// A frame of N points is held by L lanes, E = N / L complex values per lane.  Radix-4 Stockham passes p = 0.. with
+// Ns = 4^p (butterfly j reads src[j + (N/4) c], writes dst[4 (j - k) + k + r Ns], k = j mod Ns) plus one radix-2
+// pass for 512 / 2048.  A lane that runs butterflies a + L b of an EVEN pass holds exactly the inputs of E / 4
+// butterflies of the next pass, so passes (0,1) and (2,3) run back to back in registers; 2048's radix-2 pass fuses
+// with pass 4 the same way.  Three register stages, two exchanges through a wave-private padded LDS buffer, no
+// workgroup barrier (first version: the frame spread over 256 threads, one LDS round trip and one __syncthreads per
+// pass, twiddles from global memory: 19.2 ms per 256 x 4 s; twiddles in LDS: 14.9 ms).  The index algebra was
+// checked against numpy.fft for the three sizes, both directions, before it was written down here.
+template <int N> struct WF {
+    static constexpr int L = (N == 512) ? 32 : 64;     // lanes per frame
+    static constexpr int E = N / L;                    // complex values per lane: 16, 16, 32
+    static constexpr int NB = E / 4;                   // radix-4 butterflies per lane and pass: 4, 4, 8
+    static constexpr int NBQ = NB / 4;                 // 1, 1, 2
+    static constexpr int LEN = N + N / 16;             // padded exchange buffer (complex values)
+    static constexpr int WAVES = (N == 2048) ? 2 : 4;  // wavefronts per workgroup (static LDS <= 64 KB)
+    static constexpr int FW = 64 / L;                  // frames a wavefront works on at a time
+};
+
+template <int N, bool INV, int P>
+__device__ __forceinline__ void bfly4(int j, const cf &i0, const cf &i1, const cf &i2, const cf &i3, cf (&o)[4],
+                                      const float2 *tw_s)
 {
-    constexpr int TWS = 1;
-    cf *src = a, *dst = b;
-    int Ns = 1;
-    // radix-4 passes while 4*Ns <= N (and N/Ns divisible by 4)
-    for (; Ns * 4 <= N && ((N / Ns) % 4) == 0; Ns *= 4) {
-        for (int j = threadIdx.x; j < N / 4; j += 256) {
-            const int k = j & (Ns - 1);
-            cf v0 = src[MR_PH(j)], v1 = src[MR_PH(j + N / 4)], v2 = src[MR_PH(j + N / 2)], v3 = src[MR_PH(j + 3 * N / 4)];
-            if (Ns > 1) {
-                const int step = k * (N / (Ns * 4)) * TWS;
-                float2 w1 = tw[step], w2 = tw[2 * step], w3 = tw[3 * step];
-                if (INV) { w1.y = -w1.y; w2.y = -w2.y; w3.y = -w3.y; }
-                v1 = cmulf(v1, {w1.x, w1.y});
-                v2 = cmulf(v2, {w2.x, w2.y});
-                v3 = cmulf(v3, {w3.x, w3.y});
-            }
-            const cf a0 = caddf(v0, v2), a1 = csubf(v0, v2), a2 = caddf(v1, v3), d = csubf(v1, v3);
-            const cf a3 = INV ? cf{-d.im, d.re} : cf{d.im, -d.re};      // (+/-) i * (v1 - v3)
-            const int j0 = ((j - k) << 2) + k;
-            dst[MR_PH(j0)] = caddf(a0, a2);
-            dst[MR_PH(j0 + Ns)] = caddf(a1, a3);
-            dst[MR_PH(j0 + 2 * Ns)] = csubf(a0, a2);
-            dst[MR_PH(j0 + 3 * Ns)] = csubf(a1, a3);
-        }
-        __syncthreads();
-        cf *t = src; src = dst; dst = t;
+    constexpr int Ns = 1 << (2 * P);
+    cf v0 = i0, v1 = i1, v2 = i2, v3 = i3;
+    if (P > 0) {
+        const int step = (j & (Ns - 1)) * (N / (Ns * 4));
+        float2 w1 = tw_s[step], w2 = tw_s[2 * step], w3 = tw_s[3 * step];
+        if (INV) { w1.y = -w1.y; w2.y = -w2.y; w3.y = -w3.y; }
+        v1 = cmulf(v1, {w1.x, w1.y});
+        v2 = cmulf(v2, {w2.x, w2.y});
+        v3 = cmulf(v3, {w3.x, w3.y});
     }
-    if (Ns < N) {                                // one radix-2 pass (Ns == N/2)
-        for (int j = threadIdx.x; j < N / 2; j += 256) {
-            const int k = j & (Ns - 1);
-            cf v0 = src[MR_PH(j)], v1 = src[MR_PH(j + N / 2)];
-            float2 w = tw[k * (N / (Ns * 2)) * TWS];
-            if (INV) w.y = -w.y;
-            v1 = cmulf(v1, {w.x, w.y});
-            const int j0 = ((j - k) << 1) + k;
-            dst[MR_PH(j0)] = caddf(v0, v1);
-            dst[MR_PH(j0 + Ns)] = csubf(v0, v1);
-        }
-        __syncthreads();
-        cf *t = src; src = dst; dst = t;
-    }
-    return src;
+    const cf a0 = caddf(v0, v2), a1 = csubf(v0, v2), a2 = caddf(v1, v3), d = csubf(v1, v3);
+    const cf a3 = INV ? cf{-d.im, d.re} : cf{d.im, -d.re};              // (+/-) i (v1 - v3)
+    o[0] = caddf(a0, a2);
+    o[1] = caddf(a1, a3);
+    o[2] = csubf(a0, a2);
+    o[3] = csubf(a1, a3);
+}
+template <int P> __device__ __forceinline__ int out_pos4(int j, int r)
+{
+    constexpr int Ns = 1 << (2 * P);
+    const int k = j & (Ns - 1);
+    return ((j - k) << 2) + k + r * Ns;
 }
 
-// tw_s[m] = exp(-2 pi i m / N) from the 2048-point table in global memory: three twiddle loads per butterfly came from
-// global memory (L1/L2 round trips in every pass) before the table was staged once per workgroup
+// passes P and P + 1 on the registers of one lane: R[b][c] = value at position a + L b + (N/4) c on entry, the
+// pass-(P+1) outputs go to the exchange buffer through PAD (position -> padded slot), and R is re-read in the same
+// layout from the buffer
+template <int N, bool INV, int P, typename PAD>
+__device__ __forceinline__ void fused_pair(cf (&R)[WF<N>::NB][4], cf *buf, const float2 *tw_s, int a, PAD pad)
+{
+    constexpr int L = WF<N>::L, NB = WF<N>::NB, NBQ = WF<N>::NBQ;
+    cf O[NB][4];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) bfly4<N, INV, P>(a + L * b, R[b][0], R[b][1], R[b][2], R[b][3], O[b], tw_s);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int be = 0; be < NBQ; ++be) {
+            const int jn = out_pos4<P>(a, r) + 4 * L * be;                 // butterfly of pass P + 1 held by this lane
+            cf Pq[4];
+            bfly4<N, INV, P + 1>(jn, O[be][r], O[NBQ + be][r], O[2 * NBQ + be][r], O[3 * NBQ + be][r], Pq, tw_s);
+#pragma unroll
+            for (int r2 = 0; r2 < 4; ++r2) buf[pad(out_pos4<P + 1>(jn, r2))] = Pq[r2];
+        }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) R[b][c] = buf[pad(a + L * b + (N / 4) * c)];
+    __builtin_amdgcn_wave_barrier();
+}
+
+// Full transform of the lane-resident frame R (layout above).  Results: Z[i] = bin pos_final<N>(i, a).
+template <int N> __device__ __forceinline__ int pos_final(int i, int a)
+{
+    if (N == 1024) return a + 64 * (i >> 2) + 256 * (i & 3);                      // i = 4 b + r
+    if (N == 2048) return a + 64 * ((i >> 2) & 3) + 256 * (i & 3) + 1024 * (i >> 4);  // i = 16 h + 4 b + r
+    return a + 32 * ((i >> 2) + 4 * (i & 1)) + 256 * ((i >> 1) & 1);            // 512: i = 4 b + cl + 2 h
+}
+template <int N, bool INV>
+__device__ __forceinline__ void wave_fft(cf (&R)[WF<N>::NB][4], cf (&Z)[WF<N>::E], cf *buf, const float2 *tw_s, int a)
+{
+    constexpr int L = WF<N>::L, NB = WF<N>::NB;
+    fused_pair<N, INV, 0>(R, buf, tw_s, a, [](int q) { return q + (q >> 4); });
+    fused_pair<N, INV, 2>(R, buf, tw_s, a, [](int q) { return q + 16 * (q >> 8); });
+    if (N == 1024) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            cf o[4];
+            bfly4<N, INV, 4>(a + L * b, R[b][0], R[b][1], R[b][2], R[b][3], o, tw_s);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Z[4 * b + r] = o[r];
+        }
+    } else if (N == 2048) {
+        cf O[NB][4];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) bfly4<N, INV, 4>(a + L * b, R[b][0], R[b][1], R[b][2], R[b][3], O[b], tw_s);
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {                                   // radix-2, Ns = 1024: j = a + 64 b + 256 r
+                float2 w = tw_s[a + 64 * b + 256 * r];
+                if (INV) w.y = -w.y;
+                const cf v = cmulf(O[(b + 4) % NB][r], {w.x, w.y});
+                Z[4 * b + r] = caddf(O[b][r], v);
+                Z[16 + 4 * b + r] = csubf(O[b][r], v);
+            }
+    } else {
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int cl = 0; cl < 2; ++cl) {                                // radix-2, Ns = 256: j = a + 32 (b + 4 cl)
+                float2 w = tw_s[a + 32 * (b + 4 * cl)];
+                if (INV) w.y = -w.y;
+                const cf v = cmulf(R[b % NB][cl + 2], {w.x, w.y});
+                Z[4 * b + cl] = caddf(R[b % NB][cl], v);
+                Z[4 * b + cl + 2] = csubf(R[b % NB][cl], v);
+            }
+    }
+}
+
+// tw_s[m] = exp(-2 pi i m / N) from the 2048-point table in global memory, once per workgroup
 template <int N>
 __device__ __forceinline__ void stage_twiddles(float2 *tw_s, const float2 *__restrict__ tw)
 {
-    for (int m = threadIdx.x; m < N; m += 256) tw_s[m] = tw[m * (MR_MAXN / N)];
+    for (int m = threadIdx.x; m < N; m += WF<N>::WAVES * 64) tw_s[m] = tw[m * (MR_MAXN / N)];
     __syncthreads();
 }
 
@@ -93,17 +166,20 @@ __device__ __forceinline__ int reflect_index(int s, int T)
     return s;
 }
 
-// frame of x + i*y, windowed, centre/reflect padded
+// frame f of x + i*y, windowed, centre / reflect padded, straight into the stage-A register layout
 template <int N>
-__device__ __forceinline__ void load_frame(cf *buf, const float *xb, const float *yb, const float *win, int f,
-                                           int hop, int T)
+__device__ __forceinline__ void load_frame(cf (&R)[WF<N>::NB][4], const float *xb, const float *yb, const float *win,
+                                           int f, int hop, int T, int a)
 {
-    for (int n = threadIdx.x; n < N; n += 256) {
-        const int s = reflect_index(f * hop + n - N / 2, T);
-        const float w = win[n];
-        buf[MR_PH(n)] = {xb[s] * w, yb[s] * w};
-    }
-    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < WF<N>::NB; ++b)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int n = a + WF<N>::L * b + (N / 4) * c;
+            const int s = reflect_index(f * hop + n - N / 2, T);
+            const float w = win[n];
+            R[b][c] = {xb[s] * w, yb[s] * w};
+        }
 }
 
 // spectra of the two real signals from Z = FFT(x + i y):  X[k] = (Z[k] + conj Z[N-k]) / 2,
@@ -111,50 +187,67 @@ __device__ __forceinline__ void load_frame(cf *buf, const float *xb, const float
 template <int N>
 __device__ __forceinline__ void split_bins(const cf *Z, int k, cf &X, cf &Y)
 {
-    const cf z = Z[MR_PH(k)], zc = Z[MR_PH((N - k) & (N - 1))];
+    const cf z = Z[k], zc = Z[(N - k) & (N - 1)];
     X = {0.5f * (z.re + zc.re), 0.5f * (z.im - zc.im)};
     Y = {0.5f * (z.im + zc.im), -0.5f * (z.re - zc.re)};
 }
 
+// the lane's frame slot of iteration `it`: frame index within the workgroup's MR_FPG frames
+template <int N> __device__ __forceinline__ int frame_slot(int it, int wave, int g)
+{
+    return (it * WF<N>::WAVES + wave) * WF<N>::FW + g;
+}
+
 // ---- pass A -------------------------------------------------------------------------------------
 template <int N>
-__global__ __launch_bounds__(256) void mr_stats_kernel(const float *__restrict__ x, long long xs,
-                                                       const float *__restrict__ y, long long ys,
-                                                       const float *__restrict__ win,
-                                                       const float2 *__restrict__ tw, int T, int hop, int n_frames,
-                                                       float eps, double *__restrict__ part)
+__global__ __launch_bounds__(WF<N>::WAVES * 64) __attribute__((amdgpu_waves_per_eu(2))) void mr_stats_kernel(const float *__restrict__ x, long long xs,
+                                                                     const float *__restrict__ y, long long ys,
+                                                                     const float *__restrict__ win,
+                                                                     const float2 *__restrict__ tw, int T, int hop,
+                                                                     int n_frames, float eps,
+                                                                     double *__restrict__ part)
 {
-    __shared__ cf bufA[MR_LEN(N)], bufB[MR_LEN(N)];
+    constexpr int L = WF<N>::L, E = WF<N>::E, WAVES = WF<N>::WAVES, FW = WF<N>::FW;
+    __shared__ cf xbuf[WAVES * FW][WF<N>::LEN];
     __shared__ float2 tw_s[N];
-    __shared__ double red[4][3];
+    __shared__ double red[WAVES][3];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane / L, a = lane % L;
     const int b = blockIdx.y;
     const float *xb = x + (size_t)b * xs, *yb = y + (size_t)b * ys;
+    cf *buf = xbuf[wave * FW + g];
     stage_twiddles<N>(tw_s, tw);
     double s_d = 0.0, s_y = 0.0, s_l = 0.0;
-    for (int fl = 0; fl < MR_FR; ++fl) {
-        const int f = blockIdx.x * MR_FR + fl;
-        if (f >= n_frames) break;                                      // block-uniform
-        load_frame<N>(bufA, xb, yb, win, f, hop, T);
-        const cf *Z = fft_lds<N, false>(bufA, bufB, tw_s);
-        for (int k = threadIdx.x; k <= N / 2; k += 256) {
-            cf X, Y;
-            split_bins<N>(Z, k, X, Y);
-            const float xm = sqrtf(fmaxf(X.re * X.re + X.im * X.im, eps));
-            const float ym = sqrtf(fmaxf(Y.re * Y.re + Y.im * Y.im, eps));
-            const float d = ym - xm;
-            s_d += (double)d * (double)d;
-            s_y += (double)ym * (double)ym;
-            s_l += (double)fabsf(logf(xm) - logf(ym));
+    for (int it = 0; it < MR_FPG / (WAVES * FW); ++it) {
+        const int f = blockIdx.x * MR_FPG + frame_slot<N>(it, wave, g);
+        if (f - g >= n_frames) break;                                   // wave-uniform (frames of a wave are f-g, f-g+1)
+        const bool live = f < n_frames;
+        cf R[WF<N>::NB][4], Z[E];
+        load_frame<N>(R, xb, yb, win, live ? f : n_frames - 1, hop, T, a);
+        wave_fft<N, false>(R, Z, buf, tw_s, a);
+#pragma unroll
+        for (int i = 0; i < E; ++i) buf[pos_final<N>(i, a)] = Z[i];
+        __builtin_amdgcn_wave_barrier();
+        if (live) {
+            for (int k = a; k <= N / 2; k += L) {
+                cf X, Y;
+                split_bins<N>(buf, k, X, Y);
+                const float xm = sqrtf(fmaxf(X.re * X.re + X.im * X.im, eps));
+                const float ym = sqrtf(fmaxf(Y.re * Y.re + Y.im * Y.im, eps));
+                const float d = ym - xm;
+                s_d += (double)d * (double)d;
+                s_y += (double)ym * (double)ym;
+                s_l += (double)fabsf(logf(xm) - logf(ym));
+            }
         }
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
     }
     s_d = wave_sum_f64(s_d); s_y = wave_sum_f64(s_y); s_l = wave_sum_f64(s_l);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (lane == 0) { red[wave][0] = s_d; red[wave][1] = s_y; red[wave][2] = s_l; }
     __syncthreads();
     if (threadIdx.x < 3) {
-        const size_t o = ((size_t)b * gridDim.x + blockIdx.x) * 3 + threadIdx.x;
-        part[o] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        double acc = 0.0;
+        for (int w = 0; w < WAVES; ++w) acc += red[w][threadIdx.x];
+        part[((size_t)b * gridDim.x + blockIdx.x) * 3 + threadIdx.x] = acc;
     }
 }
 
@@ -184,48 +277,69 @@ __global__ __launch_bounds__(256) void mr_finish_kernel(const double *__restrict
 
 // ---- pass B -------------------------------------------------------------------------------------
 template <int N>
-__global__ __launch_bounds__(256) void mr_grad_kernel(const float *__restrict__ x, long long xs,
-                                                      const float *__restrict__ y, long long ys,
-                                                      const float *__restrict__ win,
-                                                      const float2 *__restrict__ tw, int T, int hop, int n_frames,
-                                                      float eps, const float *__restrict__ coef,
-                                                      float *__restrict__ scratch)
+__global__ __launch_bounds__(WF<N>::WAVES * 64) __attribute__((amdgpu_waves_per_eu(2))) void mr_grad_kernel(const float *__restrict__ x, long long xs,
+                                                                    const float *__restrict__ y, long long ys,
+                                                                    const float *__restrict__ win,
+                                                                    const float2 *__restrict__ tw, int T, int hop,
+                                                                    int n_frames, float eps,
+                                                                    const float *__restrict__ coef,
+                                                                    float *__restrict__ scratch)
 {
-    __shared__ cf bufA[MR_LEN(N)], bufB[MR_LEN(N)];
+    constexpr int L = WF<N>::L, E = WF<N>::E, NB = WF<N>::NB, WAVES = WF<N>::WAVES, FW = WF<N>::FW;
+    __shared__ cf xbuf[WAVES * FW][WF<N>::LEN];
     __shared__ float2 tw_s[N];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane / L, a = lane % L;
     const int b = blockIdx.y;
     const float *xb = x + (size_t)b * xs, *yb = y + (size_t)b * ys;
     const float c_sc = coef[0], c_log = coef[1];
+    cf *buf = xbuf[wave * FW + g];
     stage_twiddles<N>(tw_s, tw);
-    for (int fl = 0; fl < MR_FR; ++fl) {
-        const int f = blockIdx.x * MR_FR + fl;
-        if (f >= n_frames) break;                                      // block-uniform
-        load_frame<N>(bufA, xb, yb, win, f, hop, T);
-        cf *Z = fft_lds<N, false>(bufA, bufB, tw_s);
-        cf *G = (Z == bufA) ? bufB : bufA;
-        for (int k = threadIdx.x; k < N; k += 256) {
-            cf g = {0.0f, 0.0f};
-            if (k <= N / 2) {
-                cf X, Y;
-                split_bins<N>(Z, k, X, Y);
-                const float px = X.re * X.re + X.im * X.im;
-                const float xm = sqrtf(fmaxf(px, eps));
-                const float ym = sqrtf(fmaxf(Y.re * Y.re + Y.im * Y.im, eps));
-                if (px > eps) {                                             // clamp passes no gradient below eps
-                    const float dl = logf(xm) - logf(ym);
-                    const float dxm = c_sc * (xm - ym) + c_log * (dl > 0.0f ? 1.0f : (dl < 0.0f ? -1.0f : 0.0f)) / xm;
-                    const float s = dxm / xm;
-                    g = {s * X.re, s * X.im};                               // dL/dRe X, dL/dIm X
+    for (int it = 0; it < MR_FPG / (WAVES * FW); ++it) {
+        const int f = blockIdx.x * MR_FPG + frame_slot<N>(it, wave, g);
+        if (f - g >= n_frames) break;                                   // wave-uniform
+        const bool live = f < n_frames;
+        cf R[NB][4], Z[E];
+        load_frame<N>(R, xb, yb, win, live ? f : n_frames - 1, hop, T, a);
+        wave_fft<N, false>(R, Z, buf, tw_s, a);
+#pragma unroll
+        for (int i = 0; i < E; ++i) buf[pos_final<N>(i, a)] = Z[i];
+        __builtin_amdgcn_wave_barrier();
+        // dL/dX at the bins this lane feeds into the inverse transform (positions a + L b + (N/4) c; zero above N/2)
+#pragma unroll
+        for (int bq = 0; bq < NB; ++bq)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int k = a + L * bq + (N / 4) * c;
+                cf gk = {0.0f, 0.0f};
+                if (c < 2 || k == N / 2) {                                  // c >= 2: k >= N/2
+                    cf X, Y;
+                    split_bins<N>(buf, k, X, Y);
+                    const float px = X.re * X.re + X.im * X.im;
+                    const float xm = sqrtf(fmaxf(px, eps));
+                    const float ym = sqrtf(fmaxf(Y.re * Y.re + Y.im * Y.im, eps));
+                    if (px > eps) {                                         // clamp passes no gradient below eps
+                        const float dl = logf(xm) - logf(ym);
+                        const float dxm =
+                            c_sc * (xm - ym) + c_log * (dl > 0.0f ? 1.0f : (dl < 0.0f ? -1.0f : 0.0f)) / xm;
+                        const float sc = dxm / xm;
+                        gk = {sc * X.re, sc * X.im};                        // dL/dRe X, dL/dIm X
+                    }
                 }
+                R[bq][c] = gk;
             }
-            G[MR_PH(k)] = g;
-        }
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
         // adjoint of the one-sided DFT: dx[n] = Re sum_{k<=N/2} G[k] e^{+2 pi i k n / N}
-        cf *gt = fft_lds<N, true>(G, Z, tw_s);
-        float *out = scratch + ((size_t)b * n_frames + f) * N;
-        for (int n = threadIdx.x; n < N; n += 256) out[n] = gt[MR_PH(n)].re * win[n];
-        __syncthreads();                                               // the next frame reuses both buffers
+        wave_fft<N, true>(R, Z, buf, tw_s, a);
+        if (live) {
+            // (overlap-adding a workgroup's 16 frames in LDS and writing one span instead was measured: the fold pass
+            // fell from 1.7 to 0.6 ms but this kernel lost 1.5-2 ms to the read-modify-writes and the lower occupancy)
+            float *out = scratch + ((size_t)b * n_frames + f) * N;
+#pragma unroll
+            for (int i = 0; i < E; ++i) {
+                const int n = pos_final<N>(i, a);
+                out[n] = Z[i].re * win[n];
+            }
+        }
     }
 }
 
@@ -272,15 +386,15 @@ static int run_resolution(const float *x, long long xs, const float *y, long lon
                           long long ds, int accumulate, hipStream_t st)
 {
     const int n_frames = 1 + T / hop;
-    const int groups = (n_frames + MR_FR - 1) / MR_FR;
-    hipLaunchKernelGGL((mr_stats_kernel<N>), dim3(groups, B), dim3(256), 0, st, x, xs, y, ys, win, tw, T, hop,
-                       n_frames, eps, part);
+    const int groups = (n_frames + MR_FPG - 1) / MR_FPG;
+    hipLaunchKernelGGL((mr_stats_kernel<N>), dim3(groups, B), dim3(WF<N>::WAVES * 64), 0, st, x, xs, y, ys, win, tw,
+                       T, hop, n_frames, eps, part);
     const long long count = (long long)B * n_frames * (N / 2 + 1);
     hipLaunchKernelGGL(mr_finish_kernel, dim3(1), dim3(256), 0, st, part, groups * B, count, w_sc, w_log, res_scale,
                        terms, coef);
     if (dx) {
-        hipLaunchKernelGGL((mr_grad_kernel<N>), dim3(groups, B), dim3(256), 0, st, x, xs, y, ys, win, tw, T, hop,
-                           n_frames, eps, coef, scratch);
+        hipLaunchKernelGGL((mr_grad_kernel<N>), dim3(groups, B), dim3(WF<N>::WAVES * 64), 0, st, x, xs, y, ys, win, tw,
+                           T, hop, n_frames, eps, coef, scratch);
         hipLaunchKernelGGL((mr_fold_kernel<N>), dim3((T + 255) / 256, B), dim3(256), 0, st, scratch, T, hop, n_frames,
                            accumulate, dx, ds);
     }
