@@ -326,7 +326,7 @@ class TBPTTLFOEffectModeling(BaseLightingModule):
                 x, lat, tgt = dry[:, :, start:end], lfo_sr[:, :, start:end], wet[:, :, start:end]
                 if is_training:
                     y, h0, c0 = em.run_chunk(x, lat, stash)
-                    optimizer.zero_grad()
+                    # no zero_grad(): bptt_l1_chunk OVERWRITES the whole flat gradient (one fill kernel less per step)
                     em.bptt_l1_chunk(x, lat, y, tgt, stash, h0, c0, w_l1 / (B * S), optimizer.flat_grad)
                     optimizer.step(grad_scale=allreduce_flat_grad(optimizer.flat_grad, world_size))
                     em.detach_hidden()

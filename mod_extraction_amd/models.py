@@ -710,6 +710,7 @@ class LSTMEffectModel(HiddenStateModel):
         """BPTT of one chunk with the L1 loss fused; the summed parameter gradient (17473,) in
         state-dict order is written to ``grad_out``."""
         B, _, Tn = x.shape
+        assert grad_out.numel() == LSTM_NPARAM and grad_out.is_contiguous()     # every element is overwritten below
         part = torch.empty((B, LSTM_NPARAM), device=x.device, dtype=torch.float32)
         xp, xs = _rows(x)
         lp, ls = _rows(latent)
