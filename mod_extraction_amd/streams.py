@@ -28,11 +28,14 @@ def _masked_stream(hip, words, device) -> torch.cuda.Stream:
     return torch.cuda.ExternalStream(st.value, device=device)
 
 
-def xcd_partition(device: torch.device, side_xcds: int = 3) -> Optional[Tuple[torch.cuda.Stream, torch.cuda.Stream]]:
+def xcd_partition(device: torch.device, side_xcds: Optional[int] = None) -> Optional[Tuple[torch.cuda.Stream, torch.cuda.Stream]]:
     """(main, side) streams on disjoint sets of XCDs, or None when the device cannot be partitioned (not a multiple of
-    32 CUs, fewer than 4 XCDs, or ``MODEX_CU_PARTITION=0``).  The pair is created once per device and kept."""
+    32 CUs, fewer than 4 XCDs, or ``MODEX_CU_PARTITION=0``).  The pair is created once per device and kept.
+    ``side_xcds`` defaults to ``MODEX_SIDE_XCDS`` or 3."""
     if device.type != "cuda" or os.environ.get("MODEX_CU_PARTITION", "1") == "0":
         return None
+    if side_xcds is None:
+        side_xcds = int(os.environ.get("MODEX_SIDE_XCDS", "3"))
     idx = device.index if device.index is not None else torch.cuda.current_device()
     key = (idx, side_xcds)
     if key in _cache:
