@@ -107,16 +107,25 @@ def mean(v):
     return sum(v) / len(v)
 
 
+def sync_replicas(opt):
+    """DDP: rank 0's initial parameters on every rank (the seeds already agree; this makes it hold by construction)."""
+    if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+        torch.distributed.broadcast(opt.flat_param, src=0)
+
+
 def build_lfo_job(device, rank, batch, kinds, overlap=True):
     from mod_extraction_amd import data_modules, lightning, models, optim
-    torch.manual_seed(43 + rank)
     import numpy as np
-    np.random.seed(43 + rank)
+    torch.manual_seed(43)                 # the replicas start from the same weights on every rank ...
+    np.random.seed(43)
     model = models.Spectral2DCNN(**CNN_CFG)
     module = lightning.LFOExtraction(model, sr=SR, use_dry=True, model_smooth_n_frames=0, should_stretch=False,
                                      loss_dict=LOSS).to(device)
     module.train()
     opt = optim.FlatAdamW(module.parameters(), lr=1e-4, betas=(0.8, 0.99))
+    sync_replicas(opt)
+    torch.manual_seed(43 + rank)          # ... and draw their own clips
+    np.random.seed(43 + rank)
     batcher = data_modules.SyntheticFxBatcher(batch, N_SAMPLES, SR, kinds, device, audio_seed=43 + rank,
                                               overlap=overlap)
     return module, opt, batcher
@@ -365,12 +374,14 @@ def run_config4(args, env):
     device = torch.device("cuda", env["local_rank"])
     B = args.batch or cfg["batch"]
     W = S = 1024
-    torch.manual_seed(44 + rank); np.random.seed(44 + rank)
+    torch.manual_seed(44); np.random.seed(44)          # same initial weights on every rank, then per-rank data streams
     cnn = models.Spectral2DCNN(**CNN_CFG)
     em = models.LSTMEffectModel()
     mod = lightning.TBPTTLFOEffectModeling(W, S, em, lfo_model=cnn, discard_invalid_lfos=False,
                                            loss_dict={"l1": 1.0, "esr": 0.0, "dc": 0.0}).to(device).train()
     opt = optim.FlatAdamW([p for p in mod.parameters() if p.requires_grad], lr=1e-4, betas=(0.8, 0.99))
+    sync_replicas(opt)
+    torch.manual_seed(44 + rank); np.random.seed(44 + rank)
     bt = data_modules.SyntheticFxBatcher(B, N_SAMPLES, SR, cfg["kinds"], device, audio_seed=44 + rank,
                                          overlap=not args.no_overlap)
     # the batch render and the FROZEN extractor's forward run one batch ahead on the side stream
