@@ -20,7 +20,13 @@ from .optim import FlatAdamW
 
 
 def dist_env() -> Dict[str, int]:
-    return {"rank": int(os.environ.get("RANK", "0")), "local_rank": int(os.environ.get("LOCAL_RANK", "0")),
+    """Rank layout from the torchrun environment.  ``MODEX_SHARE_GPU=1`` (testing the multi-rank code paths on a box
+    with fewer GPUs than ranks; use it with ``MODEX_DIST_BACKEND=gloo`` -- RCCL refuses two ranks on one device) maps
+    LOCAL_RANK onto the devices that exist."""
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("MODEX_SHARE_GPU") == "1" and torch.cuda.device_count() > 0:
+        local %= torch.cuda.device_count()
+    return {"rank": int(os.environ.get("RANK", "0")), "local_rank": local,
             "world_size": int(os.environ.get("WORLD_SIZE", "1"))}
 
 
@@ -29,7 +35,7 @@ def init_distributed(backend: Optional[str] = None) -> Dict[str, int]:
     env = dist_env()
     if env["world_size"] > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("MODEX_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend == "nccl":

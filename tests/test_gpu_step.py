@@ -225,3 +225,32 @@ def test_train_step_through_the_rccl_init_path_world_size_1(dev):
         dist.destroy_process_group()
     assert base[0] == with_pg[0] and torch.equal(base[1], with_pg[1])
     assert base[2] == with_pg[2] and set(base[2]) == {"train/l1", "train/fdl1", "train/sdl1", "train/mse", "train/loss"}
+
+
+@pytest.mark.parametrize("config", [3, 4])
+def test_bench_two_ranks_sharing_the_gpu_over_gloo(config):
+    """bench.py's N > 1 path -- torchrun environment, barrier + max-over-ranks timing, per-rank clip shards, the flat
+    gradient all-reduce, rank 0 printing the one JSON line -- with TWO ranks on this box's single GPU.  RCCL refuses two
+    ranks on one device, so the collectives go through gloo (MODEX_DIST_BACKEND) and LOCAL_RANK is folded onto the
+    existing device (MODEX_SHARE_GPU): the code path is the driver's multi-GPU launch, only the transport differs."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MODEX_SHARE_GPU="1", MODEX_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--config", str(config), "--steps", "2",
+           "--warmup", "1", "--batch", "8"]
+    res = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]                 # rank 0 only
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["scaling"] == "weak"
+    assert out["config"]["global_batch"] == 16 and out["config"]["parallelism"] == "dp2"
+    assert out["value"] > 0 and "cpu_baseline" not in out      # the CPU baseline is an N = 1 leg
+    assert out["roofline"]["frac"] is None or out["roofline"]["frac"] > 0
