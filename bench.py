@@ -213,7 +213,8 @@ def timed_loop(step, steps, world, device, timer_names, key_fn=None):
     if world > 1:
         torch.distributed.all_reduce(dt_t, op=torch.distributed.ReduceOp.MAX)
     per_step = [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]
-    stats = {"min": round(min(per_step), 3), "median": round(statistics.median(per_step), 3), "max": round(max(per_step), 3)}
+    stats = {"min": round(min(per_step), 3), "median": round(statistics.median(per_step), 3), "max": round(max(per_step), 3),
+             "slowest_step": per_step.index(max(per_step))}
     return float(dt_t), kt.results(), stats, out
 
 
@@ -514,7 +515,7 @@ def run_config5(args, env):
         pred = (0.9 * wet + 0.1 * dry).requires_grad_(True)       # stand-in prediction: the loss path is what is measured
         loss = loss_fn(pred, wet)
         loss.backward()
-        return loss
+        return loss.detach()        # (a live graph of the previous step changes the allocator's pattern: one 40 ms hipMalloc)
 
     for _ in range(args.warmup):
         step()

@@ -365,7 +365,15 @@ __global__ __launch_bounds__(256) void mr_fold_kernel(const float *__restrict__ 
         if (f_hi > n_frames - 1) f_hi = n_frames - 1;
         int f_lo = (p - N + hop) / hop;                                 // ceil((p - N + 1) / hop)
         if (p - N + 1 <= 0) f_lo = 0;
-        for (int f = f_lo; f <= f_hi; ++f) acc += sb[(size_t)f * N + (p - f * hop)];
+        // same summation order as a plain loop, four loads in flight
+        const float *q = sb + (size_t)f_lo * N + (p - f_lo * hop);
+        const int step = N - hop;
+        int f = f_lo;
+        for (; f + 3 <= f_hi; f += 4, q += 4 * (size_t)step) {
+            const float a0 = q[0], a1 = q[step], a2 = q[2 * (size_t)step], a3 = q[3 * (size_t)step];
+            acc += a0; acc += a1; acc += a2; acc += a3;
+        }
+        for (; f <= f_hi; ++f, q += step) acc += q[0];
     }
     float *o = dx + (size_t)b * ds + n;
     *o = accumulate ? *o + acc : acc;
