@@ -8,7 +8,10 @@ word on gfx950): measured on config 4 (128 clips, MI355X, tools/exp_cumask.py), 
     no masks 81.2 | main 4 XCDs + side 4 XCDs 75.6 | main 5 + side 3 73.2 | main 6 + side 2 72.3 | masks sharing XCDs 81.2
 The default gives the recurrence 5 of 8 XCDs and the prefetch work 3 (robust when the prefetch work grows).
 Not for the LFO-extraction step: there the main stream is throughput-bound on all 256 CUs, and masking only the (light)
-side stream made the step 14 % SLOWER (75.9 -> 86.5 ms, 1, 2 or 4 side XCDs alike).
+side stream made the step 14 % SLOWER (75.9 -> 86.5 ms, 1, 2 or 4 side XCDs alike): a masked queue next to torch's default
+queue serialises the two.  With BOTH streams created through hipExtStreamCreateWithCUMask (tools/exp_cumask_headline.py):
+main on every CU + side on one XCD 74.6 ms against 75.1 with the default streams -- 0.7 %, not adopted; main on 7 XCDs + side
+on the 8th 80.5; side on 8 CUs of every XCD 79.1.
 """
 import ctypes
 import os
