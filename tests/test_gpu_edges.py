@@ -1,0 +1,128 @@
+"""GPU parity at the edges of the kernels' internal tilings (ragged and minimum sizes), against the CPU oracle:
+LSTM-64 chunk lengths around the 32-step stash slabs and the 256-step output blocks, batch 1; MR-STFT clips whose
+frame counts are not multiples of the 16 frames a workgroup (or the 1 / 2 frames a wavefront) takes, and the shortest
+clip reflect padding allows; flanger clips that end inside a 256-sample chunk.  Tolerances as in the kernels' own test
+files (audio 1e-5 absolute, LSTM gradients 1e-4 of each tensor's max, MR-STFT value 1e-5 relative / gradient against the
+fp64 oracle, flanger bit-exact)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import fx as ofx, losses as olosses, models as om, modulations as omod
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("B,T", [(1, 1), (2, 2), (1, 31), (2, 33), (1, 64), (2, 255), (1, 257), (3, 300), (1, 513)])
+def test_lstm_chunk_lengths_around_the_slab_and_block_sizes(dev, B, T):
+    from mod_extraction_amd import models as am
+    torch.manual_seed(100 * B + T)
+    ref = om.LSTMEffectModel(1, 1, 64, 1)
+    mine = am.LSTMEffectModel(1, 1, 64, 1)
+    mine.load_state_dict(ref.state_dict())
+    mine = mine.to(dev)
+    W = 40                                               # warm-up chunk: a non-zero state enters the chunk under test
+    x = torch.rand(B, 1, W + T) * 1.6 - 0.8
+    lat = torch.rand(B, 1, W + T)
+    wet = (0.6 * x + 0.3 * torch.roll(x, 2, -1)).clamp(-1, 1)
+    ref.clear_hidden(); ref(x[..., :W], lat[..., :W]); ref.detach_hidden()
+    y_r = ref(x[..., W:], lat[..., W:])
+    torch.nn.functional.l1_loss(y_r, wet[..., W:]).backward()
+    xd, ld, wd = x.to(dev), lat.to(dev), wet.to(dev)
+    mine.clear_hidden(); mine.run_chunk(xd[..., :W], ld[..., :W]); mine.detach_hidden()
+    stash = torch.empty((B, T, 384), device=dev)
+    y_m, h0, c0 = mine.run_chunk(xd[..., W:], ld[..., W:], stash)
+    assert float((y_m.cpu() - y_r.detach()).abs().max()) < 1e-5
+    assert float((mine.hidden[0].cpu() - ref.hidden[0].detach()).abs().max()) < 1e-5
+    assert float((mine.hidden[1].cpu() - ref.hidden[1].detach()).abs().max()) < 2e-5
+    # the inference variant of the forward kernel (no stash) gives the same output
+    mine.clear_hidden(); mine.run_chunk(xd[..., :W], ld[..., :W]); mine.detach_hidden()
+    y_i = mine.run_chunk(xd[..., W:], ld[..., W:])[0]
+    assert float((y_i - y_m).abs().max()) < 1e-6
+    grad = torch.empty(am.LSTM_NPARAM, device=dev)
+    mine.bptt_l1_chunk(xd[..., W:], ld[..., W:], y_m, wd[..., W:], stash, h0, c0, 1.0 / (B * T), grad)
+    off = 0
+    for n, p in ref.named_parameters():
+        k = p.numel()
+        a, r = grad[off:off + k].cpu(), p.grad.reshape(-1)
+        e = float((a - r).abs().max() / r.abs().max().clamp_min(1e-12))
+        assert e < 1e-4, (n, e)
+        off += k
+
+
+@pytest.mark.parametrize("B,T", [(1, 1025), (1, 1100), (2, 1999), (1, 4097), (3, 3851)])
+def test_mrstft_ragged_frame_counts_and_shortest_clip(dev, B, T):
+    """T = 1025 is the shortest clip the 2048-point resolution's reflect padding accepts (pad 1024 < T); the others leave
+    frame counts that are not multiples of 16 (frames per workgroup) or 2 (frames per wavefront at n_fft 512)."""
+    from mod_extraction_amd import losses as alosses
+    torch.manual_seed(B + T)
+    t = torch.arange(T) / 44100.0
+    y = (0.5 * torch.sin(2 * np.pi * 330.0 * t) + 0.2 * torch.rand(B, 1, T) - 0.1).clamp(-1, 1)
+    x = (0.8 * y + 0.1 * torch.roll(y, 7, -1) + 0.05 * torch.randn(B, 1, T)).clamp(-1, 1)
+
+    class MR64(olosses.MultiResolutionSTFTLoss):
+        def _mag(self, v, n_fft, hop, win):
+            s = torch.stft(v.reshape(-1, v.size(-1)), n_fft, hop, win, torch.hann_window(win, dtype=torch.float64),
+                           return_complex=True)
+            return torch.sqrt(torch.clamp(s.real ** 2 + s.imag ** 2, min=self.eps))
+    x64 = x.double().requires_grad_(True)
+    loss64 = MR64()(x64, y.double())
+    loss64.backward()
+    x32 = x.clone().requires_grad_(True)
+    loss32 = olosses.get_loss_func_by_name("mrstft")(x32, y)
+    loss32.backward()
+    xd = x.to(dev).requires_grad_(True)
+    loss_m = alosses.get_loss_func_by_name("mrstft")(xd, y.to(dev))
+    loss_m.backward()
+    assert abs(float(loss_m) - float(loss64)) < 1e-5 * abs(float(loss64)), (float(loss_m), float(loss64))
+    scale = x64.grad.abs().max()
+    e_mine = float((xd.grad.cpu().double() - x64.grad).abs().max() / scale)
+    e_oracle32 = float((x32.grad.double() - x64.grad).abs().max() / scale)
+    assert e_mine < 2e-3 and e_mine < max(2.0 * e_oracle32, 1e-4), (e_mine, e_oracle32)
+
+
+@pytest.mark.parametrize("B,N", [(1, 1), (1, 255), (2, 257), (3, 1000), (1, 4099)])
+def test_flanger_clip_lengths_inside_a_chunk_bit_exact(dev, B, N):
+    from mod_extraction_amd import fx as afx
+    torch.manual_seed(7 * B + N)
+    x = torch.rand(B, N) * 2 - 1
+    mod = torch.stack([omod.make_mod_signal(N, 44100, 0.7 + 1.3 * i, 0.4 * i, "cos") for i in range(B)])
+    for mm, ml in ((1.0, 10.0), (30.0, 10.0)):
+        Mm, Ml = ofx.delay_samples(mm, 44100), ofx.delay_samples(ml, 44100)
+        p = dict(feedback=torch.rand(B) * 0.7, min_delay_width=torch.rand(B), width=torch.rand(B),
+                 depth=torch.rand(B), mix=torch.rand(B))
+        po = ofx.derive_params(B, Mm, Ml, **p)
+        y_ref = ofx.flanger_np(x.numpy(), mod.numpy(), po, Mm + Ml)
+        y_ref = y_ref[0] if isinstance(y_ref, tuple) else y_ref
+        consts = afx.derive_clip_constants(B, dev, Mm, Ml, **{k: v.to(dev) for k, v in p.items()})
+        md = torch.full((B,), Mm + Ml, dtype=torch.int32, device=dev)
+        y = afx.flanger_forward(x.to(dev), mod.to(dev), consts, md, Mm + Ml)
+        assert np.array_equal(y.cpu().numpy(), y_ref), (N, mm, np.abs(y.cpu().numpy() - y_ref).max())
+
+
+@pytest.mark.parametrize("N", [1, 3, 63, 65, 255, 257, 1000])
+def test_phaser_clip_lengths_inside_a_block(dev, N):
+    """lead + N ending inside a 4-sample cut-off update, a 64-sample sub-block and a 256-sample block of the producer /
+    consumer kernel; both kernels (state-space and JUCE operation order) against oracle_ref.c:orc_phaser at 1e-5."""
+    from mod_extraction_amd import fx as afx
+    torch.manual_seed(N)
+    lead = torch.tensor([0, 1, 62, 259], dtype=torch.int32)
+    B = lead.numel()
+    src = torch.rand(B, N + 259) * 1.6 - 0.8
+    p = {"rate_hz": torch.tensor([0.5, 3.0, 1.3, 2.2]), "depth": torch.tensor([1.0, 0.2, 0.6, 0.9]),
+         "centre_frequency_hz": torch.tensor([70.0, 18000.0, 440.0, 1300.0]),
+         "feedback": torch.tensor([0.0, 0.7, 0.25, 0.5]), "mix": torch.tensor([1.0, 0.2, 0.5, 0.8])}
+    pd = {k: v.to(dev) for k, v in p.items()}
+    y = torch.empty(B, N, device=dev)
+    y_exact = torch.empty(B, N, device=dev)
+    dry = torch.empty(B, N, device=dev)
+    afx.phaser_forward(src.to(dev), pd, lead.to(dev), 44100.0, N, out=y, dry_out=dry)
+    afx.phaser_forward(src.to(dev), pd, lead.to(dev), 44100.0, N, out=y_exact, exact_order=True)
+    for b in range(B):
+        L = int(lead[b])
+        ref = ofx.phaser_np(src[b:b + 1, :L + N].numpy(), [float(p["rate_hz"][b])], [float(p["depth"][b])],
+                            [float(p["centre_frequency_hz"][b])], [float(p["feedback"][b])], [float(p["mix"][b])], 44100.0)
+        assert np.array_equal(dry[b].cpu().numpy(), src[b, L:L + N].numpy())
+        for name, out in (("state-space", y), ("juce-order", y_exact)):
+            err = np.abs(out[b].cpu().numpy() - ref[0, L:]).max()
+            assert err < 1e-5, (name, b, N, err)

@@ -1,7 +1,7 @@
 """Experiment: headline step (config 3) with the side stream (batch render: phaser / flanger) confined to a few XCDs.
 A CU-masked side stream next to torch's DEFAULT main stream serialised the two (75.9 -> 86.5 ms); here BOTH streams are
 created with hipExtStreamCreateWithCUMask (the main one with every CU enabled, or with the complement).
-    python tools/exp_cumask_headline.py
+    python tools/exp_cumask_headline.py [2]        # 2: config 2 (all phaser, bs 64) instead of the headline
 """
 import ctypes, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -25,8 +25,11 @@ def masked_stream(words):
     return torch.cuda.ExternalStream(st.value, device=dev)
 
 
+CFG2 = len(sys.argv) > 1 and sys.argv[1] == "2"          # config 2: all phaser, 64 clips
+
+
 def run(main_words, side_words, steps=12):
-    module, opt, batcher = bench.build_lfo_job(dev, 0, 256, ("flanger", "chorus", "phaser"))
+    module, opt, batcher = bench.build_lfo_job(dev, 0, 64 if CFG2 else 256, ("phaser",) if CFG2 else ("flanger", "chorus", "phaser"))
     runner = tr.Trainer(log_fn=None)
     if side_words is not None:
         batcher.use_side_stream(masked_stream(side_words))
