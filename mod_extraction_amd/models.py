@@ -181,8 +181,9 @@ class _CNNStack(torch.autograd.Function):
                 if keep_splits:
                     ctx.splits[l] = (x_hi, x_lo)
                 del x_hi, x_lo
-            elif precision == "f16x3" and l == 0 and cin == 2 and BLOCK1_F16:
-                # first block: (kernel row, channel) pairs are the operand's 16 channels; one K stage
+            elif precision == "f16x3" and l == 0 and cin == 2 and BLOCK1_F16 and int(dilations[0]) == 1:
+                # first block: (kernel row, channel) pairs are the operand's 16 channels; one K stage (the kernel is built for
+                # the undilated first block of every shipped config; a dilated one takes the exact-fp32 kernel below)
                 xk_hi = torch.empty((B, H, 1, PITCH, 16), device=dev, dtype=torch.float16)
                 xk_lo = torch.empty((B, H, 1, PITCH, 16), device=dev, dtype=torch.float16)
                 _hip.call("mx_conv_prep_fwd_kvec_f16", _hip.ptr(cur), _hip.ptr(stats), B, H, n_frames, _hip.ptr(xk_hi),

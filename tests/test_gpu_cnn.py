@@ -141,3 +141,26 @@ def test_lfo_loss_kernel(dev):
         for k in w:
             assert abs(float(terms_m[k]) - float(terms_r[k])) < 2e-6, k
         assert rel_err(yh.grad.cpu(), y_hat.grad) < 1e-5
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "f32"])
+@pytest.mark.parametrize("over", [
+    dict(out_channels=[64] * 4, temp_dilations=[1, 16, 2, 8], n_mels=32, latent_dim=3),
+    dict(out_channels=[64] * 3, temp_dilations=[2, 4, 1], n_mels=64, latent_dim=2),          # dilated FIRST block
+    dict(out_channels=[64] * 5, temp_dilations=[1, 2, 4, 8, 16], n_mels=128, latent_dim=4),  # the class defaults' dilations
+], ids=["4blocks-permuted", "3blocks-dilated-first", "5blocks-pow2"])
+def test_cnn_other_members_of_the_supported_family(dev, over, precision):
+    """Block counts, dilation orders, mel-bin counts and latent widths other than the shipped spectral_2dcnn.yml, inside
+    what Spectral2DCNN accepts (everything else raises NotImplementedError, test below)."""
+    ref, mine = make_pair(dev, n_samples=22272, **over)
+    mine.conv_precision = precision
+    ref.eval(); mine.eval()
+    run_pair(dev, ref, mine, audio(3, 22272), (2, 7, 10, 31))
+
+
+def test_cnn_outside_the_family_raises(dev):
+    from mod_extraction_amd import models as amodels
+    for bad in (dict(kernel_size=(3, 3)), dict(pool_size=(3, 1)), dict(out_channels=[32] * 6), dict(use_ln=False),
+                dict(temp_dilations=[1, 1, 2, 4, 8, 32]), dict(n_mels=100), dict(n_samples=200000)):
+        with pytest.raises((NotImplementedError, AssertionError)):
+            amodels.Spectral2DCNN(**{**CFG, "n_samples": 88200, **bad})
