@@ -126,3 +126,73 @@ def test_phaser_clip_lengths_inside_a_block(dev, N):
         for name, out in (("state-space", y), ("juce-order", y_exact)):
             err = np.abs(out[b].cpu().numpy() - ref[0, L:]).max()
             assert err < 1e-5, (name, b, N, err)
+
+
+@pytest.mark.parametrize("W,S,n", [(512, 256, 6000), (100, 37, 3000), (1024, 1024, 5000)])
+def test_tbptt_training_with_other_warmup_and_step_lengths(dev, W, S, n):
+    """TBPTT training batch with warm-up != step length, step lengths off the kernels' slab sizes and a tail that does
+    not fill a step, against the oracle running torch.optim.AdamW on the CPU: kept clips, optimizer steps, wet_hat, losses
+    and the weights after the steps (bulk statistic: Adam is ill-conditioned where a gradient is ~eps)."""
+    from mod_extraction_amd import lightning as al, models as am, optim
+    from oracle import lightning as ol
+    torch.manual_seed(W + S)
+    B = 3
+    dry = torch.rand(B, 1, n) * 1.6 - 0.8
+    wet = (0.7 * dry + 0.2 * torch.roll(dry, 5, -1)).clamp(-1, 1)
+    frames = 64
+    lfo = torch.stack([omod.make_mod_signal(frames, frames / (n / 44100.0), f, p, "cos")
+                       for f, p in ((6.0, 0.2), (9.0, 1.0), (7.5, 3.0))])
+    ref = om.LSTMEffectModel()
+    init = {k: v.clone() for k, v in ref.state_dict().items()}
+    em = am.LSTMEffectModel(); em.load_state_dict(init)
+    ld = {"l1": 1.0, "esr": 0.0, "dc": 0.0}
+    mod = al.TBPTTLFOEffectModeling(W, S, em, lfo_model=None, model_smooth_n_frames=0, should_stretch=False,
+                                    discard_invalid_lfos=False, loss_dict=ld).to(dev).train()
+    opt = optim.FlatAdamW(mod.parameters(), lr=1e-3, betas=(0.8, 0.99))
+    loss, dd, _ = mod.common_step((dry.to(dev), wet.to(dev), lfo.to(dev), None), is_training=True, optimizer=opt, world_size=1)
+    ropt = torch.optim.AdamW(ref.parameters(), lr=1e-3, betas=(0.8, 0.99))
+    res = ol.tbptt_common_step(ref, ropt, dry, wet, lfo, W, S, ld, is_training=True, model_smooth_n_frames=0,
+                               should_stretch=False, discard_invalid_lfos=False)
+    assert opt.step_count == res["steps"] == (n - W) // S
+    assert dd["wet_hat"].shape == res["wet_hat"].shape
+    assert float((dd["wet_hat"].cpu() - res["wet_hat"]).abs().max()) < 1e-4
+    assert abs(float(loss) - float(res["loss"])) < 1e-5
+    for k, v in em.state_dict().items():
+        want = ref.state_dict()[k]
+        d = (v.cpu() - want).abs()
+        moved = (want - init[k]).abs()
+        assert float(d.median()) < 0.02 * max(float(moved.median()), 1e-9), k
+
+
+@pytest.mark.parametrize("over,n_samples", [
+    (dict(hop_len=128, n_mels=64), 30000),
+    (dict(hop_len=512, n_mels=96, sr=22050, out_channels=[64] * 5, temp_dilations=[1, 2, 4, 8, 16]), 88200),
+    (dict(hop_len=300, n_mels=128, sr=48000), 48000),
+])
+def test_logmel_other_hops_rates_and_band_counts(dev, over, n_samples):
+    """mel front end away from the shipped (hop 256, 256 bands, 44.1 kHz): frame count, filter bank and framing follow
+    the arguments, values against the oracle's torchaudio restatement at the log-mel tolerance of tests/test_gpu_cnn.py."""
+    from mod_extraction_amd import models as amodels
+    cfg = dict(in_ch=2, n_samples=n_samples, sr=44100, n_fft=1024, hop_len=256, n_mels=256, kernel_size=(5, 13),
+               out_channels=[64] * 6, temp_dilations=[1, 1, 2, 4, 8, 16], pool_size=(2, 1), latent_dim=1, use_ln=True)
+    cfg.update(over)
+    torch.manual_seed(0)
+    ref = om.Spectral2DCNN(**cfg)
+    mine = amodels.Spectral2DCNN(**cfg)
+    mine.load_state_dict(ref.state_dict(), strict=True)
+    mine = mine.to(dev)
+    g = torch.Generator().manual_seed(3)
+    x = torch.rand(2, 2, n_samples, generator=g) * 1.6 - 0.8
+    masks = (1, 5, 3, 17)
+    with torch.no_grad():
+        want = ref.log_mel(x, masks)
+        got = mine.log_mel(x.to(dev), masks).cpu()
+    n_frames = n_samples // cfg["hop_len"] + 1
+    assert want.shape[-1] == n_frames and got.shape[:3] == want.shape[:3]
+    assert torch.all(got[..., n_frames:] == 0)
+    got = got[..., :n_frames]
+    floor = np.log(1e-7)
+    live = want > floor + 1.0
+    err = (got - want).abs()
+    assert float(err[live].max()) <= 2e-5 + 1e-5 * float(want[live].abs().max()), float(err[live].max())
+    assert float(err[~live].max()) < 0.05 if (~live).any() else True
