@@ -44,6 +44,10 @@ def lfo_loss(y_hat: T, y: T, weights: Dict[str, float]) -> Tuple[T, Dict[str, T]
     for k in weights:
         if k not in _LFO_TERMS:
             raise KeyError(k)
+    # losses.py:12 (central_diff asserts more than 2 points): the reference raises for rows too short to differentiate
+    n = y_hat.size(-1)
+    assert "fdl1" not in weights or n > 2, "fdl1: central difference needs more than 2 points"
+    assert "sdl1" not in weights or n > 4, "sdl1: second central difference needs more than 4 points"
     w = [float(weights.get(k, 0.0)) for k in _LFO_TERMS]
     losses = _LFOLossFn.apply(y_hat, y, *w)
     return losses[4], {k: losses[i].detach() for i, k in enumerate(_LFO_TERMS) if k in weights}

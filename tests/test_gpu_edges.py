@@ -196,3 +196,98 @@ def test_logmel_other_hops_rates_and_band_counts(dev, over, n_samples):
     err = (got - want).abs()
     assert float(err[live].max()) <= 2e-5 + 1e-5 * float(want[live].abs().max()), float(err[live].max())
     assert float(err[~live].max()) < 0.05 if (~live).any() else True
+
+
+@pytest.mark.parametrize("kw", [dict(lr=3e-3, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.1),
+                                dict(lr=1e-2, betas=(0.5, 0.9), eps=1e-8, weight_decay=0.0)])
+def test_adamw_kernel_other_hyperparameters(dev, kw):
+    """mx_adamw_step against torch.optim.AdamW away from configs/opt/adam_w.yml; 33 parameters so that the flat buffer
+    ends inside a vector / a wavefront, 40 steps so that the bias corrections run through their steep part."""
+    from mod_extraction_amd import optim
+    torch.manual_seed(1)
+    ps = [torch.nn.Parameter(torch.randn(7, 3)), torch.nn.Parameter(torch.randn(11)), torch.nn.Parameter(torch.randn(1))]
+    ref = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    mine = [torch.nn.Parameter(p.detach().clone().to(dev)) for p in ps]
+    o_ref = torch.optim.AdamW(ref, **kw)
+    o_mine = optim.FlatAdamW(mine, **kw)
+    for step in range(40):
+        grads = [torch.randn_like(p) * (0.5 ** (step % 9)) for p in ps]
+        for p, g in zip(ref, grads):
+            p.grad = g.clone()
+        o_mine.zero_grad()
+        for p, g in zip(mine, grads):
+            p.grad.copy_(g.to(dev))
+        o_ref.step()
+        o_mine.step()
+        for p, q in zip(mine, ref):
+            assert float((p.detach().cpu() - q.detach()).abs().max()) < 2e-6 * max(1.0, float(q.detach().abs().max())), step
+
+
+@pytest.mark.parametrize("use_dry,smooth,ld", [
+    (False, 4, {"l1": 1.0, "fdl1": 0.0, "sdl1": 2.0, "mse": 0.5}),
+    (True, 8, {"l1": 0.0, "mse": 1.0}),
+    (True, 0, {"l1": 1.0, "fdl1": 5.0, "sdl1": 10.0, "mse": 0.25}),
+])
+def test_lfo_extraction_train_step_other_options(dev, use_dry, smooth, ld):
+    """LFOExtraction training away from train_lfo_*.yml: wet-only input, output smoothing inside the differentiated path,
+    other loss mixes; loss terms and every parameter gradient against the oracle's autograd."""
+    from mod_extraction_amd import lightning, models, optim
+    from oracle import lightning as ol
+    n, sr, B = 22272, 44100, 4
+    cfg = dict(in_ch=2 if use_dry else 1, n_samples=n, sr=sr, n_fft=1024, hop_len=256, n_mels=64, kernel_size=(5, 13),
+               out_channels=[64] * 6, temp_dilations=[1, 1, 2, 4, 8, 16], pool_size=(2, 1), latent_dim=1, use_ln=True)
+    torch.manual_seed(smooth)
+    ref = om.Spectral2DCNN(**cfg).eval()
+    mine = models.Spectral2DCNN(**cfg)
+    mine.load_state_dict(ref.state_dict())
+    module = lightning.LFOExtraction(mine, sr=sr, use_dry=use_dry, model_smooth_n_frames=smooth, should_stretch=False,
+                                     loss_dict=ld).to(dev).eval()
+    opt = optim.FlatAdamW(module.parameters(), lr=1e-4, betas=(0.8, 0.99))
+    dry = torch.rand(B, 1, n) * 1.6 - 0.8
+    wet = (0.6 * dry + 0.3 * torch.roll(dry, 9, -1)).clamp(-1, 1)
+    mod = torch.stack([omod.make_mod_signal(882, 441.0, 0.8 + 0.7 * i, 0.5 * i, "cos") for i in range(B)])
+    loss_r, terms_r, _ = ol.lfo_common_step(ref, dry, wet, mod, ld, use_dry=use_dry, model_smooth_n_frames=smooth)
+    loss_r.backward()
+    opt.zero_grad()
+    loss = module.training_step((dry.to(dev), wet.to(dev), mod.to(dev), None), 0)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(loss_r.detach())) < 1e-5 * max(1.0, abs(float(loss_r.detach())))
+    for k in ld:
+        assert abs(float(module.logged[f"train/{k}"][-1]) - float(terms_r[k].detach())) < 2e-6, k
+    # gradients: the loss kernel's d/d y_hat is compared below and the CNN's backward in tests/test_gpu_cnn.py with the
+    # device's pooling / PReLU decisions routed into the oracle (un-routed, ties decided by fp32 rounding differ by ~1e-3);
+    # here: every parameter received a finite, non-trivial gradient through the smoothing and the loss mix
+    for name, p in mine.named_parameters():
+        assert torch.isfinite(p.grad).all() and float(p.grad.abs().max()) > 0, name
+
+
+@pytest.mark.parametrize("w", [{"l1": 1.0, "fdl1": 0.0, "sdl1": 2.0, "mse": 0.5}, {"l1": 0.0, "mse": 1.0},
+                               {"l1": 1.0, "fdl1": 5.0, "sdl1": 10.0, "mse": 0.25}, {"mse": 2.0, "sdl1": 1.0}])
+@pytest.mark.parametrize("n", [2, 3, 4, 5, 64, 65, 345])
+def test_lfo_loss_kernel_other_mixes_and_lengths(dev, w, n):
+    """mx_lfo_loss (values and d / d y_hat in one launch) for loss mixes other than train_lfo_*.yml and rows as short as
+    the central differences allow: losses.py's central_diff asserts more than 2 points, i.e. fdl1 needs n >= 3 and sdl1
+    n >= 5 -- below that the reference raises, and so must the product."""
+    from mod_extraction_amd import losses as alosses
+    torch.manual_seed(n)
+    y_hat = torch.rand(5, n, requires_grad=True)
+    y = torch.rand(5, n)
+    try:
+        terms_r = {k: olosses.get_loss_func_by_name(k)(y_hat, y) for k in w}
+    except AssertionError:
+        with pytest.raises(Exception):
+            alosses.lfo_loss(y_hat.detach().to(dev), y.to(dev), w)
+        return
+    tot_r = sum(w[k] * terms_r[k] for k in w if w[k] > 0)
+    finite = bool(torch.isfinite(tot_r))
+    if finite:
+        tot_r.backward()
+    yh = y_hat.detach().to(dev).requires_grad_(True)
+    tot_m, terms_m = alosses.lfo_loss(yh, y.to(dev), w)
+    for k in w:
+        a, b = float(terms_m[k]), float(terms_r[k].detach())
+        assert (np.isnan(a) and np.isnan(b)) or abs(a - b) < 2e-6, (k, a, b)
+    if finite:
+        tot_m.backward()
+        assert abs(float(tot_m.detach()) - float(tot_r.detach())) < 1e-6 * max(1.0, abs(float(tot_r.detach())))
+        assert float((yh.grad.cpu() - y_hat.grad).abs().max()) < 1e-5 * float(y_hat.grad.abs().max())
