@@ -76,6 +76,32 @@ class MSELoss(_SingleTerm):
     term = "mse"
 
 
+class LogMelLoss(nn.Module):
+    """losses.py:105-130 (``log_mel_l1``; no shipped config uses it): L1 between the log-mel spectrograms of input and
+    target on the K4 kernel.  A METRIC here: the log-mel kernel has no backward, so a prediction that requires grad
+    raises instead of silently returning a constant."""
+
+    def __init__(self, sr: float = 44100, n_fft: int = 1024, hop_len: int = 256, n_mels: int = 256,
+                 eps: float = 1e-7) -> None:
+        super().__init__()
+        from .models import MelSpectrogramHIP, PITCH
+        self.eps, self.hop_len, self.pitch = eps, hop_len, PITCH
+        self.spectrogram = MelSpectrogramHIP(int(sr), n_fft, hop_len, n_mels)
+
+    def forward(self, input: T, target: T) -> T:
+        if input.requires_grad and torch.is_grad_enabled():
+            raise NotImplementedError("log_mel_l1 is forward-only on this path (evaluation metric)")
+        assert input.shape == target.shape and input.ndim == 3
+        n_frames = input.size(-1) // self.hop_len + 1
+        if n_frames > self.pitch:
+            raise NotImplementedError(f"log_mel_l1: at most {self.pitch} frames per clip")
+        if self.spectrogram.mel_scale.fb.device != input.device:
+            self.spectrogram.to(input.device)
+        a = self.spectrogram.log_mel(input.detach(), n_frames, self.eps)[..., :n_frames]
+        b = self.spectrogram.log_mel(target.detach(), n_frames, self.eps)[..., :n_frames]
+        return (a - b).abs().mean()
+
+
 def get_loss_func_by_name(name: str) -> nn.Module:
     if name == "l1":
         return L1Loss()
@@ -91,5 +117,7 @@ def get_loss_func_by_name(name: str) -> nn.Module:
     elif name == "mrstft":
         from .effect_losses import get_effect_loss
         return get_effect_loss(name)
+    elif name == "log_mel_l1":
+        return LogMelLoss()
     else:
         raise KeyError

@@ -65,9 +65,27 @@ class MultiResolutionSTFTLoss(nn.Module):
         return total / len(self.cfg)
 
 
+class LogMelLoss(nn.Module):
+    """losses.py:105-130: L1 between log(clip(MelSpectrogram(x), eps)) of input and target (torchaudio MelSpectrogram
+    sample_rate 44100, n_fft 1024, hop 256, 256 HTK mels, power 2, centre -- the front end of models.py restated in
+    oracle/models.py:MelFrontEnd, which the reference-held CNN fixtures pin)."""
+
+    def __init__(self, sr: float = 44100, n_fft: int = 1024, hop_len: int = 256, n_mels: int = 256,
+                 eps: float = 1e-7) -> None:
+        super().__init__()
+        from .models import MelFrontEnd
+        self.eps = eps
+        self.spectrogram = MelFrontEnd(int(sr), n_fft, hop_len, n_mels)
+
+    def forward(self, input: T, target: T) -> T:
+        a = torch.log(torch.clip(self.spectrogram(input), min=self.eps))
+        b = torch.log(torch.clip(self.spectrogram(target), min=self.eps))
+        return nn.functional.l1_loss(a, b)
+
+
 def get_loss_func_by_name(name: str) -> nn.Module:
     table = {"l1": nn.L1Loss, "fdl1": FirstDerivativeL1Loss, "sdl1": SecondDerivativeL1Loss, "mse": nn.MSELoss,
-             "esr": ESRLoss, "dc": DCLoss, "mrstft": MultiResolutionSTFTLoss}
+             "esr": ESRLoss, "dc": DCLoss, "mrstft": MultiResolutionSTFTLoss, "log_mel_l1": LogMelLoss}
     if name not in table:
         raise KeyError(name)
     return table[name]()

@@ -291,3 +291,18 @@ def test_lfo_loss_kernel_other_mixes_and_lengths(dev, w, n):
         tot_m.backward()
         assert abs(float(tot_m.detach()) - float(tot_r.detach())) < 1e-6 * max(1.0, abs(float(tot_r.detach())))
         assert float((yh.grad.cpu() - y_hat.grad).abs().max()) < 1e-5 * float(y_hat.grad.abs().max())
+
+
+def test_log_mel_l1_metric(dev):
+    """losses.py:105-130 / get_loss_func_by_name("log_mel_l1"): value against the oracle; forward-only by contract."""
+    from mod_extraction_amd import losses as alosses
+    torch.manual_seed(11)
+    y = torch.rand(3, 1, 30000) * 1.6 - 0.8
+    x = (0.8 * y + 0.1 * torch.roll(y, 4, -1)).clamp(-1, 1)
+    want = float(olosses.get_loss_func_by_name("log_mel_l1")(x, y))
+    fn = alosses.get_loss_func_by_name("log_mel_l1")
+    got = float(fn(x.to(dev), y.to(dev)))
+    assert abs(got - want) < 1e-5 * max(1.0, abs(want)), (got, want)
+    assert float(fn(y.to(dev), y.to(dev))) == 0.0
+    with pytest.raises(NotImplementedError):
+        fn(x.to(dev).requires_grad_(True), y.to(dev))
