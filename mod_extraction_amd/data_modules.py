@@ -85,11 +85,14 @@ class SyntheticFxBatcher:
                 self.ms[k] = _rng(v) if isinstance(v, dict) else v
         self.n_lfo = n_samples // 100                               # datasets.py:382
         self.lfo_sr = self.sr // 100
-        self.kind_id = torch.tensor([{"flanger": 0, "chorus": 1, "phaser": 2}[k] for k in self.kinds])
-        self.rows_fx = torch.nonzero(self.kind_id != 2).view(-1).to(torch.int32).to(device)
+        # "dry": no effect -- the wet slot carries the untouched chunk and the LFO is a label only (datasets.py:365-398 as
+        # RandomAudioChunkAndModSigDataModule uses it, data_modules.py:331-371)
+        self.kind_id = torch.tensor([{"flanger": 0, "chorus": 1, "phaser": 2, "dry": 3}[k] for k in self.kinds])
+        self.rows_fx = torch.nonzero(self.kind_id < 2).view(-1).to(torch.int32).to(device)
         self.rows_ph = torch.nonzero(self.kind_id == 2).view(-1).to(torch.int32).to(device)
         self.has_ph = bool((self.kind_id == 2).any())
-        self.has_fx = bool((self.kind_id != 2).any())
+        self.has_fx = bool((self.kind_id < 2).any())
+        self.has_dry = bool((self.kind_id == 3).any())
         self.fixed_lead = fixed_lead
         # phaser: the reference renders n + sr/rate samples and crops (datasets.py:428-449)
         self.max_lead = int(self.sr / self.ph["rate_hz"][0] + 0.5) if self.has_ph else 0
@@ -247,6 +250,8 @@ class SyntheticFxBatcher:
             mod_ph = make_mod_signals(N, self.sr, d["rate_hz"], half_pi, None, None, d["lead"], n_out=self.n_lfo)
             mod = torch.where((self.kind_id == 2).to(dev).unsqueeze(1), mod_ph, mod)
         dry, wet = self.audio[:, 0, :], self.audio[:, 1, :]
+        if self.has_dry:
+            wet.copy_(dry)                           # effect rows are overwritten below
         if self.has_fx:
             consts = {"lfo_scale": (d["width"] * self.max_lfo_delay).contiguous(),
                       "min_delay": (d["min_delay_width"] * self.max_min_delay).contiguous(),
@@ -398,6 +403,20 @@ class FlangerCPUDataModule(_SyntheticDataModule):
 class PedalboardPhaserDataModule(_SyntheticDataModule):
     """data_modules.py:259-328."""
     kinds = ("phaser",)
+
+
+class RandomAudioChunkAndModSigDataModule(_SyntheticDataModule):
+    """data_modules.py:331-371 (configs/eval_lfo_rand.yml): unprocessed chunks with random LFO labels, batches of
+    ``(None, chunk, mod_sig, fx_params)`` -- the input of the random-LFO baseline (models.RandomLFO, use_dry false)."""
+    kinds = ("dry",)
+
+    def train_batch(self):
+        _, wet, mod, params = super().train_batch()
+        return None, wet, mod, params
+
+    def val_batch(self):
+        _, wet, mod, params = super().val_batch()
+        return None, wet, mod, params
 
 
 class InterwovenDataModule(_SyntheticDataModule):

@@ -306,3 +306,36 @@ def test_log_mel_l1_metric(dev):
     assert float(fn(y.to(dev), y.to(dev))) == 0.0
     with pytest.raises(NotImplementedError):
         fn(x.to(dev).requires_grad_(True), y.to(dev))
+
+
+def test_random_chunk_and_mod_sig_data_module_with_the_random_lfo_baseline(dev):
+    """configs/eval_lfo_rand.yml's object graph: RandomAudioChunkAndModSigDataModule (data_modules.py:331-371) hands out
+    (None, unprocessed chunk, random LFO label, fx_params); LFOExtraction with models.RandomLFO and use_dry false scores a
+    perturbed-ground-truth guess against the label."""
+    from mod_extraction_amd import data_modules, lightning, models
+    torch.manual_seed(5); np.random.seed(5)
+    dm = data_modules.RandomAudioChunkAndModSigDataModule(
+        batch_size=5, n_samples=88200, sr=44100, val_num_examples_per_epoch=10,
+        fx_config={"mod_sig": {"rate_hz": {"min": 0.5, "max": 3.0}, "phase": {"min": 0.0, "max": 6.28318530718},
+                               "shapes": ["cos", "tri", "rect_cos", "inv_rect_cos", "saw", "rsaw"], "exp": 1.0}})
+    dm.setup(dev, rank=0, seed=5)
+    dry, wet, mod, params = dm.val_batch()
+    assert dry is None and wet.shape == (5, 1, 88200) and mod.shape == (5, 882)
+    assert float(wet.abs().max()) > 0.1                                   # an unprocessed chunk, not silence
+    for i in range(5):                                                    # the label is the LFO of the drawn parameters
+        ref = omod.make_mod_signal(882, 441.0, float(params["rate_hz"][i]), float(params["phase"][i]), params["shape"][i])
+        assert float((mod[i].cpu() - ref).abs().max()) < 2e-5
+    base = models.RandomLFO(345, 172.5, use_shape_gt=True, use_phase_gt=True, use_freq_gt=True, freq_min=0.5, freq_max=3.0,
+                            phase_error=0.0, freq_error=0.0)
+    module = lightning.LFOExtraction(base, sr=44100, use_dry=False, model_smooth_n_frames=0, should_stretch=False,
+                                     loss_dict={"l1": 1.0, "mse": 0.0}).to(dev).eval()
+    loss, data, _ = module.common_step((dry, wet, mod, params), is_training=False)
+    assert data["mod_sig_hat"].shape == (5, 345)
+    # ground-truth shape / phase / rate and no error: the guess is the label up to the two sampling grids (345 points at
+    # 172.5 Hz against 882 points at 441 Hz resampled), which differ around the jumps of the saw shapes
+    assert float(loss) < 0.02
+    noisy = models.RandomLFO(345, 172.5, use_shape_gt=True, use_phase_gt=True, use_freq_gt=True, phase_error=0.5,
+                             freq_error=0.25)
+    module2 = lightning.LFOExtraction(noisy, sr=44100, use_dry=False, model_smooth_n_frames=0,
+                                      loss_dict={"l1": 1.0, "mse": 0.0}).to(dev).eval()
+    assert float(module2.common_step((dry, wet, mod, params), is_training=False)[0]) > float(loss)
