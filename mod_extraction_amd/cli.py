@@ -176,13 +176,23 @@ class CustomLightningCLI:
     the host RNGs that drive the data stream are then re-seeded with ``seed + rank`` (Lightning gives each rank its
     own stream through the distributed sampler and per-worker seeds)."""
 
+    # cli.py:22-50: the reference keeps accelerator / callbacks / logger here; this loop has its checkpoint policy and
+    # logger built in, so scripts that pass `trainer_defaults=CustomLightningCLI.trainer_defaults` keep working
+    trainer_defaults: Dict[str, Any] = {}
+
     def __init__(self, args: List[str], trainer_defaults: Optional[Dict[str, Any]] = None, run: bool = True,
                  device: Optional[torch.device] = None, allow_missing_ckpt: Optional[bool] = None,
                  log_dir: str = "lightning_logs") -> None:
-        assert args and args[0] in ("fit", "validate")
-        self.subcommand = args[0]
+        assert args
+        if args[0] in ("fit", "validate"):
+            self.subcommand = args[0]
+        else:                                    # LightningCLI(run=False): build the object graph only, no subcommand
+            assert not run, "a subcommand (fit | validate) is required unless run=False"
+            self.subcommand = None
         cfg_path = args[args.index("-c") + 1] if "-c" in args else args[args.index("--config") + 1]
         self.config = apply_links(load_config(cfg_path))
+        if "--ckpt_path" in args:                # command-line override, as `validate --config c --ckpt_path p`
+            self.config["ckpt_path"] = args[args.index("--ckpt_path") + 1]
         self.seed = self.config.get("seed_everything")
         if self.seed is not None:
             seed_everything(int(self.seed))

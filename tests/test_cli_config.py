@@ -125,3 +125,21 @@ def test_reference_trained_and_model_configs_parse():
             cfg["init_args"].pop("smooth_n_frames")
         obj = cli.instantiate(cfg)
         assert type(obj).__name__ == cfg["class_path"].rsplit(".", 1)[1], path
+
+
+def test_cli_without_subcommand_builds_the_graph_only():
+    """LightningCLI(args=["-c", cfg], run=False) as scripts/extract_model_weights.py uses it; a --ckpt_path on the command
+    line overrides the config's; running without a subcommand is refused."""
+    old = os.getcwd()
+    os.chdir(os.path.join(ROOT, "scripts"))
+    try:
+        c = cli.CustomLightningCLI(args=["-c", "../configs/train_lfo_phaser.yml"], run=False, device=CPU,
+                                   trainer_defaults=cli.CustomLightningCLI.trainer_defaults)
+        assert c.subcommand is None and isinstance(c.model, lightning.LFOExtraction)
+        with pytest.raises(AssertionError):
+            cli.CustomLightningCLI(args=["-c", "../configs/train_lfo_phaser.yml"], run=True, device=CPU)
+        with pytest.raises(FileNotFoundError):
+            cli.CustomLightningCLI(args=["validate", "--config", "../configs/train_lfo_phaser.yml", "--ckpt_path",
+                                         "/nonexistent/x.ckpt"], run=False, device=CPU)
+    finally:
+        os.chdir(old)

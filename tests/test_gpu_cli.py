@@ -117,3 +117,66 @@ def test_fit_effect_model_tbptt(tmp_path, dev):
     h = c.trainer.history[0]
     for k in ("train/l1", "train/esr", "train/dc", "train/loss", "val/l1", "val/loss"):
         assert k in h and h[k] == h[k]
+
+
+def test_extract_model_weights_and_validate_ckpt_scripts(tmp_path, dev):
+    """The train -> extract -> validate workflow of the reference's scripts (extract_model_weights.py, validate_ckpt.py):
+    a TBPTT run's checkpoint and config stored as <models>/<name>.{ckpt,yml}; the effect model's weights come out as a
+    plain state dict that loads strictly into models.LSTMEffectModel and equals the trained module's, the frozen
+    extractor's likewise; `validate --ckpt_path` on the pair reports the effect-model metrics."""
+    import importlib.util
+    import shutil
+    import subprocess
+    import sys
+    from mod_extraction_amd import cli, models
+    write(tmp_path, "small_cnn.yml", MODEL)
+    cfg = write(tmp_path, "em.yml", """
+        seed_everything: 45
+        custom: {model_name: lstm_small, dataset_name: synth}
+        trainer: {max_epochs: 1, limit_train_batches: 1, limit_val_batches: 1}
+        data:
+          class_path: mod_extraction.data_modules.RandomAudioChunkDryWetDataModule
+          init_args: {batch_size: 3, train_num_examples_per_epoch: 3, val_num_examples_per_epoch: 3,
+                      n_samples: 22272, sr: 44100}
+        model:
+          class_path: mod_extraction.lightning.TBPTTLFOEffectModeling
+          init_args:
+            warmup_n_samples: 1024
+            step_n_samples: 1024
+            effect_model:
+              class_path: mod_extraction.models.LSTMEffectModel
+              init_args: {in_ch: 1, out_ch: 1, n_hidden: 64, latent_dim: 1}
+            lfo_model: small_cnn.yml
+            freeze_lfo_model: true
+            use_dry: true
+            model_smooth_n_frames: 8
+            should_stretch: false
+            discard_invalid_lfos: false
+            loss_dict: {l1: 1.0, esr: 0.0, dc: 0.0}
+        optimizer:
+          class_path: torch.optim.AdamW
+          init_args: {lr: 1e-3, betas: [0.8, 0.99]}
+    """)
+    c = cli.CustomLightningCLI(args=["fit", "-c", cfg], trainer_defaults={"log_fn": None}, log_dir=str(tmp_path / "logs"))
+    mdir = tmp_path / "models"
+    mdir.mkdir()
+    name = "lstm_small__synth__last"
+    shutil.copy(tmp_path / "logs" / "version_0" / "checkpoints" / "last.ckpt", mdir / f"{name}.ckpt")
+    shutil.copy(cfg, mdir / f"{name}.yml")
+    shutil.copy(tmp_path / "small_cnn.yml", mdir / "small_cnn.yml")
+    spec = importlib.util.spec_from_file_location("extract_model_weights", os.path.join(ROOT, "scripts", "extract_model_weights.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    for attr, want in (("effect_model", c.model.effect_model), ("lfo_model", c.model.lfo_model)):
+        pt = mod.extract(str(mdir), name, attr, device=dev)
+        sd = torch.load(pt, map_location="cpu", weights_only=True)
+        assert list(sd.keys()) == list(want.state_dict().keys())
+        for k, v in want.state_dict().items():
+            assert torch.equal(sd[k], v.cpu()), (attr, k)
+    # the last extraction wrote the extractor; the effect model's file is what lfo / effect weight paths point at
+    pt = mod.extract(str(mdir), name, "effect_model", device=dev)
+    models.LSTMEffectModel(1, 1, 64, 1).load_state_dict(torch.load(pt, map_location="cpu", weights_only=True), strict=True)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "validate_ckpt.py"), name, "--dir", str(mdir)],
+                         cwd=str(mdir), capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    assert "val/l1" in res.stdout and "val/esr" in res.stdout and "val/loss" in res.stdout
