@@ -92,6 +92,8 @@ def peak_normalize(audio: T, peak_db: float) -> T:
 class RandomAudioChunkDataset:
     """datasets.py:86-233.  Items are (1, n_samples) float32 host tensors."""
 
+    get_file_paths = staticmethod(list_files)       # datasets.py:230-241, under the reference's name
+
     def __init__(self, input_dir: str, n_samples: int, sr: float, ext: str = "wav", num_examples_per_epoch: int = 10000,
                  silence_fraction_allowed: float = 0.2, silence_threshold_energy: float = 1e-6, n_retries: int = 10,
                  check_dataset: bool = True, min_suitable_files_fraction: float = 0.5, end_buffer_n_samples: int = 0,

@@ -113,6 +113,26 @@ class MonoFlangerChorusModule(nn.Module):
         # the reference registers delay_buf / out_buf buffers (fx.py:43-44); here the delay line
         # lives in LDS for the duration of the kernel and the output is the returned tensor.
 
+    def check_param(self, param: Param, bs: int, out_n_dim: int = 2, can_be_one: bool = True) -> Param:
+        """fx.py:46-70: range check of one effect parameter ((bs,) tensor or float in [0, 1], or [0, 1) when it may not be
+        one) and its broadcast view; ``forward`` applies the same checks inside ``derive_clip_constants``."""
+        if isinstance(param, T):
+            assert param.shape == (bs,)
+            assert param.min() >= 0
+            assert param.max() <= 1.0 if can_be_one else param.max() < 1.0
+            if out_n_dim not in (2, 3):
+                raise ValueError
+            return param.view((-1,) + (1,) * (out_n_dim - 1))
+        assert param >= 0
+        assert param <= 1.0 if can_be_one else param < 1.0
+        return param
+
+    def apply_effect(self, x: T, mod_sig: T, feedback: Param, min_delay_width: Param, width: Param, depth: Param,
+                     mix: Param) -> T:
+        """fx.py:72-119 (the per-sample loop) = one kernel launch here; ``forward`` is this under no_grad, as in the
+        reference."""
+        return self.forward(x, mod_sig, feedback, min_delay_width, width, depth, mix)
+
     def forward(self, x: T, mod_sig: T, feedback: Param = 0.0, min_delay_width: Param = 1.0,
                 width: Param = 1.0, depth: Param = 1.0, mix: Param = 1.0) -> T:
         assert x.ndim == 3

@@ -67,9 +67,20 @@ class L1Loss(_SingleTerm):
 class FirstDerivativeL1Loss(_SingleTerm):
     term = "fdl1"
 
+    @staticmethod
+    def calc_first_derivative(x: T) -> T:
+        """losses.py:80-84 (analysis helper; the loss itself differentiates inside the kernel)."""
+        assert x.size(-1) > 2
+        return (x[..., 2:] - x[..., :-2]) / 2.0
+
 
 class SecondDerivativeL1Loss(_SingleTerm):
     term = "sdl1"
+
+    @staticmethod
+    def calc_second_derivative(x: T) -> T:
+        """losses.py:97-102."""
+        return FirstDerivativeL1Loss.calc_first_derivative(FirstDerivativeL1Loss.calc_first_derivative(x))
 
 
 class MSELoss(_SingleTerm):
@@ -100,6 +111,15 @@ class LogMelLoss(nn.Module):
         a = self.spectrogram.log_mel(input.detach(), n_frames, self.eps)[..., :n_frames]
         b = self.spectrogram.log_mel(target.detach(), n_frames, self.eps)[..., :n_frames]
         return (a - b).abs().mean()
+
+
+def apply_reduction(losses: T, reduction: str = "none") -> T:
+    """losses.py:133-139."""
+    if reduction == "mean":
+        return losses.mean()
+    if reduction == "sum":
+        return losses.sum()
+    return losses
 
 
 def get_loss_func_by_name(name: str) -> nn.Module:

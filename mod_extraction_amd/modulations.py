@@ -94,6 +94,46 @@ def valid_mod_sig_mask(mod_sig: T, min_top_corners: int = 1, max_top_corners: in
     return valid
 
 
+def mod_sig_to_corners(mod_sig: T, n_frames: int) -> (T, T):
+    """modulations.py:212-216: corners of the LFOs resampled to ``n_frames`` points."""
+    from . import util
+    assert mod_sig.ndim == 2
+    return find_corners(util.linear_interpolate_last_dim(mod_sig, n_frames))
+
+
+def check_mod_sig(mod_sig: T, top_corners: T, bottom_corners: T, min_top_corners: int = 1, max_top_corners: int = 6,
+                  min_bottom_corners: int = 1, max_bottom_corners: int = 6,
+                  min_fraction_between_corners: float = 0.10) -> bool:
+    """modulations.py:311-343 for ONE LFO and the corner maps the caller holds (the batched form on the device is
+    ``valid_mod_sig_mask``): corner counts within bounds and neighbouring corners of a kind at least
+    ``int(min_fraction_between_corners * n)`` frames apart."""
+    assert mod_sig.ndim == 1 and mod_sig.shape == top_corners.shape == bottom_corners.shape
+    min_gap = int(min_fraction_between_corners * mod_sig.size(0))
+    for corners, lo, hi in ((top_corners, min_top_corners, max_top_corners),
+                            (bottom_corners, min_bottom_corners, max_bottom_corners)):
+        if not lo <= int(corners.sum()) <= hi:
+            return False
+    for corners in (top_corners, bottom_corners):
+        at = torch.nonzero(corners == 1).view(-1)
+        if at.numel() > 1 and int((at[1:] - at[:-1]).min()) < min_gap:
+            return False
+    return True
+
+
+def corners_to_mod_sig(top_corners: T, bottom_corners: T) -> T:
+    """modulations.py:241-257: the triangle LFO through the corners of ONE row -- 1 at the top corners, 0 at the bottom
+    ones, straight lines in between, 0 outside the first / last corner and when either kind is absent."""
+    assert top_corners.ndim == 1 and top_corners.shape == bottom_corners.shape
+    out = torch.zeros(top_corners.shape, dtype=torch.float32, device=top_corners.device)
+    if float(top_corners.max()) == 0 or float(bottom_corners.max()) == 0:
+        return out
+    knots = sorted([(int(i), 1.0) for i in torch.nonzero(top_corners == 1).view(-1)]
+                   + [(int(i), 0.0) for i in torch.nonzero(bottom_corners == 1).view(-1)])
+    for (l, lv), (r, rv) in zip(knots[:-1], knots[1:]):
+        out[l:r + 1] = torch.linspace(lv, rv, r - l + 1, device=out.device)
+    return out
+
+
 def find_valid_mod_sig_indices(mod_sig: T) -> List[int]:
     """modulations.py:346-356 (host list, like the reference; one small D2H copy)."""
     return torch.nonzero(valid_mod_sig_mask(mod_sig)).view(-1).tolist()

@@ -111,3 +111,25 @@ def test_product_tremolo_on_the_host_matches_the_reference(golden_dir):
         fx.apply_tremolo(x, mod, 1.5)
     with pytest.raises(AssertionError):
         fx.apply_tremolo(x, mod[:2], 0.5)
+
+
+def test_corner_helpers_of_one_row():
+    """check_mod_sig / corners_to_mod_sig (modulations.py:241-257,311-343): host bookkeeping on one LFO row, checked on
+    hand-built corner maps (the batched device forms are covered by the bit-exact corner tests on the GPU)."""
+    from mod_extraction_amd import modulations as am
+    n = 40
+    top, bot = torch.zeros(n), torch.zeros(n)
+    top[[10, 30]] = 1
+    bot[[0, 20]] = 1
+    m = am.corners_to_mod_sig(top, bot)
+    assert m.shape == (n,) and float(m[10]) == 1.0 and float(m[20]) == 0.0 and float(m[30]) == 1.0
+    assert torch.allclose(m[:11], torch.linspace(0, 1, 11)) and torch.allclose(m[20:31], torch.linspace(0, 1, 11))
+    assert float(m[31:].abs().max()) == 0.0                       # nothing after the last corner
+    assert float(am.corners_to_mod_sig(top, torch.zeros(n)).abs().max()) == 0.0
+    sig = torch.rand(n)
+    assert am.check_mod_sig(sig, top, bot) is True                # 2 + 2 corners, 20 frames apart (>= int(0.1 * 40) = 4)
+    close = torch.zeros(n); close[[10, 12]] = 1
+    assert am.check_mod_sig(sig, close, bot) is False             # two top corners 2 frames apart
+    assert am.check_mod_sig(sig, torch.zeros(n), bot) is False    # no top corner
+    many = torch.zeros(n); many[::5] = 1
+    assert am.check_mod_sig(sig, many, bot) is False              # 8 top corners > 6
