@@ -28,8 +28,10 @@ CLASS_ALIASES = {"torch.optim.AdamW": "mod_extraction_amd.optim.FlatAdamW"}
 LINKS = [  # (source path, destination path) -- configs/cli_config.yml:21-45
     ("data.init_args.n_samples", "model.init_args.model.init_args.n_samples"),
     ("data.init_args.n_samples", "model.init_args.lfo_model.init_args.n_samples"),
+    ("data.init_args.n_samples", "model.init_args.param_model.init_args.n_samples"),
     ("data.init_args.shared_args.n_samples", "model.init_args.model.init_args.n_samples"),
     ("data.init_args.shared_args.n_samples", "model.init_args.lfo_model.init_args.n_samples"),
+    ("data.init_args.shared_args.n_samples", "model.init_args.param_model.init_args.n_samples"),
     ("data.init_args.sr", "model.init_args.sr"),
     ("data.init_args.shared_args.sr", "model.init_args.sr"),
     ("data.init_args.sr", "model.init_args.model.init_args.sr"),
@@ -83,12 +85,19 @@ def _get(cfg: Dict[str, Any], dotted: str) -> Any:
 
 
 def _set_if_possible(cfg: Dict[str, Any], dotted: str, value: Any) -> bool:
+    """cli.py:71-103 (link_arguments_if_possible): the destination receives the source value when it is reachable and
+    NOT already given -- a value written in the YAML stays (configs/models/baseline_rand_lfo.yml keeps its 345 frames at
+    172.5 Hz although the data module runs 88200 samples at 44.1 kHz; the reference logs "overriding" there but its
+    assignment sits in the other branch)."""
     keys = dotted.split(".")
     cur: Any = cfg
     for k in keys[:-1]:
         if not isinstance(cur, dict) or k not in cur or not isinstance(cur[k], dict):
             return False
         cur = cur[k]
+    if keys[-1] in cur and cur[keys[-1]] != value:
+        log.info("link %s: destination already set to %r, keeping it (source %r)", dotted, cur[keys[-1]], value)
+        return False
     cur[keys[-1]] = value
     return True
 

@@ -69,6 +69,8 @@ def test_reference_configs_parse(name):
     assert isinstance(inner, (models.Spectral2DCNN, models.RandomLFO))
     if isinstance(inner, models.Spectral2DCNN):
         assert inner.n_frames == 345
+    else:                                   # baseline_rand_lfo.yml: the values written in the YAML survive the links
+        assert (inner.n_samples, inner.sr) == (345, 172.5)
     if "optimizer" in cfg:
         assert cli.resolve_class(cfg["optimizer"]["class_path"]) is optim.FlatAdamW
 
@@ -143,3 +145,30 @@ def test_cli_without_subcommand_builds_the_graph_only():
                                          "/nonexistent/x.ckpt"], run=False, device=CPU)
     finally:
         os.chdir(old)
+
+
+def test_links_fill_missing_values_and_keep_explicit_ones(tmp_path):
+    """cli.py:71-103: data.n_samples / sr reach the nested model when its YAML leaves them out, and stay out of the way
+    when it sets them."""
+    import textwrap
+    base = """
+        data:
+          class_path: mod_extraction.data_modules.FlangerCPUDataModule
+          init_args: {batch_size: 2, n_samples: 22272, sr: 44100}
+        model:
+          class_path: mod_extraction.lightning.LFOExtraction
+          init_args:
+            use_dry: false
+            model:
+              class_path: mod_extraction.models.RandomLFO
+              init_args: {%s}
+    """
+    for inner, want in (("n_samples: 87, sr: 172.5", (87, 172.5)), ("sr: 172.5", (22272, 172.5)), ("", None)):
+        p = tmp_path / "c.yml"
+        p.write_text(textwrap.dedent(base % inner))
+        cfg = cli.apply_links(cli.load_config(str(p)))
+        ia = cfg["model"]["init_args"]["model"]["init_args"] or {}
+        if want is None:
+            assert ia.get("n_samples") == 22272 and ia.get("sr") == 44100
+        else:
+            assert (ia["n_samples"], ia["sr"]) == want
