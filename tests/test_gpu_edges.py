@@ -339,3 +339,42 @@ def test_random_chunk_and_mod_sig_data_module_with_the_random_lfo_baseline(dev):
     module2 = lightning.LFOExtraction(noisy, sr=44100, use_dry=False, model_smooth_n_frames=0,
                                       loss_dict={"l1": 1.0, "mse": 0.0}).to(dev).eval()
     assert float(module2.common_step((dry, wet, mod, params), is_training=False)[0]) > float(loss)
+
+
+def test_lfo_extraction_sub_batch_size_path(dev):
+    """lightning.py:160-185: with sub_batch_size the step runs the extractor on slices of the batch and averages their
+    losses.  Equal slices => the same loss and the same parameter gradients as the whole batch (same device decisions
+    on both paths), and the loss of the oracle's whole-batch step."""
+    from mod_extraction_amd import lightning, models, optim
+    from oracle import lightning as ol
+    n, sr, B = 22272, 44100, 4
+    cfg = dict(in_ch=2, n_samples=n, sr=sr, n_fft=1024, hop_len=256, n_mels=64, kernel_size=(5, 13),
+               out_channels=[64] * 6, temp_dilations=[1, 1, 2, 4, 8, 16], pool_size=(2, 1), latent_dim=1, use_ln=True)
+    ld = {"l1": 1.0, "fdl1": 5.0, "sdl1": 10.0, "mse": 0.0}
+    torch.manual_seed(21)
+    ref = om.Spectral2DCNN(**cfg).eval()
+    dry = torch.rand(B, 1, n) * 1.6 - 0.8
+    wet = (0.6 * dry + 0.3 * torch.roll(dry, 9, -1)).clamp(-1, 1)
+    mod = torch.stack([omod.make_mod_signal(882, 441.0, 0.8 + 0.7 * i, 0.5 * i, "cos") for i in range(B)])
+    params = {"rate_hz": torch.rand(B), "shape": ["cos"] * B}
+    grads, losses = [], []
+    for sub in (None, 2, 1):
+        mine = models.Spectral2DCNN(**cfg)
+        mine.load_state_dict(ref.state_dict())
+        module = lightning.LFOExtraction(mine, sr=sr, use_dry=True, model_smooth_n_frames=0, should_stretch=False,
+                                         sub_batch_size=sub, loss_dict=ld).to(dev).eval()
+        opt = optim.FlatAdamW(module.parameters(), lr=1e-4, betas=(0.8, 0.99))
+        opt.zero_grad()
+        loss = module.training_step((dry.to(dev), wet.to(dev), mod.to(dev), {"rate_hz": params["rate_hz"].to(dev),
+                                                                            "shape": params["shape"]}), 0)
+        loss.backward()
+        grads.append(opt.flat_grad.clone())
+        losses.append(float(loss.detach()))
+        if sub is not None:
+            assert len(module.logged["train/loss"]) == B // sub           # one log entry per slice
+    loss_r, _, _ = ol.lfo_common_step(ref, dry, wet, mod, ld)
+    for l in losses:
+        assert abs(l - float(loss_r.detach())) < 1e-5 * max(1.0, abs(float(loss_r.detach())))
+    scale = float(grads[0].abs().max())
+    for g in grads[1:]:
+        assert float((g - grads[0]).abs().max()) < 2e-5 * scale
