@@ -254,3 +254,38 @@ def test_bench_two_ranks_sharing_the_gpu_over_gloo(config):
     assert out["config"]["global_batch"] == 16 and out["config"]["parallelism"] == "dp2"
     assert out["value"] > 0 and "cpu_baseline" not in out      # the CPU baseline is an N = 1 leg
     assert out["roofline"]["frac"] is None or out["roofline"]["frac"] > 0
+
+
+@pytest.mark.parametrize("mode", ["lfo", "tbptt"])
+def test_two_rank_step_equals_the_single_process_step_on_the_joined_batch(tmp_path, mode):
+    """Data parallelism end to end on the real kernels: two ranks (sharing this box's GPU, collectives over gloo), each
+    with half of a fixed batch of 4 clips, take ONE optimizer step -- forward, backward, sum all-reduce of the flat
+    gradient, AdamW with the 1/world scale -- and must land on the parameters of ONE process stepping on all 4 clips
+    (every loss term is a mean over clips and LayerNorm is per clip, so the averaged gradients are the joined batch's).
+    mode "tbptt": the same for the effect-modelling batch -- four truncated-BPTT optimizer steps of the LSTM-64, one
+    all-reduce each."""
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    worker = os.path.join(root, "tests", "helpers", "ddp_equivalence_worker.py")
+    one, two = str(tmp_path / "one.pt"), str(tmp_path / "two.pt")
+    res = subprocess.run([sys.executable, worker, one, "4", mode], capture_output=True, text=True, timeout=600,
+                         env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
+    assert res.returncode == 0, res.stderr[-2000:]
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MODEX_SHARE_GPU="1", MODEX_DIST_BACKEND="gloo")
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                          "127.0.0.1", "--master-port", str(port), worker, two, "4", mode], env=env, capture_output=True, text=True,
+                         timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    a, b = torch.load(one), torch.load(two)
+    assert a["world"] == 1 and b["world"] == 2
+    moved = float((a["param"] - b["param"]).abs().max())
+    # one AdamW step moves every weight by ~lr = 1e-3; the two paths must agree to a small fraction of that
+    assert moved < (2e-5 if mode == "lfo" else 1e-4), moved      # tbptt: four Adam steps of 1e-3 each
+    if mode == "tbptt":
+        assert a["steps"] == b["steps"] == 4
+    assert abs(a["loss"] - b["loss"]) < 0.5                      # rank 0 reports its own half's loss: same order of magnitude
