@@ -44,6 +44,11 @@ def _rng(v: Any) -> Tuple[float, float]:
     return float(v[0]), float(v[1])
 
 
+def _vec(x: Any, dtype: torch.dtype = torch.float32) -> T:
+    """util.sample_* return a scalar for n = 1, as the reference's do: the batch-wide draws want a 1-element tensor then"""
+    return x.to(dtype) if isinstance(x, torch.Tensor) else torch.tensor([x], dtype=dtype)
+
+
 def _fx_from_config(cfg: Optional[Dict[str, Any]], default: Dict[str, Any]) -> Dict[str, Any]:
     out = dict(default)
     if cfg:
@@ -133,7 +138,7 @@ class SyntheticFxBatcher:
 
     # ---- host-side parameter draws -------------------------------------------------------------
     def _uniform(self, lo: float, hi: float) -> T:
-        return util.sample_uniform(lo, hi, n=self.B).float()
+        return _vec(util.sample_uniform(lo, hi, n=self.B))
 
     def _choose(self, per_kind: Dict[str, Tuple[float, float]]) -> T:
         """one vectorised draw per effect kind, merged by slot"""
@@ -186,9 +191,9 @@ class SyntheticFxBatcher:
         if self.rng_order == "reference":
             return self._sample_params_reference_order()
         B = self.B
-        rate = util.sample_log_uniform(*self.ms["rate_hz"], n=B).float()
+        rate = _vec(util.sample_log_uniform(*self.ms["rate_hz"], n=B))
         phase = self._uniform(*self.ms["phase"])
-        shape_idx = util.randint(0, len(self.ms["shapes"]), n=B)
+        shape_idx = _vec(util.randint(0, len(self.ms["shapes"]), n=B), torch.int64)
         shapes = [self.ms["shapes"][int(i)] for i in shape_idx]
         is_ph = self.kind_id == 2
         p: Dict[str, Any] = {}
@@ -201,9 +206,9 @@ class SyntheticFxBatcher:
         lead = torch.zeros(B, dtype=torch.int32)
         centre = torch.full((B,), 440.0)
         if self.has_ph:
-            ph_rate = util.sample_log_uniform(*self.ph["rate_hz"], n=B).float()   # datasets.py:429-432
+            ph_rate = _vec(util.sample_log_uniform(*self.ph["rate_hz"], n=B))   # datasets.py:429-432
             ph_depth = self._uniform(*self.ph["depth"])                           # datasets.py:460-465 order
-            centre = util.sample_log_uniform(*self.ph["centre_frequency_hz"], n=B).float()
+            centre = _vec(util.sample_log_uniform(*self.ph["centre_frequency_hz"], n=B))
             ph_fb = self._uniform(*self.ph["feedback"])
             ph_mix = self._uniform(*self.ph["mix"])
             rate = torch.where(is_ph, ph_rate, rate)

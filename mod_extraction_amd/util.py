@@ -45,4 +45,4 @@ def sample_log_uniform(low: float, high: float, n: int = 1) -> Union[float, T]:
     if low == high:
         return low if n == 1 else torch.full(size=(n,), fill_value=low)
     x = loguniform.rvs(low, high, size=n)
-    return float(x) if n == 1 else torch.from_numpy(x)
+    return float(x[0]) if n == 1 else torch.from_numpy(x)

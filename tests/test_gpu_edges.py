@@ -378,3 +378,28 @@ def test_lfo_extraction_sub_batch_size_path(dev):
     scale = float(grads[0].abs().max())
     for g in grads[1:]:
         assert float((g - grads[0]).abs().max()) < 2e-5 * scale
+
+
+@pytest.mark.parametrize("kinds", [("flanger",), ("chorus",), ("phaser",), ("dry",)])
+def test_batcher_with_a_single_clip(dev, kinds):
+    """batch_size 1: the reference's util.sample_* return scalars for n = 1 (so do the mirrors); the batch-wide draws
+    must still work, and the one clip is rendered like any other (flanger / chorus bit-exact, phaser 1e-5)."""
+    from mod_extraction_amd import data_modules
+    from oracle import lightning as ol
+    torch.manual_seed(8); np.random.seed(8)
+    n, sr = 22272, 44100
+    bt = data_modules.SyntheticFxBatcher(1, n, sr, kinds, dev, audio_seed=3)
+    params = bt.sample_params()
+    dry, wet, mod, fxp = bt.render(params)
+    assert dry.shape == wet.shape == (1, 1, n) and mod.shape == (1, n // 100)
+    assert torch.isfinite(wet).all() and torch.isfinite(mod).all()
+    if kinds[0] == "dry":
+        assert torch.equal(dry, wet)
+        return
+    d_r, w_r, m_r = ol.synth_batch(params, bt.kinds, bt.src.cpu().numpy(), n, sr, {"flanger": 1.0, "chorus": 30.0},
+                                   mod_override=mod.cpu().numpy())
+    assert torch.equal(dry.cpu(), d_r)
+    if kinds[0] == "phaser":
+        assert float((wet.cpu() - w_r).abs().max()) < 1e-5
+    else:
+        assert torch.equal(wet.cpu(), w_r)
