@@ -36,7 +36,8 @@ if mode == "tbptt":
     loss = module.training_step((dry[sl].to(dev), wet[sl].to(dev), mod[sl].to(dev), None), 0, optimizer=opt, world_size=world)
     torch.cuda.synchronize()
     if rank == 0:
-        torch.save({"param": opt.flat_param.cpu(), "loss": float(loss), "world": world, "steps": opt.step_count}, out_path)
+        torch.save({"param": opt.flat_param.cpu(), "grad": opt.flat_grad.cpu() / world, "loss": float(loss), "world": world,
+                    "steps": opt.step_count}, out_path)
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
@@ -59,7 +60,8 @@ batch = (dry[sl].to(dev), wet[sl].to(dev), mod[sl].to(dev), None)
 loss = trainer.Trainer(log_fn=None).train_step(module, opt, batch)
 torch.cuda.synchronize()
 if rank == 0:
-    torch.save({"param": opt.flat_param.cpu(), "loss": float(loss.detach()), "world": world}, out_path)
+    torch.save({"param": opt.flat_param.cpu(), "grad": opt.flat_grad.cpu() / world, "loss": float(loss.detach()), "world": world},
+               out_path)
 if world > 1:
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()

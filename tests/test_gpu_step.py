@@ -283,9 +283,13 @@ def test_two_rank_step_equals_the_single_process_step_on_the_joined_batch(tmp_pa
     assert res.returncode == 0, res.stderr[-2000:]
     a, b = torch.load(one), torch.load(two)
     assert a["world"] == 1 and b["world"] == 2
-    moved = float((a["param"] - b["param"]).abs().max())
-    # one AdamW step moves every weight by ~lr = 1e-3; the two paths must agree to a small fraction of that
-    assert moved < (2e-5 if mode == "lfo" else 1e-4), moved      # tbptt: four Adam steps of 1e-3 each
+    # the averaged gradient of the two ranks IS the joined batch's gradient (last optimizer step's, for tbptt) ...
+    g1, g2 = a["grad"], b["grad"]
+    assert float((g1 - g2).abs().max()) < (1e-5 if mode == "lfo" else 1e-3) * float(g1.abs().max())
+    # ... and so are the parameters after AdamW: every weight moves by ~lr = 1e-3 per step; compared in bulk, because
+    # Adam turns a gradient at the 1e-8 noise floor into a +-lr/2 step whose sign is rounding
+    d = (a["param"] - b["param"]).abs()
+    assert float(d.median()) < 1e-6 and float(torch.quantile(d[:: max(1, d.numel() // 100000)], 0.999)) < (2e-5 if mode == "lfo" else 1e-4)
     if mode == "tbptt":
         assert a["steps"] == b["steps"] == 4
     assert abs(a["loss"] - b["loss"]) < 0.5                      # rank 0 reports its own half's loss: same order of magnitude
