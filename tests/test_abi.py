@@ -64,3 +64,20 @@ def test_product_never_imports_oracle():
                 src = open(os.path.join(d, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
                 assert "liboracle_ref" not in src, f
+
+
+def test_entry_points_reject_bad_arguments_before_touching_the_device(so_path):
+    """Every entry point validates its arguments first and returns MX_ERR_ARG / MX_ERR_UNSUPPORTED (never throws, never
+    launches): NULL pointers and non-positive sizes are refused here on a box without a GPU."""
+    from mod_extraction_amd import _hip
+    lib = _hip.load()
+    zeros = {ctypes.c_void_p: None, ctypes.c_int64: 0, ctypes.c_int32: 0, ctypes.c_float: 0.0, ctypes.c_double: 0.0}
+    skip = {"mx_abi_version", "mx_set_probe_mode"}
+    checked = 0
+    for name, argtypes in _hip.SIGNATURES.items():
+        if name in skip:
+            continue
+        rc = getattr(lib, name)(*[zeros[t] for t in argtypes])
+        assert rc in (-1, -2), (name, rc)                     # MX_ERR_ARG or MX_ERR_UNSUPPORTED
+        checked += 1
+    assert checked >= 40

@@ -403,3 +403,48 @@ def test_batcher_with_a_single_clip(dev, kinds):
         assert float((wet.cpu() - w_r).abs().max()) < 1e-5
     else:
         assert torch.equal(wet.cpu(), w_r)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 63, 64, 65, 882])
+def test_lfo_and_interpolation_at_tiny_lengths(dev, n):
+    """K1 + util.linear_interpolate_last_dim on rows as short as one point, against the oracle: phase bookkeeping shapes
+    bit-exact, cosine family 1e-5; interpolation (align_corners) bit-exact, including n_in = 1 / n_out = 1."""
+    from mod_extraction_amd import modulations as am, util as autil
+    from oracle import util as outil
+    for shape in ("tri", "saw", "rsaw"):
+        want = omod.make_mod_signal(n, 441.0, 2.7, 0.9, shape)
+        got = am.make_mod_signal(n, 441.0, 2.7, 0.9, shape, device=dev).cpu()
+        assert torch.equal(got, want), shape
+    for shape in ("cos", "rect_cos", "inv_rect_cos", "sqr"):
+        want = omod.make_mod_signal(n, 441.0, 2.7, 0.9, shape)
+        got = am.make_mod_signal(n, 441.0, 2.7, 0.9, shape, device=dev).cpu()
+        assert float((got - want).abs().max()) < 1e-5, shape
+    x = torch.rand(3, n)
+    for n_out in (1, 2, 5, n, 2 * n + 1, 345):
+        if n == 1 and n_out != 1:
+            continue                                   # the reference's interpolation needs two points to stretch
+        want = outil.linear_interpolate_last_dim(x, n_out)
+        got = autil.linear_interpolate_last_dim(x.to(dev), n_out).cpu()
+        assert torch.equal(got, want), (n, n_out)
+
+
+@pytest.mark.parametrize("n", [3, 4, 5, 9, 33])
+def test_corner_kernels_on_short_rows(dev, n):
+    """K9 (find_corners, smoothen, stretch_corners, validity filter) on rows a few frames long, bit-exact against the oracle."""
+    from mod_extraction_amd import modulations as am
+    torch.manual_seed(n)
+    m = torch.rand(4, n)
+    t_o, b_o = omod.find_corners(m)
+    t_g, b_g = am.find_corners(m.to(dev))
+    assert torch.equal(t_g.cpu(), t_o.float()) and torch.equal(b_g.cpu(), b_o.float())
+    for k in (0, 2, n):
+        if 1 < k <= n:
+            got, want = am.smoothen(m.to(dev), k).cpu(), omod.smoothen(m, k)
+            if k <= 8:                                  # the windows the reference's configs use (4, 8): same summation order
+                assert torch.equal(got, want), k
+            else:                                       # torch's mean switches to a blocked sum for long rows: 1 ulp apart
+                assert float((got - want).abs().max()) < 2e-7, k
+    st_o = omod.stretch_corners(m, max_n_corners=16, smooth_n_frames=0)
+    st_g = am.stretch_corners(m.to(dev), max_n_corners=16, smooth_n_frames=0).cpu()
+    assert torch.equal(st_g, st_o)
+    assert am.find_valid_mod_sig_indices(m.to(dev)) == omod.find_valid_mod_sig_indices(m)
