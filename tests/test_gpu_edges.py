@@ -448,3 +448,40 @@ def test_corner_kernels_on_short_rows(dev, n):
     st_g = am.stretch_corners(m.to(dev), max_n_corners=16, smooth_n_frames=0).cpu()
     assert torch.equal(st_g, st_o)
     assert am.find_valid_mod_sig_indices(m.to(dev)) == omod.find_valid_mod_sig_indices(m)
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(fft_sizes=(512, 2048), hop_sizes=(128, 512), win_lengths=(512, 2048)),        # full-length windows, 75 % overlap
+    dict(fft_sizes=(2048,), hop_sizes=(2048,), win_lengths=(1024,)),                   # no overlap at all (hop = n_fft)
+    dict(fft_sizes=(1024, 1024, 512), hop_sizes=(7, 1000, 500), win_lengths=(33, 1024, 100)),   # odd hops / tiny windows
+])
+def test_mrstft_other_resolution_sets(dev, cfg):
+    """MultiResolutionSTFTLoss with resolution sets other than auraloss's defaults (the kernels take fft sizes, hops and
+    windows as arguments): value against the fp64 oracle, gradient as in tests/test_gpu_mrstft.py."""
+    from mod_extraction_amd import mrstft
+    torch.manual_seed(len(cfg["fft_sizes"]))
+    B, T = 2, 9001
+    t = torch.arange(T) / 44100.0
+    y = (0.5 * torch.sin(2 * np.pi * 330.0 * t) + 0.2 * torch.rand(B, 1, T) - 0.1).clamp(-1, 1)
+    x = (0.8 * y + 0.1 * torch.roll(y, 7, -1) + 0.05 * torch.randn(B, 1, T)).clamp(-1, 1)
+
+    class MR64(olosses.MultiResolutionSTFTLoss):
+        def _mag(self, v, n_fft, hop, win):
+            s = torch.stft(v.reshape(-1, v.size(-1)), n_fft, hop, win, torch.hann_window(win, dtype=torch.float64),
+                           return_complex=True)
+            return torch.sqrt(torch.clamp(s.real ** 2 + s.imag ** 2, min=self.eps))
+    x64 = x.double().requires_grad_(True)
+    loss64 = MR64(**cfg)(x64, y.double())
+    loss64.backward()
+    x32 = x.clone().requires_grad_(True)
+    olosses.MultiResolutionSTFTLoss(**cfg)(x32, y).backward()
+    xd = x.to(dev).requires_grad_(True)
+    loss_m = mrstft.MultiResolutionSTFTLoss(**cfg)(xd, y.to(dev))
+    loss_m.backward()
+    assert abs(float(loss_m.detach()) - float(loss64.detach())) < 1e-5 * abs(float(loss64.detach()))
+    scale = x64.grad.abs().max()
+    e_mine = float((xd.grad.cpu().double() - x64.grad).abs().max() / scale)
+    e_oracle32 = float((x32.grad.double() - x64.grad).abs().max() / scale)
+    # full-length windows make the log-magnitude term's 1 / |X| steeper still: fp32 itself (the oracle in fp32) is only good
+    # to ~3e-3 there, so the bound is the fp32 oracle's own error against fp64, not an absolute figure
+    assert e_mine < 1e-2 and e_mine < max(2.0 * e_oracle32, 1e-4), (e_mine, e_oracle32)
