@@ -135,3 +135,42 @@ def test_spectral_tcn_models_vs_oracle(dev, kind):
         assert p.grad is not None, nm
         a, b = p.grad.cpu().double(), g64[nm].grad
         assert float((a - b).abs().max() / b.abs().max().clamp_min(1e-30)) < 2e-5, nm
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,kw", [
+    ("tcn", dict(n_samples=22272, out_channels=[48, 64, 96], dilations=[1, 4, 2], kernel_size=7, latent_dim=2, use_res=True)),
+    ("tcn", dict(n_samples=30000, out_channels=[32, 32], dilations=[1, 8], kernel_size=3, use_ln=False, use_res=False)),
+    ("dstcn", dict(n_samples=22272, out_channels=[24, 40, 56], dilations=[1, 2, 4], kernel_size=5)),
+], ids=["tcn-3blocks-k7", "tcn-no-ln-no-res", "dstcn-3blocks-k5"])
+def test_spectral_tcn_other_geometries(dev, kind, kw):
+    """SpectralTCN / SpectralDSTCN away from configs/models/spectral_tcn.yml: other lengths, block counts, channel widths,
+    dilation orders, kernel sizes, with and without LayerNorm / residual branches; forward 1e-5 against the fp32 oracle,
+    gradients 2e-5 of each tensor's max against the fp64 oracle (see the test above for why fp64 arbitrates)."""
+    from mod_extraction_amd import models
+    from oracle import models as om
+    torch.manual_seed(5)
+    Ref = om.SpectralTCN if kind == "tcn" else om.SpectralDSTCN
+    Mine = models.SpectralTCN if kind == "tcn" else models.SpectralDSTCN
+    ref = Ref(**kw)
+    with torch.no_grad():
+        for b in ref.tcn.blocks:
+            b.act.weight.uniform_(0.05, 0.45)
+    mine = Mine(**kw)
+    mine.load_state_dict(ref.state_dict(), strict=True)
+    mine = mine.to(dev)
+    n = kw["n_samples"]
+    x = (0.3 * torch.sin(2 * np.pi * 330.0 * torch.arange(n) / 44100.0).view(1, 1, -1) + 0.4 * (torch.rand(3, 1, n) * 2 - 1)).clamp(-1, 1)
+    ref64 = Ref(**kw).double()
+    ref64.load_state_dict({k: v.double() for k, v in ref.state_dict().items()})
+    out_r, out_m, out_64 = ref(x), mine(x.to(dev)), ref64(x.double())
+    assert out_m.shape == out_r.shape
+    assert float((out_m.detach().cpu() - out_r.detach()).abs().max()) < 1e-5 * max(1.0, float(out_r.detach().abs().max()))
+    w = torch.linspace(0.5, 1.5, out_r.numel()).view_as(out_r)
+    (out_64 * w.double()).sum().backward()
+    (out_m * w.to(dev)).sum().backward()
+    g64 = dict(ref64.named_parameters())
+    for nm, p in mine.named_parameters():
+        assert p.grad is not None, nm
+        a, b = p.grad.cpu().double(), g64[nm].grad
+        assert float((a - b).abs().max() / b.abs().max().clamp_min(1e-30)) < 2e-5, nm
