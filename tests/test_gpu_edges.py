@@ -485,3 +485,20 @@ def test_mrstft_other_resolution_sets(dev, cfg):
     # full-length windows make the log-magnitude term's 1 / |X| steeper still: fp32 itself (the oracle in fp32) is only good
     # to ~3e-3 there, so the bound is the fp32 oracle's own error against fp64, not an absolute figure
     assert e_mine < 1e-2 and e_mine < max(2.0 * e_oracle32, 1e-4), (e_mine, e_oracle32)
+
+
+@pytest.mark.parametrize("B,T", [(1, 1), (1, 63), (3, 65), (2, 4097), (5, 1000)])
+def test_effect_loss_sums_at_odd_sizes(dev, B, T):
+    """mx_effect_loss_sums (L1 / MSE / ESR / DC of losses.py:14-67) on clips that do not fill a wavefront or a block, against
+    the oracle's torch expressions; a silent target exercises the eps of the ESR / DC denominators."""
+    from mod_extraction_amd import effect_losses
+    torch.manual_seed(B * 1000 + T)
+    y = torch.rand(B, 1, T) * 1.6 - 0.8
+    y[0] = 0.0                                              # silent target clip: denominators are eps
+    x = (0.7 * y + 0.1 * torch.randn(B, 1, T)).clamp(-1, 1)
+    got = effect_losses.effect_loss_terms(x.to(dev), y.to(dev))
+    want = {"l1": torch.nn.functional.l1_loss(x, y), "mse": torch.nn.functional.mse_loss(x, y),
+            "esr": olosses.ESRLoss()(x, y), "dc": olosses.DCLoss()(x, y)}
+    for k, v in want.items():
+        a, b = float(got[k]), float(v)
+        assert abs(a - b) <= 2e-5 * max(1.0, abs(b)), (k, a, b)
