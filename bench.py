@@ -9,9 +9,15 @@
   5                          large-batch stress: flanger render + multi-resolution STFT loss forward / backward,
                              bs = 256 x 4 s per GPU (2048 x 4 s over 8 GPUs)
 
-    python bench.py --gpus 1 --steps 100 --warmup 3 [--config 3]
+    python bench.py --gpus N --steps K --warmup W [--config 3]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+
+Outside torchrun the first form is a LAUNCHER: it never touches the GPU itself, starts the N rank processes (fresh
+children; through torch.distributed.run when N > 1) and relays rank 0's JSON line.  At N = 1 on the headline config it
+then measures configs 2 / 4 / 5 the same way (one fresh process each) and appends them as `other_configs`, so a single
+driver run carries every BASELINE configuration.  `--worker` runs one measurement in the calling process (use that
+form under rocprofv3).
 
 One step of config 2 / 3 = on-device batch synthesis (LFO synth, flanger/chorus, phaser; inputs are generated in
 HBM) -> log-mel -> 6-block 2D-CNN forward -> L1 + 5*FDL1 + 10*SDL1 loss -> backward -> gradient all-reduce (RCCL)
@@ -34,7 +40,9 @@ Extra objects in the JSON line:
   step_ms       min / median / max over the timed steps (HIP events on the main stream)
   exact_fp32_path  (config 2 / 3, N = 1) the same step with the exact-fp32 MFMA convolutions, 3 steps
   cpu_baseline  the CPU oracle (oracle/: torch fp32 + C effects, "port") timed on this host's cores on a bounded
-                sample (rank 0, N = 1 only).
+                sample (rank 0, N = 1 only); `reference_shaped` inside it = SURVEY 8d's form (B = 16, the flanger as the
+                reference's python loop per sample, timed on a short stretch and extrapolated).
+  other_configs (N = 1, config 3) value / ms / roofline / floors of configs 2, 4, 5, each measured in its own process.
 """
 import argparse
 import json
@@ -43,7 +51,7 @@ import statistics
 import sys
 import time
 
-import torch
+torch = None        # imported by the worker only: the launcher process must never initialise the GPU
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -156,11 +164,50 @@ def cpu_baseline_lfo(kinds, batch_cpu: int = 8, steps: int = 5):
         ol.lfo_train_step(model, opt, dry, wet, mod, LOSS)
         times.append(time.perf_counter() - t0)
     t = sum(times[1:]) / steps
-    return {"value": batch_cpu * N_SAMPLES / SR / t, "unit": "audio-seconds/s", "cores": cores, "kind": "port",
-            "sample": f"{steps} train steps (after 1 warm-up) of the CPU oracle on {batch_cpu} clips x 2 s, same "
-                      f"{'/'.join(kinds)} recipe; torch fp32 CNN on {cores} threads (host has {os.cpu_count()} cores; more "
-                      f"threads are slower), effects = single-threaded C restatement (faster than the reference's python "
-                      f"per-sample loop, so this baseline is conservative; SURVEY 8d asked for B = 16 on all cores)"}
+    out = {"value": batch_cpu * N_SAMPLES / SR / t, "unit": "audio-seconds/s", "cores": cores, "kind": "port",
+           "sample": f"{steps} train steps (after 1 warm-up) of the CPU oracle on {batch_cpu} clips x 2 s, same "
+                     f"{'/'.join(kinds)} recipe; torch fp32 CNN on {cores} threads (host has {os.cpu_count()} cores; more "
+                     f"threads are slower), effects = single-threaded C restatement (faster than the reference's python "
+                     f"per-sample loop, so this baseline is conservative; `reference_shaped` is the SURVEY 8d form)"}
+    out["reference_shaped"] = cpu_reference_shaped(kinds, model, opt, cores)
+    return out
+
+
+def cpu_reference_shaped(kinds, model, opt, cores, batch_cpu: int = 16, n_probe: int = 4410):
+    """SURVEY 8d's CPU baseline: B = 16, the flanger / chorus rendered the way the reference renders them -- one python
+    iteration of tiny torch ops per sample (oracle.fx.flanger_torch_loop, the execution shape of fx.py:104-115) -- timed on
+    `n_probe` samples per effect and extrapolated linearly to 88200 (the loop's cost per sample does not depend on the
+    position), plus ONE measured oracle step (phaser in C as pedalboard is, torch fp32 CNN forward / backward / AdamW)."""
+    from oracle import fx as ofx, lightning as ol
+    from mod_extraction_amd.data_modules import SyntheticFxBatcher
+    sampler = SyntheticFxBatcher(batch_cpu, N_SAMPLES, SR, kinds, torch.device("cpu"))
+    p = sampler.sample_params()
+    src = (torch.rand(batch_cpu, N_SAMPLES + sampler.max_lead) * 2 - 1).mul_(sampler.peak).numpy()
+    t0 = time.perf_counter()
+    dry, wet, mod = ol.synth_batch(p, sampler.kinds, src, N_SAMPLES, SR, {"flanger": 1.0, "chorus": 30.0})
+    t_synth_c = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    ol.lfo_train_step(model, opt, dry, wet, mod, LOSS)
+    t_step = time.perf_counter() - t0
+    loop_s, per_sample_us = 0.0, {}
+    for kind, max_min_ms in (("flanger", 1.0), ("chorus", 30.0)):
+        rows = [i for i, k in enumerate(sampler.kinds) if k == kind]
+        if not rows:
+            continue
+        x = dry[rows, :, :n_probe]
+        lfo = torch.rand(len(rows), n_probe)
+        par = [torch.as_tensor(p[k])[rows].float() for k in ("feedback", "min_delay_width", "width", "depth", "mix")]
+        t0 = time.perf_counter()
+        ofx.flanger_torch_loop(x, lfo, ofx.delay_samples(max_min_ms, SR), ofx.delay_samples(10.0, SR), *par)
+        dt = time.perf_counter() - t0
+        per_sample_us[kind] = round(1e6 * dt / n_probe, 1)
+        loop_s += dt * N_SAMPLES / n_probe
+    total = t_step + t_synth_c + loop_s
+    return {"value": batch_cpu * N_SAMPLES / SR / total, "unit": "audio-seconds/s", "cores": cores, "kind": "port",
+            "batch": batch_cpu, "python_loop_us_per_sample": per_sample_us, "seconds": {"cnn_step": round(t_step, 2),
+            "effects_in_c": round(t_synth_c, 2), "python_sample_loops_extrapolated": round(loop_s, 2)},
+            "sample": f"B = {batch_cpu} x 2 s: one oracle train step (torch fp32 CNN on {cores} threads) + the per-sample python "
+                      f"loop of fx.py:104-115 timed on {n_probe} samples per effect module and extrapolated x{N_SAMPLES // n_probe}"}
 
 
 def conv_key(name, a):
@@ -378,15 +425,46 @@ def run_config4(args, env):
     torch.manual_seed(44); np.random.seed(44)          # same initial weights on every rank, then per-rank data streams
     cnn = models.Spectral2DCNN(**CNN_CFG)
     em = models.LSTMEffectModel()
-    mod = lightning.TBPTTLFOEffectModeling(W, S, em, lfo_model=cnn, discard_invalid_lfos=False,
-                                           loss_dict={"l1": 1.0, "esr": 0.0, "dc": 0.0}).to(device).train()
+    # configs/train_em_dry_wet.yml: model_smooth_n_frames 8, should_stretch true, discard_invalid_lfos true.  No pretrained
+    # extractor exists in this image and an untrained CNN's output has no valid row at all, so the frozen CNN's forward runs
+    # in full and its output is then overwritten with the ground-truth LFO + 1 % noise (what a trained extractor delivers):
+    # the validity filter, the row gather and the ragged batch B' <= B are exercised as in a real run.  --em-no-discard
+    # gives the round-1/2 form (random extractor output, every row kept).
+    class KnownAnswerExtractor(torch.nn.Module):
+        def __init__(self, net):
+            super().__init__()
+            self.net, self.answer = net, None
+            self.n_frames = net.n_frames
+
+        def forward(self, x):
+            hat, latent = self.net(x)
+            if self.answer is not None:
+                tgt = util.linear_interpolate_last_dim(self.answer, hat.size(-1), align_corners=True).unsqueeze(1)
+                hat = (tgt + 0.01 * (torch.rand_like(tgt) - 0.5)).clamp_(0.0, 1.0) + 0.0 * hat
+            return hat, latent
+
+    from mod_extraction_amd import util
+    discard = not args.em_no_discard
+    extractor = KnownAnswerExtractor(cnn) if discard else cnn
+    loss_dict = {"l1": 0.0, "esr": 0.0, "dc": 0.0}
+    for item in args.em_loss.split(","):
+        name, _, w = item.partition("=")
+        loss_dict[name.strip()] = float(w) if w else 1.0
+    mod = lightning.TBPTTLFOEffectModeling(W, S, em, lfo_model=extractor, discard_invalid_lfos=discard, should_stretch=True,
+                                           model_smooth_n_frames=8, loss_dict=loss_dict).to(device).train()
     opt = optim.FlatAdamW([p for p in mod.parameters() if p.requires_grad], lr=1e-4, betas=(0.8, 0.99))
     sync_replicas(opt)
     torch.manual_seed(44 + rank); np.random.seed(44 + rank)
     bt = data_modules.SyntheticFxBatcher(B, N_SAMPLES, SR, cfg["kinds"], device, audio_seed=44 + rank,
                                          overlap=not args.no_overlap)
     # the batch render and the FROZEN extractor's forward run one batch ahead on the side stream
-    bt.ahead_fn = lambda b: mod.prepare_ahead((b[0], b[1], None, None))
+    def ahead(b):
+        if discard:
+            extractor.answer = b[2]
+        return mod.prepare_ahead((b[0], b[1], None, None))
+
+    bt.ahead_fn = ahead
+    kept = []
     n_chunks = (int((338 / 345) * N_SAMPLES) - W) // S
     # the latency-bound recurrence and the prefetch work on disjoint XCDs (mod_extraction_amd/streams.py), as in Trainer.fit
     from mod_extraction_amd import streams
@@ -398,11 +476,14 @@ def run_config4(args, env):
 
     def step():
         dry, wet, _, _ = bt.next_batch()
-        return mod.training_step((dry, wet, None, None), 0, optimizer=opt, world_size=world, prep=bt.last_ahead)
+        out = mod.training_step((dry, wet, None, None), 0, optimizer=opt, world_size=world, prep=bt.last_ahead)
+        kept.append(mod.last_kept)
+        return out
 
     for _ in range(max(1, args.warmup)):
         step()
     mod.logged.clear()
+    kept.clear()
     names = {"mx_lstm_fwd", "mx_lstm_bwd_l1", "mx_phaser_fwd", "mx_reduce_rows", "mx_adamw_step"}
     dt, timings, step_ms, loss = timed_loop(step, args.steps, world, device, names)
     if rank != 0:
@@ -457,7 +538,11 @@ def run_config4(args, env):
                                f"{W}-sample warm-up and {n_chunks} optimizer steps of {S} samples per batch, L1 loss, bs={B} x 2 s "
                                f"@44.1 kHz per GPU, synthetic dry + this package's phaser render as the wet target",
                    "baseline_config": 4, "global_batch": world * B, "n_samples": N_SAMPLES, "parallelism": f"dp{world}",
-                   "optimizer_steps_per_batch": n_chunks,
+                   "optimizer_steps_per_batch": n_chunks, "loss_dict": loss_dict,
+                   "lfo_filter": ("model_smooth_n_frames 8, should_stretch, discard_invalid_lfos (train_em_dry_wet.yml); frozen CNN forward "
+                                  "runs in full, its output is replaced by the ground-truth LFO + 1 % noise (no pretrained extractor in "
+                                  "this image; an untrained one leaves no valid row)") if discard else "none (--em-no-discard)",
+                   "clips_trained_per_batch": {"mean": round(mean(kept), 1), "min": min(kept), "of": B},
                    "pipelining": ("batch render + frozen extractor forward of batch i+1 on a side stream under the TBPTT loop of "
                                   "batch i" + ("; recurrence on 5 XCDs, prefetch work on the other 3 (CU-masked streams)" if part is not None
                                                else "")) if not args.no_overlap else "none"},
@@ -573,7 +658,7 @@ def cpu_baseline_stress(N, batch_cpu: int = 8):
                       f"loop per sample --, torch fp32 MR-STFT forward + backward on {cores} threads)"}
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None, help="timed steps (default: 100 for config 2/3, 5 for 4, 20 for 5)")
@@ -585,13 +670,114 @@ def main():
     ap.add_argument("--conv-precision", choices=["f16x3", "f32"], default=None,
                     help="arithmetic of the 64->64 convolutions (default: the package default, f16x3)")
     ap.add_argument("--no-cu-partition", action="store_true",
-                    help="config 4: let the dispatcher place the recurrence and the prefetch work on the same XCDs")
+                    help="config 4: let the dispatcher place the recurrence and the prefetch work on the same CUs")
     ap.add_argument("--no-overlap", action="store_true",
                     help="render each batch on the main stream instead of one step ahead on a side stream")
-    args = ap.parse_args()
+    ap.add_argument("--em-loss", default="l1", help="config 4: comma list name=weight of the effect-model loss "
+                    "(default l1=1, the shipped train_em_dry_wet.yml; BASELINE's wording is 'mrstft=1')")
+    ap.add_argument("--em-no-discard", action="store_true",
+                    help="config 4: no LFO validity filter, random-init extractor output used as is (the round-1/2 form)")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="N = 1, config 3: do not append the configs 2 / 4 / 5 measurements (`other_configs`)")
+    ap.add_argument("--worker", action="store_true",
+                    help="run the measurement in THIS process (set by the launcher; use it under rocprofv3)")
+    args = ap.parse_args(argv)
     if args.steps is None:
         args.steps = {2: 100, 3: 100, 4: 5, 5: 20}[args.config]
+    return args
 
+
+# ---------------------------------------------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` outside torchrun.  This process never touches the GPU (it does not even import
+# torch); it starts fresh worker processes -- one per rank through torch.distributed.run for N > 1 -- and relays rank
+# 0's JSON line.  For the N = 1 headline it then runs the other BASELINE configurations the same way and appends
+# them to that line as `other_configs`, so one driver run carries every config.
+def _free_port() -> int:
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run_child(cmd, timeout_s):
+    """Run one worker command; returns (json dict or None, return code, stderr tail).  stderr is relayed."""
+    import subprocess
+    try:
+        res = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=timeout_s)
+    except subprocess.TimeoutExpired as e:
+        return None, 124, f"timeout after {timeout_s} s: {' '.join(cmd)}\n{(e.stderr or '')[-2000:]}"
+    if res.stderr:
+        sys.stderr.write(res.stderr)
+        sys.stderr.flush()
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    out = None
+    if lines:
+        try:
+            out = json.loads(lines[-1])
+        except ValueError:
+            out = None
+    return out, res.returncode, res.stderr[-2000:]
+
+
+def _worker_cmd(args, config, steps, extra=()):
+    cmd = ["--gpus", str(args.gpus), "--config", str(config), "--steps", str(steps), "--warmup", str(args.warmup)]
+    if args.batch:
+        cmd += ["--batch", str(args.batch)]
+    if args.conv_precision:
+        cmd += ["--conv-precision", args.conv_precision]
+    for flag in ("no_cu_partition", "no_overlap"):
+        if getattr(args, flag):
+            cmd.append("--" + flag.replace("_", "-"))
+    if args.em_loss != "l1":
+        cmd += ["--em-loss", args.em_loss]
+    if args.em_no_discard:
+        cmd.append("--em-no-discard")
+    return cmd + list(extra)
+
+
+def launch(args) -> int:
+    script = os.path.join(ROOT, "bench.py")
+    flags = (["--no-cpu-baseline"] if args.no_cpu_baseline else []) + (["--no-fp32-leg"] if args.no_fp32_leg else [])
+    if args.gpus > 1:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), script] + \
+              _worker_cmd(args, args.config, args.steps, flags)
+    else:
+        cmd = [sys.executable, script, "--worker"] + _worker_cmd(args, args.config, args.steps, flags)
+    out, rc, err = _run_child(cmd, 3000)
+    if out is None:
+        sys.stderr.write(f"bench worker failed (rc {rc})\n")
+        return rc or 1
+    if args.gpus == 1 and args.config == 3 and not args.no_other_configs and not args.batch and not args.conv_precision:
+        others = {}
+        for c, steps in ((2, 30), (4, 5), (5, 20)):
+            t0 = time.perf_counter()
+            o, rc_c, err_c = _run_child([sys.executable, script, "--worker"] +
+                                        _worker_cmd(args, c, steps, ["--no-cpu-baseline", "--no-fp32-leg"]), 900)
+            if o is None:
+                others[str(c)] = {"error": f"rc {rc_c}", "stderr_tail": err_c[-400:]}
+                continue
+            keep = {k: o[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "roofline", "step_ms",
+                                      "kernels", "fx_kernels", "fx_kernel_frac_of_serial_floor", "fx_kernel_frac_of_hbm",
+                                      "fx_kernel_frac_of_independent_floor", "ms_per_batch_by_entry_point",
+                                      "avg_launch_ms_in_step", "final_loss", "loss_variants") if k in o}
+            keep["workload"] = o["config"]["workload"]
+            keep["process_wall_s"] = round(time.perf_counter() - t0, 1)
+            others[str(c)] = keep
+        out["other_configs"] = others
+    print(json.dumps(out), flush=True)
+    return 0
+
+
+def main():
+    args = parse_args()
+    under_torchrun = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if not (args.worker or under_torchrun):
+        sys.exit(launch(args))
+
+    global torch
+    import torch as _torch
+    torch = _torch
     from mod_extraction_amd import trainer as tr
     env = tr.init_distributed()
     world = env["world_size"]

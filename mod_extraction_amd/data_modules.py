@@ -375,6 +375,12 @@ class _SyntheticDataModule:
         if self._batcher is not None:
             self._batcher.ahead_fn = fn
 
+    def pause_ahead(self, paused: bool) -> None:
+        """Validation hands out batches of the training batcher when there is no validation corpus: the prefetch hook
+        must not run for those (``validation_step`` evaluates ``prepare`` itself)."""
+        if self._batcher is not None:
+            self._batcher.ahead_fn = None if paused else self._ahead_fn
+
     def use_side_stream(self, stream) -> None:
         for b in (self._batcher, self._val_batcher):
             if b is not None:

@@ -258,9 +258,9 @@ class TBPTTLFOEffectModeling(BaseLightingModule):
                 mod_sig = self.center_crop_mod_sig(mod_sig, mod_sig_hat.size(-1))
         return mod_sig_hat, mod_sig, orig - mod_sig_hat.size(-1)
 
-    def prepare(self, batch):
-        """lightning.py:310-337: everything before the LSTM loop.  Returns None if no clip has a valid
-        LFO, else (dry, wet, mod_sig_hat, mod_sig, lfo_at_sample_rate (B',1,n'))."""
+    def _prepare_all_rows(self, batch):
+        """lightning.py:310-326 for EVERY clip of the batch, without a host synchronisation: extractor forward, smooth /
+        stretch / crop, and the validity verdict of each row as a device tensor (None when nothing is discarded)."""
         dry, wet, mod_sig, fx_params = batch
         assert dry.size(-1) == wet.size(-1) >= self.warmup_n_samples + self.step_n_samples
         lfo_in = stack_dry_wet(dry, wet) if self.use_dry else wet
@@ -270,11 +270,18 @@ class TBPTTLFOEffectModeling(BaseLightingModule):
         n_samples = int((n_frames / (n_frames + removed)) * dry.size(-1))
         dry = self.center_crop_mod_sig(dry, n_samples)
         wet = self.center_crop_mod_sig(wet, n_samples)
-        if self.discard_invalid_lfos:
-            keep = torch.nonzero(valid_mod_sig_mask(mod_sig_hat)).view(-1)
-            if keep.numel() == 0:
-                log.info("No valid LFO signals found")
-                return None
+        valid = valid_mod_sig_mask(mod_sig_hat) if self.discard_invalid_lfos else None
+        return dry, wet, mod_sig_hat, mod_sig, valid
+
+    def _select_rows(self, dry, wet, mod_sig_hat, mod_sig, keep):
+        """lightning.py:327-337: drop the clips without a valid LFO (``keep``: host index tensor or None = all rows)
+        and resample the LFOs to the audio rate."""
+        self.last_kept = dry.size(0) if keep is None else int(keep.numel())      # clips that train this batch
+        if keep is not None and keep.numel() == 0:
+            log.info("No valid LFO signals found")
+            return None
+        if keep is not None and keep.numel() < dry.size(0):
+            keep = keep.to(dry.device, non_blocking=True)
             dry, wet, mod_sig_hat = dry[keep], wet[keep], mod_sig_hat[keep]
             if mod_sig is not None:
                 mod_sig = mod_sig[keep]
@@ -282,24 +289,45 @@ class TBPTTLFOEffectModeling(BaseLightingModule):
         lfo_sr = linear_interpolate_last_dim(mod_sig_hat, dry.size(-1), align_corners=True).unsqueeze(1)
         return dry, wet, mod_sig_hat, mod_sig, lfo_sr
 
-    PREP_NONE = "no valid LFO"          # prefetched marker: prepare() ran and found nothing to train on
+    def prepare(self, batch):
+        """lightning.py:310-337: everything before the LSTM loop.  Returns None if no clip has a valid
+        LFO, else (dry, wet, mod_sig_hat, mod_sig, lfo_at_sample_rate (B',1,n'))."""
+        dry, wet, mod_sig_hat, mod_sig, valid = self._prepare_all_rows(batch)
+        keep = None if valid is None else torch.nonzero(valid.cpu()).view(-1)
+        return self._select_rows(dry, wet, mod_sig_hat, mod_sig, keep)
 
     def prepare_ahead(self, batch):
         """``prepare`` for a data module's ``set_ahead_fn``: everything before the LSTM loop depends only on the batch
         and on the FROZEN extractor, so it can run one batch ahead on the side stream (the reference gets the same
-        overlap from its DataLoader workers for the rendering; the extractor forward is prefetched on top)."""
-        out = self.prepare(batch)
-        return self.PREP_NONE if out is None else out
+        overlap from its DataLoader workers for the rendering; the extractor forward is prefetched on top).
+        It must not block the host -- the caller still has the 83 optimizer steps of the CURRENT batch to enqueue -- so
+        the row verdicts of ``discard_invalid_lfos`` travel to pinned host memory asynchronously behind an event, and
+        the gather of the surviving rows happens in ``finish_prepare`` when the batch is consumed."""
+        dry, wet, mod_sig_hat, mod_sig, valid = self._prepare_all_rows(batch)
+        prep = {"dry": dry, "wet": wet, "mod_sig_hat": mod_sig_hat, "mod_sig": mod_sig, "valid_host": None, "ready": None}
+        if valid is not None:
+            host = torch.empty(valid.shape, dtype=valid.dtype, pin_memory=True)
+            host.copy_(valid, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(valid.device))
+            prep["valid_host"], prep["ready"], prep["valid"] = host, ev, valid
+        return prep
+
+    def finish_prepare(self, prep):
+        """Second half of a prefetched ``prepare``: wait for the (long finished) verdict copy, gather the valid rows on
+        the consuming stream.  Returns what ``prepare`` returns."""
+        keep = None
+        if prep["valid_host"] is not None:
+            prep["ready"].synchronize()
+            keep = torch.nonzero(prep["valid_host"]).view(-1)
+        return self._select_rows(prep["dry"], prep["wet"], prep["mod_sig_hat"], prep["mod_sig"], keep)
 
     def common_step(self, batch, is_training: bool, optimizer=None, world_size: int = 1, prep=None):
         """lightning.py:302-419."""
         from .effect_losses import effect_loss_terms
         from .trainer import allreduce_flat_grad
         prefix = "train" if is_training else "val"
-        if prep is None:
-            prep = self.prepare(batch)
-        elif isinstance(prep, str):
-            prep = None
+        prep = self.prepare(batch) if prep is None else self.finish_prepare(prep)
         n_chunks_max = (batch[0].size(-1) - self.warmup_n_samples) // self.step_n_samples
         if prep is None:
             if is_training and world_size > 1:          # stay in lock-step with the other ranks

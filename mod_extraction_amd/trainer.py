@@ -135,8 +135,17 @@ class Trainer:
         module.eval()
         module.logged.clear()
         n = n_steps or _limit(datamodule.val_steps_per_epoch(), self.limit_val_batches)
-        for i in range(n):
-            module.validation_step(datamodule.val_batch(), i)
+        # validation_step recomputes prepare() itself: a prefetch hook left installed by fit() would run the frozen
+        # extractor a second time per batch on the side stream and throw the result away
+        pause = getattr(datamodule, "pause_ahead", None)
+        if pause is not None:
+            pause(True)
+        try:
+            for i in range(n):
+                module.validation_step(datamodule.val_batch(), i)
+        finally:
+            if pause is not None:
+                pause(False)
         out = reduce_metrics(module.logged, self.env["world_size"], metric_names(module, "val"))
         module.logged.clear()
         return out
@@ -303,11 +312,24 @@ class CheckpointKeeper:
                                  "kth_best_model_path": self.best_path or "", "kth_value": torch.tensor(self.best),
                                  "last_model_path": last}}
 
+    def _owns(self, path: Optional[str]) -> bool:
+        """True for a file inside THIS run's checkpoint directory (the only files this keeper may delete)."""
+        if not path:
+            return False
+        mine = os.path.realpath(self.dirpath)
+        return os.path.commonpath([mine, os.path.realpath(path)]) == mine
+
     def load_state(self, callbacks: Dict[str, Any]) -> None:
+        """Resume: the best SCORE always carries over; the best PATH only when the checkpoint was written into this
+        keeper's own directory.  The CLI resumes into a fresh `version_N+1/checkpoints`, and Lightning 2.0.2's
+        ModelCheckpoint likewise drops `best_k_models` / `kth_best_model_path` when `dirpath` changed -- the earlier
+        run's files (often the very `ckpt_path` being resumed) are never this run's to delete."""
         for key, st in callbacks.items():
             if str(key).startswith("ModelCheckpoint") and st.get("best_model_score") is not None:
                 self.best = float(st["best_model_score"])
-                self.best_path = st.get("best_model_path") or None
+                path = st.get("best_model_path") or None
+                same_dir = os.path.realpath(str(st.get("dirpath") or "")) == os.path.realpath(self.dirpath)
+                self.best_path = path if (same_dir and self._owns(path)) else None
 
     def update(self, module, optimizer, epoch: int, step: int, metrics: Dict[str, float], rank: int = 0) -> None:
         if rank != 0:
@@ -315,7 +337,7 @@ class CheckpointKeeper:
         v = metrics.get("val/loss")
         improved = v is not None and v < self.best
         if improved:
-            if self.best_path and os.path.exists(self.best_path):
+            if self._owns(self.best_path) and os.path.exists(self.best_path):
                 os.remove(self.best_path)
             self.best, self.best_path = v, os.path.join(self.dirpath, self.name(epoch, step))
         kw = dict(callbacks=self.state(v), hyper_parameters=self.hyper_parameters)

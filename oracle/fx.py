@@ -131,3 +131,36 @@ def phaser_np(x: np.ndarray, rate, depth, centre, feedback, mix, sr: float, want
     _cref.lib().orc_phaser(_cref.fptr(x), *[_cref.fptr(a) for a in ps], B, N, float(sr),
                            _cref.fptr(y), _cref.fptr(lfo))
     return (y, lfo) if want_lfo else y
+
+
+def flanger_torch_loop(x: torch.Tensor, mod_sig: torch.Tensor, M_min: int, M_lfo: int, feedback: torch.Tensor,
+                       min_delay_width: torch.Tensor, width: torch.Tensor, depth: torch.Tensor,
+                       mix: torch.Tensor) -> torch.Tensor:
+    """The reference's OWN execution shape of fx.py:92-119: index tensors for the whole clip up front, then one
+    python iteration per sample, each a handful of tiny batched torch ops on the (B, 1, M) delay line.  Used only
+    (a) by bench.py's ``cpu_baseline.reference_shaped`` leg to time what the reference pays per sample, and
+    (b) by tests/test_oracle_golden.py to cross-check the C restatement (bit-identical).
+    x (B, 1, N), mod_sig (B, N), parameters (B,) fp32."""
+    B, C, N = x.shape
+    M = M_min + M_lfo
+    ring = torch.zeros(B, C, M)
+    acc = torch.zeros(B, C, N)
+    w_pos = (torch.arange(N) % M).view(1, 1, N).expand(B, C, N)
+    base = min_delay_width.view(B, 1, 1) * M_min
+    delay = (M_lfo * width.view(B, 1, 1) * mod_sig.unsqueeze(1).expand(B, C, N)) + base
+    r_pos = (w_pos - delay + M) % M
+    lo = torch.floor(r_pos)
+    frac = r_pos - lo
+    lo = lo.to(torch.long)
+    hi = (lo + 1) % M
+    fb, dp = feedback.view(B, 1), depth.view(B, 1)
+    for n in range(N):
+        dry_n = x[:, :, n]
+        a = torch.gather(ring, -1, lo[:, :, n].unsqueeze(-1)).squeeze(-1)
+        b = torch.gather(ring, -1, hi[:, :, n].unsqueeze(-1)).squeeze(-1)
+        f = frac[:, :, n]
+        tap = (f * b) + ((1.0 - f) * a)
+        ring[:, :, w_pos[0, 0, n]] = dry_n + (fb * tap)
+        acc[:, :, n] = dry_n + (dp * tap)
+    m = mix.view(B, 1, 1)
+    return torch.clip(((1.0 - m) * x) + (m * acc), -1.0, 1.0)

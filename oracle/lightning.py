@@ -85,7 +85,7 @@ def lfo_train_step(model, opt: torch.optim.Optimizer, dry: T, wet: T, mod_sig: T
     loss, terms, _ = lfo_common_step(model, dry, wet, mod_sig, loss_dict, masks=masks)
     loss.backward()
     opt.step()
-    return float(loss), {k: float(v) for k, v in terms.items()}
+    return float(loss.detach()), {k: float(v.detach()) for k, v in terms.items()}
 
 
 def tbptt_common_step(effect_model, opt: Optional[torch.optim.Optimizer], dry: T, wet: T, mod_sig_hat: T,

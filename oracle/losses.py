@@ -68,7 +68,9 @@ class MultiResolutionSTFTLoss(nn.Module):
 class LogMelLoss(nn.Module):
     """losses.py:105-130: L1 between log(clip(MelSpectrogram(x), eps)) of input and target (torchaudio MelSpectrogram
     sample_rate 44100, n_fft 1024, hop 256, 256 HTK mels, power 2, centre -- the front end of models.py restated in
-    oracle/models.py:MelFrontEnd, which the reference-held CNN fixtures pin)."""
+    oracle/models.py:MelFrontEnd.  That front end is torchaudio 0.13.1 arithmetic restated from its published
+    definition: PARITY UNPINNED -- the CNN fixtures are generated with a name-only torchaudio stub and start AFTER the
+    front end, so nothing reference-held checks the filter bank; only its torch.stft part is pinned)."""
 
     def __init__(self, sr: float = 44100, n_fft: int = 1024, hop_len: int = 256, n_mels: int = 256,
                  eps: float = 1e-7) -> None:

@@ -253,3 +253,20 @@ def make_combined_mod_sig(n_samples: int, sr: float, freq: float, phase: float, 
         length = b - a + 1
         sig[a:b + 1] = make_mod_signal(length, length, freq=1.0, phase=0.0, shape=util.choice(shapes))
     return sig
+
+
+def make_concave_convex_mod_sig(n_samples: int, sr: float, freq: float, phase: float = 0.0, concave_min: float = 0.2,
+                                concave_max: float = 1.0, convex_min: float = 1.0, convex_max: float = 3.0,
+                                concave_prob: float = 0.5) -> torch.Tensor:
+    """modulations.py:163-188: a triangle whose monotone segments are each raised to a random exponent
+    (two host draws per segment: concave or convex, then the exponent)."""
+    sig = make_mod_signal(n_samples, sr, freq, phase, shape="tri")
+    top, bot = find_corners(sig.unsqueeze(0))
+    ends = [int(c) for c in ((top + bot).squeeze(0) == 1).nonzero(as_tuple=True)[0]] + [sig.size(0)]
+    power = torch.ones_like(sig)
+    start = 0
+    for end in ends:
+        lo, hi = (concave_min, concave_max) if util.sample_uniform(0.0, 1.0) < concave_prob else (convex_min, convex_max)
+        power[start:end] = util.sample_uniform(lo, hi)
+        start = end
+    return sig ** power

@@ -121,22 +121,38 @@ def test_batch_synthesis_and_train_step(dev):
     assert opt.step_count == 1
 
 
-def test_eval_lfo_variants_vs_oracle(dev):
-    """(f) rank 2: quasi-periodic / combined / concave-convex LFOs -- same host RNG stream as the oracle
-    (which is pinned bit-exactly to the reference), device kernels for synthesis / corners / resampling."""
+def test_eval_lfo_variants_vs_reference_golden(dev, golden_dir):
+    """(f) rank 2: quasi-periodic / combined / concave-convex LFOs (modulations.py:104-210).  The PRODUCT (host control
+    flow and RNG draws in the reference's order; synthesis, corners, resampling in the device kernels) under the same
+    seeds against vectors of the REAL reference functions (tests/golden/make_golden_misc.py -> eval_lfo_variants.npz;
+    the oracle is checked against the same vectors bit for bit in tests/test_oracle_golden.py).  Lengths and section
+    boundaries must agree exactly; values to 1e-5 (device cos / pow differ from the host's in the last ulp)."""
+    import sys
+    sys.path.insert(0, golden_dir)
+    import make_golden_misc as mg
     from mod_extraction_amd import modulations as amod
-    for seed in range(4):
-        base_o = omod.make_mod_signal(882, 441.0, 2.3, 0.4, "cos")
-        base_g = amod.make_mod_signal(882, 441.0, 2.3, 0.4, "cos", device=dev)
-        torch.manual_seed(seed); q_o = omod.make_quasi_periodic(base_o.clone(), 0.1, 0.3, 0.1, 0.3)
-        torch.manual_seed(seed); q_g = amod.make_quasi_periodic(base_g.clone(), 0.1, 0.3, 0.1, 0.3)
-        assert q_g.shape == q_o.shape and float((q_g.cpu() - q_o).abs().max()) < 1e-5
-        torch.manual_seed(seed); c_o = omod.make_combined_mod_sig(882, 441.0, 2.3, 0.4, ["cos", "tri", "saw"])
-        torch.manual_seed(seed); c_g = amod.make_combined_mod_sig(882, 441.0, 2.3, 0.4, ["cos", "tri", "saw"], device=dev)
-        assert c_g.shape == c_o.shape and float((c_g.cpu() - c_o).abs().max()) < 1e-5
-    torch.manual_seed(7)
-    cc = amod.make_concave_convex_mod_sig(882, 441.0, 1.7, 0.2, device=dev)
-    assert cc.shape == (882,) and float(cc.min()) >= 0.0 and float(cc.max()) <= 1.0
+    g = np.load(os.path.join(golden_dir, "eval_lfo_variants.npz"))
+    worst = 0.0
+
+    def check(y, want, tag):
+        nonlocal worst
+        assert tuple(y.shape) == want.shape, (tag, y.shape, want.shape)
+        err = float(np.abs(y.cpu().numpy() - want).max())
+        worst = max(worst, err)
+        assert err < 1e-5, (tag, err)
+
+    for i, (seed, shape, freq, phase, l0, l1, r0, r1, split) in enumerate(mg.QUASI_CASES):
+        base = amod.make_mod_signal(882, 441.0, freq, phase, shape, device=dev)
+        torch.manual_seed(seed); np.random.seed(seed)
+        check(amod.make_quasi_periodic(base.clone(), l0, l1, r0, r1, split), g[f"quasi_{i}"], ("quasi", i))
+    for i, (seed, n, sr, freq, phase, shapes) in enumerate(mg.COMBINED_CASES):
+        torch.manual_seed(seed); np.random.seed(seed)
+        check(amod.make_combined_mod_sig(n, sr, freq, phase, list(shapes), device=dev), g[f"combined_{i}"], ("combined", i))
+    for i, (seed, n, sr, freq, phase, a0, a1, b0, b1, prob) in enumerate(mg.CONCAVE_CASES):
+        torch.manual_seed(seed); np.random.seed(seed)
+        check(amod.make_concave_convex_mod_sig(n, sr, freq, phase, a0, a1, b0, b1, prob, device=dev), g[f"concave_{i}"],
+              ("concave", i))
+    print(f"[measured] eval LFO variants vs reference vectors: max abs err {worst:.2e} (gate 1e-5)")
 
 
 def test_file_backed_batch_matches_disk_and_oracle(dev, tmp_path):
@@ -254,6 +270,41 @@ def test_bench_two_ranks_sharing_the_gpu_over_gloo(config):
     assert out["config"]["global_batch"] == 16 and out["config"]["parallelism"] == "dp2"
     assert out["value"] > 0 and "cpu_baseline" not in out      # the CPU baseline is an N = 1 leg
     assert out["roofline"]["frac"] is None or out["roofline"]["frac"] > 0
+
+
+def _run_bench(argv, env=None, timeout=900):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + argv, env=dict(os.environ, **(env or {})), cwd=root,
+                         capture_output=True, text=True, timeout=timeout)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` OUTSIDE torchrun (the form the driver uses): the launcher process starts the two rank
+    processes itself through torch.distributed.run on a free port and relays rank 0's line (two ranks on this box's one
+    GPU, collectives over gloo as in the test above)."""
+    out = _run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "8"],
+                     env={"MODEX_SHARE_GPU": "1", "MODEX_DIST_BACKEND": "gloo"})
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["config"]["global_batch"] == 16
+    assert out["value"] > 0 and "other_configs" not in out
+
+
+def test_bench_single_gpu_line_carries_every_config():
+    """N = 1: the headline line carries `roofline`, and configs 2 / 4 / 5 measured in their own processes at their
+    BASELINE sizes under `other_configs` (CPU legs skipped here to keep the test short)."""
+    out = _run_bench(["--gpus", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-fp32-leg"], timeout=1500)
+    assert out["n_gpus"] == 1 and out["config"]["baseline_config"] == 3 and out["roofline"]["frac"] > 0
+    oc = out["other_configs"]
+    assert sorted(oc) == ["2", "4", "5"]
+    for c, o in oc.items():
+        assert "error" not in o, o
+        assert o["value"] > 0 and o["ms_per_step"] > 0 and o["roofline"]["frac"] > 0, (c, o)
 
 
 @pytest.mark.parametrize("mode", ["lfo", "tbptt"])

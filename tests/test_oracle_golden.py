@@ -110,3 +110,39 @@ def test_param_stream(golden_dir):
     for name, (lo, hi) in (("feedback", (0.0, 0.7)), ("min_delay_width", (0.0, 1.0)), ("width", (0.25, 1.0)),
                            ("depth", (0.25, 1.0)), ("mix", (0.25, 1.0))):
         assert np.array_equal(outil.sample_uniform(lo, hi, n=8).numpy(), g[name])
+
+
+def test_eval_lfo_variants_bit_exact(golden_dir):
+    """(f) rank 2 -- make_quasi_periodic / make_combined_mod_sig / make_concave_convex_mod_sig (modulations.py:104-210):
+    the oracle under the same host RNG seeds against vectors of the REAL functions (make_golden_misc.py)."""
+    import sys
+    sys.path.insert(0, golden_dir)
+    import make_golden_misc as mg
+    g = load(golden_dir, "eval_lfo_variants.npz")
+    for i, (seed, shape, freq, phase, l0, l1, r0, r1, split) in enumerate(mg.QUASI_CASES):
+        base = omod.make_mod_signal(882, 441.0, freq, phase, shape)
+        torch.manual_seed(seed); np.random.seed(seed)
+        y = omod.make_quasi_periodic(base.clone(), l0, l1, r0, r1, split).numpy()
+        assert np.array_equal(y, g[f"quasi_{i}"]), ("quasi", i)
+    for i, (seed, n, sr, freq, phase, shapes) in enumerate(mg.COMBINED_CASES):
+        torch.manual_seed(seed); np.random.seed(seed)
+        y = omod.make_combined_mod_sig(n, sr, freq, phase, list(shapes)).numpy()
+        assert np.array_equal(y, g[f"combined_{i}"]), ("combined", i)
+    for i, (seed, n, sr, freq, phase, a0, a1, b0, b1, prob) in enumerate(mg.CONCAVE_CASES):
+        torch.manual_seed(seed); np.random.seed(seed)
+        y = omod.make_concave_convex_mod_sig(n, sr, freq, phase, a0, a1, b0, b1, prob).numpy()
+        assert np.array_equal(y, g[f"concave_{i}"]), ("concave", i)
+
+
+def test_python_loop_flanger_equals_c_restatement():
+    """oracle.fx.flanger_torch_loop (the reference's execution shape, used by bench.py's `reference_shaped` CPU leg)
+    and the C restatement pinned by flanger.npz give the same bits."""
+    torch.manual_seed(3)
+    B, N = 3, 1500
+    x, mod = torch.rand(B, 1, N) * 2 - 1, torch.rand(B, N)
+    ps = [torch.rand(B) * 0.7, torch.rand(B), torch.rand(B) * 0.75 + 0.25, torch.rand(B) * 0.75 + 0.25, torch.rand(B) * 0.75 + 0.25]
+    for m_min in (44, 1323):
+        y = ofx.flanger_torch_loop(x, mod, m_min, 441, *ps)
+        ref = ofx.MonoFlangerChorusModule(B, 1, N, 44100.0, m_min / 44.1, 10.0)
+        assert ref.max_min_delay_samples == m_min
+        assert torch.equal(y, ref(x, mod, *ps))

@@ -6,7 +6,7 @@ PAT=${1:-.}; BATCH=${2:-256}
 for v in A B; do
   if [ $v = A ]; then export MODEX_HIP_LIB=$PWD/mod_extraction_amd/_lib/libmodex_A.so; else unset MODEX_HIP_LIB; fi
   rm -rf gpurun_out/abp_$v
-  rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/abp_$v -- python3 bench.py --steps 2 --warmup 1 --batch $BATCH --no-cpu-baseline > gpurun_out/abp_$v.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/abp_$v -- python3 bench.py --worker --steps 2 --warmup 1 --batch $BATCH --no-cpu-baseline > gpurun_out/abp_$v.log 2>&1
   f=$(find gpurun_out/abp_$v -name "*kernel_stats.csv" | head -1)
   echo "== $v"
   python3 - "$f" "$PAT" <<'PY'

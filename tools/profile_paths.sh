@@ -1,6 +1,9 @@
 # rocprofv3 kernel statistics of the non-headline configs (tools/bench_paths.py): usage  tools/profile_paths.sh <tag>
+set -eu
+: "${1:?usage: tools/profile_paths.sh <tag>}"
+: "${GRAFT_REPO_ROOT:?run on the GPU box through gpurun}"
 export TMPDIR=/tmp
-cd $GRAFT_REPO_ROOT
+cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/$1
 rm -rf $O; mkdir -p $O
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 tools/bench_paths.py > $O/bench_paths.json 2> $O/stats.err

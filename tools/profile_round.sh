@@ -1,18 +1,21 @@
 # rocprofv3 summaries of one round (run on the GPU box through gpurun):  bash tools/profile_round.sh r02
 # kernel statistics of every BASELINE config (bench.py --config 2..5) + the PMC passes of the headline roofline kernel.
+set -eu
+: "${1:?usage: tools/profile_round.sh <rNN>}"
+: "${GRAFT_REPO_ROOT:?run on the GPU box through gpurun}"
 export TMPDIR=/tmp
-cd $GRAFT_REPO_ROOT
-R=${1:-r02}
+cd "$GRAFT_REPO_ROOT"
+R=$1
 O=gpurun_out/$R
 rm -rf $O; mkdir -p $O
 stats() { c=$1; steps=$2
-  rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c$c -- python3 bench.py --config $c --steps $steps --warmup 1 --no-cpu-baseline --no-fp32-leg > $O/bench_c${c}_under_rocprof.json 2> $O/stats_c$c.err
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c$c -- python3 bench.py --worker --config $c --steps $steps --warmup 1 --no-cpu-baseline --no-fp32-leg > $O/bench_c${c}_under_rocprof.json 2> $O/stats_c$c.err
   cp $(find $O/stats_c$c -name "*kernel_stats.csv" | head -1) $O/bench_c${c}_kernel_stats.csv
   rm -rf $O/stats_c$c
 }
 stats 3 5; stats 2 10; stats 4 2; stats 5 5
 run_pmc() { n=$1; shift
-  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $O/pmc_$n -- python3 bench.py --steps 2 --warmup 1 --batch 64 --no-cpu-baseline --no-fp32-leg > $O/pmc_$n.log 2>&1
+  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $O/pmc_$n -- python3 bench.py --worker --steps 2 --warmup 1 --batch 64 --no-cpu-baseline --no-fp32-leg > $O/pmc_$n.log 2>&1
 }
 run_pmc sq SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE
 python tools/pmc_summary.py $O/pmc_sq > $O/pmc_b64_sq.txt
