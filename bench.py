@@ -32,7 +32,7 @@ Extra objects in the JSON line:
                 forward; config 5: the MR-STFT kernels (HBM).
   kernels       the other measured launches.  The sample-recurrent kernels (flanger, phaser, LSTM forward / backward)
                 carry, next to their algorithmic HBM rate (SURVEY.md 8d bytes / HIP-event duration / 8 TB/s), a MEASURED
-                SERIAL FLOOR: the same launch with `mx_set_probe_mode(1)` -- identical LDS traffic and dependent chain,
+                SERIAL FLOOR: the same launch through its `*_probe` twin entry point -- identical LDS traffic and dependent chain,
                 no global-memory traffic inside the loop -- and `frac_of_serial_floor` = floor / real duration.
                 north_star's "fx.py recurrent kernel >= 60 % of its measured roofline" is `fx_kernel_frac_of_serial_floor`
                 (the flanger / chorus launch): for a kernel whose HBM time is 1 % of its dependency chain the chain,
@@ -268,18 +268,15 @@ def timed_loop(step, steps, world, device, timer_names, key_fn=None):
 def fx_floor_pass(batcher, params, n=3):
     """Real and probe-mode (no global traffic inside the loop) durations of the effect launches of one batch."""
     from mod_extraction_amd import _hip
+    import contextlib
     res = {}
     for mode in (0, 1):
-        _hip.call("mx_set_probe_mode", mode)
-        try:
-            with torch.no_grad():
-                batcher.render(params)
-                with _hip.KernelTimer({"mx_flanger_fwd", "mx_phaser_fwd"}) as kt:
-                    for _ in range(n):
-                        batcher.render(params)
-                res[mode] = {k: mean(v) for k, v in kt.results().items()}
-        finally:
-            _hip.call("mx_set_probe_mode", 0)
+        with (_hip.probe_twins() if mode else contextlib.nullcontext()), torch.no_grad():
+            batcher.render(params)
+            with _hip.KernelTimer({"mx_flanger_fwd", "mx_phaser_fwd"}) as kt:
+                for _ in range(n):
+                    batcher.render(params)
+            res[mode] = {k: mean(v) for k, v in kt.results().items()}
     return res
 
 
@@ -466,9 +463,9 @@ def run_config4(args, env):
     bt.ahead_fn = ahead
     kept = []
     n_chunks = (int((338 / 345) * N_SAMPLES) - W) // S
-    # the latency-bound recurrence and the prefetch work on disjoint XCDs (mod_extraction_amd/streams.py), as in Trainer.fit
+    # the latency-bound recurrence and the prefetch work on disjoint CUs (mod_extraction_amd/streams.py), as in Trainer.fit
     from mod_extraction_amd import streams
-    part = None if (args.no_overlap or args.no_cu_partition) else streams.xcd_partition(device)
+    part = None if (args.no_overlap or args.no_cu_partition) else streams.cu_partition(device, main_workgroups=B)
     if part is not None:
         bt.use_side_stream(part[1])
         part[0].wait_stream(torch.cuda.current_stream(device))
@@ -493,9 +490,9 @@ def run_config4(args, env):
     lat, wet = torch.rand(B, 1, S, device=device), torch.rand(B, 1, S, device=device) * 2 - 1
     stash, grad = torch.empty(B, S, 384, device=device), torch.zeros(models.LSTM_NPARAM, device=device)
     iso = {}
+    import contextlib
     for mode in (0, 1):
-        _hip.call("mx_set_probe_mode", mode)
-        try:
+        with (_hip.probe_twins() if mode else contextlib.nullcontext()):
             em.clear_hidden()
             y, h0, c0 = em.run_chunk(x, lat, stash)
             em.bptt_l1_chunk(x, lat, y, wet, stash, h0, c0, 1.0 / (B * S), grad)
@@ -504,8 +501,6 @@ def run_config4(args, env):
                     y, h0, c0 = em.run_chunk(x, lat, stash)
                     em.bptt_l1_chunk(x, lat, y, wet, stash, h0, c0, 1.0 / (B * S), grad)
             iso[mode] = {k: mean(v) for k, v in kt.results().items()}
-        finally:
-            _hip.call("mx_set_probe_mode", 0)
     em.clear_hidden()
     fwd_bytes = B * S * (12.0 + 1536.0)
     bwd_bytes = B * S * (1536.0 + 16.0) + B * 17473 * 4.0
@@ -544,7 +539,7 @@ def run_config4(args, env):
                                   "this image; an untrained one leaves no valid row)") if discard else "none (--em-no-discard)",
                    "clips_trained_per_batch": {"mean": round(mean(kept), 1), "min": min(kept), "of": B},
                    "pipelining": ("batch render + frozen extractor forward of batch i+1 on a side stream under the TBPTT loop of "
-                                  "batch i" + ("; recurrence on 5 XCDs, prefetch work on the other 3 (CU-masked streams)" if part is not None
+                                  "batch i" + ("; recurrence on 20 CUs of every XCD, prefetch work on the other 12 of every XCD (CU-masked streams)" if part is not None
                                                else "")) if not args.no_overlap else "none"},
         "roofline": kernels["lstm_fwd_kernel"],
         "kernels": kernels,

@@ -31,11 +31,7 @@ extern "C" {
 
 /* ABI version, bumped on any signature change. */
 int mx_abi_version(void);
-/* Measurement aid (bench.py, SURVEY.md section 8d "measured serial floor"): mode != 0 makes the sample-recurrent
- * kernels (mx_flanger_fwd, mx_phaser_fwd, mx_lstm_fwd, mx_lstm_bwd_l1) run their dependent chain without any
- * global-memory traffic inside the loop; their outputs are then meaningless.  Process-wide; 0 restores normal
- * operation.  No reference counterpart. */
-int mx_set_probe_mode(int32_t mode);
+/* The library keeps no mutable global state: every entry point is a function of its arguments and its stream. */
 
 /* ---- K1: LFO synthesis -- mod_extraction/modulations.py:16-57 (make_mod_signal) -------------
  * One row per LFO.  freq, phase, exp: (B,) float32; shape: (B,) int32 in
@@ -68,6 +64,14 @@ int mx_flanger_fwd(const float *x, int64_t x_stride, const float *mod, int64_t n
                    const float *mix, const float *one_minus_mix, const int32_t *max_delay,
                    int32_t max_delay_max, const int32_t *rows, int64_t n_rows, int64_t B, int64_t N,
                    float *y, int64_t y_stride, float *mod_up, int64_t *dbg_prev, float *dbg_frac, void *stream);
+/* Measurement twin of mx_flanger_fwd (bench.py, SURVEY.md section 8d "measured serial floor"): the same launch with NO
+ * global-memory traffic inside the sample loop (constant inputs, only the last chunk stored), i.e. the kernel's
+ * dependent chain alone.  Outputs are meaningless; never called by the product.  No reference counterpart. */
+int mx_flanger_fwd_probe(const float *x, int64_t x_stride, const float *mod, int64_t n_mod, const float *lfo_scale,
+                   const float *min_delay, const float *feedback, const float *depth,
+                   const float *mix, const float *one_minus_mix, const int32_t *max_delay,
+                   int32_t max_delay_max, const int32_t *rows, int64_t n_rows, int64_t B, int64_t N,
+                   float *y, int64_t y_stride, float *mod_up, int64_t *dbg_prev, float *dbg_frac, void *stream);
 
 /* ---- K3: phaser -- call site mod_extraction/datasets.py:455-482 (pedalboard==0.7.3 Phaser = JUCE
  * dsp::Phaser<float>: 6 first-order TPT all-pass stages + feedback, sine LFO at sr/4 on a log
@@ -81,6 +85,13 @@ int mx_flanger_fwd(const float *x, int64_t x_stride, const float *mod, int64_t n
  * inside each all-pass stage; 0 uses the algebraically identical FMA form (4-5x shorter dependency chain,
  * results within 1e-6). */
 int mx_phaser_fwd(const float *x, int64_t x_stride, const float *rate, const float *depth,
+                  const float *centre, const float *feedback, const float *mix, const int32_t *lead,
+                  const int32_t *rows, int64_t n_rows, int64_t B, int64_t N, double sr, int32_t exact_order,
+                  float *y, int64_t y_stride, float *dry_out, void *stream);
+/* Measurement twin of mx_phaser_fwd (bench.py, SURVEY.md section 8d "measured serial floor"): the same launch with NO
+ * global-memory traffic inside the sample loop (constant inputs, only the last chunk stored), i.e. the kernel's
+ * dependent chain alone.  Outputs are meaningless; never called by the product.  No reference counterpart. */
+int mx_phaser_fwd_probe(const float *x, int64_t x_stride, const float *rate, const float *depth,
                   const float *centre, const float *feedback, const float *mix, const int32_t *lead,
                   const int32_t *rows, int64_t n_rows, int64_t B, int64_t N, double sr, int32_t exact_order,
                   float *y, int64_t y_stride, float *dry_out, void *stream);
@@ -263,11 +274,25 @@ int mx_lstm_fwd(const float *x, int64_t x_stride, const float *lfo, int64_t lfo_
                 const float *w_hh, const float *b_ih, const float *b_hh, const float *fc_w, const float *fc_b,
                 const float *h_in, const float *c_in, float *h_out, float *c_out, float *y, int64_t y_stride,
                 float *stash, int64_t B, int64_t T, void *stream);
+/* Measurement twin of mx_lstm_fwd (bench.py, SURVEY.md section 8d "measured serial floor"): the same launch with NO
+ * global-memory traffic inside the sample loop (constant inputs, only the last chunk stored), i.e. the kernel's
+ * dependent chain alone.  Outputs are meaningless; never called by the product.  No reference counterpart. */
+int mx_lstm_fwd_probe(const float *x, int64_t x_stride, const float *lfo, int64_t lfo_stride, const float *w_ih,
+                const float *w_hh, const float *b_ih, const float *b_hh, const float *fc_w, const float *fc_b,
+                const float *h_in, const float *c_in, float *h_out, float *c_out, float *y, int64_t y_stride,
+                float *stash, int64_t B, int64_t T, void *stream);
 /* BPTT of one chunk with nn.L1Loss fused: loss = loss_scale * sum |y - wet| (loss_scale = w/(B*T)).
  * h_init, c_init (B,64): state at the chunk start (detached, lightning.py:383).  part (B,17473):
  * per-clip gradient rows in state-dict order [weight_ih | weight_hh | bias_ih | bias_hh | fc.weight |
  * fc.bias]; sum them with mx_reduce_rows. */
 int mx_lstm_bwd_l1(const float *x, int64_t x_stride, const float *lfo, int64_t lfo_stride, const float *y,
+                   int64_t y_stride, const float *wet, int64_t wet_stride, const float *stash,
+                   const float *w_hh, const float *fc_w, const float *h_init, const float *c_init,
+                   float loss_scale, float *part, int64_t B, int64_t T, void *stream);
+/* Measurement twin of mx_lstm_bwd_l1 (bench.py, SURVEY.md section 8d "measured serial floor"): the same launch with NO
+ * global-memory traffic inside the sample loop (constant inputs, only the last chunk stored), i.e. the kernel's
+ * dependent chain alone.  Outputs are meaningless; never called by the product.  No reference counterpart. */
+int mx_lstm_bwd_l1_probe(const float *x, int64_t x_stride, const float *lfo, int64_t lfo_stride, const float *y,
                    int64_t y_stride, const float *wet, int64_t wet_stride, const float *stash,
                    const float *w_hh, const float *fc_w, const float *h_init, const float *c_init,
                    float loss_scale, float *part, int64_t B, int64_t T, void *stream);

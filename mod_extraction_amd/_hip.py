@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # MODEX_HIP_LIB: load another build of the same library (kernel experiments); there is no non-HIP fallback
 SO_PATH = os.environ.get("MODEX_HIP_LIB") or os.path.join(_HERE, "_lib", "libmodex_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _ERR = {-1: "MX_ERR_ARG (bad argument)", -2: "MX_ERR_UNSUPPORTED (size not supported)",
         -3: "MX_ERR_LAUNCH (HIP launch error)"}
@@ -22,7 +22,6 @@ _P, _I64, _I32, _F32, _F64 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ct
 # name -> argtypes; must list every symbol include/modex_hip.h declares (tests check this)
 SIGNATURES = {
     "mx_abi_version": [],
-    "mx_set_probe_mode": [_I32],
     "mx_lfo_synth": [_P, _P, _P, _P, _P, _I64, _I64, _I64, _F32, _P, _P],
     "mx_interp_linear": [_P, _I64, _I64, _I64, _P, _P],
     "mx_flanger_fwd": [_P, _I64, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _I32, _P, _I64, _I64, _I64,
@@ -72,6 +71,11 @@ SIGNATURES = {
                        _I64, _P],
     "mx_adamw_step": [_P, _P, _P, _P, _I64, _I64, _F32, _F32, _F32, _F32, _F32, _F32, _P],
 }
+
+# measurement twins (same signatures): the dependent chain of the sample-recurrent kernels without global traffic
+PROBE_TWINS = ("mx_flanger_fwd", "mx_phaser_fwd", "mx_lstm_fwd", "mx_lstm_bwd_l1")
+for _name in PROBE_TWINS:
+    SIGNATURES[_name + "_probe"] = SIGNATURES[_name]
 
 _lib: Optional[ctypes.CDLL] = None
 
@@ -142,15 +146,33 @@ class KernelTimer:
         return out
 
 
+class probe_twins:
+    """bench.py / tools only: inside this context the four sample-recurrent entry points are routed to their
+    ``*_probe`` twins (serial-floor measurement; results are meaningless).  Host-side routing of THIS binding -- the
+    shared library itself has no mode switch."""
+    on = False
+
+    def __enter__(self):
+        probe_twins.on = True
+        return self
+
+    def __exit__(self, *exc):
+        probe_twins.on = False
+
+
 def call(name: str, *args) -> None:
     kt = KernelTimer.active
+    if probe_twins.on and name in PROBE_TWINS:
+        fn_name = name + "_probe"
+    else:
+        fn_name = name
     if kt is not None and name in kt.names:
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
-        rc = getattr(load(), name)(*args)
+        rc = getattr(load(), fn_name)(*args)
         b.record()
         kt.pairs.append((name if kt.key_fn is None else f"{name}#{kt.key_fn(name, args)}", a, b))
     else:
-        rc = getattr(load(), name)(*args)
+        rc = getattr(load(), fn_name)(*args)
     if rc != 0:
         raise HipLibraryError(f"{name} failed: {_ERR.get(rc, rc)}")

@@ -13,7 +13,6 @@
 
 #define MX_WAVE 64
 
-extern int g_mx_probe;          // abi.hip: != 0 -> serial kernels skip their global I/O (bench.py's serial-floor measurement)
 
 static inline int mx_launch_status()
 {

@@ -165,12 +165,12 @@ __global__ __launch_bounds__(64) void flanger_kernel(
 // one batch); rows: optional list of n_rows clip indices to process (others untouched).
 // Optional outputs: mod_up (B,N) resampled LFO; dbg_prev (B,N) int64 / dbg_frac (B,N) for the
 // index-parity tests.
-MX_EXPORT int mx_flanger_fwd(const float *x, int64_t x_stride, const float *mod, int64_t n_mod, const float *lfo_scale,
+static int flanger_fwd_launch(const float *x, int64_t x_stride, const float *mod, int64_t n_mod, const float *lfo_scale,
                              const float *min_delay, const float *feedback, const float *depth,
                              const float *mix, const float *one_minus_mix, const int32_t *max_delay,
                              int32_t max_delay_max, const int32_t *rows, int64_t n_rows, int64_t B,
                              int64_t N, float *y, int64_t y_stride, float *mod_up, int64_t *dbg_prev, float *dbg_frac,
-                             void *stream)
+                             void *stream, int probe)
 {
     if (!x || !mod || !lfo_scale || !min_delay || !feedback || !depth || !mix || !one_minus_mix ||
         !max_delay || !y || B <= 0 || N <= 0 || n_mod <= 0)
@@ -195,6 +195,27 @@ MX_EXPORT int mx_flanger_fwd(const float *x, int64_t x_stride, const float *mod,
     hipLaunchKernelGGL(flanger_kernel, dim3((unsigned)items), dim3(64), lds, (hipStream_t)stream, x, (long long)x_stride, mod,
                        (int)n_mod, interp_scale_host(n_mod, N), lfo_scale, min_delay, feedback, depth,
                        mix, one_minus_mix, max_delay, rows, (int)N, lfo_off, y, (long long)y_stride, mod_up, (long long *)dbg_prev,
-                       dbg_frac, g_mx_probe);
+                       dbg_frac, probe);
     return mx_launch_status();
+}
+
+MX_EXPORT int mx_flanger_fwd(const float *x, int64_t x_stride, const float *mod, int64_t n_mod, const float *lfo_scale,
+                             const float *min_delay, const float *feedback, const float *depth,
+                             const float *mix, const float *one_minus_mix, const int32_t *max_delay,
+                             int32_t max_delay_max, const int32_t *rows, int64_t n_rows, int64_t B,
+                             int64_t N, float *y, int64_t y_stride, float *mod_up, int64_t *dbg_prev, float *dbg_frac,
+                             void *stream)
+{
+    return flanger_fwd_launch(x, x_stride, mod, n_mod, lfo_scale, min_delay, feedback, depth, mix, one_minus_mix, max_delay, max_delay_max, rows, n_rows, B, N, y, y_stride, mod_up, dbg_prev, dbg_frac, stream, 0);
+}
+
+// Measurement twin (bench.py's serial floor): the SAME launch with no global-memory traffic inside the sample loop -- inputs are constants, only the last chunk is stored.  Results are meaningless; nothing in the product calls it.
+MX_EXPORT int mx_flanger_fwd_probe(const float *x, int64_t x_stride, const float *mod, int64_t n_mod, const float *lfo_scale,
+                             const float *min_delay, const float *feedback, const float *depth,
+                             const float *mix, const float *one_minus_mix, const int32_t *max_delay,
+                             int32_t max_delay_max, const int32_t *rows, int64_t n_rows, int64_t B,
+                             int64_t N, float *y, int64_t y_stride, float *mod_up, int64_t *dbg_prev, float *dbg_frac,
+                             void *stream)
+{
+    return flanger_fwd_launch(x, x_stride, mod, n_mod, lfo_scale, min_delay, feedback, depth, mix, one_minus_mix, max_delay, max_delay_max, rows, n_rows, B, N, y, y_stride, mod_up, dbg_prev, dbg_frac, stream, 1);
 }

@@ -255,10 +255,10 @@ __global__ __launch_bounds__(128 * KQ) void lstm_fwd_kernel(const float *__restr
 // entering the chunk (read only: the BPTT of the chunk needs it again), h_out / c_out (B,64): the state leaving it
 // (may alias h_in / c_in when no backward follows); y (B rows, stride ys); stash (B, T, 384) or NULL when no
 // backward follows.
-MX_EXPORT int mx_lstm_fwd(const float *x, int64_t x_stride, const float *lfo, int64_t lfo_stride, const float *w_ih,
+static int lstm_fwd_launch(const float *x, int64_t x_stride, const float *lfo, int64_t lfo_stride, const float *w_ih,
                           const float *w_hh, const float *b_ih, const float *b_hh, const float *fc_w,
                           const float *fc_b, const float *h_in, const float *c_in, float *h_out, float *c_out, float *y,
-                          int64_t y_stride, float *stash, int64_t B, int64_t T, void *stream)
+                          int64_t y_stride, float *stash, int64_t B, int64_t T, void *stream, int probe)
 {
     if (!x || !lfo || !w_ih || !w_hh || !b_ih || !b_hh || !fc_w || !fc_b || !h_in || !c_in || !h_out || !c_out || !y ||
         B <= 0 || T <= 0)
@@ -272,12 +272,29 @@ MX_EXPORT int mx_lstm_fwd(const float *x, int64_t x_stride, const float *lfo, in
     if (kq == 2)
         hipLaunchKernelGGL(lstm_fwd_kernel<2>, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, x,
                            (long long)x_stride, lfo, (long long)lfo_stride, w_ih, w_hh, b_ih, b_hh, fc_w, fc_b, h_in, c_in,
-                           h_out, c_out, y, (long long)y_stride, stash, (int)T, g_mx_probe);
+                           h_out, c_out, y, (long long)y_stride, stash, (int)T, probe);
     else
         hipLaunchKernelGGL(lstm_fwd_kernel<4>, dim3((unsigned)B), dim3(512), 0, (hipStream_t)stream, x,
                            (long long)x_stride, lfo, (long long)lfo_stride, w_ih, w_hh, b_ih, b_hh, fc_w, fc_b, h_in, c_in,
-                           h_out, c_out, y, (long long)y_stride, stash, (int)T, g_mx_probe);
+                           h_out, c_out, y, (long long)y_stride, stash, (int)T, probe);
     return mx_launch_status();
+}
+
+MX_EXPORT int mx_lstm_fwd(const float *x, int64_t x_stride, const float *lfo, int64_t lfo_stride, const float *w_ih,
+                          const float *w_hh, const float *b_ih, const float *b_hh, const float *fc_w,
+                          const float *fc_b, const float *h_in, const float *c_in, float *h_out, float *c_out, float *y,
+                          int64_t y_stride, float *stash, int64_t B, int64_t T, void *stream)
+{
+    return lstm_fwd_launch(x, x_stride, lfo, lfo_stride, w_ih, w_hh, b_ih, b_hh, fc_w, fc_b, h_in, c_in, h_out, c_out, y, y_stride, stash, B, T, stream, 0);
+}
+
+// Measurement twin (bench.py's serial floor): the SAME launch with no global-memory traffic inside the sample loop -- inputs are constants, only the last chunk is stored.  Results are meaningless; nothing in the product calls it.
+MX_EXPORT int mx_lstm_fwd_probe(const float *x, int64_t x_stride, const float *lfo, int64_t lfo_stride, const float *w_ih,
+                          const float *w_hh, const float *b_ih, const float *b_hh, const float *fc_w,
+                          const float *fc_b, const float *h_in, const float *c_in, float *h_out, float *c_out, float *y,
+                          int64_t y_stride, float *stash, int64_t B, int64_t T, void *stream)
+{
+    return lstm_fwd_launch(x, x_stride, lfo, lfo_stride, w_ih, w_hh, b_ih, b_hh, fc_w, fc_b, h_in, c_in, h_out, c_out, y, y_stride, stash, B, T, stream, 1);
 }
 
 // ---- truncated BPTT of one chunk with the L1 loss fused: the serial part --------------------------
@@ -495,10 +512,10 @@ __global__ __launch_bounds__(LS_THREADS) void lstm_bwd_kernel(const float *__res
 }
 
 // part: (B, 17473) gradient rows, one per clip, to be summed with mx_reduce_rows(part, B, 17473, ...).
-MX_EXPORT int mx_lstm_bwd_l1(const float *x, int64_t x_stride, const float *lfo, int64_t lfo_stride, const float *y,
+static int lstm_bwd_l1_launch(const float *x, int64_t x_stride, const float *lfo, int64_t lfo_stride, const float *y,
                              int64_t y_stride, const float *wet, int64_t wet_stride, const float *stash,
                              const float *w_hh, const float *fc_w, const float *h_init, const float *c_init,
-                             float loss_scale, float *part, int64_t B, int64_t T, void *stream)
+                             float loss_scale, float *part, int64_t B, int64_t T, void *stream, int probe)
 {
     if (!x || !lfo || !y || !wet || !stash || !w_hh || !fc_w || !h_init || !c_init || !part || B <= 0 || T <= 0)
         return MX_ERR_ARG;
@@ -513,6 +530,23 @@ MX_EXPORT int mx_lstm_bwd_l1(const float *x, int64_t x_stride, const float *lfo,
     }
     hipLaunchKernelGGL(lstm_bwd_kernel, dim3((unsigned)B), dim3(LS_THREADS), lds, (hipStream_t)stream, x,
                        (long long)x_stride, lfo, (long long)lfo_stride, y, (long long)y_stride, wet, (long long)wet_stride,
-                       stash, w_hh, fc_w, h_init, c_init, loss_scale, part, (int)T, g_mx_probe);
+                       stash, w_hh, fc_w, h_init, c_init, loss_scale, part, (int)T, probe);
     return mx_launch_status();
+}
+
+MX_EXPORT int mx_lstm_bwd_l1(const float *x, int64_t x_stride, const float *lfo, int64_t lfo_stride, const float *y,
+                             int64_t y_stride, const float *wet, int64_t wet_stride, const float *stash,
+                             const float *w_hh, const float *fc_w, const float *h_init, const float *c_init,
+                             float loss_scale, float *part, int64_t B, int64_t T, void *stream)
+{
+    return lstm_bwd_l1_launch(x, x_stride, lfo, lfo_stride, y, y_stride, wet, wet_stride, stash, w_hh, fc_w, h_init, c_init, loss_scale, part, B, T, stream, 0);
+}
+
+// Measurement twin (bench.py's serial floor): the SAME launch with no global-memory traffic inside the sample loop -- inputs are constants, only the last chunk is stored.  Results are meaningless; nothing in the product calls it.
+MX_EXPORT int mx_lstm_bwd_l1_probe(const float *x, int64_t x_stride, const float *lfo, int64_t lfo_stride, const float *y,
+                             int64_t y_stride, const float *wet, int64_t wet_stride, const float *stash,
+                             const float *w_hh, const float *fc_w, const float *h_init, const float *c_init,
+                             float loss_scale, float *part, int64_t B, int64_t T, void *stream)
+{
+    return lstm_bwd_l1_launch(x, x_stride, lfo, lfo_stride, y, y_stride, wet, wet_stride, stash, w_hh, fc_w, h_init, c_init, loss_scale, part, B, T, stream, 1);
 }

@@ -341,10 +341,10 @@ __global__ __launch_bounds__(128) void phaser_mat_kernel(const float *__restrict
 // dry_out (optional, same stride as y): the matching crop of the source.
 // exact_order != 0: evaluate every all-pass stage in JUCE's operation order (v = G (x - s); y = v + s;
 // s = v + y; out = 2 y - x) on the scalar kernel; 0: the algebraically identical 8 x 8 state-space step on 64 lanes.
-MX_EXPORT int mx_phaser_fwd(const float *x, int64_t x_stride, const float *rate, const float *depth,
+static int phaser_fwd_launch(const float *x, int64_t x_stride, const float *rate, const float *depth,
                             const float *centre, const float *feedback, const float *mix, const int32_t *lead,
                             const int32_t *rows, int64_t n_rows, int64_t B, int64_t N, double sr, int32_t exact_order,
-                            float *y, int64_t y_stride, float *dry_out, void *stream)
+                            float *y, int64_t y_stride, float *dry_out, void *stream, int probe)
 {
     if (!x || !rate || !depth || !centre || !feedback || !mix || !y || B <= 0 || N <= 0 || sr <= 0.0) return MX_ERR_ARG;
     if (N >= (1ll << 30)) return MX_ERR_UNSUPPORTED;
@@ -356,6 +356,23 @@ MX_EXPORT int mx_phaser_fwd(const float *x, int64_t x_stride, const float *rate,
                            feedback, mix, lead, rows, (int)items, (int)N, (float)sr, sr, y, (long long)y_stride, dry_out);
     else
         hipLaunchKernelGGL(phaser_mat_kernel, dim3((unsigned)items), dim3(128), 0, (hipStream_t)stream, x, (long long)x_stride, rate, depth,
-                           centre, feedback, mix, lead, rows, (int)items, (int)N, sr, y, (long long)y_stride, dry_out, g_mx_probe);
+                           centre, feedback, mix, lead, rows, (int)items, (int)N, sr, y, (long long)y_stride, dry_out, probe);
     return mx_launch_status();
+}
+
+MX_EXPORT int mx_phaser_fwd(const float *x, int64_t x_stride, const float *rate, const float *depth,
+                            const float *centre, const float *feedback, const float *mix, const int32_t *lead,
+                            const int32_t *rows, int64_t n_rows, int64_t B, int64_t N, double sr, int32_t exact_order,
+                            float *y, int64_t y_stride, float *dry_out, void *stream)
+{
+    return phaser_fwd_launch(x, x_stride, rate, depth, centre, feedback, mix, lead, rows, n_rows, B, N, sr, exact_order, y, y_stride, dry_out, stream, 0);
+}
+
+// Measurement twin (bench.py's serial floor): the SAME launch with no global-memory traffic inside the sample loop -- inputs are constants, only the last chunk is stored.  Results are meaningless; nothing in the product calls it.
+MX_EXPORT int mx_phaser_fwd_probe(const float *x, int64_t x_stride, const float *rate, const float *depth,
+                            const float *centre, const float *feedback, const float *mix, const int32_t *lead,
+                            const int32_t *rows, int64_t n_rows, int64_t B, int64_t N, double sr, int32_t exact_order,
+                            float *y, int64_t y_stride, float *dry_out, void *stream)
+{
+    return phaser_fwd_launch(x, x_stride, rate, depth, centre, feedback, mix, lead, rows, n_rows, B, N, sr, exact_order, y, y_stride, dry_out, stream, 1);
 }

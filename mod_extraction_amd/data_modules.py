@@ -270,7 +270,7 @@ class SyntheticFxBatcher:
         return self.audio[:, 0:1, :], self.audio[:, 1:2, :], mod, fx_params
 
     def use_side_stream(self, stream) -> None:
-        """render ahead on ``stream`` (e.g. one confined to a few XCDs, streams.xcd_partition) instead of the private one"""
+        """render ahead on ``stream`` (e.g. one confined to its own CUs, streams.cu_partition) instead of the private one"""
         if self.overlap:
             self._side = stream
 

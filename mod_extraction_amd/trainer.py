@@ -158,10 +158,10 @@ class Trainer:
         main = None
         if prefetch:
             datamodule.set_ahead_fn(module.prepare_ahead)        # frozen-extractor forward one batch ahead (side stream)
-            # the latency-bound recurrence and the prefetch work on disjoint XCDs (streams.py)
+            # the latency-bound recurrence and the prefetch work on disjoint CUs (streams.py)
             from . import streams
             dev = next(module.parameters()).device
-            part = streams.xcd_partition(dev) if dev.type == "cuda" and hasattr(datamodule, "use_side_stream") else None
+            part = streams.cu_partition(dev, main_workgroups=getattr(datamodule, "batch_size", 0)) if dev.type == "cuda" and hasattr(datamodule, "use_side_stream") else None
             if part is not None:
                 main = part[0]
                 datamodule.use_side_stream(part[1])

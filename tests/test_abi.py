@@ -72,7 +72,7 @@ def test_entry_points_reject_bad_arguments_before_touching_the_device(so_path):
     from mod_extraction_amd import _hip
     lib = _hip.load()
     zeros = {ctypes.c_void_p: None, ctypes.c_int64: 0, ctypes.c_int32: 0, ctypes.c_float: 0.0, ctypes.c_double: 0.0}
-    skip = {"mx_abi_version", "mx_set_probe_mode"}
+    skip = {"mx_abi_version"}
     checked = 0
     for name, argtypes in _hip.SIGNATURES.items():
         if name in skip:

@@ -117,3 +117,31 @@ def test_tbptt_checkpoint_prefixes(tmp_path):
     assert {k.split(".")[0] for k in sd} == {"effect_model", "lfo_model"}
     ref = om.LSTMEffectModel()
     ref.load_state_dict({k[len("effect_model."):]: v for k, v in sd.items() if k.startswith("effect_model.")}, strict=True)
+
+
+def test_resume_never_deletes_the_previous_runs_checkpoints(tmp_path):
+    """`fit --ckpt_path run1/best.ckpt` continues in a NEW version directory; the first improving epoch of
+    the resumed run must not remove run 1's best file (Lightning's ModelCheckpoint forgets best_k_models when dirpath
+    changed).  The best SCORE carries over; within one directory the old best is still replaced."""
+    torch.manual_seed(4)
+    m = small_module()
+    run1, run2 = tmp_path / "version_0" / "checkpoints", tmp_path / "version_1" / "checkpoints"
+    k1 = trainer.CheckpointKeeper(str(run1), "lfo_2dcnn", "synth")
+    k1.update(m, None, epoch=0, step=10, metrics={"val/loss": 0.5})
+    best1 = run1 / "lfo_2dcnn__synth__epoch_0_step_10.ckpt"
+    assert best1.exists()
+    t2 = trainer.Trainer(max_epochs=3, log_fn=None, checkpoints=trainer.CheckpointKeeper(str(run2), "lfo_2dcnn", "synth"))
+    trainer.resume_from_checkpoint(str(best1), m, None, t2)
+    k2 = t2.checkpoints
+    assert k2.best == 0.5 and k2.best_path is None               # the score carries over, the foreign path does not
+    k2.update(m, None, epoch=1, step=20, metrics={"val/loss": 0.6})   # not better than run 1: only last.ckpt
+    assert sorted(os.listdir(run2)) == ["last.ckpt"]
+    k2.update(m, None, epoch=2, step=30, metrics={"val/loss": 0.4})   # improves: run 1's file must survive
+    assert best1.exists() and (run1 / "last.ckpt").exists()
+    assert sorted(os.listdir(run2)) == ["last.ckpt", "lfo_2dcnn__synth__epoch_2_step_30.ckpt"]
+    k2.update(m, None, epoch=3, step=40, metrics={"val/loss": 0.3})   # own earlier best IS replaced
+    assert sorted(os.listdir(run2)) == ["last.ckpt", "lfo_2dcnn__synth__epoch_3_step_40.ckpt"]
+    # resuming INTO the same directory keeps managing that directory's best file
+    k3 = trainer.CheckpointKeeper(str(run2), "lfo_2dcnn", "synth")
+    k3.load_state(torch.load(run2 / "last.ckpt", weights_only=False)["callbacks"])
+    assert k3.best_path is not None and os.path.basename(k3.best_path) == "lfo_2dcnn__synth__epoch_3_step_40.ckpt"

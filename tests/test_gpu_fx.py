@@ -219,9 +219,9 @@ def test_apply_tremolo_vs_reference_golden(golden_dir, dev):
     assert np.array_equal(fx.apply_tremolo(x, mod, 0.0).cpu().numpy(), g["trem_y_00"])
 
 
-def test_probe_mode_is_a_measurement_switch_only(dev):
-    """mx_set_probe_mode(1) (bench.py's serial-floor measurement) drops the global traffic of the recurrent kernels;
-    mode 0 must restore exact results -- the switch is process-wide state of the library."""
+def test_probe_twins_are_separate_entry_points(dev):
+    """The serial-floor measurement of bench.py goes through `*_probe` twin entry points (same launch, no global traffic
+    in the sample loop); the library has no mode switch, so ordinary calls before, between and after are exact."""
     from mod_extraction_amd import _hip, fx as afx
     torch.manual_seed(2)
     x = torch.rand(4, 1, 30000, device=dev) * 2 - 1
@@ -229,10 +229,7 @@ def test_probe_mode_is_a_measurement_switch_only(dev):
     fl = afx.MonoFlangerChorusModule(4, 1, 30000, 44100, 1.0, 10.0)
     p = dict(feedback=0.5, min_delay_width=0.3, width=0.8, depth=0.9, mix=0.7)
     y0 = fl(x, mod, **p).clone()
-    _hip.call("mx_set_probe_mode", 1)
-    try:
+    with _hip.probe_twins():
         y1 = fl(x, mod, **p).clone()
-    finally:
-        _hip.call("mx_set_probe_mode", 0)
     y2 = fl(x, mod, **p)
     assert torch.equal(y0, y2) and not torch.equal(y0, y1)

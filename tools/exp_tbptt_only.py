@@ -37,9 +37,9 @@ def loop(n=4):
 
 
 print(f"unmasked stream            {loop():7.2f} ms per batch of 83 optimizer steps")
-main, side = streams.xcd_partition(dev)
+main, side = streams.cu_partition(dev)
 with torch.cuda.stream(main):
-    print(f"main stream of the XCD partition (5 XCDs) {loop():7.2f} ms")
+    print(f"main stream of the CU partition (160 CUs) {loop():7.2f} ms")
 # CPU time of the same loop when the GPU work is enqueued without waiting
 t0 = time.perf_counter()
 mod.training_step(batch, 0, optimizer=opt, world_size=1, prep=prep)
