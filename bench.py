@@ -418,7 +418,7 @@ def run_config4(args, env):
     rank, world = env["rank"], env["world_size"]
     device = torch.device("cuda", env["local_rank"])
     B = args.batch or cfg["batch"]
-    W = S = 1024
+    W, S = 1024, args.em_step        # train_em_dry_wet.yml: warm-up 1024, steps of 1024 samples
     torch.manual_seed(44); np.random.seed(44)          # same initial weights on every rank, then per-rank data streams
     cnn = models.Spectral2DCNN(**CNN_CFG)
     em = models.LSTMEffectModel()
@@ -481,7 +481,8 @@ def run_config4(args, env):
         step()
     mod.logged.clear()
     kept.clear()
-    names = {"mx_lstm_fwd", "mx_lstm_bwd_l1", "mx_phaser_fwd", "mx_reduce_rows", "mx_adamw_step"}
+    names = {"mx_lstm_fwd", "mx_lstm_bwd_l1", "mx_lstm_bwd", "mx_effect_loss_grad", "mx_mrstft_loss", "mx_phaser_fwd", "mx_reduce_rows",
+             "mx_adamw_step"}
     dt, timings, step_ms, loss = timed_loop(step, args.steps, world, device, names)
     if rank != 0:
         return None
@@ -670,6 +671,8 @@ def parse_args(argv=None):
                     help="render each batch on the main stream instead of one step ahead on a side stream")
     ap.add_argument("--em-loss", default="l1", help="config 4: comma list name=weight of the effect-model loss "
                     "(default l1=1, the shipped train_em_dry_wet.yml; BASELINE's wording is 'mrstft=1')")
+    ap.add_argument("--em-step", type=int, default=1024, help="config 4: samples per truncated-BPTT step (the MR-STFT loss needs "
+                    "more than 1024: its 2048-point frames are reflect-padded by 1024 samples, in the reference as well)")
     ap.add_argument("--em-no-discard", action="store_true",
                     help="config 4: no LFO validity filter, random-init extractor output used as is (the round-1/2 form)")
     ap.add_argument("--no-other-configs", action="store_true",
@@ -727,6 +730,8 @@ def _worker_cmd(args, config, steps, extra=()):
         cmd += ["--em-loss", args.em_loss]
     if args.em_no_discard:
         cmd.append("--em-no-discard")
+    if args.em_step != 1024:
+        cmd += ["--em-step", str(args.em_step)]
     return cmd + list(extra)
 
 
@@ -756,7 +761,7 @@ def launch(args) -> int:
                                       "kernels", "fx_kernels", "fx_kernel_frac_of_serial_floor", "fx_kernel_frac_of_hbm",
                                       "fx_kernel_frac_of_independent_floor", "ms_per_batch_by_entry_point",
                                       "avg_launch_ms_in_step", "final_loss", "loss_variants") if k in o}
-            keep["workload"] = o["config"]["workload"]
+            keep["config"] = o["config"]
             keep["process_wall_s"] = round(time.perf_counter() - t0, 1)
             others[str(c)] = keep
         out["other_configs"] = others

@@ -289,6 +289,13 @@ int mx_lstm_bwd_l1(const float *x, int64_t x_stride, const float *lfo, int64_t l
                    int64_t y_stride, const float *wet, int64_t wet_stride, const float *stash,
                    const float *w_hh, const float *fc_w, const float *h_init, const float *c_init,
                    float loss_scale, float *part, int64_t B, int64_t T, void *stream);
+/* The same BPTT for ANY loss -- mod_extraction/lightning.py:380-382 back-propagates whatever calc_and_log_losses returns
+ * (losses.py:142-160): dy (B rows, stride dy_stride) = d loss / d y of every output sample of the chunk, produced by
+ * mx_effect_loss_grad (L1 / MSE / ESR / DC), mx_mrstft_loss (dx) or their sum.  Other arguments as mx_lstm_bwd_l1. */
+int mx_lstm_bwd(const float *x, int64_t x_stride, const float *lfo, int64_t lfo_stride, const float *y,
+                int64_t y_stride, const float *dy, int64_t dy_stride, const float *stash, const float *w_hh,
+                const float *fc_w, const float *h_init, const float *c_init, float *part, int64_t B, int64_t T,
+                void *stream);
 /* Measurement twin of mx_lstm_bwd_l1 (bench.py, SURVEY.md section 8d "measured serial floor"): the same launch with NO
  * global-memory traffic inside the sample loop (constant inputs, only the last chunk stored), i.e. the kernel's
  * dependent chain alone.  Outputs are meaningless; never called by the product.  No reference counterpart. */
@@ -326,6 +333,12 @@ int mx_tcn_ln_bwd(const float *x, const float *dxhat, const float *stats, const 
  * part (B,4) = per-clip sums of |y - y_hat|, (y - y_hat)^2, y^2, (y - y_hat). */
 int mx_effect_loss_sums(const float *y_hat, int64_t y_hat_stride, const float *y, int64_t y_stride, int64_t B,
                         int64_t T, float *part, void *stream);
+/* d (w_l1 L1 + w_mse MSE + w_esr ESR + w_dc DC) / d y_hat ('mean' reductions; nn.L1Loss, nn.MSELoss, losses.py:33-38,
+ * 61-66) into dy (B rows, stride dy_stride); accumulate != 0 adds onto what dy holds (e.g. the MR-STFT gradient).
+ * The backward half of losses.py:142-160 for the effect model (lightning.py:380-382). */
+int mx_effect_loss_grad(const float *y_hat, int64_t y_hat_stride, const float *y, int64_t y_stride, int64_t B,
+                        int64_t T, float w_l1, float w_mse, float w_esr, float w_dc, float eps, int32_t accumulate,
+                        float *dy, int64_t dy_stride, void *stream);
 
 /* ---- K11: multi-resolution STFT loss -- mod_extraction/losses.py:155-156 (auraloss==0.4.0
  * MultiResolutionSTFTLoss(reduction="mean"), third-party: restated from its published defaults,

@@ -60,6 +60,7 @@ SIGNATURES = {
     "mx_check_mod_sig": [_P, _I64, _I64, _I32, _I32, _I32, _I32, _I32, _P, _P],
     "mx_lstm_fwd": [_P, _I64, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _I64, _I64, _P],
     "mx_lstm_bwd_l1": [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _P, _P, _P, _P, _F32, _P, _I64, _I64, _P],
+    "mx_lstm_bwd": [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _P, _P, _P, _P, _P, _I64, _I64, _P],
     "mx_sgemm_f32": [_P, _I64, _I64, _I64, _P, _I64, _I64, _I64, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I32, _P],
     "mx_tcn_im2col": [_P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _P, _P],
     "mx_tcn_col2im": [_P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _P, _P],
@@ -67,6 +68,7 @@ SIGNATURES = {
     "mx_tcn_act_bwd": [_P, _P, _P, _I64, _I64, _I64, _P, _P, _P],
     "mx_tcn_ln_bwd": [_P, _P, _P, _P, _I64, _I64, _I64, _P, _P],
     "mx_effect_loss_sums": [_P, _I64, _P, _I64, _I64, _I64, _P, _P],
+    "mx_effect_loss_grad": [_P, _I64, _P, _I64, _I64, _I64, _F32, _F32, _F32, _F32, _F32, _I32, _P, _I64, _P],
     "mx_mrstft_loss": [_P, _I64, _P, _I64, _I64, _I64, _I32, _P, _P, _P, _P, _F32, _F32, _F32, _P, _P, _P, _P, _P,
                        _I64, _P],
     "mx_adamw_step": [_P, _P, _P, _P, _I64, _I64, _F32, _F32, _F32, _F32, _F32, _F32, _P],

@@ -314,8 +314,11 @@ __global__ __launch_bounds__(LS_THREADS) void lstm_bwd_kernel(const float *__res
                                                               const float *__restrict__ fc_w,
                                                               const float *__restrict__ h_init,
                                                               const float *__restrict__ c_init, float loss_scale,
+                                                              const float *__restrict__ dy, long long dys,
                                                               float *__restrict__ part, int T, int probe)
 {
+    // d loss / d y of every step: `dy` rows when given (any loss, mx_lstm_bwd), else the fused nn.L1Loss
+    // loss_scale * sign(y - wet) (mx_lstm_bwd_l1: one launch and one (B, T) tensor less per optimizer step)
     // slab buffer = [row -1 (only its c plane: c of the step before the slab)] [32 rows of 6 planes] [row 32 (only its h
     // plane: h of the step after the slab)] ; dzy (32) ; lfo (36) ; x (36) of steps t0 .. t0 + 33
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -340,7 +343,7 @@ __global__ __launch_bounds__(LS_THREADS) void lstm_bwd_kernel(const float *__res
     const int dg_rd = rg * 4;                                  // + 64 c: the c-th 16-byte chunk of this lane's run of 16 rows
     const bool owner = rg < 8;
     const int dg_wr = ls_dg_slot(q * LS_H + k);
-    const float *yb = y + (size_t)b * ys, *wb = wet + (size_t)b * ws;
+    const float *yb = y + (size_t)b * ys, *wb = dy ? yb : wet + (size_t)b * ws;
     const float *sb = stash + (size_t)b * T * LS_STASH;
     const float *xb = x + (size_t)b * xs, *lb = lfo + (size_t)b * ls;
     // weight gradients (they do not feed the recurrence): dW_hh = sum_t dg_t (x) h_{t-1} accumulates on the otherwise idle
@@ -378,8 +381,14 @@ __global__ __launch_bounds__(LS_THREADS) void lstm_bwd_kernel(const float *__res
         if (tid >= 64 && tid < 64 + LS_SLAB) {
             const int t = t0 + tid - 64;
             if (t < T) {
-                const float yv = yb[t], e = yv - wb[t];
-                pre_dzy = loss_scale * (e > 0.0f ? 1.0f : (e < 0.0f ? -1.0f : 0.0f)) * (1.0f - yv * yv);
+                const float yv = yb[t];
+                float g;
+                if (dy) g = dy[(size_t)b * dys + t];
+                else {
+                    const float e = yv - wb[t];
+                    g = loss_scale * (e > 0.0f ? 1.0f : (e < 0.0f ? -1.0f : 0.0f));
+                }
+                pre_dzy = g * (1.0f - yv * yv);
             } else
                 pre_dzy = 0.0f;
         }
@@ -515,9 +524,9 @@ __global__ __launch_bounds__(LS_THREADS) void lstm_bwd_kernel(const float *__res
 static int lstm_bwd_l1_launch(const float *x, int64_t x_stride, const float *lfo, int64_t lfo_stride, const float *y,
                              int64_t y_stride, const float *wet, int64_t wet_stride, const float *stash,
                              const float *w_hh, const float *fc_w, const float *h_init, const float *c_init,
-                             float loss_scale, float *part, int64_t B, int64_t T, void *stream, int probe)
+                             float loss_scale, const float *dy, int64_t dy_stride, float *part, int64_t B, int64_t T, void *stream, int probe)
 {
-    if (!x || !lfo || !y || !wet || !stash || !w_hh || !fc_w || !h_init || !c_init || !part || B <= 0 || T <= 0)
+    if (!x || !lfo || !y || (!wet && !dy) || !stash || !w_hh || !fc_w || !h_init || !c_init || !part || B <= 0 || T <= 0)
         return MX_ERR_ARG;
     if (T >= (1ll << 30)) return MX_ERR_UNSUPPORTED;
     const size_t lds = (size_t)(2 * LS_SLAB_FLOATS + 768 + LS_THREADS) * sizeof(float);
@@ -530,7 +539,7 @@ static int lstm_bwd_l1_launch(const float *x, int64_t x_stride, const float *lfo
     }
     hipLaunchKernelGGL(lstm_bwd_kernel, dim3((unsigned)B), dim3(LS_THREADS), lds, (hipStream_t)stream, x,
                        (long long)x_stride, lfo, (long long)lfo_stride, y, (long long)y_stride, wet, (long long)wet_stride,
-                       stash, w_hh, fc_w, h_init, c_init, loss_scale, part, (int)T, probe);
+                       stash, w_hh, fc_w, h_init, c_init, loss_scale, dy, (long long)dy_stride, part, (int)T, probe);
     return mx_launch_status();
 }
 
@@ -539,7 +548,7 @@ MX_EXPORT int mx_lstm_bwd_l1(const float *x, int64_t x_stride, const float *lfo,
                              const float *w_hh, const float *fc_w, const float *h_init, const float *c_init,
                              float loss_scale, float *part, int64_t B, int64_t T, void *stream)
 {
-    return lstm_bwd_l1_launch(x, x_stride, lfo, lfo_stride, y, y_stride, wet, wet_stride, stash, w_hh, fc_w, h_init, c_init, loss_scale, part, B, T, stream, 0);
+    return lstm_bwd_l1_launch(x, x_stride, lfo, lfo_stride, y, y_stride, wet, wet_stride, stash, w_hh, fc_w, h_init, c_init, loss_scale, nullptr, 0, part, B, T, stream, 0);
 }
 
 // Measurement twin (bench.py's serial floor): the SAME launch with no global-memory traffic inside the sample loop -- inputs are constants, only the last chunk is stored.  Results are meaningless; nothing in the product calls it.
@@ -548,5 +557,19 @@ MX_EXPORT int mx_lstm_bwd_l1_probe(const float *x, int64_t x_stride, const float
                              const float *w_hh, const float *fc_w, const float *h_init, const float *c_init,
                              float loss_scale, float *part, int64_t B, int64_t T, void *stream)
 {
-    return lstm_bwd_l1_launch(x, x_stride, lfo, lfo_stride, y, y_stride, wet, wet_stride, stash, w_hh, fc_w, h_init, c_init, loss_scale, part, B, T, stream, 1);
+    return lstm_bwd_l1_launch(x, x_stride, lfo, lfo_stride, y, y_stride, wet, wet_stride, stash, w_hh, fc_w, h_init, c_init, loss_scale, nullptr, 0, part, B, T, stream, 1);
+}
+
+
+// The same truncated BPTT for ANY loss (lightning.py:380-382 back-propagates whatever calc_and_log_losses returns:
+// losses.py:142-160): dy (B rows, stride dy_stride) = d loss / d y of every output sample, evaluated by the caller
+// (mx_effect_loss_grad for L1 / MSE / ESR / DC, mx_mrstft_loss for the multi-resolution STFT loss, or their sum).
+MX_EXPORT int mx_lstm_bwd(const float *x, int64_t x_stride, const float *lfo, int64_t lfo_stride, const float *y,
+                          int64_t y_stride, const float *dy, int64_t dy_stride, const float *stash, const float *w_hh,
+                          const float *fc_w, const float *h_init, const float *c_init, float *part, int64_t B, int64_t T,
+                          void *stream)
+{
+    if (!dy || dy_stride < T) return MX_ERR_ARG;
+    return lstm_bwd_l1_launch(x, x_stride, lfo, lfo_stride, y, y_stride, nullptr, 0, stash, w_hh, fc_w, h_init, c_init, 0.0f,
+                              dy, dy_stride, part, B, T, stream, 0);
 }

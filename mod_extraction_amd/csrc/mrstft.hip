@@ -23,6 +23,13 @@
 #define MR_FPG 16        // frames per workgroup (passes A and B); the partial-sum workspace is sized for >= 8
 
 struct cf { float re, im; };
+// Complex multiply, every product rounded on its own (the file is compiled with -ffp-contract=off).  Measured with the two
+// twiddle FMAs written by hand (2 mul + 2 fma instead of 4 mul + 2 add): the three resolutions take 9.95 ms instead of
+// 10.95 ms per 256 x 4 s -- and x == y no longer gives loss == 0 and gradient == 0 exactly as the reference does
+// (tests/test_gpu_mrstft.py::test_mrstft_identical_signals): the loss packs the two real signals as x + i y into ONE
+// transform, and the spectra separate exactly for x == y only while the arithmetic is symmetric under the index mirror
+// k -> N - k, which maps a butterfly's twiddle w to -i conj(w) and thereby SWAPS the two products of a complex multiply;
+// an FMA rounds one of them and not the other, whichever way it is written.
 __device__ __forceinline__ cf cmulf(cf a, cf b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
 __device__ __forceinline__ cf caddf(cf a, cf b) { return {a.re + b.re, a.im + b.im}; }
 __device__ __forceinline__ cf csubf(cf a, cf b) { return {a.re - b.re, a.im - b.im}; }
@@ -185,6 +192,13 @@ __device__ __forceinline__ void load_frame(cf (&R)[WF<N>::NB][4], const float *x
 // spectra of the two real signals from Z = FFT(x + i y):  X[k] = (Z[k] + conj Z[N-k]) / 2,
 // Y[k] = (Z[k] - conj Z[N-k]) / (2 i)
 template <int N>
+__device__ __forceinline__ void split_bins_at(const cf *Z, int k, int km, cf &X, cf &Y)   // km = (N - k) mod N
+{
+    const cf z = Z[k], zc = Z[km];
+    X = {0.5f * (z.re + zc.re), 0.5f * (z.im - zc.im)};
+    Y = {0.5f * (z.im + zc.im), -0.5f * (z.re - zc.re)};
+}
+template <int N>
 __device__ __forceinline__ void split_bins(const cf *Z, int k, cf &X, cf &Y)
 {
     const cf z = Z[k], zc = Z[(N - k) & (N - 1)];
@@ -276,8 +290,15 @@ __global__ __launch_bounds__(256) void mr_finish_kernel(const double *__restrict
 }
 
 // ---- pass B -------------------------------------------------------------------------------------
+// N = 2048 holds 32 complex values per lane and fills the 256 registers of two waves per SIMD: 6 loop-invariant
+// addresses still live in scratch (18 before the mirror bins became constant offsets, see the bin pass below).  Measured
+// with MR_GRAD2048_EU = 1 (512 registers, no scratch, one wave per SIMD): 10.10 instead of 9.95 ms for the three
+// resolutions -- occupancy is worth more than the six scratch loads per frame, so 2 stays.
+#ifndef MR_GRAD2048_EU
+#define MR_GRAD2048_EU 2
+#endif
 template <int N>
-__global__ __launch_bounds__(WF<N>::WAVES * 64) __attribute__((amdgpu_waves_per_eu(2))) void mr_grad_kernel(const float *__restrict__ x, long long xs,
+__global__ __launch_bounds__(WF<N>::WAVES * 64) __attribute__((amdgpu_waves_per_eu(N == 2048 ? MR_GRAD2048_EU : 2))) void mr_grad_kernel(const float *__restrict__ x, long long xs,
                                                                     const float *__restrict__ y, long long ys,
                                                                     const float *__restrict__ win,
                                                                     const float2 *__restrict__ tw, int T, int hop,
@@ -304,7 +325,12 @@ __global__ __launch_bounds__(WF<N>::WAVES * 64) __attribute__((amdgpu_waves_per_
 #pragma unroll
         for (int i = 0; i < E; ++i) buf[pos_final<N>(i, a)] = Z[i];
         __builtin_amdgcn_wave_barrier();
-        // dL/dX at the bins this lane feeds into the inverse transform (positions a + L b + (N/4) c; zero above N/2)
+        // dL/dX at the bins this lane feeds into the inverse transform (positions a + L b + (N/4) c; zero above N/2).
+        // Mirror bins N - k as constant offsets from ONE register that is opaque to the optimiser in every iteration:
+        // written as (N - k) & (N - 1) each address is loop invariant, gets hoisted out of the frame loop and, for
+        // N = 2048 (all 256 registers taken by the transform), lives in scratch: 20 dependent scratch loads per frame.
+        int am = N - a;
+        asm volatile("" : "+v"(am));
 #pragma unroll
         for (int bq = 0; bq < NB; ++bq)
 #pragma unroll
@@ -313,7 +339,7 @@ __global__ __launch_bounds__(WF<N>::WAVES * 64) __attribute__((amdgpu_waves_per_
                 cf gk = {0.0f, 0.0f};
                 if (c < 2 || k == N / 2) {                                  // c >= 2: k >= N/2
                     cf X, Y;
-                    split_bins<N>(buf, k, X, Y);
+                    split_bins_at<N>(buf, k, (bq == 0 && c == 0) ? (am & (N - 1)) : am - (L * bq + (N / 4) * c), X, Y);
                     const float px = X.re * X.re + X.im * X.im;
                     const float xm = sqrtf(fmaxf(px, eps));
                     const float ym = sqrtf(fmaxf(Y.re * Y.re + Y.im * Y.im, eps));

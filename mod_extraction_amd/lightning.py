@@ -192,10 +192,13 @@ class TBPTTLFOEffectModeling(BaseLightingModule):
         if lfo_model is not None and not freeze_lfo_model:
             raise NotImplementedError("the LSTM kernels do not propagate gradients into the LFO model; every "
                                       "shipped config trains with freeze_lfo_model: true")
+        from .effect_losses import GRAD_NAMES
         for name, w in self.loss_dict.items():
-            if w > 0 and name != "l1":
-                raise NotImplementedError("the fused BPTT kernel back-propagates nn.L1Loss only (the shipped "
-                                          "configs use l1: 1.0, esr: 0.0, dc: 0.0)")
+            if w > 0 and name not in GRAD_NAMES:
+                raise NotImplementedError(f"effect-model loss '{name}' has no gradient kernel (supported: {GRAD_NAMES})")
+        # only nn.L1Loss weighted (every shipped config): the BPTT kernel evaluates its gradient itself
+        self._fused_l1 = all(w <= 0 or name == "l1" for name, w in self.loss_dict.items())
+        self._mrstft = None
         self.warmup_n_samples, self.step_n_samples = warmup_n_samples, step_n_samples
         self.effect_model = effect_model
         self.lfo_model_weights_path = lfo_model_weights_path
@@ -324,7 +327,7 @@ class TBPTTLFOEffectModeling(BaseLightingModule):
 
     def common_step(self, batch, is_training: bool, optimizer=None, world_size: int = 1, prep=None):
         """lightning.py:302-419."""
-        from .effect_losses import effect_loss_terms
+        from .effect_losses import effect_loss_grad, effect_loss_terms
         from .trainer import allreduce_flat_grad
         prefix = "train" if is_training else "val"
         prep = self.prepare(batch) if prep is None else self.finish_prepare(prep)
@@ -354,8 +357,15 @@ class TBPTTLFOEffectModeling(BaseLightingModule):
                 x, lat, tgt = dry[:, :, start:end], lfo_sr[:, :, start:end], wet[:, :, start:end]
                 if is_training:
                     y, h0, c0 = em.run_chunk(x, lat, stash)
-                    # no zero_grad(): bptt_l1_chunk OVERWRITES the whole flat gradient (one fill kernel less per step)
-                    em.bptt_l1_chunk(x, lat, y, tgt, stash, h0, c0, w_l1 / (B * S), optimizer.flat_grad)
+                    # no zero_grad(): the BPTT launch OVERWRITES the whole flat gradient (one fill kernel less per step)
+                    if self._fused_l1:
+                        em.bptt_l1_chunk(x, lat, y, tgt, stash, h0, c0, w_l1 / (B * S), optimizer.flat_grad)
+                    else:       # lightning.py:380-382 with any loss_dict: d loss / d y from the loss kernels, then BPTT
+                        if "mrstft" in self.loss_dict and self._mrstft is None:
+                            from .mrstft import MultiResolutionSTFTLoss
+                            self._mrstft = MultiResolutionSTFTLoss()
+                        dy = effect_loss_grad(y, tgt, self.loss_dict, mrstft=self._mrstft)
+                        em.bptt_chunk(x, lat, y, dy, stash, h0, c0, optimizer.flat_grad)
                     optimizer.step(grad_scale=allreduce_flat_grad(optimizer.flat_grad, world_size))
                     em.detach_hidden()
                     done += 1
@@ -370,6 +380,9 @@ class TBPTTLFOEffectModeling(BaseLightingModule):
             m = wet_hat.size(-1)
             dry_c, wet_c, wet_hat = dry[:, :, W:m], wet[:, :, W:m].contiguous(), wet_hat[:, :, W:m].contiguous()
             terms = effect_loss_terms(wet_hat, wet_c)
+            for name in self.loss_dict:
+                if name not in terms:
+                    terms[name] = L.get_loss_func_by_name(name)(wet_hat, wet_c)
             loss = None
             for name, w in self.loss_dict.items():
                 self.log(f"{prefix}/{name}", terms[name])

@@ -722,6 +722,22 @@ class LSTMEffectModel(HiddenStateModel):
                   _hip.ptr(h0.contiguous()), _hip.ptr(c0.contiguous()), float(loss_scale), _hip.ptr(part), B, Tn, _hip.stream())
         _hip.call("mx_reduce_rows", _hip.ptr(part), B, LSTM_NPARAM, 0, _hip.ptr(grad_out), _hip.stream())
 
+    def bptt_chunk(self, x: T, latent: T, y: T, dy: T, stash: T, h0: T, c0: T, grad_out: T) -> None:
+        """BPTT of one chunk for ANY loss: ``dy`` (B,1,T) or (B,T) = d loss / d y (``effect_losses.effect_loss_grad``);
+        the summed parameter gradient (17473,) in state-dict order is written to ``grad_out``."""
+        B, _, Tn = x.shape
+        assert grad_out.numel() == LSTM_NPARAM and grad_out.is_contiguous()
+        dy = dy.view(B, Tn)
+        assert dy.stride(1) == 1
+        part = torch.empty((B, LSTM_NPARAM), device=x.device, dtype=torch.float32)
+        xp, xs = _rows(x)
+        lp, ls = _rows(latent)
+        yp, ys = _rows(y)
+        _hip.call("mx_lstm_bwd", xp, xs, lp, ls, yp, ys, dy.data_ptr(), dy.stride(0), _hip.ptr(stash),
+                  _hip.ptr(self.lstm.weight_hh_l0.detach().contiguous()), _hip.ptr(self.fc.weight.detach().contiguous()),
+                  _hip.ptr(h0.contiguous()), _hip.ptr(c0.contiguous()), _hip.ptr(part), B, Tn, _hip.stream())
+        _hip.call("mx_reduce_rows", _hip.ptr(part), B, LSTM_NPARAM, 0, _hip.ptr(grad_out), _hip.stream())
+
     def forward(self, x: T, latent: T) -> T:
         """Inference / validation forward (no autograd graph; training goes through the fused TBPTT
         step of ``lightning.TBPTTLFOEffectModeling``)."""

@@ -21,6 +21,30 @@ def _windows(fft_sizes: Sequence[int], win_lengths: Sequence[int], device) -> T:
     return w.to(device)
 
 
+def mrstft_value_and_grad(mod: "MultiResolutionSTFTLoss", a: T, t: T, need_grad: bool = True, scale: float = 1.0):
+    """a, t: (B, T) rows (unit inner stride).  Returns (scale * loss as a device scalar, d (scale * loss) / d a or None)."""
+    assert a.shape == t.shape and a.ndim == 2 and a.stride(1) == 1 and t.stride(1) == 1
+    B, Tn = a.shape
+    dev = a.device
+    n_res = len(mod.fft_sizes)
+    frames = [1 + Tn // h for h in mod.hop_sizes]
+    part = torch.empty(3 * B * max(-(-f // 8) for f in frames), device=dev, dtype=torch.float64)
+    coef = torch.empty(2, device=dev, dtype=torch.float32)
+    terms = torch.empty(2 * n_res + 1, device=dev, dtype=torch.float32)
+    scratch = torch.empty(B * max(f * n for f, n in zip(frames, mod.fft_sizes)), device=dev,
+                          dtype=torch.float32) if need_grad else None
+    dx = torch.empty((B, Tn), device=dev, dtype=torch.float32) if need_grad else None
+    ffts = (ctypes.c_int32 * n_res)(*mod.fft_sizes)
+    hops = (ctypes.c_int32 * n_res)(*mod.hop_sizes)
+    win, tw = mod.buffers_on(dev)
+    _hip.call("mx_mrstft_loss", a.data_ptr(), a.stride(0), t.data_ptr(), t.stride(0), B, Tn, n_res,
+              ctypes.cast(ffts, ctypes.c_void_p), ctypes.cast(hops, ctypes.c_void_p), _hip.ptr(win), _hip.ptr(tw),
+              float(mod.w_sc * scale), float(mod.w_log_mag * scale), float(mod.eps), _hip.ptr(part), _hip.ptr(coef),
+              _hip.ptr(scratch), _hip.ptr(terms), _hip.ptr(dx), Tn, _hip.stream())
+    mod.last_terms = terms.detach()
+    return terms[2 * n_res], dx
+
+
 class _MRSTFTFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, y_hat: T, y: T, mod: "MultiResolutionSTFTLoss"):
@@ -28,28 +52,11 @@ class _MRSTFTFn(torch.autograd.Function):
         Tn = y_hat.size(-1)
         a = y_hat.reshape(-1, Tn).contiguous().float()
         t = y.reshape(-1, Tn).contiguous().float()
-        B = a.size(0)
-        dev = a.device
-        n_res = len(mod.fft_sizes)
-        frames = [1 + Tn // h for h in mod.hop_sizes]
-        part = torch.empty(3 * B * max(-(-f // 8) for f in frames), device=dev, dtype=torch.float64)
-        coef = torch.empty(2, device=dev, dtype=torch.float32)
-        terms = torch.empty(2 * n_res + 1, device=dev, dtype=torch.float32)
         need_grad = y_hat.requires_grad
-        scratch = torch.empty(B * max(f * n for f, n in zip(frames, mod.fft_sizes)), device=dev,
-                              dtype=torch.float32) if need_grad else None
-        dx = torch.empty_like(a) if need_grad else None
-        ffts = (ctypes.c_int32 * n_res)(*mod.fft_sizes)
-        hops = (ctypes.c_int32 * n_res)(*mod.hop_sizes)
-        win, tw = mod.buffers_on(dev)
-        _hip.call("mx_mrstft_loss", _hip.ptr(a), a.stride(0), _hip.ptr(t), t.stride(0), B, Tn, n_res,
-                  ctypes.cast(ffts, ctypes.c_void_p), ctypes.cast(hops, ctypes.c_void_p), _hip.ptr(win), _hip.ptr(tw),
-                  float(mod.w_sc), float(mod.w_log_mag), float(mod.eps), _hip.ptr(part), _hip.ptr(coef),
-                  _hip.ptr(scratch), _hip.ptr(terms), _hip.ptr(dx), Tn, _hip.stream())
-        ctx.save_for_backward(dx if need_grad else torch.empty(0, device=dev))
+        value, dx = mrstft_value_and_grad(mod, a, t, need_grad)
+        ctx.save_for_backward(dx if need_grad else torch.empty(0, device=a.device))
         ctx.shape = y_hat.shape
-        mod.last_terms = terms.detach()
-        return terms[2 * n_res]
+        return value
 
     @staticmethod
     def backward(ctx, g: T):

@@ -305,6 +305,8 @@ def test_bench_single_gpu_line_carries_every_config():
     for c, o in oc.items():
         assert "error" not in o, o
         assert o["value"] > 0 and o["ms_per_step"] > 0 and o["roofline"]["frac"] > 0, (c, o)
+        assert o["config"]["baseline_config"] == int(c)
+    assert 0 < oc["4"]["config"]["clips_trained_per_batch"]["mean"] <= 128        # the YAML's LFO validity filter is on
 
 
 @pytest.mark.parametrize("mode", ["lfo", "tbptt"])
