@@ -293,12 +293,14 @@ def fx_blocks(batcher, params, res):
                  "is the governing roofline")
     if n_ph and "mx_phaser_fwd" in res[0]:
         lead = params["lead"].double()[batcher.kind_id == 2]
-        bytes_ph = float(((lead + N) * 4).sum()) + n_ph * N * 8.0
+        bytes_ph = float(((lead + N) * (4 + 4 + 2)).sum()) + n_ph * N * 8.0
         out["phaser_kernel"] = hbm_block(
-            f"phaser_mat_kernel ({n_ph} clips x ({N} + lead) samples, datasets.py:455-482)", bytes_ph,
+            f"phaser_scan_kernel ({n_ph} clips x ({N} + lead) samples, datasets.py:455-482)", bytes_ph,
             res[0]["mx_phaser_fwd"], res[1].get("mx_phaser_fwd"),
-            note="4 B/sample read over lead + N samples, 8 B/sample written (wet + cropped dry); one wavefront per clip, "
-                 "8x8 state-space step per sample")
+            note="4 B/sample read twice over lead + N samples (both passes of the scan), 8 B/sample written (wet + cropped dry), "
+                 "1 B/sample of cut-offs parked and re-read; one workgroup per clip, the clip cut into 512 chunks whose affine "
+                 "state maps are built in parallel and chained (csrc/phaser.hip) -- VALU-bound, no per-sample dependency chain "
+                 "longer than a chunk")
     return out
 
 

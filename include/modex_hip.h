@@ -81,20 +81,22 @@ int mx_flanger_fwd_probe(const float *x, int64_t x_stride, const float *mod, int
  * feedback, mix (B,) fp32; lead (B,) int32 = samples rendered before the output window (the
  * reference renders n + sr/rate samples and crops at a random offset, datasets.py:428-449), NULL = 0;
  * rows/n_rows: optional subset of clips.  y: row b at y + b*y_stride = processed[lead:lead+N];
- * dry_out (optional, same stride): the matching crop of x.  exact_order != 0 keeps JUCE's operation order
- * inside each all-pass stage; 0 uses the algebraically identical FMA form (4-5x shorter dependency chain,
- * results within 1e-6). */
+ * dry_out (optional, same stride): the matching crop of x.  exact_order != 0: every sample in JUCE's operation order on
+ * one wavefront per clip (the bit reference); 0: the same recurrence as a linear scan over time (512 chunks per clip run
+ * in parallel, their affine maps chained; results within 1e-6).  workspace (optional): floats, row i of the processed
+ * clips at workspace + i * workspace_stride, >= ceil((lead + N) / 4) each (the cut-off of every 4-sample group, kept
+ * between the two passes of the scan; without it the cut-offs are evaluated twice). */
 int mx_phaser_fwd(const float *x, int64_t x_stride, const float *rate, const float *depth,
                   const float *centre, const float *feedback, const float *mix, const int32_t *lead,
                   const int32_t *rows, int64_t n_rows, int64_t B, int64_t N, double sr, int32_t exact_order,
-                  float *y, int64_t y_stride, float *dry_out, void *stream);
+                  float *y, int64_t y_stride, float *dry_out, float *workspace, int64_t workspace_stride, void *stream);
 /* Measurement twin of mx_phaser_fwd (bench.py, SURVEY.md section 8d "measured serial floor"): the same launch with NO
  * global-memory traffic inside the sample loop (constant inputs, only the last chunk stored), i.e. the kernel's
  * dependent chain alone.  Outputs are meaningless; never called by the product.  No reference counterpart. */
 int mx_phaser_fwd_probe(const float *x, int64_t x_stride, const float *rate, const float *depth,
                   const float *centre, const float *feedback, const float *mix, const int32_t *lead,
                   const int32_t *rows, int64_t n_rows, int64_t B, int64_t N, double sr, int32_t exact_order,
-                  float *y, int64_t y_stride, float *dry_out, void *stream);
+                  float *y, int64_t y_stride, float *dry_out, float *workspace, int64_t workspace_stride, void *stream);
 
 /* ---- K4: log-mel front end -- mod_extraction/models.py:170-181,199-208
  * (torchaudio MelSpectrogram: n_fft 1024, hann, centre/reflect, power 2, mel filter bank `fb`)

@@ -3,20 +3,11 @@
 // third-party source absent from the reference tree: PARITY UNPINNED, checked against
 // oracle/csrc/oracle_ref.c:orc_phaser, which restates the published JUCE algorithm).
 //
-// One wavefront per clip.  The recurrence (in - lastOut -> 6 first-order TPT all-pass stages -> out;
-// lastOut = out * feedback) is strictly serial per sample.  Per block of 256 samples the 64 lanes evaluate the
-// 64 LFO / cut-off updates in parallel (sin, pow, fp64 tan -> G = g / (1 + g), one per lane); the samples
-// themselves run as a LINEAR STATE-SPACE step on all 64 lanes (phaser_mat_kernel, the default):
-//     z = (s0..s5, lastOut, in)  ->  (s0'..s5', lastOut', y) = A(G) z,     A: 8 x 8, constant for 4 samples,
-// one matrix entry per lane (lane = 8 row + col), a step = one FMA + a DPP all-reduce over the 8 columns; the
-// next step uses the TRANSPOSED lane layout (one FMA + an all-reduce over the 8 rows: row_ror:8 and two
-// v_permlane swaps), so the state vector never has to be transposed back: ~12 instructions per sample on a
-// 6-deep dependent chain, against ~35 wave-uniform instructions (8 deep) of the scalar form.  The entries of
-// A are products of a per-update table (powers of 2G-1 etc., written to LDS by the lane that owns the update)
-// picked by per-lane static indices.  Algebraically identical to JUCE's stage order, rounding differs
-// (<= 1e-6 on audio); exact_order != 0 keeps the scalar kernel in JUCE's operation order for bit tests.
-// sin / pow / log10 are evaluated in fp64 and rounded once, which reproduces the host libm's (correctly
-// rounded) float results; the LFO phase accumulator is advanced sequentially in fp32 (as JUCE does) to stay bit-faithful.
+// Two kernels.  phaser_kernel: one wavefront per clip, every sample in JUCE's operation order, strictly serial -- the bit
+// reference (exact_order != 0).  phaser_scan_kernel (default): the same recurrence as a linear scan over time, one
+// workgroup per clip, one chunk of the clip per lane (see its header below).
+// sin / pow / log10 are evaluated in fp64 and rounded once, which reproduces the host libm's (correctly rounded) float
+// results; the LFO phase accumulator advances in fp32 exactly as JUCE's does.
 // `lead` samples are processed (filter warm-up, LFO phase) before the N output samples: the
 // reference renders n + sr/rate samples and crops at a random offset (datasets.py:428-449).
 // Algorithmic HBM traffic: 8 B/sample (+4 B/sample when the cropped dry clip is also written).
@@ -125,64 +116,95 @@ __global__ __launch_bounds__(64 * PH_WPB) void phaser_kernel(const float *__rest
     }
 }
 
-// ---- the default kernel: 8 x 8 state-space step on 64 lanes (see the header) ------------------------------
-#define PM_TAB 20                 // table row pitch (floats): P[0..6] = (2G-1)^e, then the 11 scale factors below
+// ---- the default kernel: the recurrence as a LINEAR SCAN over time -------------------------------------------------
+// For a given cut-off sequence the phaser is a linear time-varying system in its 7-vector state z = (s0..s5, lastOut):
+//     z(n+1) = A(G_n) z(n) + b(G_n) x(n).
+// The cut-offs do not depend on the state (LFO only), so the clip is cut into PS_P = 512 chunks, one per LANE, and
+//   A  every lane runs its chunk EIGHT times in registers -- from the seven unit states with silent input and from the
+//      zero state with the real input -- which gives the chunk's affine map  z_end = M z_start + v  (the scalar all-pass
+//      cascade costs 38 flops per sample and run; a dense 8 x 8 step would cost 128), and on the way evaluates its
+//      cut-off updates (one fp64 sin / pow / tan per 4 samples: each update of the clip is still evaluated exactly once)
+//      and parks them in a workspace;
+//   B  seven lanes of one wave chain the 512 maps (a 7 x 7 mat-vec per chunk, ~25 us): the state at every chunk start;
+//   C  every lane re-runs its chunk from its true start state in JUCE's operation order and writes the output window.
+// No sample waits for its predecessor outside a chunk of ~345: 85 clips x (2 s + lead) take ~0.4 ms where the
+// state-space step on a producer / consumer wave pair (round 2, one dependent 8 x 8 step per sample) took 7.8 ms.
+// Rounding: phase C is the reference's own arithmetic; only the chunk-start states carry the re-association error of the
+// maps (~1e-7 of the state, it decays like any state perturbation of the stable all-pass loop).
+// The LFO phase at a chunk start must equal what 44 100 sequential fp32 additions give (JUCE accumulates in fp32; a
+// closed form in fp64 is 1e-5 rad off after a few thousand steps): ps_phase_after() below reproduces them exactly in
+// O(binades) steps.
+#define PS_WAVES 8
+#define PS_P (64 * PS_WAVES)       // chunks (lanes) per clip
+#define PS_MV 57                   // floats per chunk map: M column-major (49) + v (7) + pad
+#define PS_LDS_FLOATS (PS_P * PS_MV + (PS_P + 1) * 8)
 
-template <int CTRL> __device__ __forceinline__ float ph_dpp(float v)
+// phase after g cut-off updates:  p <- fl(p + inc);  while (p >= 2 pi) p <- fl(p - 2 pi)   (oracle_ref.c:orc_phaser)
+// Inside one binade [2^e, 2^(e+1)) every representable p is a multiple of ulp = 2^(e-23), so fl(p + inc) = p + d with ONE
+// constant d = rn(inc / ulp) ulp -- except that a tie (inc / ulp = I + 1/2 exactly) rounds to even and can make the FIRST
+// step from an odd multiple differ from all later ones.  Hence: three real steps; if the last two are equal and all
+// three values share a binade, jump  p += j d  (exact in fp32: stays inside the binade, below 2 pi, one step of margin),
+// then continue with real steps across the binade edge / the wrap.  ~25 rounds per LFO period; checked against the
+// sequential loop for 600 (rate, count) pairs including constructed ties (tools/probe/check_phase_jump.py).
+__device__ __forceinline__ float ps_step(float p, float inc, float two_pi)
 {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+    p = __fadd_rn(p, inc);
+    while (p >= two_pi) p = __fsub_rn(p, two_pi);
+    return p;
 }
-// table slots of the scale factor S and the exponent e of matrix entry A[k][j] = S (2G-1)^e
-// rows k: 0..5 = all-pass states, 6 = lastOut, 7 = output; columns j: 0..5 states, 6 = lastOut, 7 = input sample
-__device__ __forceinline__ void ph_entry(int k, int j, int &s_idx, int &p_idx)
+__device__ float ps_phase_after(int g, float inc, float two_pi)
 {
-    if (k <= 5) {
-        if (j < k) { s_idx = 9; p_idx = k - 1 - j; }            //  c3 c2 c1^(k-1-j)
-        else if (j == k) { s_idx = 8; p_idx = 0; }              //  c4
-        else if (j <= 5) { s_idx = 7; p_idx = 0; }              //  0
-        else if (j == 6) { s_idx = 11; p_idx = k; }             // -c3 c1^k
-        else { s_idx = 10; p_idx = k; }                         //  c3 c1^k
-    } else {
-        const int base = k == 6 ? 12 : 15;                      // feedback row / wet row
-        if (j <= 5) { s_idx = base; p_idx = 5 - j; }            //  g c2 c1^(5-j)
-        else if (j == 6) { s_idx = base + 1; p_idx = 6; }       // -g c1^6
-        else { s_idx = base + 2; p_idx = 6; }                   //  g c1^6  (+ dry on the output row)
+    float p = 0.0f;
+    int rem = g;
+    while (rem > 0) {
+        const float p1 = ps_step(p, inc, two_pi);
+        p = p1;
+        if (--rem == 0) break;
+        const float p2 = ps_step(p1, inc, two_pi);
+        p = p2;
+        if (--rem == 0) break;
+        const float p3 = ps_step(p2, inc, two_pi);
+        p = p3;
+        if (--rem == 0) break;
+        const float d1 = __fsub_rn(p2, p1), d2 = __fsub_rn(p3, p2);
+        const int e1 = (__float_as_int(p1) >> 23) & 0xff, e2 = (__float_as_int(p2) >> 23) & 0xff, e3 = (__float_as_int(p3) >> 23) & 0xff;
+        if (d1 == d2 && d2 > 0.0f && e1 == e2 && e2 == e3 && e3 > 0 && e3 < 0xfe) {
+            const double edge = (double)__int_as_float((e3 + 1) << 23);          // 2^(e+1)
+            const double lim = edge < (double)two_pi ? edge : (double)two_pi;
+            long long j = (long long)floor((lim - (double)p3) / (double)d2) - 1;
+            if (j > rem) j = rem;
+            if (j > 0) {
+                p = (float)((double)p3 + (double)j * (double)d2);
+                rem -= (int)j;
+            }
+        }
     }
+    return p;
 }
 
-// One workgroup = one clip = TWO wavefronts.  The PRODUCER wave runs everything that does not depend on the filter
-// state one 64-sample sub-block ahead -- input load, the sequential fp32 phase accumulation, the 64 cut-off updates of
-// a 256-sample block and their table rows, and for every update the four per-lane factors (a1, i1, a2, i2) of the two
-// lane layouts, written to an LDS ring as one float4 per lane -- and stores the finished blocks (clip, coalesced).
-// The CONSUMER wave runs the dependent chain only: per update one ds_read_b128 of its factors, one broadcast read of
-// the 4 samples, and the 4 state-space steps (~9 instructions per sample; the single-wave version spent 15).
-// The two waves meet at one workgroup barrier per 64 samples.
-#define PM_SUB 16                 // cut-off updates (x 4 samples) per sub-block
-#define PM_RING (PM_SUB * 64 * 4) // floats per ring buffer
-#define PM2_LDS (2 * 256 + 2 * 256 + 2 * 64 * PM_TAB + 2 * PM_RING + 320)
-
-__global__ __launch_bounds__(128) void phaser_mat_kernel(const float *__restrict__ x, long long x_stride,
-                                                         const float *__restrict__ rate,
-                                                         const float *__restrict__ depth,
-                                                         const float *__restrict__ centre,
-                                                         const float *__restrict__ feedback,
-                                                         const float *__restrict__ mix,
-                                                         const int *__restrict__ lead_arr,
-                                                         const int *__restrict__ rows, int n_items, int N,
-                                                         double sr, float *__restrict__ y, long long y_stride,
-                                                         float *__restrict__ dry_out, int probe)
+__global__ __launch_bounds__(PS_P) void phaser_scan_kernel(const float *__restrict__ x, long long x_stride,
+                                                           const float *__restrict__ rate,
+                                                           const float *__restrict__ depth,
+                                                           const float *__restrict__ centre,
+                                                           const float *__restrict__ feedback,
+                                                           const float *__restrict__ mix,
+                                                           const int *__restrict__ lead_arr,
+                                                           const int *__restrict__ rows, int n_items, int N, double sr,
+                                                           float *__restrict__ y, long long y_stride,
+                                                           float *__restrict__ dry_out, float *__restrict__ gws,
+                                                           long long gws_stride, int probe)
 {
-    __shared__ __attribute__((aligned(16))) float lds_all[PM2_LDS];
-    const int lane = threadIdx.x & 63;
-    const bool producer = threadIdx.x >= 64;
+    extern __shared__ __attribute__((aligned(16))) float ps_lds[];
+    float *mv = ps_lds, *zs = ps_lds + PS_P * PS_MV;
+    const int p = threadIdx.x, lane = p & 63;
     const int item = blockIdx.x;
-    float *xbuf = lds_all, *ybuf = xbuf + 512, *tabs = ybuf + 512, *ring = tabs + 2 * 64 * PM_TAB, *sink = ring + 2 * PM_RING;
     const int b = rows ? rows[item] : item;
     const int lead = lead_arr ? lead_arr[b] : 0;
     const int total = lead + N;
     const float *xb = x + (size_t)b * x_stride;
     float *yb = y + (size_t)b * y_stride;
     float *db = dry_out ? dry_out + (size_t)b * y_stride : nullptr;
+    float *gw = gws + (size_t)item * gws_stride;
 
     const float two_pi = 6.283185307179586476925286766559f;
     const float pi_f = 3.14159265358979323846f;
@@ -194,185 +216,176 @@ __global__ __launch_bounds__(128) void phaser_mat_kernel(const float *__restrict
     const float fb = feedback[b];
     const float wet_g = mix[b], dry_g = __fsub_rn(1.0f, mix[b]);
 
-    // lane = 8 r + c.  Layout 1 (even samples): the lane holds z[c] and entry A[r][c]; layout 2 (odd samples): it
-    // holds z[r] and entry A[c][r].  The input column / row (index 7) enters as a separate product (inj * sample).
-    const int r = lane >> 3, c = lane & 7;
-    int s1, p1, s2, p2;
-    ph_entry(r, c, s1, p1);
-    ph_entry(c, r, s2, p2);
-    const float dry_add = lane == 63 ? dry_g : 0.0f;            // A[7][7] = wet c1^6 + dry
-    const float keep1 = c == 7 ? 0.0f : 1.0f, keep2 = r == 7 ? 0.0f : 1.0f;
+    const int n_groups = (total + 3) >> 2;                       // cut-off updates = groups of 4 samples from sample 0
+    const int gpc = (n_groups + PS_P - 1) / PS_P;                // groups per chunk
+    const int g0 = p * gpc, g1 = min(g0 + gpc, n_groups);        // this lane's groups [g0, g1) (empty beyond the clip)
 
-    float phase = 0.0f;                                         // producer state
-    float z = 0.0f;                                             // consumer state: the state vector, layout 1
-    const int n_sub = ((total + PH_BLOCK - 1) / PH_BLOCK) * 4;  // whole 256-sample blocks
-    // The cut-off updates of a block (sequential fp32 phase accumulation, then per lane sin -> pow -> tan in fp64, the
-    // expensive part of the producer) are prepared ONE BLOCK AHEAD, a quarter per sub-block iteration, so that no
-    // iteration is much longer than the consumer's; two table buffers.
-    float my_phase = 0.0f, st_osc = 0.0f, st_fc = 0.0f;
-    auto prep_phase = [&]() {       // lane k keeps the phase of update k of the next block
-        for (int k = 0; k < PH_BLOCK / 4; ++k) {
-            if (lane == k) my_phase = phase;
-            phase = __fadd_rn(phase, inc);
-            while (phase >= two_pi) phase = __fsub_rn(phase, two_pi);
-        }
-    };
-    auto prep_sin = [&]() { st_osc = (float)sin((double)__fsub_rn(my_phase, pi_f)); };
-    auto prep_pow = [&]() {
-        float lfo = __fadd_rn(__fmul_rn(st_osc, osc_vol), norm_centre);
+    const bool use_ws = gws != nullptr && (long long)n_groups <= gws_stride;
+    // one cut-off update (oracle_ref.c:orc_phaser; sin / pow / tan in fp64 and rounded once = the host libm's float results)
+    auto cutoff = [&](float ph) {
+        const float osc = (float)sin((double)__fsub_rn(ph, pi_f));
+        float lfo = __fadd_rn(__fmul_rn(osc, osc_vol), norm_centre);
         lfo = lfo < 0.0f ? 0.0f : (lfo > 1.0f ? 1.0f : lfo);
-        st_fc = (float)pow(10.0, (double)__fadd_rn(__fmul_rn(lfo, __fsub_rn(log_max, log_min)), log_min));
+        const float fc = (float)pow(10.0, (double)__fadd_rn(__fmul_rn(lfo, __fsub_rn(log_max, log_min)), log_min));
+        const float gg = (float)tan(3.14159265358979323846 * (double)fc / sr);
+        return __fdiv_rn(gg, __fadd_rn(1.0f, gg));
     };
-    auto prep_table = [&](float *tab) {
-        float gg = (float)tan(3.14159265358979323846 * (double)st_fc / sr);
-        const float G = __fdiv_rn(gg, __fadd_rn(1.0f, gg));
-        // all-pass stage: out = c1 in + c2 s, s' = c3 in + c4 s
-        const float c1 = 2.0f * G - 1.0f, c2 = 2.0f - 2.0f * G, c3 = 2.0f * G, c4 = 1.0f - 2.0f * G;
-        const float q2 = c1 * c1, q3 = q2 * c1, q4 = q2 * q2, q5 = q4 * c1, q6 = q4 * q2;
-        float4 *row = (float4 *)(tab + lane * PM_TAB);
-        row[0] = make_float4(1.0f, c1, q2, q3);
-        row[1] = make_float4(q4, q5, q6, 0.0f);
-        row[2] = make_float4(c4, c3 * c2, c3, -c3);
-        row[3] = make_float4(fb * c2, -fb, fb, wet_g * c2);
-        row[4] = make_float4(-wet_g, wet_g, 0.0f, 0.0f);
-        __builtin_amdgcn_wave_barrier();                        // LDS operations of one wave complete in order
-    };
-    if (producer) {                                             // block 0
-        prep_phase(); prep_sin(); prep_pow(); prep_table(tabs);
-    }
 
-    for (int g = 0; g <= n_sub + 1; ++g) {
-        if (producer) {
-            // ---- store the block the consumer finished two iterations ago
-            if (g >= 2 && ((g - 2) & 3) == 3) {
-                const int nb = (g - 2) >> 2;
-                const float *yb_l = ybuf + (nb & 1) * 256, *xb_l = xbuf + (nb & 1) * 256;
+#define PS_STAGE(S)                                   \
+    v = __fmul_rn(G, __fsub_rn(out, S));             \
+    yk = __fadd_rn(v, S);                            \
+    S = __fadd_rn(v, yk);                            \
+    out = __fsub_rn(__fmul_rn(2.0f, yk), out);
+
+    // ---- A: the chunk's affine map, the cut-offs on the way
+    float S[8][7];
 #pragma unroll
-                for (int j = 0; j < PH_BLOCK / 64; ++j) {
-                    const int n = nb * PH_BLOCK + j * 64 + lane;
-                    if (n >= lead && n < total && (!probe || n + PH_BLOCK >= total)) {
-                        const float m = yb_l[j * 64 + lane];
-                        yb[n - lead] = m < -1.0f ? -1.0f : (m > 1.0f ? 1.0f : m);
-                        if (db) db[n - lead] = xb_l[j * 64 + lane];
-                    }
-                }
-            }
-            if (g < n_sub) {
-                const int nb = g >> 2, sub = g & 3;
-                if (sub == 0) {
-                    // (1) coalesced load of 256 input samples into LDS
-                    float *xl = xbuf + (nb & 1) * 256;
+    for (int r = 0; r < 8; ++r)
 #pragma unroll
-                    for (int j = 0; j < PH_BLOCK / 64; ++j) {
-                        const int n = nb * PH_BLOCK + j * 64 + lane;
-                        xl[j * 64 + lane] = probe ? 0.25f : (n < total ? xb[n] : 0.0f);
-                    }
-                }
-                // (2, 3) a quarter of the next block's cut-off updates
-                if (sub == 0) prep_phase();
-                else if (sub == 1) prep_sin();
-                else if (sub == 2) prep_pow();
-                else prep_table(tabs + ((nb + 1) & 1) * 64 * PM_TAB);
-                const float *tab = tabs + (nb & 1) * 64 * PM_TAB;
-                // (4) the per-lane factors of the 16 updates of this sub-block
-                float4 *rg = (float4 *)(ring + (g & 1) * PM_RING) + lane;
-#pragma unroll 4
-                for (int u = 0; u < PM_SUB; ++u) {
-                    const float *tr = tab + (sub * PM_SUB + u) * PM_TAB;
-                    const float e1 = fmaf(tr[s1], tr[p1], dry_add), e2 = fmaf(tr[s2], tr[p2], dry_add);
-                    const float a1 = e1 * keep1, a2 = e2 * keep2;
-                    rg[u * 64] = make_float4(a1, e1 - a1, a2, e2 - a2);      // entry / input weight of both layouts
-                }
-            }
-        } else if (g >= 1 && g - 1 < n_sub) {
-            // ---- the dependent chain of sub-block g - 1
-            const int gc = g - 1, nb = gc >> 2, sub = gc & 3;
-            const float4 *rg = (const float4 *)(ring + (gc & 1) * PM_RING) + lane;
-            const float *xl = xbuf + (nb & 1) * 256 + sub * 64;
-            float *yl = ybuf + (nb & 1) * 256 + sub * 64;
-            // the output row lands in lanes r == 7 (layout 1) / c == 7 (layout 2): lanes 56 and 7 write it, the others a sink
-            float *o1 = lane == 56 ? yl : sink + lane, *o2 = lane == 7 ? yl : sink + lane;
-            float4 cf = rg[0], xin = *(const float4 *)xl;
-            for (int u = 0; u < PM_SUB; ++u) {
-                const float a1 = cf.x, i1 = cf.y, a2 = cf.z, i2 = cf.w;
-                const float4 xv = xin;
-                {
-                    const int un = u + 1 < PM_SUB ? u + 1 : u;             // the next update's factors and samples
-                    cf = rg[un * 64];
-                    xin = *(const float4 *)(xl + 4 * un);
-                }
-#define PH_STEP1(XV, SLOT)                                                                         \
-    {                                                                                              \
-        float p = fmaf(a1, z, i1 * XV);                                                            \
-        p += ph_dpp<0xB1>(p);               /* quad_perm [1,0,3,2] */                              \
-        p += ph_dpp<0x4E>(p);               /* quad_perm [2,3,0,1] */                              \
-        p += ph_dpp<0x141>(p);              /* row_half_mirror: sum over the 8 columns */          \
-        o1[SLOT] = p;                                                                              \
-        z = p;                                                                                     \
-    }
-#define PH_STEP2(XV, SLOT)                                                                         \
-    {                                                                                              \
-        float p = fmaf(a2, z, i2 * XV);                                                            \
-        p += ph_dpp<0x128>(p);              /* row_ror:8 */                                        \
-        auto sa = __builtin_amdgcn_permlane16_swap(__float_as_int(p), __float_as_int(p), false, false); \
-        p = __int_as_float(sa[0]) + __int_as_float(sa[1]);                                         \
-        auto sb_ = __builtin_amdgcn_permlane32_swap(__float_as_int(p), __float_as_int(p), false, false); \
-        p = __int_as_float(sb_[0]) + __int_as_float(sb_[1]);   /* sum over the 8 rows */           \
-        o2[SLOT] = p;                                                                              \
-        z = p;                                                                                     \
-    }
-                PH_STEP1(xv.x, 0)
-                PH_STEP2(xv.y, 1)
-                PH_STEP1(xv.z, 2)
-                PH_STEP2(xv.w, 3)
-#undef PH_STEP1
-#undef PH_STEP2
-                o1 += 4;
-                o2 += 4;
+        for (int c = 0; c < 7; ++c) S[r][c] = r == c ? 1.0f : 0.0f;
+    float phase = ps_phase_after(min(g0, n_groups), inc, two_pi);
+    for (int g = g0; g < g1; ++g) {
+        float xv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = 4 * g + j;
+            xv[j] = probe ? 0.25f : (n < total ? xb[n] : 0.0f);
+        }
+        const float G = cutoff(phase);
+        phase = ps_step(phase, inc, two_pi);
+        if (use_ws) gw[g] = G;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const float in = r == 7 ? xv[j] : 0.0f;
+                float out = __fsub_rn(in, S[r][6]), v, yk;
+                PS_STAGE(S[r][0]) PS_STAGE(S[r][1]) PS_STAGE(S[r][2]) PS_STAGE(S[r][3]) PS_STAGE(S[r][4]) PS_STAGE(S[r][5])
+                S[r][6] = __fmul_rn(out, fb);
             }
         }
-        __syncthreads();
     }
+    {
+        float *m = mv + p * PS_MV;
+#pragma unroll
+        for (int c = 0; c < 7; ++c)
+#pragma unroll
+            for (int r = 0; r < 7; ++r) m[c * 7 + r] = S[c][r];      // column c = image of unit state c
+#pragma unroll
+        for (int r = 0; r < 7; ++r) m[49 + r] = S[7][r];
+    }
+    __syncthreads();
+
+    // ---- B: chain the maps (wave 0; lane r < 7 owns row r, the new state is broadcast with v_readlane)
+    if (p < 64) {
+        const int r = lane < 7 ? lane : 0;
+        float z[7], mine = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 7; ++c) z[c] = 0.0f;
+        for (int q = 0; q < PS_P; ++q) {
+            if (lane < 7) zs[q * 8 + lane] = mine;
+            const float *m = mv + q * PS_MV;
+            float acc = m[49 + r];
+#pragma unroll
+            for (int c = 0; c < 7; ++c) acc = __builtin_fmaf(m[c * 7 + r], z[c], acc);
+            mine = acc;
+#pragma unroll
+            for (int c = 0; c < 7; ++c) z[c] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc), c));
+        }
+    }
+    __syncthreads();
+
+    // ---- C: the chunk from its true start state, JUCE's operation order, output window
+    {
+        float s0 = zs[p * 8 + 0], s1 = zs[p * 8 + 1], s2 = zs[p * 8 + 2], s3 = zs[p * 8 + 3], s4 = zs[p * 8 + 4],
+              s5 = zs[p * 8 + 5], last = zs[p * 8 + 6];
+        float phase_c = use_ws ? 0.0f : ps_phase_after(min(g0, n_groups), inc, two_pi);
+        for (int g = g0; g < g1; ++g) {
+            float G;
+            if (use_ws) G = gw[g];
+            else {                                               // workspace too small for this clip: evaluate the cut-off again
+                G = cutoff(phase_c);
+                phase_c = ps_step(phase_c, inc, two_pi);
+            }
+            float xv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = 4 * g + j;
+                xv[j] = probe ? 0.25f : (n < total ? xb[n] : 0.0f);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = 4 * g + j;
+                const float in = xv[j];
+                float out = __fsub_rn(in, last), v, yk;
+                PS_STAGE(s0) PS_STAGE(s1) PS_STAGE(s2) PS_STAGE(s3) PS_STAGE(s4) PS_STAGE(s5)
+                last = __fmul_rn(out, fb);
+                float m = __fadd_rn(__fmul_rn(out, wet_g), __fmul_rn(in, dry_g));
+                m = m < -1.0f ? -1.0f : (m > 1.0f ? 1.0f : m);
+                if (n >= lead && n < total && (!probe || g + 1 == g1)) {
+                    yb[n - lead] = m;
+                    if (db) db[n - lead] = in;
+                }
+            }
+        }
+    }
+#undef PS_STAGE
 }
 
 // x: source audio, row b at x + b*x_stride, at least lead[b] + N samples; rate, depth, centre,
 // feedback, mix: (B,) fp32; lead: (B,) int32 warm-up samples (NULL = 0); rows/n_rows: optional
 // subset of clip indices.  y: row b at y + b*y_stride, N samples = processed[lead : lead+N];
 // dry_out (optional, same stride as y): the matching crop of the source.
-// exact_order != 0: evaluate every all-pass stage in JUCE's operation order (v = G (x - s); y = v + s;
-// s = v + y; out = 2 y - x) on the scalar kernel; 0: the algebraically identical 8 x 8 state-space step on 64 lanes.
+// exact_order != 0: the whole clip sample by sample on one wavefront in JUCE's operation order (the bit reference);
+// 0: the time-parallel linear scan above.  workspace: floats, row `item` at workspace + item * workspace_stride, at least
+// ceil((lead + N) / 4) floats per processed clip (the cut-off of every 4-sample group, kept between the two passes of
+// the scan); optional: NULL or too short a row makes the kernel evaluate the cut-offs twice instead.
 static int phaser_fwd_launch(const float *x, int64_t x_stride, const float *rate, const float *depth,
                             const float *centre, const float *feedback, const float *mix, const int32_t *lead,
                             const int32_t *rows, int64_t n_rows, int64_t B, int64_t N, double sr, int32_t exact_order,
-                            float *y, int64_t y_stride, float *dry_out, void *stream, int probe)
+                            float *y, int64_t y_stride, float *dry_out, float *workspace, int64_t workspace_stride,
+                            void *stream, int probe)
 {
     if (!x || !rate || !depth || !centre || !feedback || !mix || !y || B <= 0 || N <= 0 || sr <= 0.0) return MX_ERR_ARG;
+    if (workspace && workspace_stride <= 0) return MX_ERR_ARG;
     if (N >= (1ll << 30)) return MX_ERR_UNSUPPORTED;
     const int64_t items = rows ? n_rows : B;
     if (items <= 0) return MX_OK;
-    const dim3 grid((unsigned)((items + PH_WPB - 1) / PH_WPB)), block(64 * PH_WPB);
-    if (exact_order)
+    if (exact_order) {
+        const dim3 grid((unsigned)((items + PH_WPB - 1) / PH_WPB)), block(64 * PH_WPB);
         hipLaunchKernelGGL(phaser_kernel, grid, block, 0, (hipStream_t)stream, x, (long long)x_stride, rate, depth, centre,
                            feedback, mix, lead, rows, (int)items, (int)N, (float)sr, sr, y, (long long)y_stride, dry_out);
-    else
-        hipLaunchKernelGGL(phaser_mat_kernel, dim3((unsigned)items), dim3(128), 0, (hipStream_t)stream, x, (long long)x_stride, rate, depth,
-                           centre, feedback, mix, lead, rows, (int)items, (int)N, sr, y, (long long)y_stride, dry_out, probe);
+    } else {
+        const size_t lds = PS_LDS_FLOATS * sizeof(float);
+        static bool attr_set[64] = {};                       // per device: one process may drive several GPUs
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+            (void)hipFuncSetAttribute((const void *)phaser_scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (dev >= 0 && dev < 64) attr_set[dev] = true;
+        }
+        hipLaunchKernelGGL(phaser_scan_kernel, dim3((unsigned)items), dim3(PS_P), lds, (hipStream_t)stream, x, (long long)x_stride,
+                           rate, depth, centre, feedback, mix, lead, rows, (int)items, (int)N, sr, y, (long long)y_stride,
+                           dry_out, workspace, (long long)workspace_stride, probe);
+    }
     return mx_launch_status();
 }
 
 MX_EXPORT int mx_phaser_fwd(const float *x, int64_t x_stride, const float *rate, const float *depth,
                             const float *centre, const float *feedback, const float *mix, const int32_t *lead,
                             const int32_t *rows, int64_t n_rows, int64_t B, int64_t N, double sr, int32_t exact_order,
-                            float *y, int64_t y_stride, float *dry_out, void *stream)
+                            float *y, int64_t y_stride, float *dry_out, float *workspace, int64_t workspace_stride,
+                            void *stream)
 {
-    return phaser_fwd_launch(x, x_stride, rate, depth, centre, feedback, mix, lead, rows, n_rows, B, N, sr, exact_order, y, y_stride, dry_out, stream, 0);
+    return phaser_fwd_launch(x, x_stride, rate, depth, centre, feedback, mix, lead, rows, n_rows, B, N, sr, exact_order, y, y_stride, dry_out, workspace, workspace_stride, stream, 0);
 }
 
 // Measurement twin (bench.py's serial floor): the SAME launch with no global-memory traffic inside the sample loop -- inputs are constants, only the last chunk is stored.  Results are meaningless; nothing in the product calls it.
 MX_EXPORT int mx_phaser_fwd_probe(const float *x, int64_t x_stride, const float *rate, const float *depth,
                             const float *centre, const float *feedback, const float *mix, const int32_t *lead,
                             const int32_t *rows, int64_t n_rows, int64_t B, int64_t N, double sr, int32_t exact_order,
-                            float *y, int64_t y_stride, float *dry_out, void *stream)
+                            float *y, int64_t y_stride, float *dry_out, float *workspace, int64_t workspace_stride,
+                            void *stream)
 {
-    return phaser_fwd_launch(x, x_stride, rate, depth, centre, feedback, mix, lead, rows, n_rows, B, N, sr, exact_order, y, y_stride, dry_out, stream, 1);
+    return phaser_fwd_launch(x, x_stride, rate, depth, centre, feedback, mix, lead, rows, n_rows, B, N, sr, exact_order, y, y_stride, dry_out, workspace, workspace_stride, stream, 1);
 }

@@ -158,8 +158,8 @@ def phaser_forward(src: T, params: Dict[str, T], lead: Optional[T], sr: float, n
     """Launch mx_phaser_fwd (pedalboard.Phaser semantics, datasets.py:455-482).
     src (B, >= lead+n_samples) source audio rows; params: rate_hz, depth, centre_frequency_hz,
     feedback, mix -- each (B,) fp32 on the device; lead (B,) int32 warm-up samples or None;
-    out / dry_out: (B, n_samples) views with contiguous rows.  exact_order=True keeps JUCE's operation
-    order inside each all-pass stage (slower: the sample-to-sample dependency chain is 4-5x longer)."""
+    out / dry_out: (B, n_samples) views with contiguous rows.  exact_order=True runs every sample in JUCE's
+    operation order on one wavefront per clip (the bit reference, ~20x slower); the default is the time-parallel scan."""
     B = src.size(0)
     y = out if out is not None else torch.empty((B, n_samples), device=src.device, dtype=torch.float32)
     sp, ss = _rows_view(src)
@@ -168,8 +168,13 @@ def phaser_forward(src: T, params: Dict[str, T], lead: Optional[T], sr: float, n
     if dry_out is not None:
         dp, ds = _rows_view(dry_out)
         assert ds == ys
+    # cut-off workspace of the scan kernel: one float per 4-sample group of the longest possible render (lead + n_samples
+    # never exceeds a source row)
+    n_items = B if rows is None else rows.numel()
+    ws_stride = (src.size(-1) + 3) // 4
+    ws = None if exact_order else torch.empty((n_items, ws_stride), device=src.device, dtype=torch.float32)
     _hip.call("mx_phaser_fwd", sp, ss, _hip.ptr(params["rate_hz"]), _hip.ptr(params["depth"]),
               _hip.ptr(params["centre_frequency_hz"]), _hip.ptr(params["feedback"]), _hip.ptr(params["mix"]),
               _hip.ptr(lead), _hip.ptr(rows), 0 if rows is None else rows.numel(), B, n_samples, float(sr),
-              1 if exact_order else 0, yp, ys, dp, _hip.stream())
+              1 if exact_order else 0, yp, ys, dp, _hip.ptr(ws), ws_stride, _hip.stream())
     return y
