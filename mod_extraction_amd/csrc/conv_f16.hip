@@ -279,49 +279,65 @@ __device__ __forceinline__ void conv_f16_epilogue(floatx16 (&acc)[CV_WT], const 
             }
         }
     } else {
-        // The two waves of a column half hold the two rows of the pooling pair.  They swap halves of their
-        // accumulators through LDS (row 1 hands over tiles 0..5, row 0 tiles 6..10: one barrier) and each pools,
-        // adds the bias and stores its half -- both rows' waves share the store work.
+        // Max-pool over the row pair + bias + argmax, stored as 16-byte vectors along w.
+        // The two waves of a column half hold the two rows of the pooling pair in the accumulator layout (lane = column w,
+        // registers = output channels).  Every tile goes through LDS once as a [32 co][32 w] fp32 image (4 KB, conflict
+        // free both ways) and comes back transposed: lane = (co row, 4 consecutive w), so that a finished tile costs
+        // 4 x 16-byte stores of pooled values + 4 x 4-byte stores of packed argmax bytes instead of 16 + 16 scalar ones
+        // with their 64-bit address arithmetic (the scalar epilogue was ~1 300 instructions per wave and tile and a third
+        // of the first block's time).  Two rounds, so that the 24 tiles in flight fit the LDS left by the K loop (96 KB):
+        //   round 0: tiles 0,1,2 (finished by the row-0 wave) and 6,7,8 (row-1 wave);  round 1: tiles 3,4,5 and 9,10.
         float *xch = reinterpret_cast<float *>(smem);
-        float *reg_a = xch + c * (6 * 16 * 64);                       // row 1 -> row 0: accumulators 0..5
-        float *reg_b = xch + 2 * (6 * 16 * 64) + c * (5 * 16 * 64);   // row 0 -> row 1: accumulators 6..10
         const int hp = h0 >> 1, Hp = a.H >> 1;
-        // bias of this lane's 2 x 16 output channels, fetched BEFORE the store loop: a load between stores makes
-        // every iteration wait (vmcnt is in order) for the previous iteration's stores to be acknowledged
-        float bias_r[2][16];
+        const int co_l = lane >> 3, w4 = (lane & 7) * 4;                // transposed role of the lane inside a tile
+        float bias_t[2][4];                                             // bias of the 4 co rows this lane stores, per channel half
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) bias_r[j][r] = a.bias[j * 32 + mfma_row(r, lane)];
-        __syncthreads();                                              // the K loop's LDS images are dead
-        if (row == 1) {
+            for (int q = 0; q < 4; ++q) bias_t[j][q] = a.bias[j * 32 + q * 8 + co_l];
+        __syncthreads();                                                // the K loop's LDS images are dead
 #pragma unroll
-            for (int i = 0; i < 6; ++i)
+        for (int round = 0; round < 2; ++round) {
+            // slot s of a wave = tile i: s < 3 -> i = 3 round + s (row-0 finishes), s >= 3 -> i = 6 + 3 round + (s - 3)
+            float *mine = xch + (size_t)((c * 2 + row) * 6) * 1024;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) reg_a[(i * 16 + r) * 64 + lane] = acc[i][r];
-        } else {
+            for (int s6 = 0; s6 < 6; ++s6) {
+                const int i = s6 < 3 ? 3 * round + s6 : 6 + 3 * round + (s6 - 3);
+                if (i >= CV_WT) continue;
 #pragma unroll
-            for (int i = 6; i < CV_WT; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) reg_b[((i - 6) * 16 + r) * 64 + lane] = acc[i][r];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < CV_WT; ++i) {
-            if ((i < 6) != (row == 0)) continue;                      // row 0 finishes 0..5, row 1 finishes 6..10
-            const int w = (i == 10 ? 5 : c * 6 + (i >> 1)) * 32 + l32;
-            const int chh = i == 10 ? c : (i & 1) ^ c, cb0 = chh * 32;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = cb0 + mfma_row(r, lane);
-                const float other = i < 6 ? reg_a[(i * 16 + r) * 64 + lane] : reg_b[((i - 6) * 16 + r) * 64 + lane];
-                const float top = i < 6 ? acc[i][r] : other, bot = i < 6 ? other : acc[i][r];
-                const bool take_bot = bot > top;                      // ties keep the first row (torch)
-                const float m = (take_bot ? bot : top) * inv + (chh ? bias_r[1][r] : bias_r[0][r]);
-                const size_t off = (((size_t)b * CV_CO + co) * Hp + hp) * CV_PITCH + w;
-                a.out[off] = w < a.Wv ? m : 0.0f;
-                a.out_amax[off] = take_bot ? 1 : 0;
+                for (int r = 0; r < 16; ++r) mine[s6 * 1024 + mfma_row(r, lane) * 32 + l32] = acc[i][r];
             }
+            __syncthreads();
+            const float *top = xch + (size_t)((c * 2 + 0) * 6) * 1024, *bot = xch + (size_t)((c * 2 + 1) * 6) * 1024;
+#pragma unroll
+            for (int s3 = 0; s3 < 3; ++s3) {
+                const int s6 = row * 3 + s3;
+                const int i = row == 0 ? 3 * round + s3 : 6 + 3 * round + s3;
+                if (i >= CV_WT) continue;
+                const int wt = i == 10 ? 5 : c * 6 + (i >> 1);           // column tile
+                const int chh = i == 10 ? c : (i & 1) ^ c;              // channel half
+                const int w = wt * 32 + w4;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int col = q * 8 + co_l;                       // co row inside the tile
+                    const floatx4 tv = *reinterpret_cast<const floatx4 *>(top + s6 * 1024 + col * 32 + w4);
+                    const floatx4 bv = *reinterpret_cast<const floatx4 *>(bot + s6 * 1024 + col * 32 + w4);
+                    const float bsum = chh ? bias_t[1][q] : bias_t[0][q];
+                    floatx4 m;
+                    unsigned am = 0;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const bool take_bot = bv[e] > tv[e];            // ties keep the first row (torch)
+                        const float v = (take_bot ? bv[e] : tv[e]) * inv + bsum;
+                        m[e] = w + e < a.Wv ? v : 0.0f;
+                        am |= (take_bot ? 1u : 0u) << (8 * e);
+                    }
+                    const size_t off = (((size_t)b * CV_CO + chh * 32 + col) * Hp + hp) * CV_PITCH + w;
+                    *reinterpret_cast<floatx4 *>(a.out + off) = m;
+                    *reinterpret_cast<unsigned *>(a.out_amax + off) = am;
+                }
+            }
+            if (round == 0) __syncthreads();                            // round 1 overwrites the images
         }
     }
 }

@@ -42,14 +42,34 @@ import re as _re
 _TOL = _re.compile(r"<=?\s*\(?\s*(\d+(\.\d+)?e-\d+|tol\b|max\()")
 _LEFT = _re.compile(r"^(?:assert\s+)?\(?([-+]?(\d+\.?\d*|\.\d+)([eE][-+]?\d+)?)\s*<")
 _measured = {}
+_NP = _re.compile(r"\b(?:np|numpy)\.float(?:16|32|64)\(([^()]*)\)")
+_SAFE = _re.compile(r"^[-+*/() .0-9eE]+$")
+
+
+def _left_value(first: str):
+    """Measured (left) side of 'assert <left> < <tol>' from pytest's evaluated explanation: a number, possibly wrapped
+    in np.float32(...), or plain arithmetic of numbers such as '(4.8e-07 / 0.146)' or 'abs((1.02 - 1.01))'."""
+    text = _NP.sub(r"\1", first)
+    if text.startswith("assert "):
+        text = text[7:]
+    left = _re.split(r"<=?", text, 1)[0].strip()
+    m = _LEFT.match(left + " <")
+    if m:
+        return float(m.group(1))
+    expr = left.replace("abs(", "(")
+    if _SAFE.match(expr):
+        try:
+            return abs(float(eval(expr, {"__builtins__": {}}, {})))       # digits and operators only (checked above)
+        except Exception:
+            return None
+    return None
 
 
 def pytest_assertion_pass(item, lineno, orig, expl):
     if not _TOL.search(orig):
         return
     first = expl.strip().splitlines()[0][:200]
-    m = _LEFT.match(first)
-    val = float(m.group(1)) if m else None
+    val = _left_value(first)
     key = (item.nodeid, lineno)
     old = _measured.get(key)
     if old is None or (val is not None and (old["worst"] is None or val > old["worst"])):
