@@ -280,6 +280,70 @@ def fx_floor_pass(batcher, params, n=3):
     return res
 
 
+def flanger_lock_steps(batcher, params):
+    """Lock-steps of the flanger launch's slowest clip, counted on the host from the integer slot bookkeeping of
+    fx.py:95-103 (what csrc/flanger.hip derives on the device): per row of 64 samples the maximal runs without an internal
+    read-after-write dependency (a run starting at a ends in front of the first k >= a with k - dep[k] >= a)."""
+    import numpy as np
+    rows = batcher.rows_fx.cpu().numpy()
+    if rows.size == 0:
+        return None
+    N = batcher.N
+    mod = make_mod_host(batcher, params)[rows]                                       # (n_fx, n_lfo)
+    up = torch.nn.functional.interpolate(torch.from_numpy(mod).unsqueeze(1), size=N, mode="linear", align_corners=True)[:, 0].numpy()
+    M = batcher.max_delay.cpu().numpy()[rows].astype(np.int64)
+    ls = (params["width"].float().numpy()[rows] * batcher.max_lfo_delay.cpu().numpy()[rows]).astype(np.float32)
+    md = (params["min_delay_width"].float().numpy()[rows] * batcher.max_min_delay.cpu().numpy()[rows]).astype(np.float32)
+    worst, total = 0, 0
+    k = np.arange(64)[None, :]
+    n_rows = -(-N // 64)
+    for i in range(rows.size):
+        d = (ls[i] * up[i] + md[i]).astype(np.float32)
+        w = np.arange(N) % M[i]
+        r = np.mod(w.astype(np.float32) - d + np.float32(M[i]), np.float32(M[i]))
+        prev = np.clip(np.floor(r).astype(np.int64), 0, M[i] - 1)
+        nxt = (prev + 1) % M[i]
+        dp = w - prev; dp[dp <= 0] += M[i]
+        dn = w - nxt; dn[dn <= 0] += M[i]
+        dep = np.minimum(dp, dn)
+        dep = np.concatenate([dep, np.full(n_rows * 64 - N, 1 << 30)]).reshape(n_rows, 64)
+        t = np.where(dep > k, -1, k - dep)                                           # newest in-row dependency of sample k
+        a = np.zeros(n_rows, dtype=np.int64)
+        steps = 0
+        while True:
+            live = a < 64
+            if not live.any():
+                break
+            steps += int(live.sum())
+            conflict = (k >= a[:, None]) & (t >= a[:, None])
+            first = np.where(conflict.any(axis=1), conflict.argmax(axis=1), 64)
+            a = np.where(live, first, a)
+        worst, total = max(worst, steps), total + steps
+    return {"slowest_clip": worst, "mean": total / rows.size}
+
+
+def make_mod_host(batcher, params):
+    """The LFO rows of a parameter draw on the host (oracle-free: the device LFO synth, copied back)."""
+    from mod_extraction_amd.data_modules import make_mod_signals, SHAPE_IDS
+    dev = batcher.device
+    d = {k: v.to(dev) for k, v in params.items() if isinstance(v, torch.Tensor)}
+    shape_id = torch.tensor([SHAPE_IDS[sh] for sh in params["shape"]], dtype=torch.int32, device=dev)
+    return make_mod_signals(batcher.n_lfo, batcher.lfo_sr, d["rate_hz"], d["phase"], shape_id, d["exp"]).cpu().numpy()
+
+
+def lds_roundtrip_ns(device, steps=200000):
+    """Time of one dependent LDS round trip of the lock-step's shape (mx_lds_roundtrip_probe), ns."""
+    from mod_extraction_amd import _hip
+    out = torch.empty(1, device=device)
+    _hip.call("mx_lds_roundtrip_probe", steps, _hip.ptr(out), _hip.stream())
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    _hip.call("mx_lds_roundtrip_probe", steps, _hip.ptr(out), _hip.stream())
+    b.record()
+    torch.cuda.synchronize()
+    return 1e6 * a.elapsed_time(b) / steps
+
+
 def fx_blocks(batcher, params, res):
     n_fx, n_ph = int(batcher.rows_fx.numel()), int(batcher.rows_ph.numel())
     N = batcher.N
@@ -288,9 +352,23 @@ def fx_blocks(batcher, params, res):
         out["flanger_kernel"] = hbm_block(
             f"flanger_kernel ({n_fx} flanger/chorus clips x {N} samples, fx.py:104-115)", n_fx * N * 8.0,
             res[0]["mx_flanger_fwd"], res[1].get("mx_flanger_fwd"),
-            note="8 B/sample: x in, y out; the 882-point LFO is resampled in-kernel. One wavefront per clip, delay line in "
-                 "LDS; the launch lasts as long as its slowest clip's read-after-write chain, so the serial floor, not HBM, "
-                 "is the governing roofline")
+            note="8 B/sample: x in, y out; the 882-point LFO is resampled in-kernel. One workgroup (4 producer waves + 1 consumer "
+                 "wave) per clip, delay line in LDS; the launch lasts as long as its slowest clip's read-after-write chain, so "
+                 "the serial floor, not HBM, is the governing roofline")
+        try:                                                # the independent floor: lock-steps x measured LDS round trip
+            ls_ = flanger_lock_steps(batcher, params)
+            rt = lds_roundtrip_ns(batcher.device)
+            fk = out["flanger_kernel"]
+            fk["lock_steps"] = ls_
+            fk["lds_roundtrip_ns"] = round(rt, 1)
+            fk["independent_floor_ms"] = round(ls_["slowest_clip"] * rt * 1e-6, 4)
+            fk["frac_of_independent_floor"] = round(fk["independent_floor_ms"] / fk["avg_launch_ms"], 4)
+            fk["independent_floor_note"] = ("lock-steps of the slowest clip (host count of the maximal dependency-free runs per row "
+                                            "of 64 samples, from fx.py:95-103's integer slot bookkeeping) x the duration of one "
+                                            "dependent LDS round trip of the lock-step's shape measured by mx_lds_roundtrip_probe "
+                                            "(2 ds_read_b32 -> 5 fp32 ops -> ds_write_b32 on one wavefront, nothing else)")
+        except Exception as e:                               # never lose the bench line over the diagnostic
+            out["flanger_kernel"]["independent_floor_error"] = repr(e)
     if n_ph and "mx_phaser_fwd" in res[0]:
         lead = params["lead"].double()[batcher.kind_id == 2]
         bytes_ph = float(((lead + N) * (4 + 4 + 2)).sum()) + n_ph * N * 8.0
@@ -394,6 +472,7 @@ def run_lfo_config(args, env, cfg_id):
     out["fx_kernels"] = fxk
     if "flanger_kernel" in fxk:
         out["fx_kernel_frac_of_serial_floor"] = fxk["flanger_kernel"].get("frac_of_serial_floor")
+        out["fx_kernel_frac_of_independent_floor"] = fxk["flanger_kernel"].get("frac_of_independent_floor")
         out["fx_kernel_frac_of_hbm"] = fxk["flanger_kernel"]["frac"]
     if world == 1 and f16 and not args.conv_precision and not args.no_fp32_leg:
         module.model.conv_precision = "f32"
@@ -629,6 +708,7 @@ def run_config5(args, env):
     }
     if "flanger_kernel" in kernels:
         out["fx_kernel_frac_of_serial_floor"] = kernels["flanger_kernel"].get("frac_of_serial_floor")
+        out["fx_kernel_frac_of_independent_floor"] = kernels["flanger_kernel"].get("frac_of_independent_floor")
         out["fx_kernel_frac_of_hbm"] = kernels["flanger_kernel"]["frac"]
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_stress(N)

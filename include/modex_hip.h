@@ -73,6 +73,12 @@ int mx_flanger_fwd_probe(const float *x, int64_t x_stride, const float *mod, int
                    int32_t max_delay_max, const int32_t *rows, int64_t n_rows, int64_t B, int64_t N,
                    float *y, int64_t y_stride, float *mod_up, int64_t *dbg_prev, float *dbg_frac, void *stream);
 
+/* Measurement aid (bench.py): `steps` dependent LDS round trips of the flanger lock-step's shape (two ds_read_b32 of the
+ * slot the previous step wrote, the five fp32 operations of fx.py:113-115, one ds_write_b32) on one wavefront, nothing
+ * else.  Its time per step x the lock-steps of a clip is a floor of mx_flanger_fwd that does not come from that kernel.
+ * out: 1 float.  No reference counterpart. */
+int mx_lds_roundtrip_probe(int64_t steps, float *out, void *stream);
+
 /* ---- K3: phaser -- call site mod_extraction/datasets.py:455-482 (pedalboard==0.7.3 Phaser = JUCE
  * dsp::Phaser<float>: 6 first-order TPT all-pass stages + feedback, sine LFO at sr/4 on a log
  * frequency axis, linear dry/wet mix), then clip to [-1,1] (datasets.py:472).  Third-party

@@ -1,43 +1,47 @@
 // flanger.hip -- K2: mono flanger / chorus (reference: mod_extraction/fx.py:72-119).
 //
-// One wavefront per clip; the circular delay line (M <= 40k floats) lives in LDS.
-// The reference executes 88 200 dependent python iterations per batch.  Here a wave walks the
-// clip in chunks of 64*V samples.  For every sample the fp32 index bookkeeping of fx.py:95-103
-// (write slot, fractional read position, prev/next slot) is evaluated with exactly the
-// reference's rounding sequence (no FMA contraction; build uses -ffp-contract=off and explicit
-// __f*_rn).  From the *integer* slots the wave derives, per chunk, the shortest distance G back
-// to a sample whose write is read inside the chunk; any run of <= G consecutive samples has no
-// internal read-after-write dependency, so it is processed by G lanes in lock step (all reads,
-// then all writes -- exactly the reference's read-before-write order, fx.py:111-115).
-// Chorus (min delay >= 485 samples) always runs 256 samples per step; a flanger near zero delay
-// degrades gracefully down to the reference's one-sample-at-a-time order (G = 1).
+// One workgroup = one clip = FIVE wavefronts; the circular delay line (M <= ~38k floats) lives in LDS.
+// The reference executes 88 200 dependent python iterations per batch.  Here the clip is walked in chunks of 256 samples
+// (4 rows of 64).  For every sample the fp32 index bookkeeping of fx.py:95-103 (write slot, fractional read position,
+// prev / next slot) is evaluated with exactly the reference's rounding sequence (no FMA contraction: the build uses
+// -ffp-contract=off and explicit __f*_rn).  From the INTEGER slots follows, per sample k of a row, the newest sample
+// t[k] = k - (distance back to the write it reads) it depends on; a run of consecutive samples [a, b) has no internal
+// read-after-write dependency iff t[k] < a for all k in it, and such a run is processed by its lanes in ONE lock-step
+// (all reads, then all writes: the reference's read-before-write order, fx.py:111-115).  Runs are maximal (greedy):
+// chorus (delay >= 485 samples) always runs 64 samples per step, a flanger near zero delay degrades gracefully down to
+// the reference's one-sample-at-a-time order.
+//   four PRODUCER waves (one chunk ahead, one row of the chunk each): input loads, the LFO (resampled in-kernel), the
+//            index bookkeeping, the run boundaries of the row (a 64-bit mask), debug outputs -> a two-slot LDS ring of
+//            float4 records.
+//   CONSUMER wave: only the dependent chain -- per lock-step two ds_read_b32, five dependent fp32 operations, one
+//            ds_write_b32 -- and the dry / wet mix + store of the finished chunk.
+// One workgroup barrier per chunk.  Round 2 ran everything on one wave with one run length per 256-sample chunk:
+// 1.40 ms for the slowest of 171 clips x 2 s, ~750 cycles per lock-step of which ~200 are the dependent chain.
 //
 // Results are bit-identical to the reference for identical mod_sig input.
 // Algorithmic HBM traffic: 12 B/sample (x, mod in; y out), 8 B/sample with the 882-point LFO
 // resampled in-kernel (util.py:15-29).
 #include "common.h"
 
-#define FL_V 4                 // samples per lane per chunk
+#define FL_V 4                 // rows of 64 samples per chunk
 #define FL_CHUNK (64 * FL_V)
-#define FL_MAX_M 40000         // 160 KB LDS = 40960 floats
+#define FL_RING_FLOATS (2 * (FL_CHUNK * 4 + 2 * FL_V) + 64)   // two slots: 256 float4 records + four 64-bit run masks; 64 dummy slots
+#define FL_MAX_M (40960 - FL_RING_FLOATS)                // 160 KB LDS = 40960 floats, minus the ring
 
-struct FlSample {
-    float x, frac;
-    int w, prev, next;
-    int dep;                   // distance (in samples) to the most recent slot write it reads
-};
-
-__global__ __launch_bounds__(64) void flanger_kernel(
+#define FL_THREADS (64 * (1 + FL_V))   // consumer wave + one producer wave per row of a chunk
+__global__ __launch_bounds__(FL_THREADS) void flanger_kernel(
     const float *__restrict__ x, long long x_stride, const float *__restrict__ mod, int n_mod, float mod_scale,
     const float *__restrict__ lfo_scale, const float *__restrict__ min_delay,
     const float *__restrict__ feedback, const float *__restrict__ depth,
     const float *__restrict__ mix, const float *__restrict__ one_minus_mix,
-    const int *__restrict__ max_delay, const int *__restrict__ rows, int N, int lfo_off,
+    const int *__restrict__ max_delay, const int *__restrict__ rows, int N, int lfo_off, int ring_off,
     float *__restrict__ y, long long y_stride, float *__restrict__ mod_up, long long *__restrict__ dbg_prev,
     float *__restrict__ dbg_frac, int probe)
 {
-    extern __shared__ float buf[];           // [M delay line | n_mod LFO row (when resampled in-kernel)]
-    const int lane = threadIdx.x;
+    extern __shared__ __attribute__((aligned(16))) float buf[];   // [M delay line | n_mod LFO row (when resampled in-kernel) | ring]
+    const int lane = threadIdx.x & 63;
+    const bool producer = threadIdx.x >= 64;
+    const int pw = (int)(threadIdx.x >> 6) - 1;                // producer wave pw prepares row pw of every chunk
     const int b = rows ? rows[blockIdx.x] : (int)blockIdx.x;
     const int M = max_delay[b];
     const float Mf = (float)M;
@@ -46,28 +50,38 @@ __global__ __launch_bounds__(64) void flanger_kernel(
     const float *xb = x + (size_t)b * x_stride;
     const float *mb = mod + (size_t)b * n_mod;
     float *yb = y + (size_t)b * y_stride;
+    float *ring = buf + ring_off;                              // slot s: records at ring + s * (4 * FL_CHUNK + 2 * FL_V)
+    constexpr int SLOT = 4 * FL_CHUNK + 2 * FL_V;
+    const int dummy_off = ring_off + 2 * SLOT;                 // one private dummy slot per consumer lane (see the lock-step loop)
 
-    for (int i = lane; i < M; i += 64) buf[i] = 0.0f;  // fx.py:92 (LDS ops of one wave are in order)
-
+    for (int i = threadIdx.x; i < M; i += FL_THREADS) buf[i] = 0.0f;  // fx.py:92
     const bool resample = (n_mod != N);
-    float *lfo = buf + lfo_off;                        // the short LFO row lives in LDS: no gather latency per chunk
+    float *lfo = buf + lfo_off;                                // the short LFO row lives in LDS: no gather latency per chunk
     if (resample)
-        for (int i = lane; i < n_mod; i += 64) lfo[i] = mb[i];
-    int w_chunk = 0;                                   // c0 % M, carried instead of a per-sample integer modulo
-    float xr[FL_V], mr[FL_V];
-    // software prefetch of the first chunk
-#pragma unroll
-    for (int j = 0; j < FL_V; ++j) {
-        int n = j * 64 + lane;
-        xr[j] = n < N && !probe ? xb[n] : 0.25f;
-        if (!resample) mr[j] = n < N && !probe ? mb[n] : 0.5f;
-    }
+        for (int i = threadIdx.x; i < n_mod; i += FL_THREADS) lfo[i] = mb[i];
+    __syncthreads();
 
-    for (int c0 = 0; c0 < N; c0 += FL_CHUNK) {
-        FlSample s[FL_V];
-        int g = 0x7fffffff;
-#pragma unroll
-        for (int j = 0; j < FL_V; ++j) {
+    const int n_chunks = (N + FL_CHUNK - 1) / FL_CHUNK;
+    // ---- producer state: the next chunk's inputs are prefetched while the current one is prepared
+    float xr = 0.25f, mr = 0.5f;
+    int w_chunk = 0;                                           // c0 % M, carried instead of a per-sample integer modulo
+    if (producer) {
+        const int n = pw * 64 + lane;
+        xr = n < N && !probe ? xb[n] : 0.25f;
+        mr = !resample && n < N && !probe ? mb[n] : 0.5f;
+    }
+    // records of row pw of chunk c -> ring slot c & 1
+    auto build = [&](int c) {
+        const int c0 = c * FL_CHUNK, j = pw;
+        float4 *rec = reinterpret_cast<float4 *>(ring + (c & 1) * SLOT);
+        unsigned long long *masks = reinterpret_cast<unsigned long long *>(ring + (c & 1) * SLOT + 4 * FL_CHUNK);
+        float xn, mn;
+        {                                                      // prefetch chunk c + 1
+            const int n = c0 + FL_CHUNK + j * 64 + lane;
+            xn = n < N && !probe ? xb[n] : 0.25f;
+            mn = !resample && n < N && !probe ? mb[n] : 0.5f;
+        }
+        {
             const int n = c0 + j * 64 + lane;
             const bool valid = n < N;
             float m;
@@ -76,7 +90,7 @@ __global__ __launch_bounds__(64) void flanger_kernel(
                 m = interp_combine(t, lfo[t.i0], lfo[t.i1]);
                 if (mod_up && valid) mod_up[(size_t)b * N + n] = m;
             } else {
-                m = mr[j];
+                m = mr;
             }
             int w = w_chunk + j * 64 + lane;                   // fx.py:95: n % M without a division
             while (w >= M) w -= M;
@@ -91,69 +105,81 @@ __global__ __launch_bounds__(64) void flanger_kernel(
             if (prev < 0) prev = 0;                            // NaN / garbage guard (never hit in contract)
             if (prev >= M) prev = M - 1;
             const int next = prev + 1 == M ? 0 : prev + 1;     // fx.py:103
-            s[j].x = xr[j];
-            s[j].frac = __fsub_rn(r, fl);                      // fx.py:101
-            s[j].w = w;
-            s[j].prev = prev;
-            s[j].next = next;
+            const float frac = __fsub_rn(r, fl);               // fx.py:101
             int dp_ = w - prev; if (dp_ <= 0) dp_ += M;        // slot w itself is "M samples ago"
             int dn_ = w - next; if (dn_ <= 0) dn_ += M;
-            s[j].dep = valid ? min(dp_, dn_) : 0x7fffffff;
-            g = min(g, s[j].dep);
+            const int dep = valid ? min(dp_, dn_) : 0x7fffffff;
             if (dbg_prev && valid) dbg_prev[(size_t)b * N + n] = prev;
-            if (dbg_frac && valid) dbg_frac[(size_t)b * N + n] = s[j].frac;
-        }
-        g = wave_min_i32(g);
-
-        // prefetch the next chunk while this one is in flight
-        float xn[FL_V], mn[FL_V];
-#pragma unroll
-        for (int j = 0; j < FL_V; ++j) {
-            int n = c0 + FL_CHUNK + j * 64 + lane;
-            xn[j] = n < N && !probe ? xb[n] : 0.25f;
-            if (!resample) mn[j] = n < N && !probe ? mb[n] : 0.5f;
-        }
-
-        float o[FL_V];
-        if (g >= FL_CHUNK) {
-            // whole chunk is dependency-free: 4 rows of 64 lanes, all reads before all writes
-            float pv[FL_V], nv[FL_V];
-#pragma unroll
-            for (int j = 0; j < FL_V; ++j) { pv[j] = buf[s[j].prev]; nv[j] = buf[s[j].next]; }
-#pragma unroll
-            for (int j = 0; j < FL_V; ++j) {
-                float it = __fadd_rn(__fmul_rn(s[j].frac, nv[j]), __fmul_rn(__fsub_rn(1.0f, s[j].frac), pv[j]));
-                buf[s[j].w] = __fadd_rn(s[j].x, __fmul_rn(fb, it));   // fx.py:114
-                o[j] = __fadd_rn(s[j].x, __fmul_rn(dp, it));          // fx.py:115
+            if (dbg_frac && valid) dbg_frac[(size_t)b * N + n] = frac;
+            // record: x, frac, 1 - frac (fx.py:113, rounded here exactly as there), slots (w | prev << 16; M < 65536)
+            rec[j * 64 + lane] = make_float4(xr, frac, __fsub_rn(1.0f, frac), __int_as_float(w | (prev << 16)));
+            // maximal dependency-free runs of the row: the run starting at a ends in front of the first k >= a whose
+            // newest dependency t[k] = k - dep[k] is inside the run (t[k] >= a).  dep >= 1, so every run is non-empty.
+            const int tk = dep > lane ? -1 : lane - dep;
+            unsigned long long ends = 0ull;
+            int a = 0;
+            while (a < 64) {
+                const unsigned long long conflict = __ballot(lane >= a && tk >= a);
+                const int bnd = conflict ? (int)__builtin_ctzll(conflict) : 64;
+                ends |= 1ull << (bnd - 1);
+                a = bnd;
             }
+            if (lane == 0) masks[j] = ends;
+        }
+        xr = xn;
+        mr = mn;
+        w_chunk += FL_CHUNK;
+        while (w_chunk >= M) w_chunk -= M;
+    };
+
+    if (producer) build(0);
+    for (int c = 0; c < n_chunks; ++c) {
+        __syncthreads();                                       // records of chunk c are complete; the consumer has left slot (c + 1) & 1
+        if (producer) {
+            if (c + 1 < n_chunks) build(c + 1);
         } else {
-            const int gr = g < 64 ? g : 64;
+            const int c0 = c * FL_CHUNK;
+            const float4 *rec = reinterpret_cast<const float4 *>(ring + (c & 1) * SLOT);
+            const unsigned long long *masks = reinterpret_cast<const unsigned long long *>(ring + (c & 1) * SLOT + 4 * FL_CHUNK);
+            float4 rc[FL_V];
+#pragma unroll
+            for (int j = 0; j < FL_V; ++j) rc[j] = rec[j * 64 + lane];
+            float o[FL_V];
 #pragma unroll
             for (int j = 0; j < FL_V; ++j) {
-                o[j] = 0.0f;
-                for (int g0 = 0; g0 < 64; g0 += gr) {
-                    if (lane >= g0 && lane < g0 + gr) {
-                        float pv = buf[s[j].prev], nv = buf[s[j].next];     // fx.py:111-112
-                        float it = __fadd_rn(__fmul_rn(s[j].frac, nv), __fmul_rn(__fsub_rn(1.0f, s[j].frac), pv));
-                        buf[s[j].w] = __fadd_rn(s[j].x, __fmul_rn(fb, it));
-                        o[j] = __fadd_rn(s[j].x, __fmul_rn(dp, it));
-                    }
-                    __builtin_amdgcn_wave_barrier();
+                const float xs = rc[j].x, frac = rc[j].y, omf = rc[j].z;
+                const int pk = __float_as_int(rc[j].w), w = pk & 0xffff, prev = (pk >> 16) & 0xffff;
+                const int next = prev + 1 == M ? 0 : prev + 1;
+                const unsigned long long m64 = masks[j];
+                const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)m64), hi = __builtin_amdgcn_readfirstlane((unsigned)(m64 >> 32));
+                unsigned long long ends = ((unsigned long long)hi << 32) | lo;
+                // No lane masking inside the chain: every lane executes every lock-step, lanes outside the run [a, bnd) read
+                // and write a private dummy slot (selecting three LDS addresses is plain vector work; an exec-mask region per
+                // step put a v_cmp -> s_and -> s_and_saveexec -> branch sequence on the dependent path of every step).
+                const int my_dummy = dummy_off + lane;
+                float oj = 0.0f;
+                int a = 0;
+                while (ends) {                                 // one lock-step per run [a, bnd)
+                    const int bnd = (int)__builtin_ctzll(ends) + 1;
+                    ends &= ends - 1;
+                    const bool act = lane >= a && lane < bnd;
+                    const float pv = buf[act ? prev : my_dummy], nv = buf[act ? next : my_dummy];   // fx.py:111-112
+                    const float it = __fadd_rn(__fmul_rn(frac, nv), __fmul_rn(omf, pv));            // fx.py:113
+                    buf[act ? w : my_dummy] = __fadd_rn(xs, __fmul_rn(fb, it));                      // fx.py:114
+                    oj = act ? __fadd_rn(xs, __fmul_rn(dp, it)) : oj;                                // fx.py:115
+                    a = bnd;
+                }
+                o[j] = oj;
+            }
+#pragma unroll
+            for (int j = 0; j < FL_V; ++j) {
+                const int n = c0 + j * 64 + lane;
+                if (n < N && (!probe || c + 1 == n_chunks)) {  // probe: only the last chunk is stored (keeps the chain live)
+                    const float v = __fadd_rn(__fmul_rn(omm, rc[j].x), __fmul_rn(mx, o[j]));         // fx.py:117
+                    yb[n] = fminf(fmaxf(v, -1.0f), 1.0f);                                           // fx.py:118
                 }
             }
         }
-#pragma unroll
-        for (int j = 0; j < FL_V; ++j) {
-            const int n = c0 + j * 64 + lane;
-            if (n < N && (!probe || n + FL_CHUNK >= N)) {     // probe: only the last chunk is stored (keeps the chain live)
-                float v = __fadd_rn(__fmul_rn(omm, s[j].x), __fmul_rn(mx, o[j]));   // fx.py:117
-                yb[n] = fminf(fmaxf(v, -1.0f), 1.0f);                              // fx.py:118
-            }
-            xr[j] = xn[j];
-            mr[j] = mn[j];
-        }
-        w_chunk += FL_CHUNK;
-        while (w_chunk >= M) w_chunk -= M;
     }
 }
 
@@ -176,7 +202,7 @@ static int flanger_fwd_launch(const float *x, int64_t x_stride, const float *mod
         !max_delay || !y || B <= 0 || N <= 0 || n_mod <= 0)
         return MX_ERR_ARG;
     if (max_delay_max < 2 || x_stride < N || y_stride < N) return MX_ERR_ARG;
-    if (max_delay_max > FL_MAX_M || N >= (1ll << 30)) return MX_ERR_UNSUPPORTED;
+    if (max_delay_max > FL_MAX_M || max_delay_max > 65535 || N >= (1ll << 30)) return MX_ERR_UNSUPPORTED;
     const int64_t items = rows ? n_rows : B;
     if (items <= 0) return MX_OK;
     static bool attr_set[64] = {};                       // per device: one process may drive several GPUs
@@ -184,18 +210,20 @@ static int flanger_fwd_launch(const float *x, int64_t x_stride, const float *mod
     (void)hipGetDevice(&dev);
     if (dev < 0 || dev >= 64 || !attr_set[dev]) {
         (void)hipFuncSetAttribute((const void *)flanger_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            FL_MAX_M * sizeof(float));
+                            (FL_MAX_M + FL_RING_FLOATS) * sizeof(float));
         if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
-    // LDS: delay line (max over the batch) + the LFO row when it is resampled in-kernel (n_mod < N)
+    // LDS: delay line (max over the batch) + the LFO row when it is resampled in-kernel (n_mod < N) + the record ring
     const int lfo_off = max_delay_max;
-    const size_t lds_floats = (size_t)max_delay_max + (n_mod != N ? (size_t)n_mod : 0);
+    size_t lds_floats = (size_t)max_delay_max + (n_mod != N ? (size_t)n_mod : 0);
+    lds_floats = (lds_floats + 3) & ~(size_t)3;                    // the ring holds float4 records
+    const int ring_off = (int)lds_floats;
     if (lds_floats > FL_MAX_M) return MX_ERR_UNSUPPORTED;
-    const size_t lds = lds_floats * sizeof(float);
-    hipLaunchKernelGGL(flanger_kernel, dim3((unsigned)items), dim3(64), lds, (hipStream_t)stream, x, (long long)x_stride, mod,
+    const size_t lds = (lds_floats + FL_RING_FLOATS) * sizeof(float);
+    hipLaunchKernelGGL(flanger_kernel, dim3((unsigned)items), dim3(FL_THREADS), lds, (hipStream_t)stream, x, (long long)x_stride, mod,
                        (int)n_mod, interp_scale_host(n_mod, N), lfo_scale, min_delay, feedback, depth,
-                       mix, one_minus_mix, max_delay, rows, (int)N, lfo_off, y, (long long)y_stride, mod_up, (long long *)dbg_prev,
-                       dbg_frac, probe);
+                       mix, one_minus_mix, max_delay, rows, (int)N, lfo_off, ring_off, y, (long long)y_stride, mod_up,
+                       (long long *)dbg_prev, dbg_frac, probe);
     return mx_launch_status();
 }
 
@@ -218,4 +246,37 @@ MX_EXPORT int mx_flanger_fwd_probe(const float *x, int64_t x_stride, const float
                              void *stream)
 {
     return flanger_fwd_launch(x, x_stride, mod, n_mod, lfo_scale, min_delay, feedback, depth, mix, one_minus_mix, max_delay, max_delay_max, rows, n_rows, B, N, y, y_stride, mod_up, dbg_prev, dbg_frac, stream, 1);
+}
+
+// ---- measurement aid: the LDS round trip of one lock-step -------------------------------------------------------------
+// One wavefront runs `steps` dependent lock-steps of the flanger's shape on a private LDS array -- two ds_read_b32 of the
+// slot written by the previous step, the five fp32 operations of fx.py:113-115, one ds_write_b32 -- with no index
+// bookkeeping, no run logic and no global traffic.  bench.py times it with HIP events: (duration / steps) x the lock-steps
+// of the slowest clip (counted on the host from the integer slot bookkeeping, tools/flanger_hops.py) is a floor of the
+// flanger launch that does NOT come from the flanger kernel itself.  out[0] receives the last value (keeps the chain live).
+__global__ __launch_bounds__(64) void lds_roundtrip_kernel(int steps, float fb, float *__restrict__ out)
+{
+    __shared__ float line[128];
+    const int lane = threadIdx.x;
+    line[lane] = 0.5f;
+    line[64 + lane] = 0.25f;
+    __builtin_amdgcn_wave_barrier();
+    float o = 0.0f;
+    int slot = lane;
+    for (int s = 0; s < steps; ++s) {
+        const float pv = line[slot], nv = line[slot ^ 64];
+        const float it = __fadd_rn(__fmul_rn(0.375f, nv), __fmul_rn(0.625f, pv));
+        slot ^= 64;
+        line[slot] = __fadd_rn(0.125f, __fmul_rn(fb, it));
+        o = __fadd_rn(0.125f, __fmul_rn(0.5f, it));
+    }
+    if (lane == 0) out[0] = o;
+}
+
+// steps dependent LDS round trips on one wavefront of one workgroup (see above); out: 1 float
+MX_EXPORT int mx_lds_roundtrip_probe(int64_t steps, float *out, void *stream)
+{
+    if (!out || steps <= 0 || steps >= (1ll << 30)) return MX_ERR_ARG;
+    hipLaunchKernelGGL(lds_roundtrip_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (int)steps, 0.5f, out);
+    return mx_launch_status();
 }
