@@ -254,7 +254,7 @@ MX_EXPORT int mx_flanger_fwd_probe(const float *x, int64_t x_stride, const float
 // bookkeeping, no run logic and no global traffic.  bench.py times it with HIP events: (duration / steps) x the lock-steps
 // of the slowest clip (counted on the host from the integer slot bookkeeping, tools/flanger_hops.py) is a floor of the
 // flanger launch that does NOT come from the flanger kernel itself.  out[0] receives the last value (keeps the chain live).
-__global__ __launch_bounds__(64) void lds_roundtrip_kernel(int steps, float fb, float *__restrict__ out)
+__global__ __launch_bounds__(64) void lds_roundtrip_kernel(int steps, int stride, float fb, float *__restrict__ out)
 {
     __shared__ float line[128];
     const int lane = threadIdx.x;
@@ -264,11 +264,13 @@ __global__ __launch_bounds__(64) void lds_roundtrip_kernel(int steps, float fb, 
     float o = 0.0f;
     int slot = lane;
     for (int s = 0; s < steps; ++s) {
-        const float pv = line[slot], nv = line[slot ^ 64];
+        // `stride` is 0 at run time, which the compiler cannot know: it has to issue the reads after the previous step's
+        // write (same slot -> a true LDS read-after-write round trip) instead of forwarding the value in a register
+        const float pv = line[slot], nv = line[slot + 64];
         const float it = __fadd_rn(__fmul_rn(0.375f, nv), __fmul_rn(0.625f, pv));
-        slot ^= 64;
         line[slot] = __fadd_rn(0.125f, __fmul_rn(fb, it));
         o = __fadd_rn(0.125f, __fmul_rn(0.5f, it));
+        slot = (slot + stride) & 63;
     }
     if (lane == 0) out[0] = o;
 }
@@ -277,6 +279,6 @@ __global__ __launch_bounds__(64) void lds_roundtrip_kernel(int steps, float fb, 
 MX_EXPORT int mx_lds_roundtrip_probe(int64_t steps, float *out, void *stream)
 {
     if (!out || steps <= 0 || steps >= (1ll << 30)) return MX_ERR_ARG;
-    hipLaunchKernelGGL(lds_roundtrip_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (int)steps, 0.5f, out);
+    hipLaunchKernelGGL(lds_roundtrip_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (int)steps, 0, 0.5f, out);
     return mx_launch_status();
 }

@@ -2,6 +2,7 @@
 1024-sample chunk, the TBPTT step logic) and the effect-model losses, against the golden vectors of
 the reference's own classes and the CPU oracle.  Tolerances: audio in [-1,1], 1e-5 absolute;
 gradients 1e-4 relative to each tensor's max (fp32, ~1k-step recurrences, device tanh/exp)."""
+import math
 import os
 
 import numpy as np
@@ -165,10 +166,31 @@ def test_streaming_effect_model_vs_reference_golden(golden_dir, dev):
         assert float(em.prev_phase) == float(g[f"phase{b}"]), b            # carried LFO phase: bit-exact
 
 
-def test_tbptt_prefetched_prepare_is_bit_identical(dev):
+class _FixedLFOExtractor(torch.nn.Module):
+    """Stands in for a TRAINED frozen extractor (none exists in this image; an untrained CNN yields no valid LFO): runs
+    the real CNN forward, then returns fixed per-row LFOs -- rows 0 and 2 valid sweeps, row 1 constant (no corner: discarded
+    by the validity filter), row 3 a 40-cycle wiggle (too many corners: discarded)."""
+
+    def __init__(self, net):
+        super().__init__()
+        self.net = net
+        self.n_frames = net.n_frames
+
+    def forward(self, x):
+        hat, latent = self.net(x)
+        t = torch.linspace(0.0, 1.0, hat.size(-1), device=hat.device)
+        rows = torch.stack([0.5 + 0.5 * torch.cos(2 * math.pi * (1.5 * t + 0.1)), torch.full_like(t, 0.3),
+                            0.5 + 0.5 * torch.cos(2 * math.pi * (2.5 * t + 0.6)), 0.5 + 0.5 * torch.cos(2 * math.pi * 40.0 * t)])
+        return rows[: hat.size(0)].unsqueeze(1) + 0.0 * hat, latent
+
+
+@pytest.mark.parametrize("yaml_flags", [False, True])
+def test_tbptt_prefetched_prepare_is_bit_identical(dev, yaml_flags):
     """The effect-modelling trainer renders batch i+1 and runs the frozen extractor on it on a side stream while the LSTM
     trains on batch i (data_modules.set_ahead_fn / lightning.prepare_ahead).  Same weights after two batches, bit for bit,
-    as with everything on the main stream."""
+    as with everything on the main stream.  yaml_flags: the shipped train_em_dry_wet.yml settings -- should_stretch and
+    discard_invalid_lfos true -- where the prefetch must hand over the validity verdicts WITHOUT blocking the host
+    (asynchronous copy behind an event) and the ragged batch (2 of 4 clips survive) is gathered when it is consumed."""
     from mod_extraction_amd import data_modules, lightning as al, models as am, optim, trainer
 
     def run(prefetch):
@@ -176,7 +198,8 @@ def test_tbptt_prefetched_prepare_is_bit_identical(dev):
         cnn = am.Spectral2DCNN(in_ch=2, n_samples=22272, n_mels=64, out_channels=[64] * 6, temp_dilations=[1, 1, 2, 4, 8, 16],
                                pool_size=(2, 1))
         em = am.LSTMEffectModel()
-        mod = al.TBPTTLFOEffectModeling(1024, 1024, em, lfo_model=cnn, discard_invalid_lfos=False,
+        mod = al.TBPTTLFOEffectModeling(1024, 1024, em, lfo_model=_FixedLFOExtractor(cnn) if yaml_flags else cnn,
+                                        discard_invalid_lfos=yaml_flags, should_stretch=True,
                                         loss_dict={"l1": 1.0, "esr": 0.0, "dc": 0.0}).to(dev).train()
         opt = optim.FlatAdamW([p for p in mod.parameters() if p.requires_grad], lr=1e-4, betas=(0.8, 0.99))
         dm = data_modules.RandomAudioChunkDryWetDataModule(batch_size=4, n_samples=22272, sr=44100, train_num_examples_per_epoch=8,
@@ -190,6 +213,8 @@ def test_tbptt_prefetched_prepare_is_bit_identical(dev):
             for i in range(2):
                 mod.training_step(dm.train_batch(), i, optimizer=opt, world_size=1)
             loss = float(torch.stack(mod.logged["train/loss"]).mean())
+        if yaml_flags:
+            assert mod.last_kept == 2                                    # rows 1 and 3 were discarded
         return opt.flat_param.clone(), opt.step_count, loss
 
     p0, n0, l0 = run(False)
