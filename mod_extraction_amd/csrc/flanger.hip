@@ -25,10 +25,15 @@
 
 #define FL_V 4                 // rows of 64 samples per chunk
 #define FL_CHUNK (64 * FL_V)
-#define FL_RING_FLOATS (2 * (FL_CHUNK * 4 + 2 * FL_V) + 64)   // two slots: 256 float4 records + four 64-bit run masks; 64 dummy slots
+#define FL_SLOT_FLOATS (FL_CHUNK * 6 + 2 * FL_V)          // 256 float4 records, 256 64-bit lane masks (run r of a row in lane r), 4 run counts
+#define FL_RING_FLOATS (2 * FL_SLOT_FLOATS)
 #define FL_MAX_M (40960 - FL_RING_FLOATS)                // 160 KB LDS = 40960 floats, minus the ring
 
 #define FL_THREADS (64 * (1 + FL_V))   // consumer wave + one producer wave per row of a chunk
+__device__ __forceinline__ unsigned lds_byte_addr(const float *p) {
+    return (unsigned)(size_t)(__attribute__((address_space(3))) const float *)p;
+}
+
 __global__ __launch_bounds__(FL_THREADS) void flanger_kernel(
     const float *__restrict__ x, long long x_stride, const float *__restrict__ mod, int n_mod, float mod_scale,
     const float *__restrict__ lfo_scale, const float *__restrict__ min_delay,
@@ -50,9 +55,8 @@ __global__ __launch_bounds__(FL_THREADS) void flanger_kernel(
     const float *xb = x + (size_t)b * x_stride;
     const float *mb = mod + (size_t)b * n_mod;
     float *yb = y + (size_t)b * y_stride;
-    float *ring = buf + ring_off;                              // slot s: records at ring + s * (4 * FL_CHUNK + 2 * FL_V)
-    constexpr int SLOT = 4 * FL_CHUNK + 2 * FL_V;
-    const int dummy_off = ring_off + 2 * SLOT;                 // one private dummy slot per consumer lane (see the lock-step loop)
+    float *ring = buf + ring_off;                              // slot s at ring + s * FL_SLOT_FLOATS
+    constexpr int SLOT = FL_SLOT_FLOATS;
 
     for (int i = threadIdx.x; i < M; i += FL_THREADS) buf[i] = 0.0f;  // fx.py:92
     const bool resample = (n_mod != N);
@@ -74,7 +78,8 @@ __global__ __launch_bounds__(FL_THREADS) void flanger_kernel(
     auto build = [&](int c) {
         const int c0 = c * FL_CHUNK, j = pw;
         float4 *rec = reinterpret_cast<float4 *>(ring + (c & 1) * SLOT);
-        unsigned long long *masks = reinterpret_cast<unsigned long long *>(ring + (c & 1) * SLOT + 4 * FL_CHUNK);
+        unsigned long long *run_mask = reinterpret_cast<unsigned long long *>(ring + (c & 1) * SLOT + 4 * FL_CHUNK);
+        int *n_runs = reinterpret_cast<int *>(ring + (c & 1) * SLOT + 6 * FL_CHUNK);
         float xn, mn;
         {                                                      // prefetch chunk c + 1
             const int n = c0 + FL_CHUNK + j * 64 + lane;
@@ -116,15 +121,19 @@ __global__ __launch_bounds__(FL_THREADS) void flanger_kernel(
             // maximal dependency-free runs of the row: the run starting at a ends in front of the first k >= a whose
             // newest dependency t[k] = k - dep[k] is inside the run (t[k] >= a).  dep >= 1, so every run is non-empty.
             const int tk = dep > lane ? -1 : lane - dep;
-            unsigned long long ends = 0ull;
-            int a = 0;
+            // Lane r keeps the lane mask of run r (lanes [a, bnd) as a 64-bit exec image): the consumer fetches a step's mask
+            // with two v_readlane instead of deriving it.
+            unsigned long long mine = 0ull;
+            int a = 0, run = 0;
             while (a < 64) {
                 const unsigned long long conflict = __ballot(lane >= a && tk >= a);
                 const int bnd = conflict ? (int)__builtin_ctzll(conflict) : 64;
-                ends |= 1ull << (bnd - 1);
+                if (lane == run) mine = (~0ull << a) & (~0ull >> (64 - bnd));
                 a = bnd;
+                ++run;
             }
-            if (lane == 0) masks[j] = ends;
+            run_mask[j * 64 + lane] = mine;
+            if (lane == 0) n_runs[j] = run;
         }
         xr = xn;
         mr = mn;
@@ -140,35 +149,78 @@ __global__ __launch_bounds__(FL_THREADS) void flanger_kernel(
         } else {
             const int c0 = c * FL_CHUNK;
             const float4 *rec = reinterpret_cast<const float4 *>(ring + (c & 1) * SLOT);
-            const unsigned long long *masks = reinterpret_cast<const unsigned long long *>(ring + (c & 1) * SLOT + 4 * FL_CHUNK);
+            const unsigned long long *run_mask = reinterpret_cast<const unsigned long long *>(ring + (c & 1) * SLOT + 4 * FL_CHUNK);
+            const int *n_runs = reinterpret_cast<const int *>(ring + (c & 1) * SLOT + 6 * FL_CHUNK);
             float4 rc[FL_V];
 #pragma unroll
             for (int j = 0; j < FL_V; ++j) rc[j] = rec[j * 64 + lane];
+            // everything a row needs from LDS and the slot arithmetic, for all four rows, BEFORE the first lock-step loop (the
+            // loops are opaque to the compiler and fence memory: whatever is left between two of them is serial time)
+            unsigned m_lo_[FL_V], m_hi_[FL_V];
+            int n_runs_[FL_V];
+            unsigned a_prev_[FL_V], a_next_[FL_V], a_w_[FL_V];
+#pragma unroll
+            for (int j = 0; j < FL_V; ++j) {
+                const int pk = __float_as_int(rc[j].w), w = pk & 0xffff, prev = (pk >> 16) & 0xffff;
+                const int next = prev + 1 == M ? 0 : prev + 1;
+                const unsigned long long m64 = run_mask[j * 64 + lane];
+                m_lo_[j] = (unsigned)m64; m_hi_[j] = (unsigned)(m64 >> 32);
+                n_runs_[j] = __builtin_amdgcn_readfirstlane(n_runs[j]);
+                a_prev_[j] = lds_byte_addr(buf + prev); a_next_[j] = lds_byte_addr(buf + next); a_w_[j] = lds_byte_addr(buf + w);
+            }
             float o[FL_V];
 #pragma unroll
             for (int j = 0; j < FL_V; ++j) {
                 const float xs = rc[j].x, frac = rc[j].y, omf = rc[j].z;
-                const int pk = __float_as_int(rc[j].w), w = pk & 0xffff, prev = (pk >> 16) & 0xffff;
-                const int next = prev + 1 == M ? 0 : prev + 1;
-                const unsigned long long m64 = masks[j];
-                const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)m64), hi = __builtin_amdgcn_readfirstlane((unsigned)(m64 >> 32));
-                unsigned long long ends = ((unsigned long long)hi << 32) | lo;
-                // No lane masking inside the chain: every lane executes every lock-step, lanes outside the run [a, bnd) read
-                // and write a private dummy slot (selecting three LDS addresses is plain vector work; an exec-mask region per
-                // step put a v_cmp -> s_and -> s_and_saveexec -> branch sequence on the dependent path of every step).
-                const int my_dummy = dummy_off + lane;
-                float oj = 0.0f;
-                int a = 0;
-                while (ends) {                                 // one lock-step per run [a, bnd)
-                    const int bnd = (int)__builtin_ctzll(ends) + 1;
-                    ends &= ends - 1;
-                    const bool act = lane >= a && lane < bnd;
-                    const float pv = buf[act ? prev : my_dummy], nv = buf[act ? next : my_dummy];   // fx.py:111-112
-                    const float it = __fadd_rn(__fmul_rn(frac, nv), __fmul_rn(omf, pv));            // fx.py:113
-                    buf[act ? w : my_dummy] = __fadd_rn(xs, __fmul_rn(fb, it));                      // fx.py:114
-                    oj = act ? __fadd_rn(xs, __fmul_rn(dp, it)) : oj;                                // fx.py:115
-                    a = bnd;
-                }
+                const unsigned m_lo = m_lo_[j], m_hi = m_hi_[j];
+                const int nr = n_runs_[j];
+                const unsigned a_prev = a_prev_[j], a_next = a_next_[j], a_w = a_w_[j];
+                // The lock-step loop, written out.  Run r executes under its lane mask, which the producer wave left in lane r of
+                // (m_lo, m_hi): two v_readlane into vcc, issued with the step counter behind the two reads of the step before,
+                // inside their LDS latency.  The dependent path of a lock-step is read -> 5 fp32 operations -> write ->
+                // s_mov exec -> not-taken branch -> read.  The compiler's own versions of this loop (selects onto a private dummy
+                // slot, or an exec region per step) put 25-30 instructions there.  A lane is active in exactly one run of its
+                // row, so `it` keeps each lane's own interpolated value.
+                float it = 0.0f, pv, nv;
+                unsigned long long sv;
+                int k;
+#define FL_LOCK_STEP                                                                                                   \
+    "ds_read_b32 %[pv], %[ap]\n"       /* fx.py:111 */                                                                 \
+    "ds_read_b32 %[nv], %[an]\n"       /* fx.py:112 */                                                                 \
+    "s_add_i32 %[k], %[k], 1\n"                                                                                        \
+    "s_cmp_lt_i32 %[k], %[nr]\n"                                                                                       \
+    "v_readlane_b32 vcc_lo, %[mlo], %[k]\n" /* lane nr (mod 64) after the last run: unused */                          \
+    "v_readlane_b32 vcc_hi, %[mhi], %[k]\n"                                                                            \
+    "s_waitcnt lgkmcnt(0)\n"                                                                                           \
+    "v_mul_f32 %[nv], %[frac], %[nv]\n"                                                                                \
+    "v_mul_f32 %[pv], %[omf], %[pv]\n"                                                                                 \
+    "v_add_f32 %[it], %[nv], %[pv]\n"  /* fx.py:113 */                                                                 \
+    "v_mul_f32 %[pv], %[fb], %[it]\n"                                                                                  \
+    "v_add_f32 %[pv], %[xs], %[pv]\n"                                                                                  \
+    "ds_write_b32 %[aw], %[pv]\n"      /* fx.py:114 */                                                                 \
+    "s_mov_b64 exec, vcc\n"
+                // four lock-steps per taken branch (a not-taken exit branch costs an issue slot, a taken one refills the
+                // instruction buffer on the dependent path)
+                asm volatile(
+                    "s_mov_b64 %[sv], exec\n"
+                    "s_mov_b32 %[k], 0\n"
+                    "v_readlane_b32 vcc_lo, %[mlo], 0\n"
+                    "v_readlane_b32 vcc_hi, %[mhi], 0\n"
+                    "s_nop 3\n"
+                    "s_mov_b64 exec, vcc\n"
+                    "Lfl_step_%=:\n"
+                    FL_LOCK_STEP "s_cbranch_scc0 Lfl_done_%=\n"
+                    FL_LOCK_STEP "s_cbranch_scc0 Lfl_done_%=\n"
+                    FL_LOCK_STEP "s_cbranch_scc0 Lfl_done_%=\n"
+                    FL_LOCK_STEP "s_cbranch_scc1 Lfl_step_%=\n"
+                    "Lfl_done_%=:\n"
+                    "s_mov_b64 exec, %[sv]\n"
+                    "s_waitcnt lgkmcnt(0)\n"
+                    : [it] "+v"(it), [pv] "=&v"(pv), [nv] "=&v"(nv), [sv] "=&s"(sv), [k] "=&s"(k)
+                    : [ap] "v"(a_prev), [an] "v"(a_next), [aw] "v"(a_w), [frac] "v"(frac), [omf] "v"(omf), [xs] "v"(xs), [fb] "s"(fb),
+                      [mlo] "v"(m_lo), [mhi] "v"(m_hi), [nr] "s"(nr)
+                    : "memory", "scc", "vcc");
+                const float oj = __fadd_rn(xs, __fmul_rn(dp, it));                                   // fx.py:115
                 o[j] = oj;
             }
 #pragma unroll
