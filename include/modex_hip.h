@@ -357,7 +357,8 @@ int mx_effect_loss_grad(const float *y_hat, int64_t y_hat_stride, const float *y
  * win_length centred in the frame).  twiddle (2048,2) device = exp(-2 pi i m/2048).
  * terms (2*n_res+1) device: [sc_0, logmag_0, ..., total].  dx: d total / d y_hat rows (stride dx_stride)
  * or NULL.  Workspaces (device): part >= 3*B*max_r ceil(frames_r/8) doubles, coef 2 floats,
- * scratch >= B*max_r(frames_r*n_fft_r) floats (needed only when dx != NULL); frames_r = 1 + T/hop_r. */
+ * scratch >= B*max_r(frames_r*(5*n_fft_r/2 + 4)) floats (needed only when dx != NULL: the frames' time-domain gradients
+ * and the bins the forward pass parks for the gradient pass); frames_r = 1 + T/hop_r. */
 int mx_mrstft_loss(const float *y_hat, int64_t y_hat_stride, const float *y, int64_t y_stride, int64_t B,
                    int64_t T, int32_t n_res, const int32_t *fft_sizes, const int32_t *hops,
                    const float *windows, const float *twiddle, float w_sc, float w_log, float eps,

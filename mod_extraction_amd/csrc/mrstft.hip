@@ -9,11 +9,16 @@
 // Three passes per resolution (12 B/sample algorithmic: x, y in, grad out):
 //   A  stats : per frame, ONE complex FFT of x + i*y (one frame per wavefront, register-staged radix-4 Stockham, see
 //              below) -> both spectra by Hermitian separation -> per-workgroup partial sums of
-//              (Ym - Xm)^2, Ym^2, |log Xm - log Ym|
-//   B  grad  : same FFT, per-bin dL/dX from the global norms evaluated by the lane that feeds the bin into the
-//              inverse FFT, window, store the frame's time-domain gradient to scratch (frames x n_fft)
+//              (Ym - Xm)^2, Ym^2, |log Xm - log Ym|; when a gradient will follow, (Re X, Im X, Ym) of every bin is left in
+//              a workspace (12 B per bin: the transform is the expensive part, not the bytes)
+//   B  grad  : per-bin dL/dX from the global norms and the parked bins -- no second forward transform --, and ONE
+//              inverse FFT per PAIR of frames: the one-sided gradient spectra of frames 2p and 2p + 1 are completed to
+//              Hermitian spectra G~ (G~[k] = G[k] / 2, G~[N - k] = conj G[k] / 2, DC and Nyquist real) and transformed
+//              as G~_a + i G~_b, whose real / imaginary parts are the two frames' time-domain gradients; window, store to
+//              scratch (frames x n_fft)
 //   C  fold  : overlap-add as a GATHER (each sample sums the frames that cover it, incl. the reflect-
 //              padded positions) -> deterministic, no atomics
+// Transforms per frame: 1.5 (it was 3: forward in A, forward again and a zero-padded inverse in B).
 // Measured per 256 clips x 4 s (all three resolutions, value + gradient): 19.2 ms (frame spread over 256 threads, an LDS
 // round trip and a __syncthreads per pass, twiddles from global memory) -> 14.9 (twiddles staged in LDS) -> 11.4 ms
 // (this file).  The FFT passes are VALU-issue bound: ~1 800 vector instructions per 1024-point frame.
@@ -21,6 +26,8 @@
 
 #define MR_MAXN 2048
 #define MR_FPG 16        // frames per workgroup (passes A and B); the partial-sum workspace is sized for >= 8
+// parked bins of one frame: Re X[0..N/2), Im X[0..N/2), Ym[0..N/2), then Re X[N/2], Ym[N/2] (Im X[N/2] == 0), padded to 16 B
+#define MR_PARK(N) (3 * (N) / 2 + 4)
 
 struct cf { float re, im; };
 // Complex multiply, every product rounded on its own (the file is compiled with -ffp-contract=off).  Measured with the two
@@ -192,13 +199,6 @@ __device__ __forceinline__ void load_frame(cf (&R)[WF<N>::NB][4], const float *x
 // spectra of the two real signals from Z = FFT(x + i y):  X[k] = (Z[k] + conj Z[N-k]) / 2,
 // Y[k] = (Z[k] - conj Z[N-k]) / (2 i)
 template <int N>
-__device__ __forceinline__ void split_bins_at(const cf *Z, int k, int km, cf &X, cf &Y)   // km = (N - k) mod N
-{
-    const cf z = Z[k], zc = Z[km];
-    X = {0.5f * (z.re + zc.re), 0.5f * (z.im - zc.im)};
-    Y = {0.5f * (z.im + zc.im), -0.5f * (z.re - zc.re)};
-}
-template <int N>
 __device__ __forceinline__ void split_bins(const cf *Z, int k, cf &X, cf &Y)
 {
     const cf z = Z[k], zc = Z[(N - k) & (N - 1)];
@@ -213,13 +213,13 @@ template <int N> __device__ __forceinline__ int frame_slot(int it, int wave, int
 }
 
 // ---- pass A -------------------------------------------------------------------------------------
-template <int N>
+template <int N, bool PARK>
 __global__ __launch_bounds__(WF<N>::WAVES * 64) __attribute__((amdgpu_waves_per_eu(2))) void mr_stats_kernel(const float *__restrict__ x, long long xs,
                                                                      const float *__restrict__ y, long long ys,
                                                                      const float *__restrict__ win,
                                                                      const float2 *__restrict__ tw, int T, int hop,
                                                                      int n_frames, float eps,
-                                                                     double *__restrict__ part)
+                                                                     double *__restrict__ part, float *__restrict__ park)
 {
     constexpr int L = WF<N>::L, E = WF<N>::E, WAVES = WF<N>::WAVES, FW = WF<N>::FW;
     __shared__ cf xbuf[WAVES * FW][WF<N>::LEN];
@@ -242,11 +242,16 @@ __global__ __launch_bounds__(WF<N>::WAVES * 64) __attribute__((amdgpu_waves_per_
         for (int i = 0; i < E; ++i) buf[pos_final<N>(i, a)] = Z[i];
         __builtin_amdgcn_wave_barrier();
         if (live) {
+            float *pk = PARK ? park + ((size_t)b * n_frames + f) * MR_PARK(N) : nullptr;
             for (int k = a; k <= N / 2; k += L) {
                 cf X, Y;
                 split_bins<N>(buf, k, X, Y);
                 const float xm = sqrtf(fmaxf(X.re * X.re + X.im * X.im, eps));
                 const float ym = sqrtf(fmaxf(Y.re * Y.re + Y.im * Y.im, eps));
+                if (PARK) {
+                    if (k < N / 2) { pk[k] = X.re; pk[N / 2 + k] = X.im; pk[N + k] = ym; }
+                    else { pk[3 * N / 2] = X.re; pk[3 * N / 2 + 1] = ym; }
+                }
                 const float d = ym - xm;
                 s_d += (double)d * (double)d;
                 s_y += (double)ym * (double)ym;
@@ -290,81 +295,102 @@ __global__ __launch_bounds__(256) void mr_finish_kernel(const double *__restrict
 }
 
 // ---- pass B -------------------------------------------------------------------------------------
-// N = 2048 holds 32 complex values per lane and fills the 256 registers of two waves per SIMD: 6 loop-invariant
-// addresses still live in scratch (18 before the mirror bins became constant offsets, see the bin pass below).  Measured
-// with MR_GRAD2048_EU = 1 (512 registers, no scratch, one wave per SIMD): 10.10 instead of 9.95 ms for the three
-// resolutions -- occupancy is worth more than the six scratch loads per frame, so 2 stays.
+// d loss / d X of one bin from the parked (Re X, Im X, Ym):  d sc / d Xm and d logmag / d Xm as in mr_finish_kernel, times
+// d Xm / d X = X / Xm; the clamp passes no gradient below eps
+__device__ __forceinline__ cf grad_bin(float xr, float xi, float ym, float eps, float c_sc, float c_log)
+{
+    // branch-free: a divergent branch per bin would also serialise the bins' loads behind one another
+    const float px = xr * xr + xi * xi;
+    const float xm = sqrtf(fmaxf(px, eps));
+    const float dl = logf(xm) - logf(ym);
+    const float dxm = c_sc * (xm - ym) + c_log * (dl > 0.0f ? 1.0f : (dl < 0.0f ? -1.0f : 0.0f)) / xm;
+    const float sc = px > eps ? dxm / xm : 0.0f;
+    return {sc * xr, sc * xi};                                          // dL/dRe X, dL/dIm X
+}
+
 #ifndef MR_GRAD2048_EU
 #define MR_GRAD2048_EU 2
 #endif
 template <int N>
-__global__ __launch_bounds__(WF<N>::WAVES * 64) __attribute__((amdgpu_waves_per_eu(N == 2048 ? MR_GRAD2048_EU : 2))) void mr_grad_kernel(const float *__restrict__ x, long long xs,
-                                                                    const float *__restrict__ y, long long ys,
+__global__ __launch_bounds__(WF<N>::WAVES * 64) __attribute__((amdgpu_waves_per_eu(N == 2048 ? MR_GRAD2048_EU : 2))) void mr_grad_kernel(const float *__restrict__ park,
                                                                     const float *__restrict__ win,
-                                                                    const float2 *__restrict__ tw, int T, int hop,
-                                                                    int n_frames, float eps,
+                                                                    const float2 *__restrict__ tw, int n_frames, float eps,
                                                                     const float *__restrict__ coef,
                                                                     float *__restrict__ scratch)
 {
-    constexpr int L = WF<N>::L, E = WF<N>::E, NB = WF<N>::NB, WAVES = WF<N>::WAVES, FW = WF<N>::FW;
+    constexpr int L = WF<N>::L, E = WF<N>::E, NB = WF<N>::NB, WAVES = WF<N>::WAVES, FW = WF<N>::FW, P = MR_PARK(N);
     __shared__ cf xbuf[WAVES * FW][WF<N>::LEN];
     __shared__ float2 tw_s[N];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane / L, a = lane % L;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane / L, a_ = lane % L;
     const int b = blockIdx.y;
-    const float *xb = x + (size_t)b * xs, *yb = y + (size_t)b * ys;
     const float c_sc = coef[0], c_log = coef[1];
     cf *buf = xbuf[wave * FW + g];
     stage_twiddles<N>(tw_s, tw);
-    for (int it = 0; it < MR_FPG / (WAVES * FW); ++it) {
-        const int f = blockIdx.x * MR_FPG + frame_slot<N>(it, wave, g);
-        if (f - g >= n_frames) break;                                   // wave-uniform
-        const bool live = f < n_frames;
+    for (int it = 0; it < MR_FPG / (2 * WAVES * FW); ++it) {
+        // the lane's position is opaque to the optimiser in every iteration: otherwise each of the ~100 window / parked-bin /
+        // output addresses built from it is loop invariant, gets hoisted out of the frame loop and, for N = 2048 (all 256
+        // registers taken by the transform), lives in scratch memory (89 spilled registers)
+        int a = a_;
+        asm volatile("" : "+v"(a));
+        // frames 2 p and 2 p + 1 share a transform
+        const int p = blockIdx.x * (MR_FPG / 2) + (it * WAVES + wave) * FW + g;
+        if (2 * (p - g) >= n_frames) break;                             // wave-uniform (pairs of a wave are p - g, p - g + 1)
+        const int f0 = 2 * p, f1 = 2 * p + 1;
+        const bool live0 = f0 < n_frames, live1 = f1 < n_frames;
+        const float *s0 = park + ((size_t)b * n_frames + (live0 ? f0 : n_frames - 1)) * P;
+        const float *s1 = park + ((size_t)b * n_frames + (live1 ? f1 : n_frames - 1)) * P;
+        const float m0 = live0 ? 1.0f : 0.0f, m1 = live1 ? 1.0f : 0.0f;
         cf R[NB][4], Z[E];
-        load_frame<N>(R, xb, yb, win, live ? f : n_frames - 1, hop, T, a);
-        wave_fft<N, false>(R, Z, buf, tw_s, a);
+        // H = G~_a + i G~_b at the positions this lane feeds into the inverse transform (a + L b + (N/4) c): the lower half
+        // (c < 2) from the lane's own bins, which also leave their mirror images (conj G_a + i conj G_b) / 2 in the wave's
+        // exchange buffer for the lanes that feed the upper half
 #pragma unroll
-        for (int i = 0; i < E; ++i) buf[pos_final<N>(i, a)] = Z[i];
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int b0 = 0; b0 < NB; b0 += 4) {
+                float v0[4][3], v1[4][3];                                // the loads of four bin pairs first: 24 requests in flight
+#pragma unroll
+                for (int bq = 0; bq < 4; ++bq)
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        const int k = a + L * (b0 + bq) + (N / 4) * c;
+                        v0[bq][q] = s0[q * (N / 2) + k];
+                        v1[bq][q] = s1[q * (N / 2) + k];
+                    }
+#pragma unroll
+                for (int bq = 0; bq < 4; ++bq) {
+                    const int k = a + L * (b0 + bq) + (N / 4) * c;
+                    cf ga = grad_bin(v0[bq][0], v0[bq][1], v0[bq][2], eps, c_sc, c_log);
+                    cf gb = grad_bin(v1[bq][0], v1[bq][1], v1[bq][2], eps, c_sc, c_log);
+                    ga = {m0 * ga.re, m0 * ga.im};
+                    gb = {m1 * gb.re, m1 * gb.im};
+                    const cf h = {0.5f * (ga.re - gb.im), 0.5f * (ga.im + gb.re)};
+                    R[b0 + bq][c] = (b0 + bq == 0 && c == 0 && a == 0) ? cf{ga.re, gb.re} : h;   // DC: real, not halved
+                    buf[N - k] = {0.5f * (ga.re + gb.im), 0.5f * (gb.re - ga.im)};  // (k = 0 lands in the pad: never read)
+                }
+            }
+        if (a == 0) {                                                    // Nyquist: real, not halved
+            const cf ga = grad_bin(s0[3 * N / 2], 0.0f, s0[3 * N / 2 + 1], eps, c_sc, c_log);
+            const cf gb = grad_bin(s1[3 * N / 2], 0.0f, s1[3 * N / 2 + 1], eps, c_sc, c_log);
+            buf[N / 2] = {m0 * ga.re, m1 * gb.re};
+        }
         __builtin_amdgcn_wave_barrier();
-        // dL/dX at the bins this lane feeds into the inverse transform (positions a + L b + (N/4) c; zero above N/2).
-        // Mirror bins N - k as constant offsets from ONE register that is opaque to the optimiser in every iteration:
-        // written as (N - k) & (N - 1) each address is loop invariant, gets hoisted out of the frame loop and, for
-        // N = 2048 (all 256 registers taken by the transform), lives in scratch: 20 dependent scratch loads per frame.
-        int am = N - a;
-        asm volatile("" : "+v"(am));
 #pragma unroll
         for (int bq = 0; bq < NB; ++bq)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int k = a + L * bq + (N / 4) * c;
-                cf gk = {0.0f, 0.0f};
-                if (c < 2 || k == N / 2) {                                  // c >= 2: k >= N/2
-                    cf X, Y;
-                    split_bins_at<N>(buf, k, (bq == 0 && c == 0) ? (am & (N - 1)) : am - (L * bq + (N / 4) * c), X, Y);
-                    const float px = X.re * X.re + X.im * X.im;
-                    const float xm = sqrtf(fmaxf(px, eps));
-                    const float ym = sqrtf(fmaxf(Y.re * Y.re + Y.im * Y.im, eps));
-                    if (px > eps) {                                         // clamp passes no gradient below eps
-                        const float dl = logf(xm) - logf(ym);
-                        const float dxm =
-                            c_sc * (xm - ym) + c_log * (dl > 0.0f ? 1.0f : (dl < 0.0f ? -1.0f : 0.0f)) / xm;
-                        const float sc = dxm / xm;
-                        gk = {sc * X.re, sc * X.im};                        // dL/dRe X, dL/dIm X
-                    }
-                }
-                R[bq][c] = gk;
-            }
+            for (int c = 2; c < 4; ++c) R[bq][c] = buf[a + L * bq + (N / 4) * c];
         __builtin_amdgcn_wave_barrier();
-        // adjoint of the one-sided DFT: dx[n] = Re sum_{k<=N/2} G[k] e^{+2 pi i k n / N}
+        // dx_a[n] + i dx_b[n] = sum_k H[k] e^{+2 pi i k n / N}: the adjoint of the one-sided DFT for both frames at once
         wave_fft<N, true>(R, Z, buf, tw_s, a);
-        if (live) {
-            // (overlap-adding a workgroup's 16 frames in LDS and writing one span instead was measured: the fold pass
-            // fell from 1.7 to 0.6 ms but this kernel lost 1.5-2 ms to the read-modify-writes and the lower occupancy)
-            float *out = scratch + ((size_t)b * n_frames + f) * N;
+        // (overlap-adding a workgroup's 16 frames in LDS and writing one span instead was measured: the fold pass
+        // fell from 1.7 to 0.6 ms but this kernel lost 1.5-2 ms to the read-modify-writes and the lower occupancy)
+        float *out0 = scratch + ((size_t)b * n_frames + f0) * N, *out1 = out0 + N;
 #pragma unroll
-            for (int i = 0; i < E; ++i) {
-                const int n = pos_final<N>(i, a);
-                out[n] = Z[i].re * win[n];
-            }
+        for (int i = 0; i < E; ++i) {
+            const int n = pos_final<N>(i, a);
+            const float w = win[n];
+            if (live0) out0[n] = Z[i].re * w;
+            if (live1) out1[n] = Z[i].im * w;
         }
     }
 }
@@ -421,14 +447,20 @@ static int run_resolution(const float *x, long long xs, const float *y, long lon
 {
     const int n_frames = 1 + T / hop;
     const int groups = (n_frames + MR_FPG - 1) / MR_FPG;
-    hipLaunchKernelGGL((mr_stats_kernel<N>), dim3(groups, B), dim3(WF<N>::WAVES * 64), 0, st, x, xs, y, ys, win, tw,
-                       T, hop, n_frames, eps, part);
+    // scratch = [ time-domain gradient frames | parked bins ]
+    float *park = scratch ? scratch + (size_t)B * n_frames * N : nullptr;
+    if (dx)
+        hipLaunchKernelGGL((mr_stats_kernel<N, true>), dim3(groups, B), dim3(WF<N>::WAVES * 64), 0, st, x, xs, y, ys, win, tw,
+                           T, hop, n_frames, eps, part, park);
+    else
+        hipLaunchKernelGGL((mr_stats_kernel<N, false>), dim3(groups, B), dim3(WF<N>::WAVES * 64), 0, st, x, xs, y, ys, win,
+                           tw, T, hop, n_frames, eps, part, (float *)nullptr);
     const long long count = (long long)B * n_frames * (N / 2 + 1);
     hipLaunchKernelGGL(mr_finish_kernel, dim3(1), dim3(256), 0, st, part, groups * B, count, w_sc, w_log, res_scale,
                        terms, coef);
     if (dx) {
-        hipLaunchKernelGGL((mr_grad_kernel<N>), dim3(groups, B), dim3(WF<N>::WAVES * 64), 0, st, x, xs, y, ys, win, tw,
-                           T, hop, n_frames, eps, coef, scratch);
+        hipLaunchKernelGGL((mr_grad_kernel<N>), dim3(groups, B), dim3(WF<N>::WAVES * 64), 0, st, park, win, tw, n_frames, eps,
+                           coef, scratch);
         hipLaunchKernelGGL((mr_fold_kernel<N>), dim3((T + 255) / 256, B), dim3(256), 0, st, scratch, T, hop, n_frames,
                            accumulate, dx, ds);
     }
@@ -440,8 +472,8 @@ static int run_resolution(const float *x, long long xs, const float *y, long lon
 // windows (n_res, 2048): row r holds the n_fft-long window of resolution r (win_length hann, centred);
 // twiddle (2048,2) = exp(-2 pi i m / 2048).  terms (2*n_res + 1): [sc_0, logmag_0, ..., total].
 // dx (B rows, stride dx_stride) = d total / d y_hat, or NULL.  Workspaces: part (doubles) >= 3 * B *
-// max_r ceil(frames_r / 8); coef (2,) floats; scratch (floats) >= B * max_r(frames_r * n_fft_r) (only
-// when dx != NULL).
+// max_r ceil(frames_r / 8); coef (2,) floats; scratch (floats) >= B * max_r(frames_r * (5 * n_fft_r / 2 + 4)) (only
+// when dx != NULL: the frames' time-domain gradients and the parked bins).
 MX_EXPORT int mx_mrstft_loss(const float *y_hat, int64_t y_hat_stride, const float *y, int64_t y_stride, int64_t B,
                              int64_t T, int32_t n_res, const int32_t *fft_sizes, const int32_t *hops,
                              const float *windows, const float *twiddle, float w_sc, float w_log, float eps,

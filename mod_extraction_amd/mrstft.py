@@ -31,7 +31,8 @@ def mrstft_value_and_grad(mod: "MultiResolutionSTFTLoss", a: T, t: T, need_grad:
     part = torch.empty(3 * B * max(-(-f // 8) for f in frames), device=dev, dtype=torch.float64)
     coef = torch.empty(2, device=dev, dtype=torch.float32)
     terms = torch.empty(2 * n_res + 1, device=dev, dtype=torch.float32)
-    scratch = torch.empty(B * max(f * n for f, n in zip(frames, mod.fft_sizes)), device=dev,
+    # per frame: n_fft samples of time-domain gradient + the parked bins (Re X, Im X, Ym) the gradient pass re-uses
+    scratch = torch.empty(B * max(f * (5 * n // 2 + 4) for f, n in zip(frames, mod.fft_sizes)), device=dev,
                           dtype=torch.float32) if need_grad else None
     dx = torch.empty((B, Tn), device=dev, dtype=torch.float32) if need_grad else None
     ffts = (ctypes.c_int32 * n_res)(*mod.fft_sizes)

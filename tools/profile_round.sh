@@ -8,12 +8,15 @@ cd "$GRAFT_REPO_ROOT"
 R=$1
 O=gpurun_out/$R
 rm -rf $O; mkdir -p $O
+ONLY=${2:-all}
 stats() { c=$1; steps=$2
-  rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c$c -- python3 bench.py --worker --config $c --steps $steps --warmup 1 --no-cpu-baseline --no-fp32-leg > $O/bench_c${c}_under_rocprof.json 2> $O/stats_c$c.err
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c$c -- python3 bench.py --worker --config $c --steps $steps --warmup 1 --no-cpu-baseline --no-fp32-leg > $O/bench_c${c}_under_rocprof.json 2> $O/stats_c$c.err \
+    || echo "config $c: rocprofv3 exited with $? (after writing its CSVs; seen at process teardown with CU-masked streams)" >> $O/notes.txt
   cp $(find $O/stats_c$c -name "*kernel_stats.csv" | head -1) $O/bench_c${c}_kernel_stats.csv
   rm -rf $O/stats_c$c
 }
-stats 3 5; stats 2 10; stats 4 2; stats 5 5
+if [ $ONLY = all ] || [ $ONLY = stats ]; then stats 3 5; stats 2 10; stats 4 2; stats 5 5; fi
+if [ $ONLY = stats ]; then rm -f $O/*.err; ls -la $O; exit 0; fi
 run_pmc() { n=$1; shift
   rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $O/pmc_$n -- python3 bench.py --worker --steps 2 --warmup 1 --batch 64 --no-cpu-baseline --no-fp32-leg > $O/pmc_$n.log 2>&1
 }
