@@ -9,7 +9,7 @@
 // Three passes per resolution (12 B/sample algorithmic: x, y in, grad out):
 //   A  stats : per frame, ONE complex FFT of x + i*y (one frame per wavefront, register-staged radix-4 Stockham, see
 //              below) -> both spectra by Hermitian separation -> per-workgroup partial sums of
-//              (Ym - Xm)^2, Ym^2, |log Xm - log Ym|; when a gradient will follow, (Re X, Im X, Ym) of every bin is left in
+//              (Ym - Xm)^2, Ym^2, |log Xm - log Ym|; when a gradient will follow, (Re X, Im X, Ym^2) of every bin is left in
 //              a workspace (12 B per bin: the transform is the expensive part, not the bytes)
 //   B  grad  : per-bin dL/dX from the global norms and the parked bins -- no second forward transform --, and ONE
 //              inverse FFT per PAIR of frames: the one-sided gradient spectra of frames 2p and 2p + 1 are completed to
@@ -26,18 +26,23 @@
 
 #define MR_MAXN 2048
 #define MR_FPG 16        // frames per workgroup (passes A and B); the partial-sum workspace is sized for >= 8
-// parked bins of one frame: Re X[0..N/2), Im X[0..N/2), Ym[0..N/2), then Re X[N/2], Ym[N/2] (Im X[N/2] == 0), padded to 16 B
+// parked bins of one frame: Re X[0..N/2), Im X[0..N/2), Ym^2[0..N/2), then Re X[N/2], Ym^2[N/2] (Im X[N/2] == 0), padded to 16 B
 #define MR_PARK(N) (3 * (N) / 2 + 4)
 
 struct cf { float re, im; };
-// Complex multiply, every product rounded on its own (the file is compiled with -ffp-contract=off).  Measured with the two
-// twiddle FMAs written by hand (2 mul + 2 fma instead of 4 mul + 2 add): the three resolutions take 9.95 ms instead of
-// 10.95 ms per 256 x 4 s -- and x == y no longer gives loss == 0 and gradient == 0 exactly as the reference does
-// (tests/test_gpu_mrstft.py::test_mrstft_identical_signals): the loss packs the two real signals as x + i y into ONE
-// transform, and the spectra separate exactly for x == y only while the arithmetic is symmetric under the index mirror
-// k -> N - k, which maps a butterfly's twiddle w to -i conj(w) and thereby SWAPS the two products of a complex multiply;
-// an FMA rounds one of them and not the other, whichever way it is written.
-__device__ __forceinline__ cf cmulf(cf a, cf b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
+// Complex multiply with the second product of each component fused (2 mul + 2 fma instead of 4 mul + 2 add; the file is
+// compiled with -ffp-contract=off, so this is the only contraction): 10.95 -> 9.95 ms for the three resolutions when it
+// was first measured.  It costs a property the unfused arithmetic had for free: the loss packs the two real signals as
+// x + i y into ONE transform, and the spectra separate EXACTLY for x == y only while the arithmetic is symmetric under the
+// index mirror k -> N - k, which maps a butterfly's twiddle w to -i conj(w) and thereby SWAPS the two products of a complex
+// multiply -- an FMA rounds one of them and not the other, whichever way it is written.  The reference gives loss == 0 and
+// gradient == 0 exactly for identical signals (two identical STFTs), so pass A detects frames whose windowed x and y are
+// bit-identical and takes Y := X for them (tests/test_gpu_mrstft.py::test_mrstft_identical_signals, also with only some
+// clips identical).
+__device__ __forceinline__ cf cmulf(cf a, cf b)
+{
+    return {__builtin_fmaf(a.re, b.re, -(a.im * b.im)), __builtin_fmaf(a.re, b.im, a.im * b.re)};
+}
 __device__ __forceinline__ cf caddf(cf a, cf b) { return {a.re + b.re, a.im + b.im}; }
 __device__ __forceinline__ cf csubf(cf a, cf b) { return {a.re - b.re, a.im - b.im}; }
 
@@ -225,38 +230,58 @@ __global__ __launch_bounds__(WF<N>::WAVES * 64) __attribute__((amdgpu_waves_per_
     __shared__ cf xbuf[WAVES * FW][WF<N>::LEN];
     __shared__ float2 tw_s[N];
     __shared__ double red[WAVES][3];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane / L, a = lane % L;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane / L, a_ = lane % L;
     const int b = blockIdx.y;
     const float *xb = x + (size_t)b * xs, *yb = y + (size_t)b * ys;
     cf *buf = xbuf[wave * FW + g];
     stage_twiddles<N>(tw_s, tw);
     double s_d = 0.0, s_y = 0.0, s_l = 0.0;
     for (int it = 0; it < MR_FPG / (WAVES * FW); ++it) {
+        int a = a_;                                                      // opaque per iteration: see mr_grad_kernel
+        asm volatile("" : "+v"(a));
         const int f = blockIdx.x * MR_FPG + frame_slot<N>(it, wave, g);
         if (f - g >= n_frames) break;                                   // wave-uniform (frames of a wave are f-g, f-g+1)
         const bool live = f < n_frames;
         cf R[WF<N>::NB][4], Z[E];
         load_frame<N>(R, xb, yb, win, live ? f : n_frames - 1, hop, T, a);
+        // a frame whose windowed signals are bit-identical has identical spectra in the reference: keep that exact
+        bool same_lane = true;
+#pragma unroll
+        for (int bq = 0; bq < WF<N>::NB; ++bq)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) same_lane = same_lane && R[bq][c].re == R[bq][c].im;
+        const unsigned long long same_mask = __ballot(same_lane);
+        const bool same = L == 64 ? same_mask == ~0ull : ((same_mask >> (32 * g)) & 0xffffffffull) == 0xffffffffull;
         wave_fft<N, false>(R, Z, buf, tw_s, a);
 #pragma unroll
         for (int i = 0; i < E; ++i) buf[pos_final<N>(i, a)] = Z[i];
         __builtin_amdgcn_wave_barrier();
         if (live) {
+            // Bin pass.  Hardware square root / log2 (1 ulp; the library versions' range fix-ups were 40 % of this kernel's
+            // instructions), log Xm - log Ym = ln2 / 2 * (log2 max(|X|^2, eps) - log2 max(|Y|^2, eps)), Ym^2 = max(|Y|^2, eps),
+            // and the frame's <= 9 terms per lane summed in fp32 before they enter the fp64 accumulators.
             float *pk = PARK ? park + ((size_t)b * n_frames + f) * MR_PARK(N) : nullptr;
-            for (int k = a; k <= N / 2; k += L) {
+            float fd = 0.0f, fy = 0.0f, fl = 0.0f;
+            auto bin = [&](int k, bool last) {
                 cf X, Y;
                 split_bins<N>(buf, k, X, Y);
-                const float xm = sqrtf(fmaxf(X.re * X.re + X.im * X.im, eps));
-                const float ym = sqrtf(fmaxf(Y.re * Y.re + Y.im * Y.im, eps));
+                if (same) Y = X;
+                const float cx = fmaxf(X.re * X.re + X.im * X.im, eps), cy = fmaxf(Y.re * Y.re + Y.im * Y.im, eps);
+                const float d = __builtin_amdgcn_sqrtf(cy) - __builtin_amdgcn_sqrtf(cx);
+                fd += d * d;
+                fy += cy;
+                fl += fabsf(__builtin_amdgcn_logf(cx) - __builtin_amdgcn_logf(cy));
                 if (PARK) {
-                    if (k < N / 2) { pk[k] = X.re; pk[N / 2 + k] = X.im; pk[N + k] = ym; }
-                    else { pk[3 * N / 2] = X.re; pk[3 * N / 2 + 1] = ym; }
+                    if (!last) { pk[k] = X.re; pk[N / 2 + k] = X.im; pk[N + k] = cy; }
+                    else { pk[3 * N / 2] = X.re; pk[3 * N / 2 + 1] = cy; }
                 }
-                const float d = ym - xm;
-                s_d += (double)d * (double)d;
-                s_y += (double)ym * (double)ym;
-                s_l += (double)fabsf(logf(xm) - logf(ym));
-            }
+            };
+#pragma unroll
+            for (int j = 0; j < N / 2 / L; ++j) bin(a + L * j, false);
+            if (a == 0) bin(N / 2, true);
+            s_d += (double)fd;
+            s_y += (double)fy;
+            s_l += (double)(0.5f * 0.69314718055994531f * fl);
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -295,16 +320,21 @@ __global__ __launch_bounds__(256) void mr_finish_kernel(const double *__restrict
 }
 
 // ---- pass B -------------------------------------------------------------------------------------
-// d loss / d X of one bin from the parked (Re X, Im X, Ym):  d sc / d Xm and d logmag / d Xm as in mr_finish_kernel, times
+// d loss / d X of one bin from the parked (Re X, Im X, Ym^2):  d sc / d Xm and d logmag / d Xm as in mr_finish_kernel, times
 // d Xm / d X = X / Xm; the clamp passes no gradient below eps
-__device__ __forceinline__ cf grad_bin(float xr, float xi, float ym, float eps, float c_sc, float c_log)
+__device__ __forceinline__ cf grad_bin(float xr, float xi, float cy, float eps, float c_sc, float c_log)
 {
-    // branch-free: a divergent branch per bin would also serialise the bins' loads behind one another
+    // branch-free (a divergent branch per bin would also serialise the bins' loads behind one another); hardware square
+    // root / reciprocal / log2 (1 ulp each, no range fix-ups: the library sqrtf, two logf and two divisions were 70 of
+    // this function's ~90 instructions and most of the kernel); Xm and Ym by the same formula, so that X == Y gives 0
     const float px = xr * xr + xi * xi;
-    const float xm = sqrtf(fmaxf(px, eps));
-    const float dl = logf(xm) - logf(ym);
-    const float dxm = c_sc * (xm - ym) + c_log * (dl > 0.0f ? 1.0f : (dl < 0.0f ? -1.0f : 0.0f)) / xm;
-    const float sc = px > eps ? dxm / xm : 0.0f;
+    const float cx = fmaxf(px, eps);
+    const float xm = __builtin_amdgcn_sqrtf(cx), ym = __builtin_amdgcn_sqrtf(cy);
+    const float rx = __builtin_amdgcn_rcpf(xm);
+    const float dl = __builtin_amdgcn_logf(cx) - __builtin_amdgcn_logf(cy);         // sign of log Xm - log Ym
+    const float sg = dl > 0.0f ? c_log : (dl < 0.0f ? -c_log : 0.0f);
+    const float dxm = c_sc * (xm - ym) + sg * rx;
+    const float sc = px > eps ? dxm * rx : 0.0f;
     return {sc * xr, sc * xi};                                          // dL/dRe X, dL/dIm X
 }
 

@@ -58,3 +58,24 @@ def test_mrstft_identical_signals(dev):
     loss.backward()
     assert float(loss) == 0.0
     assert float(x.grad.abs().max()) == 0.0
+
+
+def test_mrstft_identical_clip_among_different_ones(dev):
+    """Only some clips of the batch equal their targets: their frames contribute exactly 0 to every sum and receive exactly
+    zero gradient (identical STFTs in the reference), the others do not -- the kernels detect bit-identical windowed frames
+    (csrc/mrstft.hip, cmulf) instead of relying on symmetric rounding."""
+    from mod_extraction_amd import losses as alosses
+    from oracle import losses as olosses
+    torch.manual_seed(1)
+    y = (torch.rand(3, 1, 9000) * 2 - 1)
+    x0 = y.clone()
+    x0[1] = (torch.rand(1, 9000) * 2 - 1) * 0.5
+    x = x0.to(dev).requires_grad_(True)
+    loss = alosses.get_loss_func_by_name("mrstft")(x, y.to(dev))
+    loss.backward()
+    g = x.grad.cpu()
+    assert float(g[0].abs().max()) == 0.0 and float(g[2].abs().max()) == 0.0
+    assert float(g[1].abs().max()) > 0.0
+    xr = x0.clone().requires_grad_(True)
+    loss_r = olosses.get_loss_func_by_name("mrstft")(xr, y)
+    assert abs(float(loss) - float(loss_r)) < 1e-5 * abs(float(loss_r))
