@@ -125,6 +125,11 @@ int mx_conv_pack_weights(const float *W, int64_t Cout, int64_t Cin, int32_t flip
  * f = PReLU(slope[c]) if slope != NULL else identity.  stats (B, C, 2). */
 int mx_plane_stats(const float *x, const float *slope, int64_t B, int64_t C, int64_t H, int64_t Wv,
                    float eps, float *stats, void *stream);
+/* The same statistics from the per-row partial sums the f16x3 forward kernels below leave when given slope_out /
+ * stats_part: part (B, H, C, 2) = {sum, sum of squares} of PReLU(out) over the Wv valid columns of one pooled row; fp64
+ * across the rows.  The LayerNorm of models.py:186 of the NEXT block without re-reading the plane. */
+int mx_plane_stats_finish(const float *part, int64_t B, int64_t C, int64_t H, int64_t Wv, float eps, float *stats,
+                          void *stream);
 
 /* LayerNorm -> Conv2d(5x13, dilation (1,dilation), same) -> +bias -> MaxPool(2,1), fused.
  * in (B,Cin,H,352): log-mel (first_layer=1) or the previous block's pooled pre-activations (their
@@ -155,9 +160,11 @@ int mx_conv_prep_fwd_f16(const float *x, const float *stats, const float *slope,
 int mx_conv_prep_dgrad_f16(const float *G, const uint8_t *amax, int64_t B, int64_t H, int64_t Wv,
                            uint32_t *amax_ws, int32_t amax_ready, float *scale, void *dz_hi, void *dz_lo,
                            void *stream);
+/* slope_out (64,) / stats_part (B, H/2, 64, 2), both optional: the PReLU slope that follows this block (models.py:194) and
+ * the partial LayerNorm statistics of the next block's input for mx_plane_stats_finish. */
 int mx_conv_block_fwd_f16(const void *x_hi, const void *x_lo, const void *w_hi, const void *w_lo,
                           const float *bias, int64_t B, int64_t H, int64_t Wv, int32_t dilation, float *out,
-                          uint8_t *out_amax, void *stream);
+                          uint8_t *out_amax, const float *slope_out, float *stats_part, void *stream);
 int mx_conv_block_dgrad_f16(const void *dz_hi, const void *dz_lo, const void *w_hi, const void *w_lo,
                             const float *scale, int64_t B, int64_t H, int64_t Wv, int32_t dilation,
                             float *dxhat, void *stream);
@@ -169,7 +176,8 @@ int mx_conv_pack_weights_kvec_f16(const float *W, void *w_hi, void *w_lo, void *
 int mx_conv_prep_fwd_kvec_f16(const float *x, const float *stats, int64_t B, int64_t H, int64_t Wv, void *xk_hi,
                               void *xk_lo, void *stream);
 int mx_conv_block1_fwd_f16(const void *xk_hi, const void *xk_lo, const void *w_hi, const void *w_lo, const float *bias,
-                           int64_t B, int64_t H, int64_t Wv, float *out, uint8_t *out_amax, void *stream);
+                           int64_t B, int64_t H, int64_t Wv, float *out, uint8_t *out_amax, const float *slope_out,
+                           float *stats_part, void *stream);
 /* weight gradient of the first block from the same k-vector operand (torch Conv2d backward w.r.t. weight,
  * models.py:187).  G, amax (B,64,H/2,352): gradient w.r.t. the pooled output and the pooling argmax; amax_bits: bit
  * pattern of max|G| (mx_ln_prelu_bwd's gmax_bits); scale (2,) receives {S, 1/S}; part: workspace of

@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # MODEX_HIP_LIB: load another build of the same library (kernel experiments); there is no non-HIP fallback
 SO_PATH = os.environ.get("MODEX_HIP_LIB") or os.path.join(_HERE, "_lib", "libmodex_hip.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _ERR = {-1: "MX_ERR_ARG (bad argument)", -2: "MX_ERR_UNSUPPORTED (size not supported)",
         -3: "MX_ERR_LAUNCH (HIP launch error)"}
@@ -32,16 +32,17 @@ SIGNATURES = {
                       _I32, _I32, _P, _P],
     "mx_conv_pack_weights": [_P, _I64, _I64, _I32, _P, _P],
     "mx_plane_stats": [_P, _P, _I64, _I64, _I64, _I64, _F32, _P, _P],
+    "mx_plane_stats_finish": [_P, _I64, _I64, _I64, _I64, _F32, _P, _P],
     "mx_conv_block_fwd": [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I32, _I32, _P, _P, _P],
     "mx_conv_block_dgrad": [_P, _P, _P, _I64, _I64, _I64, _I32, _P, _P],
     "mx_conv_pack_weights_f16": [_P, _I32, _P, _P, _P],
     "mx_conv_prep_fwd_f16": [_P, _P, _P, _I64, _I64, _I64, _P, _P, _P],
     "mx_conv_prep_dgrad_f16": [_P, _P, _I64, _I64, _I64, _P, _I32, _P, _P, _P, _P],
-    "mx_conv_block_fwd_f16": [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I32, _P, _P, _P],
+    "mx_conv_block_fwd_f16": [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I32, _P, _P, _P, _P, _P],
     "mx_conv_block_dgrad_f16": [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I32, _P, _P],
     "mx_conv_pack_weights_kvec_f16": [_P, _P, _P, _P],
     "mx_conv_prep_fwd_kvec_f16": [_P, _P, _I64, _I64, _I64, _P, _P, _P],
-    "mx_conv_block1_fwd_f16": [_P, _P, _P, _P, _P, _I64, _I64, _I64, _P, _P, _P],
+    "mx_conv_block1_fwd_f16": [_P, _P, _P, _P, _P, _I64, _I64, _I64, _P, _P, _P, _P, _P],
     "mx_conv_block_wgrad_sp_f16": [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I32, _I64, _P, _P, _P],
     "mx_conv_pack_weights_sp_f16": [_P, _P, _P, _P],
     "mx_conv_prep_gpool_cl_f16": [_P, _P, _P, _I64, _I64, _I64, _P, _P, _P, _P, _P],

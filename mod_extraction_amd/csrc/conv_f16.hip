@@ -254,6 +254,12 @@ struct ConvF16Args {
     float *out;                    // forward: (B, 64, H/2, 352) pooled pre-activations; dgrad: (B, 64, H, 352)
     unsigned char *out_amax;       // forward
     int H, Wv;
+    // forward, optional: the LayerNorm statistics of the NEXT block are those of PReLU(out) per (clip, channel) plane; with
+    // slope_out (64,) the epilogue leaves {sum, sum of squares} per (clip, pooled row, channel) in stats_part
+    // (B, H/2, 64, 2) and mx_plane_stats_finish turns them into mean / rstd: the plane is never re-read (norm.hip
+    // plane_stats_kernel swept 5.9 GB per step for them)
+    const float *slope_out;
+    float *stats_part;
 };
 
 // Epilogue shared by the conv kernels.  Wave = (output row, column half c); accumulator layout
@@ -295,6 +301,17 @@ __device__ __forceinline__ void conv_f16_epilogue(floatx16 (&acc)[CV_WT], const 
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int q = 0; q < 4; ++q) bias_t[j][q] = a.bias[j * 32 + q * 8 + co_l];
+        const bool want_stats = a.stats_part != nullptr;               // workgroup-uniform
+        float slope_t[2][4];
+        float st_s[2][4], st_q[2][4];                                   // [j = channel half ^ c][q]: sums over this lane's columns
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                slope_t[j][q] = want_stats ? a.slope_out[j * 32 + q * 8 + co_l] : 1.0f;
+                st_s[j][q] = 0.0f;
+                st_q[j][q] = 0.0f;
+            }
         __syncthreads();                                                // the K loop's LDS images are dead
 #pragma unroll
         for (int round = 0; round < 2; ++round) {
@@ -323,21 +340,60 @@ __device__ __forceinline__ void conv_f16_epilogue(floatx16 (&acc)[CV_WT], const 
                     const floatx4 tv = *reinterpret_cast<const floatx4 *>(top + s6 * 1024 + col * 32 + w4);
                     const floatx4 bv = *reinterpret_cast<const floatx4 *>(bot + s6 * 1024 + col * 32 + w4);
                     const float bsum = chh ? bias_t[1][q] : bias_t[0][q];
+                    const float sl = chh ? slope_t[1][q] : slope_t[0][q];
                     floatx4 m;
                     unsigned am = 0;
+                    float ts = 0.0f, tq = 0.0f;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const bool take_bot = bv[e] > tv[e];            // ties keep the first row (torch)
                         const float v = (take_bot ? bv[e] : tv[e]) * inv + bsum;
                         m[e] = w + e < a.Wv ? v : 0.0f;
                         am |= (take_bot ? 1u : 0u) << (8 * e);
+                        const float t = m[e] > 0.0f ? m[e] : sl * m[e];  // PReLU(0) = 0: pad columns add nothing
+                        ts += t;
+                        tq += t * t;
                     }
+                    // accumulator index j = channel half ^ c = i & 1 (tile 10: 0), the same for both rows' tiles of a slot:
+                    // a compile-time constant after unrolling
+                    st_s[(3 * round + s3) & 1][q] += ts;
+                    st_q[(3 * round + s3) & 1][q] += tq;
                     const size_t off = (((size_t)b * CV_CO + chh * 32 + col) * Hp + hp) * CV_PITCH + w;
                     *reinterpret_cast<floatx4 *>(a.out + off) = m;
                     *reinterpret_cast<unsigned *>(a.out_amax + off) = am;
                 }
             }
             if (round == 0) __syncthreads();                            // round 1 overwrites the images
+        }
+        if (want_stats) {
+            // [wave][j][q][lane] partial sums -> thread co < 64 adds the 4 waves x 8 column lanes of its channel in a fixed order
+            __syncthreads();                                            // the round-1 images are dead
+            const int wv = c * 2 + row;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    xch[((wv * 2 + j) * 4 + q) * 64 + lane] = st_s[j][q];
+                    xch[2048 + ((wv * 2 + j) * 4 + q) * 64 + lane] = st_q[j][q];
+                }
+            __syncthreads();
+            const int co = threadIdx.x;
+            if (co < CV_CO) {
+                const int chh = co >> 5, q = (co >> 3) & 3, col = co & 7;
+                float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+                for (int w4i = 0; w4i < 4; ++w4i) {                     // wave (c, row): channel half chh sits in j = chh ^ c
+                    const int j = chh ^ (w4i >> 1);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        s1 += xch[((w4i * 2 + j) * 4 + q) * 64 + col * 8 + e];
+                        s2 += xch[2048 + ((w4i * 2 + j) * 4 + q) * 64 + col * 8 + e];
+                    }
+                }
+                float *sp = a.stats_part + (((size_t)b * Hp + hp) * CV_CO + co) * 2;
+                sp[0] = s1;
+                sp[1] = s2;
+            }
         }
     }
 }
@@ -833,12 +889,12 @@ MX_EXPORT int mx_conv_prep_dgrad_f16(const float *G, const uint8_t *amax, int64_
 // forward conv (64 -> 64 channels, dilation in {1,2,4}) from prepared operands
 MX_EXPORT int mx_conv_block_fwd_f16(const void *x_hi, const void *x_lo, const void *w_hi, const void *w_lo,
                                     const float *bias, int64_t B, int64_t H, int64_t Wv, int32_t dilation, float *out,
-                                    uint8_t *out_amax, void *stream)
+                                    uint8_t *out_amax, const float *slope_out, float *stats_part, void *stream)
 {
-    if (!x_hi || !x_lo || !w_hi || !w_lo || !bias || !out || !out_amax) return MX_ERR_ARG;
+    if (!x_hi || !x_lo || !w_hi || !w_lo || !bias || !out || !out_amax || (stats_part && !slope_out)) return MX_ERR_ARG;
     if (B <= 0 || B > 65535 || H < 2 || (H & 1) || Wv <= 0 || Wv > CV_PITCH) return MX_ERR_UNSUPPORTED;
     ConvF16Args a{(const _Float16 *)x_hi, (const _Float16 *)x_lo, (const _Float16 *)w_hi, (const _Float16 *)w_lo, bias,
-                  nullptr, out, out_amax, (int)H, (int)Wv};
+                  nullptr, out, out_amax, (int)H, (int)Wv, slope_out, stats_part};
     return dispatch_f16(dilation, 0, a, (int)B, (hipStream_t)stream);
 }
 
@@ -850,7 +906,7 @@ MX_EXPORT int mx_conv_block_dgrad_f16(const void *dz_hi, const void *dz_lo, cons
     if (!dz_hi || !dz_lo || !w_hi || !w_lo || !scale || !dxhat) return MX_ERR_ARG;
     if (B <= 0 || B > 65535 || H < 2 || (H & 1) || Wv <= 0 || Wv > CV_PITCH) return MX_ERR_UNSUPPORTED;
     ConvF16Args a{(const _Float16 *)dz_hi, (const _Float16 *)dz_lo, (const _Float16 *)w_hi, (const _Float16 *)w_lo,
-                  nullptr, scale, dxhat, nullptr, (int)H, (int)Wv};
+                  nullptr, scale, dxhat, nullptr, (int)H, (int)Wv, nullptr, nullptr};
     return dispatch_f16(dilation, 1, a, (int)B, (hipStream_t)stream);
 }
 
@@ -879,11 +935,11 @@ MX_EXPORT int mx_conv_prep_fwd_kvec_f16(const float *x, const float *stats, int6
 // forward conv of the first block (2 -> 64 channels, dilation 1) + bias + max-pool from the k-vector operand
 MX_EXPORT int mx_conv_block1_fwd_f16(const void *xk_hi, const void *xk_lo, const void *w_hi, const void *w_lo,
                                      const float *bias, int64_t B, int64_t H, int64_t Wv, float *out, uint8_t *out_amax,
-                                     void *stream)
+                                     const float *slope_out, float *stats_part, void *stream)
 {
-    if (!xk_hi || !xk_lo || !w_hi || !w_lo || !bias || !out || !out_amax) return MX_ERR_ARG;
+    if (!xk_hi || !xk_lo || !w_hi || !w_lo || !bias || !out || !out_amax || (stats_part && !slope_out)) return MX_ERR_ARG;
     if (B <= 0 || B > 65535 || H < 2 || (H & 1) || Wv <= 0 || Wv > CV_PITCH) return MX_ERR_UNSUPPORTED;
     ConvF16Args a{(const _Float16 *)xk_hi, (const _Float16 *)xk_lo, (const _Float16 *)w_hi, (const _Float16 *)w_lo, bias,
-                  nullptr, out, out_amax, (int)H, (int)Wv};
+                  nullptr, out, out_amax, (int)H, (int)Wv, slope_out, stats_part};
     return launch_f16_dma<1, 0, 1, 1>(a, (int)B, (hipStream_t)stream);
 }

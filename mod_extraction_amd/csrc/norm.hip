@@ -79,6 +79,41 @@ MX_EXPORT int mx_plane_stats(const float *x, const float *slope, int64_t B, int6
     return mx_launch_status();
 }
 
+// The same statistics from the per-row partial sums a forward convolution's epilogue leaves (conv_f16.hip, stats_part
+// (B, H, C, 2): {sum, sum of squares} of PReLU(out) over the valid columns of one pooled row, fp32 over <= 352 terms);
+// fp64 across the rows.
+__global__ __launch_bounds__(256) void plane_stats_finish_kernel(const float *__restrict__ part, int n_planes, int C, int H,
+                                                                 int Wv, float eps, float *__restrict__ stats)
+{
+    const int plane = blockIdx.x * 256 + threadIdx.x;
+    if (plane >= n_planes) return;
+    const int b = plane / C, c = plane - b * C;
+    typedef float floatx2 __attribute__((ext_vector_type(2)));
+    const floatx2 *p = reinterpret_cast<const floatx2 *>(part) + (size_t)b * H * C + c;
+    double s = 0.0, ss = 0.0;
+    for (int h = 0; h < H; ++h) {
+        const floatx2 v = p[(size_t)h * C];
+        s += (double)v[0];
+        ss += (double)v[1];
+    }
+    const double n = (double)H * (double)Wv;
+    const double mean = s / n;
+    double var = ss / n - mean * mean;
+    var = var > 0.0 ? var : 0.0;
+    stats[plane * 2] = (float)mean;
+    stats[plane * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+MX_EXPORT int mx_plane_stats_finish(const float *part, int64_t B, int64_t C, int64_t H, int64_t Wv, float eps, float *stats,
+                                    void *stream)
+{
+    if (!part || !stats || B <= 0 || C <= 0 || H <= 0 || Wv <= 0 || Wv > CV_PITCH) return MX_ERR_ARG;
+    const int n = (int)(B * C);
+    hipLaunchKernelGGL(plane_stats_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, part, n,
+                       (int)C, (int)H, (int)Wv, eps, stats);
+    return mx_launch_status();
+}
+
 // LayerNorm backward fused with the backward of the PReLU in front of it.
 //   p      (B,C,H,352): pooled pre-activations of the previous block (input of PReLU)
 //   dxhat  (B,C,H,352): gradient w.r.t. the normalised tensor (from mx_conv_block_dgrad); overwritten

@@ -134,6 +134,7 @@ BLOCK1_F16 = os.environ.get("MODEX_BLOCK1", "f16x3") != "f32"
 WGRAD_SPARSE = os.environ.get("MODEX_WGRAD", "sparse") != "dense"
 WGRAD_SPARSE_MAX_T = int(os.environ.get("MODEX_WGRAD_SP_MAXT", "4"))     # dilations above it: dense kernel (no shared fragment blocks)
 DGRAD_SPARSE = os.environ.get("MODEX_DGRAD", "sparse") != "dense"
+STATS_FUSED = os.environ.get("MODEX_STATS", "fused") != "sweep"   # next block's LayerNorm statistics from the forward epilogue
 LN_FUSED = os.environ.get("MODEX_LN", "fused") != "sweep"      # LayerNorm-backward statistics from the data-gradient epilogue
 
 
@@ -158,6 +159,7 @@ class _CNNStack(torch.autograd.Function):
         dev = logmel.device
         st = _hip.stream()
         cur, slope = logmel, None
+        stats_part = None                 # {sum, sum of squares} per pooled row left by the previous block's forward epilogue
         saved: List[T] = []
         # the fp16 operand pairs of the 64-channel blocks are kept for the weight gradient when a backward pass
         # will follow (5.9 GB at 256 clips x 2 s: cheaper than re-deriving them from the saved activations)
@@ -166,8 +168,14 @@ class _CNNStack(torch.autograd.Function):
         for l in range(n_blocks):
             w, b, a = params[3 * l], params[3 * l + 1], params[3 * l + 2]
             stats = torch.empty((B, cin, 2), device=dev, dtype=torch.float32)
-            _hip.call("mx_plane_stats", _hip.ptr(cur), _hip.ptr(slope), B, cin, H, n_frames, LN_EPS,
-                      _hip.ptr(stats), st)
+            if stats_part is not None:
+                _hip.call("mx_plane_stats_finish", _hip.ptr(stats_part), B, cin, H, n_frames, LN_EPS, _hip.ptr(stats), st)
+            else:
+                _hip.call("mx_plane_stats", _hip.ptr(cur), _hip.ptr(slope), B, cin, H, n_frames, LN_EPS,
+                          _hip.ptr(stats), st)
+            stats_part = None
+            fuse_stats = STATS_FUSED and l + 1 < n_blocks          # (the head takes the last block's output as it is)
+            a_out = a.contiguous()
             p = torch.empty((B, 64, H // 2, PITCH), device=dev, dtype=torch.float32)
             amax = torch.empty((B, 64, H // 2, PITCH), device=dev, dtype=torch.uint8)
             if _use_f16(cin, precision):
@@ -176,8 +184,11 @@ class _CNNStack(torch.autograd.Function):
                 _hip.call("mx_conv_prep_fwd_f16", _hip.ptr(cur), _hip.ptr(stats), _hip.ptr(slope), B, H, n_frames,
                           _hip.ptr(x_hi), _hip.ptr(x_lo), st)
                 w_hi, w_lo = _pack_f16(w, 0)
+                if fuse_stats:
+                    stats_part = torch.empty((B, H // 2, 64, 2), device=dev, dtype=torch.float32)
                 _hip.call("mx_conv_block_fwd_f16", _hip.ptr(x_hi), _hip.ptr(x_lo), _hip.ptr(w_hi), _hip.ptr(w_lo),
-                          _hip.ptr(b.contiguous()), B, H, n_frames, int(dilations[l]), _hip.ptr(p), _hip.ptr(amax), st)
+                          _hip.ptr(b.contiguous()), B, H, n_frames, int(dilations[l]), _hip.ptr(p), _hip.ptr(amax),
+                          _hip.ptr(a_out) if fuse_stats else None, _hip.ptr(stats_part), st)
                 if keep_splits:
                     ctx.splits[l] = (x_hi, x_lo)
                 del x_hi, x_lo
@@ -192,8 +203,11 @@ class _CNNStack(torch.autograd.Function):
                 wk_lo = torch.empty(13 * 2 * 64 * 8, device=dev, dtype=torch.float16)
                 _hip.call("mx_conv_pack_weights_kvec_f16", _hip.ptr(w.detach().contiguous()), _hip.ptr(wk_hi),
                           _hip.ptr(wk_lo), st)
+                if fuse_stats:
+                    stats_part = torch.empty((B, H // 2, 64, 2), device=dev, dtype=torch.float32)
                 _hip.call("mx_conv_block1_fwd_f16", _hip.ptr(xk_hi), _hip.ptr(xk_lo), _hip.ptr(wk_hi), _hip.ptr(wk_lo),
-                          _hip.ptr(b.contiguous()), B, H, n_frames, _hip.ptr(p), _hip.ptr(amax), st)
+                          _hip.ptr(b.contiguous()), B, H, n_frames, _hip.ptr(p), _hip.ptr(amax),
+                          _hip.ptr(a_out) if fuse_stats else None, _hip.ptr(stats_part), st)
                 if keep_splits:
                     ctx.splits[l] = (xk_hi, xk_lo)              # the weight gradient consumes the same operand
                 del xk_hi, xk_lo
@@ -203,7 +217,7 @@ class _CNNStack(torch.autograd.Function):
                           _hip.ptr(b.contiguous()), B, cin, H, n_frames, int(dilations[l]), 1 if l == 0 else 0,
                           _hip.ptr(p), _hip.ptr(amax), st)
             saved += [cur, stats, amax]
-            cur, slope, cin, H = p, a.contiguous(), 64, H // 2
+            cur, slope, cin, H = p, a_out, 64, H // 2
         wout, bout = params[3 * n_blocks], params[3 * n_blocks + 1]
         L = wout.size(0)
         latent = torch.empty((B, 64, n_frames), device=dev, dtype=torch.float32)

@@ -129,9 +129,25 @@ def test_block_f16x3_kernels(dev, T, W, H):
     w_hi, w_lo = am._pack_f16(w.detach().to(dev), 0)
     p = torch.empty((B, 64, H // 2, PITCH), device=dev)
     amax = torch.empty((B, 64, H // 2, PITCH), device=dev, dtype=torch.uint8)
+    # with the slope of the PReLU that follows, the epilogue also leaves the next block's LayerNorm statistics as per-row sums
+    sl_out = (torch.rand(64) * 0.4 + 0.05).to(dev)
+    st_part = torch.empty((B, H // 2, 64, 2), device=dev)
     _hip.call("mx_conv_block_fwd_f16", _hip.ptr(x_hi), _hip.ptr(x_lo), _hip.ptr(w_hi), _hip.ptr(w_lo),
-              _hip.ptr(b.detach().to(dev)), B, H, W, T, _hip.ptr(p), _hip.ptr(amax), st)
+              _hip.ptr(b.detach().to(dev)), B, H, W, T, _hip.ptr(p), _hip.ptr(amax), _hip.ptr(sl_out), _hip.ptr(st_part), st)
     assert rel(p.cpu()[..., :W], p_r.detach()) < 1e-5
+    stats_swept, stats_fused = torch.empty((B, 64, 2), device=dev), torch.empty((B, 64, 2), device=dev)
+    _hip.call("mx_plane_stats", _hip.ptr(p), _hip.ptr(sl_out), B, 64, H // 2, W, 1e-5, _hip.ptr(stats_swept), st)
+    _hip.call("mx_plane_stats_finish", _hip.ptr(st_part), B, 64, H // 2, W, 1e-5, _hip.ptr(stats_fused), st)
+    y_r = torch.where(p_r.detach() > 0, p_r.detach(), sl_out.cpu().view(1, 64, 1, 1) * p_r.detach())
+    mean_r, var_r = y_r.double().mean(dim=(2, 3)), y_r.double().var(dim=(2, 3), unbiased=False)
+    # mean against the plane's standard deviation, rstd relatively: both at fp32 rounding level
+    assert float(((stats_fused[..., 0].cpu().double() - mean_r).abs() / var_r.sqrt()).max()) < 2e-6
+    assert float((stats_fused[..., 1].cpu().double() * (var_r + 1e-5).sqrt() - 1).abs().max()) < 2e-6
+    assert float((stats_fused - stats_swept).abs().max() / stats_swept.abs().max()) < 2e-6
+    p2 = torch.empty_like(p)
+    _hip.call("mx_conv_block_fwd_f16", _hip.ptr(x_hi), _hip.ptr(x_lo), _hip.ptr(w_hi), _hip.ptr(w_lo),
+              _hip.ptr(b.detach().to(dev)), B, H, W, T, _hip.ptr(p2), _hip.ptr(amax), None, None, st)
+    assert torch.equal(p2, p)                                                     # the optional outputs change nothing else
     am_r = (z_r[:, :, 1::2] > z_r[:, :, 0::2]).to(torch.uint8)
     assert float((amax.cpu()[..., :W] != am_r).float().mean()) < 1e-4          # ties aside, the same argmax
     # gradient operand from the REFERENCE's argmax, so that all gradients below are comparable element by element

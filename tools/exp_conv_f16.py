@@ -55,7 +55,7 @@ def run(B=64):
             def fwd():
                 return lib.mx_conv_block_fwd_f16(vp(x_hi.data_ptr()), vp(x_lo.data_ptr()), vp(w_hi.data_ptr()),
                                                  vp(w_lo.data_ptr()), vp(bias.data_ptr()), i64(B), i64(H), i64(345), i32(T),
-                                                 vp(out_p.data_ptr()), vp(am.data_ptr()), st)
+                                                 vp(out_p.data_ptr()), vp(am.data_ptr()), None, None, st)
 
             def dgr():
                 return lib.mx_conv_block_dgrad_f16(vp(x_hi.data_ptr()), vp(x_lo.data_ptr()), vp(w_hi.data_ptr()),
