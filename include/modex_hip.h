@@ -225,13 +225,31 @@ int mx_conv_block_wgrad_sp_f16(const void *g_hi, const void *g_lo, const void *g
  *                              (all or NULL): the block's forward operand pair (B,H,4,352,16) = the normalised input
  *                              xhat, and ln_part (B,64,H,2,2) floats <- {sum dxhat, sum dxhat * xhat} per (plane, row,
  *                              position half): the plane statistics mx_ln_prelu_bwd needs, taken while the values are
- *                              in registers instead of by a sweep over dxhat and p */
+ *                              in registers instead of by a sweep over dxhat and p.  gx_bits (2 uint32, zeroed by the
+ *                              caller; optional, needs ln_part): receives the bit patterns of max|dxhat| and max|xhat|
+ *                              of the launch (atomic max) for mx_ln_bwd_finish */
 int mx_conv_pack_weights_sp_f16(const float *W, void *w_hi, void *w_lo, void *stream);
 int mx_conv_prep_gpool_cl_f16(const float *G, const uint8_t *amax, const float *scale, int64_t B, int64_t H, int64_t Wv,
                               void *g_hi, void *g_lo, void *g_idx, void *gidx, void *stream);
 int mx_conv_block_dgrad_sp_f16(const void *g_hi, const void *g_lo, const void *g_idx, const void *w_hi, const void *w_lo,
                                const float *scale, int64_t B, int64_t H, int64_t Wv, int32_t dilation, float *dxhat,
-                               const void *x_hi, const void *x_lo, float *ln_part, void *stream);
+                               const void *x_hi, const void *x_lo, float *ln_part, uint32_t *gx_bits, void *stream);
+/* LayerNorm / PReLU backward (torch autograd of models.py:186,194) written STRAIGHT INTO the pooled operand of the block below,
+ * for blocks whose two gradients both take the pooled channels-last pair: dL/dp never exists in fp32 (8 B per element less
+ * than mx_ln_prelu_bwd + mx_conv_prep_gpool_cl_f16).  The f16x3 scale is needed before the pass, so it comes from an upper
+ * bound on max|G| instead of the maximum itself:
+ *   mx_ln_bwd_finish: ln_part (B,C,H,2,2), stats (B,C,2), slope (C,), gx_bits (2,) as left by mx_conv_block_dgrad_sp_f16 ->
+ *                     m12 (B,C,2) = plane means {dxhat, dxhat * xhat}; scale (2,) = {S, 1/S}, S the power of two that puts
+ *                     max_p rstd_p max(1,|slope|) (max|dxhat| + |m1_p| + max|xhat| |m2_p|) into [512, 1024); bound_ws: 1 uint32
+ *   mx_ln_prelu_bwd_gpool_f16: p, dxhat, amax (B,64,Hp,352) -> g_hi, g_lo (B,Hp,4,352,16), g_idx (B,Hp,4,352), gidx
+ *                     (B,64,Hp,22,2; optional) exactly as mx_conv_prep_gpool_cl_f16 would from G; part: workspace of
+ *                     B*64*Hp*6*2 floats; dslope_part, gsum_part (B*64,): the per-plane sums mx_ln_prelu_bwd returns */
+int mx_ln_bwd_finish(const float *ln_part, const float *stats, const float *slope, const uint32_t *gx_bits, int64_t B,
+                     int64_t C, int64_t H, int64_t Wv, float *m12, uint32_t *bound_ws, float *scale, void *stream);
+int mx_ln_prelu_bwd_gpool_f16(const float *p, const float *dxhat, const uint8_t *amax, const float *stats,
+                              const float *slope, const float *m12, const float *scale, int64_t B, int64_t Hp, int64_t Wv,
+                              void *g_hi, void *g_lo, void *g_idx, void *gidx, float *part, float *dslope_part,
+                              float *gsum_part, void *stream);
 
 /* LayerNorm backward fused with the backward of the PReLU in front of it.  p (B,C,H,352): input of
  * that PReLU; dxhat_inout: in = grad w.r.t. the normalised tensor, out = G = dL/dp (in place);

@@ -34,6 +34,8 @@ struct DgradSpArgs {
     int H, Wv;
     const _Float16 *x_hi, *x_lo;        // LN only: (B, H, 4, 352, 16) operand pair of the block's forward pass (= xhat)
     float *ln_part;                     // LN only: (B, 64, H, 2, 2) partial sums {dxhat, dxhat * xhat} per (row, position half)
+    unsigned *gx_bits;                  // LN only, optional: bit patterns of max |dxhat| and max |xhat| over the launch (atomicMax;
+                                        // zeroed by the caller) -- the inputs of mx_ln_bwd_finish's bound on max |G|
 };
 
 __device__ __forceinline__ floatx16 ds_smfmac(half8 a, half16 b, floatx16 c, int idx)
@@ -241,6 +243,7 @@ __global__ __launch_bounds__(256, 1) void dgrad_sp_f16x3_kernel(DgradSpArgs a)
     const float inv = a.scale[1] * (1.0f / DS_WSCALE);
     const int h = h0 + row;
     float s1a[2][16], s2a[2][16];                               // [weight fragment j: ci tile j ^ c][channel hh*16 + i]
+    float mxd = 0.0f, mxx = 0.0f;                               // running max |dxhat|, max |xhat| of this lane
     half8 xh[LN ? CV_WT : 1][2], xl[LN ? CV_WT : 1][2];         // all of the wave's xhat vectors, requested up front: one
     if (LN) {                                                   // memory round trip per workgroup instead of eleven
 #pragma unroll
@@ -275,9 +278,19 @@ __global__ __launch_bounds__(256, 1) void dgrad_sp_f16x3_kernel(DgradSpArgs a)
                 const float xv = (float)xh[u][i >> 3][i & 7] + (float)xl[u][i >> 3][i & 7];
                 s1a[jf][i] += v;
                 s2a[jf][i] += v * xv;
+                mxd = fmaxf(mxd, fabsf(v));
+                mxx = fmaxf(mxx, w < a.Wv ? fabsf(xv) : 0.0f);
             }
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);
+    }
+    if (LN && a.gx_bits) {                                      // (order of non-negative floats = order of their bits)
+        mxd = wave_max_f32(mxd);
+        mxx = wave_max_f32(mxx);
+        if (lane == 0) {
+            atomicMax(a.gx_bits, __float_as_uint(mxd));
+            atomicMax(a.gx_bits + 1, __float_as_uint(mxx));
+        }
     }
     if (LN) {
         // sum over the 32 positions held by the lanes of each half (same hh), in a fixed order, through wave-private
@@ -405,6 +418,183 @@ __global__ __launch_bounds__(256) void gpool_cl_prep_kernel(const float *__restr
     }
 }
 
+// ---- LayerNorm / PReLU backward fused INTO the pooled-operand pass ---------------------------------------------------
+// mx_ln_prelu_bwd writes G = dL/dp (fp32, 4 B per element) only for gpool_cl_prep_kernel to read it back, scale it, split it
+// and transpose it.  When the consumer block takes nothing but the pooled channels-last pair (blocks 2-4: both gradients on
+// the sparse instruction), G never needs to exist: this kernel is gpool_cl_prep_kernel with the LayerNorm / PReLU backward as
+// its load stage.  What stood in the way is the f16x3 scale, a power of two from max|G| over the whole tensor, which is only
+// known after the pass: mx_ln_bwd_finish replaces it by an UPPER BOUND from quantities that exist before --
+//   |G| <= rstd_p max(1, |slope_c|) (max|dxhat| + |m1_p| + max|xhat| |m2_p|)       maximised over the planes p = (clip, channel),
+// max|dxhat| and max|xhat| from the data-gradient epilogue (dgrad_sp_f16x3_kernel, gx_bits), m1_p, m2_p = the plane means of
+// dxhat and dxhat * xhat it already leaves (ln_part).  A bound 2^k above the true maximum costs precision only on elements
+// below 2^(k-18) of the maximum (their fp16 `lo` half turns subnormal); it can never overflow.
+//   p, dxhat (B,64,Hp,352) fp32, stats (B,64,2), slope (64,), m12 (B,64,2) = {m1, m2} (mx_ln_bwd_finish), scale {S, 1/S}
+//   -> g_hi, g_lo, g_idx, gidx as gpool_cl_prep_kernel; part (B,64,Hp,6,2) = {d loss / d slope, sum of G} per workgroup and
+//      channel (summed by mx_plane_partials_sum: the PReLU-slope and bias gradients)
+__global__ __launch_bounds__(256) void lnbwd_gpool_kernel(const float *__restrict__ p, const float *__restrict__ dxhat,
+                                                          const unsigned char *__restrict__ amax,
+                                                          const float *__restrict__ stats, const float *__restrict__ slope,
+                                                          const float *__restrict__ m12, const float *__restrict__ scale,
+                                                          int Hp, int Wv, _Float16 *__restrict__ g_hi,
+                                                          _Float16 *__restrict__ g_lo, unsigned *__restrict__ g_idx,
+                                                          unsigned char *__restrict__ gidx, float *__restrict__ part)
+{
+    __shared__ float tile[64][GP_TW + 1];
+    __shared__ unsigned char tam[64][GP_TW + 4];
+    __shared__ __attribute__((aligned(16))) unsigned char idxb[64][16];
+    const int wt = blockIdx.x, hp = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
+    const float S = scale[0];
+    constexpr int NIT = 64 * (GP_TW / 4) / 256;                 // (channel, 4 positions) items per thread: channels tid/16 + 16 k
+    floatx4 pv[NIT], gv[NIT];
+    uchar4 av[NIT];
+    float mean[NIT], rstd[NIT], sl[NIT], m1[NIT], m2[NIT];
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {                             // all loads first
+        const int i = tid + 256 * k, ch = i / (GP_TW / 4), c4 = i % (GP_TW / 4), w0 = wt * GP_TW + c4 * 4;
+        const size_t off = (((size_t)b * 64 + ch) * Hp + hp) * CV_PITCH + (w0 < CV_PITCH ? w0 : 0);
+        pv[k] = *reinterpret_cast<const floatx4 *>(p + off);
+        gv[k] = *reinterpret_cast<const floatx4 *>(dxhat + off);
+        av[k] = *reinterpret_cast<const uchar4 *>(amax + off);
+        const size_t pl = (size_t)b * 64 + ch;
+        mean[k] = stats[pl * 2]; rstd[k] = stats[pl * 2 + 1]; sl[k] = slope[ch];
+        m1[k] = m12[pl * 2]; m2[k] = m12[pl * 2 + 1];
+    }
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+        const int i = tid + 256 * k, ch = i / (GP_TW / 4), c4 = i % (GP_TW / 4), w0 = wt * GP_TW + c4 * 4;
+        const uchar4 am = av[k];
+        float tds = 0.0f, tgs = 0.0f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {                           // the arithmetic of ln_prelu_bwd_kernel (norm.hip), term by term
+            const bool valid = w0 + e < Wv;
+            const bool pos = pv[k][e] > 0.0f;
+            const float x = pos ? pv[k][e] : sl[k] * pv[k][e];
+            const float xh = (x - mean[k]) * rstd[k];
+            const float dx = rstd[k] * (gv[k][e] - m1[k] - xh * m2[k]);
+            const float r = valid ? (pos ? dx : sl[k] * dx) : 0.0f;
+            tds += (valid && !pos) ? dx * pv[k][e] : 0.0f;
+            tgs += r;
+            tile[ch][c4 * 4 + e] = r * S;
+        }
+        // the 16 threads of a channel are 16 consecutive lanes: fixed-order sum, one partial per (channel, workgroup)
+#pragma unroll
+        for (int d = 1; d < 16; d <<= 1) {
+            tds += __shfl_xor(tds, d, 16);
+            tgs += __shfl_xor(tgs, d, 16);
+        }
+        if (c4 == 0) {
+            float *q = part + (((((size_t)b * 64 + ch) * Hp + hp) * gridDim.x) + wt) * 2;
+            q[0] = tds;
+            q[1] = tgs;
+        }
+        tam[ch][c4 * 4 + 0] = am.x & 1; tam[ch][c4 * 4 + 1] = am.y & 1; tam[ch][c4 * 4 + 2] = am.z & 1; tam[ch][c4 * 4 + 3] = am.w & 1;
+        if (gidx) {
+            const unsigned byte = (am.x & 1u) | ((2u + (am.y & 1u)) << 2) | ((am.z & 1u) << 4) | ((2u + (am.w & 1u)) << 6);
+            idxb[ch][(((c4 >> 2) * 2 + (c4 & 1)) * 2) + ((c4 >> 1) & 1)] = (unsigned char)byte;
+        }
+    }
+    __syncthreads();
+    if (gidx && tid < 128) {
+        const int ch = tid >> 1, pr = tid & 1, ks0 = wt * (GP_TW / 16) + pr * 2;
+        if (ks0 < 22)
+            *reinterpret_cast<unsigned long long *>(gidx + ((((size_t)b * 64 + ch) * Hp + hp) * 22 + ks0) * 4) =
+                *reinterpret_cast<const unsigned long long *>(&idxb[ch][pr * 8]);
+    }
+#pragma unroll
+    for (int it = 0; it < GP_TW / 32; ++it) {
+        const int pos = (tid >> 3) + 32 * it, cg = tid & 7, w = wt * GP_TW + pos;
+        if (w >= CV_PITCH) continue;
+        half8 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float v = tile[cg * 8 + j][pos];
+            const _Float16 hv = (_Float16)v;
+            hi[j] = hv;
+            lo[j] = (_Float16)(v - (float)hv);
+        }
+        const size_t o = ((((size_t)b * Hp + hp) * 4 + (cg >> 1)) * CV_PITCH + w) * 16 + (cg & 1) * 8;
+        *reinterpret_cast<half8 *>(g_hi + o) = hi;
+        *reinterpret_cast<half8 *>(g_lo + o) = lo;
+        if (cg < 4) {
+            unsigned word = 0;
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int col = (j < 4 ? 4 * hf + j : 8 + 4 * hf + (j - 4));
+                    const unsigned f = 2u * (j & 1) + tam[cg * 16 + col][pos];
+                    word |= f << (16 * hf + 2 * j);
+                }
+            g_idx[(((size_t)b * Hp + hp) * 4 + cg) * CV_PITCH + w] = word;
+        }
+    }
+}
+
+// plane means of dxhat and dxhat * xhat from the data gradient's partial sums, and the bound on max |G| (above)
+__global__ __launch_bounds__(256) void ln_bwd_finish_kernel(const float *__restrict__ ln_part, const float *__restrict__ stats,
+                                                            const float *__restrict__ slope,
+                                                            const unsigned *__restrict__ gx_bits, int n_planes, int C, int H,
+                                                            int Wv, float *__restrict__ m12, unsigned *__restrict__ bound_bits)
+{
+    const int plane = blockIdx.x * 256 + threadIdx.x;
+    float bound = 0.0f;
+    if (plane < n_planes) {
+        typedef float floatx2 __attribute__((ext_vector_type(2)));
+        const floatx2 *lp = reinterpret_cast<const floatx2 *>(ln_part) + (size_t)plane * (2 * H);
+        double s1 = 0.0, s2 = 0.0;
+        for (int i = 0; i < 2 * H; ++i) {
+            const floatx2 v = lp[i];
+            s1 += (double)v[0];
+            s2 += (double)v[1];
+        }
+        const double n = (double)H * (double)Wv;
+        const float m1 = (float)(s1 / n), m2 = (float)(s2 / n);
+        m12[plane * 2] = m1;
+        m12[plane * 2 + 1] = m2;
+        const float mxd = __uint_as_float(gx_bits[0]), mxx = __uint_as_float(gx_bits[1]);
+        const float sl = fabsf(slope[plane % C]);
+        // (1 + 2^-20): the bound is evaluated in fp32 like the values it bounds
+        bound = stats[plane * 2 + 1] * fmaxf(1.0f, sl) * (mxd + fabsf(m1) + mxx * fabsf(m2)) * 1.000001f;
+    }
+    bound = wave_max_f32(bound);
+    if ((threadIdx.x & 63) == 0) atomicMax(bound_bits, __float_as_uint(bound));
+}
+
+__global__ void pow2_scale_from_bits_kernel(const unsigned *__restrict__ bits, float *__restrict__ scale)
+{
+    const float m = __uint_as_float(*bits);
+    int e = 0;
+    if (m > 0.0f && m < 3.0e38f) {
+        frexpf(m, &e);                 // m = f * 2^e, f in [0.5, 1)
+        e = 10 - e;                    // m * 2^(10 - e) in [512, 1024)
+        e = e > 100 ? 100 : (e < -100 ? -100 : e);
+    }
+    scale[0] = ldexpf(1.0f, e);
+    scale[1] = ldexpf(1.0f, -e);
+}
+
+// out_a[plane], out_b[plane] = sums of the K {a, b} pairs of a plane (fp64, fixed order)
+__global__ __launch_bounds__(256) void plane_partials_sum_kernel(const float *__restrict__ part, int n_planes, int K,
+                                                                 float *__restrict__ out_a, float *__restrict__ out_b)
+{
+    const int plane = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (plane >= n_planes) return;
+    typedef float floatx2 __attribute__((ext_vector_type(2)));
+    const floatx2 *q = reinterpret_cast<const floatx2 *>(part) + (size_t)plane * K;
+    double a = 0.0, b = 0.0;
+    for (int i = lane; i < K; i += 64) {
+        const floatx2 v = q[i];
+        a += (double)v[0];
+        b += (double)v[1];
+    }
+    a = wave_sum_f64(a);
+    b = wave_sum_f64(b);
+    if (lane == 0) {
+        out_a[plane] = (float)a;
+        out_b[plane] = (float)b;
+    }
+}
+
 template <int T, bool LN>
 static int launch_dgrad_sp(const DgradSpArgs &a, int B, hipStream_t st)
 {
@@ -448,20 +638,63 @@ MX_EXPORT int mx_conv_prep_gpool_cl_f16(const float *G, const uint8_t *amax, con
     return mx_launch_status();
 }
 
+// ln_part (B,64,H,2,2), stats (B,64,2), slope (64,), gx_bits (2,) from mx_conv_block_dgrad_sp_f16 -> m12 (B,64,2) plane means
+// {dxhat, dxhat * xhat} and scale (2,) = {S, 1/S}, S the power of two that puts the BOUND on max |G| into [512, 1024);
+// bound_ws: 1 uint workspace
+MX_EXPORT int mx_ln_bwd_finish(const float *ln_part, const float *stats, const float *slope, const uint32_t *gx_bits,
+                               int64_t B, int64_t C, int64_t H, int64_t Wv, float *m12, uint32_t *bound_ws, float *scale,
+                               void *stream)
+{
+    if (!ln_part || !stats || !slope || !gx_bits || !m12 || !bound_ws || !scale || B <= 0 || C <= 0 || H <= 0 || Wv <= 0 ||
+        Wv > CV_PITCH)
+        return MX_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(bound_ws, 0, sizeof(uint32_t), st) != hipSuccess) return MX_ERR_LAUNCH;
+    const int n = (int)(B * C);
+    hipLaunchKernelGGL(ln_bwd_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ln_part, stats, slope, gx_bits, n,
+                       (int)C, (int)H, (int)Wv, m12, bound_ws);
+    hipLaunchKernelGGL(pow2_scale_from_bits_kernel, dim3(1), dim3(1), 0, st, bound_ws, scale);
+    return mx_launch_status();
+}
+
+// LayerNorm / PReLU backward straight into the pooled operand of the block below (see lnbwd_gpool_kernel): p, dxhat, amax
+// (B,64,Hp,352) -> g_hi, g_lo (B,Hp,4,352,16), g_idx (B,Hp,4,352), gidx (B,64,Hp,22,2) (optional), part (B,64,Hp,6,2);
+// dslope_part, gsum_part (B*64,): the per-plane sums of mx_ln_prelu_bwd
+MX_EXPORT int mx_ln_prelu_bwd_gpool_f16(const float *p, const float *dxhat, const uint8_t *amax, const float *stats,
+                                        const float *slope, const float *m12, const float *scale, int64_t B, int64_t Hp,
+                                        int64_t Wv, void *g_hi, void *g_lo, void *g_idx, void *gidx, float *part,
+                                        float *dslope_part, float *gsum_part, void *stream)
+{
+    if (!p || !dxhat || !amax || !stats || !slope || !m12 || !scale || !g_hi || !g_lo || !g_idx || !part || !dslope_part ||
+        !gsum_part || B <= 0 || Hp <= 0 || Wv <= 0 || Wv > CV_PITCH)
+        return MX_ERR_ARG;
+    if (B > 65535 || Hp > 65535) return MX_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned tiles = (CV_PITCH + GP_TW - 1) / GP_TW;
+    hipLaunchKernelGGL(lnbwd_gpool_kernel, dim3(tiles, (unsigned)Hp, (unsigned)B), dim3(256), 0, st, p, dxhat, amax, stats, slope,
+                       m12, scale, (int)Hp, (int)Wv, (_Float16 *)g_hi, (_Float16 *)g_lo, (unsigned *)g_idx,
+                       (unsigned char *)gidx, part);
+    const int n = (int)(B * 64);
+    hipLaunchKernelGGL(plane_partials_sum_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, part, n, (int)(Hp * tiles),
+                       dslope_part, gsum_part);
+    return mx_launch_status();
+}
+
 // data gradient from the pooled channels-last operand and the fragment-packed weights; dxhat (B,64,H,352).
 // x_hi, x_lo, ln_part (all or none): the block's forward operand pair (B,H,4,352,16) and the (B,64,H,2,2) partial sums
 // {sum dxhat, sum dxhat * xhat} that mx_ln_prelu_bwd takes in place of its own statistics sweep.
 MX_EXPORT int mx_conv_block_dgrad_sp_f16(const void *g_hi, const void *g_lo, const void *g_idx, const void *w_hi,
                                          const void *w_lo, const float *scale, int64_t B, int64_t H, int64_t Wv,
                                          int32_t dilation, float *dxhat, const void *x_hi, const void *x_lo,
-                                         float *ln_part, void *stream)
+                                         float *ln_part, uint32_t *gx_bits, void *stream)
 {
     if (!g_hi || !g_lo || !g_idx || !w_hi || !w_lo || !scale || !dxhat) return MX_ERR_ARG;
     if ((x_hi || x_lo || ln_part) && !(x_hi && x_lo && ln_part)) return MX_ERR_ARG;
+    if (gx_bits && !ln_part) return MX_ERR_ARG;
     if (B <= 0 || B > 65535 || H < 2 || (H & 1) || Wv <= 0 || Wv > CV_PITCH - 1) return MX_ERR_UNSUPPORTED;
     DgradSpArgs a{(const _Float16 *)g_hi, (const _Float16 *)g_lo, (const unsigned *)g_idx, (const _Float16 *)w_hi,
                   (const _Float16 *)w_lo, scale, dxhat, (int)H, (int)Wv, (const _Float16 *)x_hi, (const _Float16 *)x_lo,
-                  ln_part};
+                  ln_part, gx_bits};
     hipStream_t st = (hipStream_t)stream;
     const bool ln = ln_part != nullptr;
     switch (dilation) {

@@ -135,6 +135,9 @@ WGRAD_SPARSE = os.environ.get("MODEX_WGRAD", "sparse") != "dense"
 WGRAD_SPARSE_MAX_T = int(os.environ.get("MODEX_WGRAD_SP_MAXT", "4"))     # dilations above it: dense kernel (no shared fragment blocks)
 DGRAD_SPARSE = os.environ.get("MODEX_DGRAD", "sparse") != "dense"
 STATS_FUSED = os.environ.get("MODEX_STATS", "fused") != "sweep"   # next block's LayerNorm statistics from the forward epilogue
+# LayerNorm / PReLU backward written straight into the pooled operand of the block below (blocks whose two gradients both run
+# on the sparse instruction): dL/dp never exists in fp32.  "split" keeps the two passes (A/B knob).
+GPOOL_FUSED = os.environ.get("MODEX_GPOOL", "fused") != "split"
 LN_FUSED = os.environ.get("MODEX_LN", "fused") != "sweep"      # LayerNorm-backward statistics from the data-gradient epilogue
 
 
@@ -146,6 +149,12 @@ def _reduce_rows(part: T, rows: int, cols: int) -> T:
     out = torch.empty(cols, device=part.device, dtype=torch.float32)
     _hip.call("mx_reduce_rows", _hip.ptr(part), rows, cols, 0, _hip.ptr(out), _hip.stream())
     return out
+
+
+def _pooled_only(l: int, cin: int, dilations, precision: str, n_frames: int) -> bool:
+    """Block l (0-based) consumes its gradient only as the pooled channels-last pair: f16x3, both gradients sparse."""
+    return (l > 0 and _use_f16(cin, precision) and WGRAD_SPARSE and DGRAD_SPARSE
+            and int(dilations[l]) <= WGRAD_SPARSE_MAX_T and n_frames <= PITCH - 1)
 
 
 class _CNNStack(torch.autograd.Function):
@@ -257,6 +266,7 @@ class _CNNStack(torch.autograd.Function):
         grads[3 * n_blocks + 1] = _reduce_rows(db_part, B, L)
         grads[3 * (n_blocks - 1) + 2] = _reduce_rows(ds_part, B, 64)
         bsum, gmax_ws = None, None       # by-products of mx_ln_prelu_bwd for the block below: bias partials, max|G| bits
+        pooled = None                    # (gc_hi, gc_lo, gc_idx, gidx, scale) left for the block below by the fused LN backward
         for l in range(n_blocks - 1, -1, -1):
             x_in, stats, amax = saved[3 * l], saved[3 * l + 1], saved[3 * l + 2]
             w = params[3 * l]
@@ -268,6 +278,7 @@ class _CNNStack(torch.autograd.Function):
                 DEBUG_TAP[f"amax{l}"] = amax.clone()
                 DEBUG_TAP[f"p{l}"] = (p_last if l == n_blocks - 1 else saved[3 * (l + 1)]).clone()
             if bsum is None:
+                assert G is not None
                 bsum = torch.empty((B, 64), device=dev, dtype=torch.float32)
                 _hip.call("mx_plane_sum", _hip.ptr(G), B * 64, H // 2, n_frames, _hip.ptr(bsum), st)
             grads[3 * l + 1] = _reduce_rows(bsum, B, 64)
@@ -293,9 +304,13 @@ class _CNNStack(torch.autograd.Function):
                 if need_routed:
                     dz_hi = torch.empty((B, H, 4, PITCH, 16), device=dev, dtype=torch.float16)
                     dz_lo = torch.empty((B, H, 4, PITCH, 16), device=dev, dtype=torch.float16)
-                _hip.call("mx_conv_prep_dgrad_f16", _hip.ptr(G), _hip.ptr(amax), B, H, n_frames, _hip.ptr(ws),
-                          1 if ready else 0, _hip.ptr(scale), _hip.ptr(dz_hi), _hip.ptr(dz_lo), st)
-                if sparse or sparse_d:
+                if pooled is not None:
+                    gc_hi, gc_lo, gc_idx, gidx, scale = pooled       # made by the LayerNorm backward of the block above
+                    pooled = None
+                else:
+                    _hip.call("mx_conv_prep_dgrad_f16", _hip.ptr(G), _hip.ptr(amax), B, H, n_frames, _hip.ptr(ws),
+                              1 if ready else 0, _hip.ptr(scale), _hip.ptr(dz_hi), _hip.ptr(dz_lo), st)
+                if gc_hi is None and (sparse or sparse_d):
                     # one pass over G: the channels-last pooled pair both sparse kernels read, the data gradient's index
                     # words and (for the weight gradient) the planar ones
                     gc_hi = torch.empty((B, Hp, 4, PITCH, 16), device=dev, dtype=torch.float16)
@@ -352,7 +367,7 @@ class _CNNStack(torch.autograd.Function):
             grads[3 * l] = dW
             if l > 0:
                 dxhat = torch.empty((B, 64, H, PITCH), device=dev, dtype=torch.float32)
-                ln_part = None
+                ln_part, fuse_g = None, False
                 if f16 and sparse_d:
                     # sparse matrix instruction, transposed tiles: pooled channels-last gradient x fragment-packed weights
                     ws_hi = torch.empty(4 * 3 * 2 * 13 * 2 * 64 * 16, device=dev, dtype=torch.float16)
@@ -360,16 +375,20 @@ class _CNNStack(torch.autograd.Function):
                     _hip.call("mx_conv_pack_weights_sp_f16", _hip.ptr(w.detach().contiguous()), _hip.ptr(ws_hi),
                               _hip.ptr(ws_lo), st)
                     if LN_FUSED:
-                        # the epilogue also leaves the plane statistics of the LayerNorm backward below (x = xhat)
+                        # the epilogue also leaves the plane statistics of the LayerNorm backward below (x = xhat) and, when
+                        # that pass writes the block below's pooled operand itself, max|dxhat| / max|xhat| for its scale
                         ln_part = torch.empty((B, 64, H, 2, 2), device=dev, dtype=torch.float32)
+                        fuse_g = (GPOOL_FUSED and DEBUG_TAP is None
+                                  and _pooled_only(l - 1, saved[3 * (l - 1)].size(1), dilations, precision, n_frames))
+                        gx_bits = torch.zeros(2, device=dev, dtype=torch.int32) if fuse_g else None
                         _hip.call("mx_conv_block_dgrad_sp_f16", _hip.ptr(gc_hi), _hip.ptr(gc_lo), _hip.ptr(gc_idx),
                                   _hip.ptr(ws_hi), _hip.ptr(ws_lo), _hip.ptr(scale), B, H, n_frames, int(dilations[l]),
-                                  _hip.ptr(dxhat), _hip.ptr(x_hi), _hip.ptr(x_lo), _hip.ptr(ln_part), st)
+                                  _hip.ptr(dxhat), _hip.ptr(x_hi), _hip.ptr(x_lo), _hip.ptr(ln_part), _hip.ptr(gx_bits), st)
                         del x_hi, x_lo
                     else:
                         _hip.call("mx_conv_block_dgrad_sp_f16", _hip.ptr(gc_hi), _hip.ptr(gc_lo), _hip.ptr(gc_idx),
                                   _hip.ptr(ws_hi), _hip.ptr(ws_lo), _hip.ptr(scale), B, H, n_frames, int(dilations[l]),
-                                  _hip.ptr(dxhat), None, None, None, st)
+                                  _hip.ptr(dxhat), None, None, None, None, st)
                     del gc_hi, gc_lo, gc_idx
                 elif f16:
                     w_hi, w_lo = _pack_f16(w, 1)
@@ -384,12 +403,33 @@ class _CNNStack(torch.autograd.Function):
                     DEBUG_TAP[f"dxhat{l}"] = dxhat.clone()
                 ds_part = torch.empty((B, 64), device=dev, dtype=torch.float32)
                 bsum = torch.empty((B, 64), device=dev, dtype=torch.float32)
-                want_gmax = _use_f16(saved[3 * (l - 1)].size(1), precision) or (l == 1 and 0 in ctx.splits)
-                gmax_ws = torch.zeros(1, device=dev, dtype=torch.int32) if want_gmax else None
-                _hip.call("mx_ln_prelu_bwd", _hip.ptr(x_in), _hip.ptr(dxhat), _hip.ptr(stats), _hip.ptr(slope_prev),
-                          B, 64, H, n_frames, _hip.ptr(ds_part), _hip.ptr(bsum), _hip.ptr(gmax_ws), _hip.ptr(ln_part), st)
+                if fuse_g:
+                    # dL/dp of the block below never exists in fp32: LayerNorm / PReLU backward -> scale from a bound on
+                    # max|G| -> split -> channels-last pooled pair + index words, one pass (csrc/dgrad_sp_f16.hip)
+                    m12 = torch.empty((B, 64, 2), device=dev, dtype=torch.float32)
+                    bound_ws = torch.empty(1, device=dev, dtype=torch.int32)
+                    scale_n = torch.empty(2, device=dev, dtype=torch.float32)
+                    _hip.call("mx_ln_bwd_finish", _hip.ptr(ln_part), _hip.ptr(stats), _hip.ptr(slope_prev), _hip.ptr(gx_bits),
+                              B, 64, H, n_frames, _hip.ptr(m12), _hip.ptr(bound_ws), _hip.ptr(scale_n), st)
+                    gn_hi = torch.empty((B, H, 4, PITCH, 16), device=dev, dtype=torch.float16)
+                    gn_lo = torch.empty((B, H, 4, PITCH, 16), device=dev, dtype=torch.float16)
+                    gn_idx = torch.empty((B, H, 4, PITCH), device=dev, dtype=torch.int32)
+                    gn_pidx = torch.empty((B, 64, H, 22, 2), device=dev, dtype=torch.int16)
+                    part2 = torch.empty((B, 64, H, 6, 2), device=dev, dtype=torch.float32)
+                    _hip.call("mx_ln_prelu_bwd_gpool_f16", _hip.ptr(x_in), _hip.ptr(dxhat), _hip.ptr(saved[3 * (l - 1) + 2]),
+                              _hip.ptr(stats), _hip.ptr(slope_prev), _hip.ptr(m12), _hip.ptr(scale_n), B, H, n_frames,
+                              _hip.ptr(gn_hi), _hip.ptr(gn_lo), _hip.ptr(gn_idx), _hip.ptr(gn_pidx), _hip.ptr(part2),
+                              _hip.ptr(ds_part), _hip.ptr(bsum), st)
+                    pooled = (gn_hi, gn_lo, gn_idx, gn_pidx, scale_n)
+                    gmax_ws, G = None, None
+                    del part2, m12, dxhat
+                else:
+                    want_gmax = _use_f16(saved[3 * (l - 1)].size(1), precision) or (l == 1 and 0 in ctx.splits)
+                    gmax_ws = torch.zeros(1, device=dev, dtype=torch.int32) if want_gmax else None
+                    _hip.call("mx_ln_prelu_bwd", _hip.ptr(x_in), _hip.ptr(dxhat), _hip.ptr(stats), _hip.ptr(slope_prev),
+                              B, 64, H, n_frames, _hip.ptr(ds_part), _hip.ptr(bsum), _hip.ptr(gmax_ws), _hip.ptr(ln_part), st)
+                    G = dxhat
                 grads[3 * (l - 1) + 2] = _reduce_rows(ds_part, B, 64)
-                G = dxhat
         return (None, None, None, None, *grads)
 
 

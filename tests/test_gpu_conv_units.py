@@ -219,7 +219,7 @@ def test_block_f16x3_kernels(dev, T, W, H):
     _hip.call("mx_conv_pack_weights_sp_f16", _hip.ptr(w.detach().to(dev).contiguous()), _hip.ptr(ws_hi), _hip.ptr(ws_lo), st)
     dx_sp = torch.empty((B, 64, H, PITCH), device=dev)
     _hip.call("mx_conv_block_dgrad_sp_f16", _hip.ptr(gc_hi), _hip.ptr(gc_lo), _hip.ptr(gc_idx), _hip.ptr(ws_hi), _hip.ptr(ws_lo),
-              _hip.ptr(scale), B, H, W, T, _hip.ptr(dx_sp), None, None, None, st)
+              _hip.ptr(scale), B, H, W, T, _hip.ptr(dx_sp), None, None, None, None, st)
     assert rel(dx_sp.cpu()[..., :W], xhat_r.grad) < 1e-5, ("sparse dgrad", rel(dx_sp.cpu()[..., :W], xhat_r.grad))
     assert bool((dx_sp[..., W:] == 0).all())
     assert rel(dx_sp, dxhat) < 5e-6                                              # same sums, different order
@@ -228,7 +228,7 @@ def test_block_f16x3_kernels(dev, T, W, H):
     dx_ln = torch.empty((B, 64, H, PITCH), device=dev)
     ln_part = torch.full((B, 64, H, 2, 2), float("nan"), device=dev)
     _hip.call("mx_conv_block_dgrad_sp_f16", _hip.ptr(gc_hi), _hip.ptr(gc_lo), _hip.ptr(gc_idx), _hip.ptr(ws_hi), _hip.ptr(ws_lo),
-              _hip.ptr(scale), B, H, W, T, _hip.ptr(dx_ln), _hip.ptr(x_hi), _hip.ptr(x_lo), _hip.ptr(ln_part), st)
+              _hip.ptr(scale), B, H, W, T, _hip.ptr(dx_ln), _hip.ptr(x_hi), _hip.ptr(x_lo), _hip.ptr(ln_part), None, st)
     assert torch.equal(dx_ln, dx_sp)
     d64, x64 = dx_sp.double().cpu(), xhat_pair.double().cpu()
     halves = [slice(0, 192), slice(192, PITCH)]                                  # position tiles 0..5 (incl. the shared 5) / 6..10
@@ -249,3 +249,39 @@ def test_block_f16x3_kernels(dev, T, W, H):
               _hip.ptr(gs_b), None, _hip.ptr(ln_part), st)
     assert rel(g_b, g_a) < 2e-6 and rel(ds_b, ds_a) < 2e-6 and rel(gs_b, gs_a) < 1e-5
     assert rel(g_b.cpu()[..., :W], x_req.grad) < 1e-5, ("ln_prelu_bwd from partials", rel(g_b.cpu()[..., :W], x_req.grad))
+    # ... and the same pass written straight into the pooled operand of the block below (dL/dp never in fp32): the data gradient
+    # also leaves max|dxhat| and max|xhat|, from which mx_ln_bwd_finish BOUNDS max|G| for the f16x3 scale
+    gx = torch.zeros(2, device=dev, dtype=torch.int32)
+    _hip.call("mx_conv_block_dgrad_sp_f16", _hip.ptr(gc_hi), _hip.ptr(gc_lo), _hip.ptr(gc_idx), _hip.ptr(ws_hi), _hip.ptr(ws_lo),
+              _hip.ptr(scale), B, H, W, T, _hip.ptr(dx_ln), _hip.ptr(x_hi), _hip.ptr(x_lo), _hip.ptr(ln_part), _hip.ptr(gx), st)
+    assert torch.equal(dx_ln, dx_sp)
+    mx = gx.view(torch.float32).cpu()
+    assert float(mx[0]) == float(dx_sp.abs().max()) and float(mx[1]) == float(xhat_pair[..., :W].abs().max())
+    m12 = torch.empty((B, 64, 2), device=dev)
+    bound_ws = torch.empty(1, device=dev, dtype=torch.int32)
+    sc3 = torch.empty(2, device=dev)
+    _hip.call("mx_ln_bwd_finish", _hip.ptr(ln_part), _hip.ptr(stats), _hip.ptr(sl_d), _hip.ptr(gx), B, 64, H, W, _hip.ptr(m12),
+              _hip.ptr(bound_ws), _hip.ptr(sc3), st)
+    S3, g_max = float(sc3[0]), float(g_b.abs().max())
+    assert S3 == 2.0 ** round(np.log2(S3)) and float(sc3[1]) == 1.0 / S3
+    assert 16.0 <= g_max * S3 < 1024.0, (g_max * S3,)          # a true bound, and within 2^6 of the maximum itself
+    am2 = (torch.rand(B, 64, H, PITCH, device=dev) < 0.5).to(torch.uint8)
+    shp = (B, H, 4, PITCH, 16)
+    fh, fl = torch.empty(shp, device=dev, dtype=torch.float16), torch.empty(shp, device=dev, dtype=torch.float16)
+    fi = torch.empty((B, H, 4, PITCH), device=dev, dtype=torch.int32)
+    fp = torch.empty((B, 64, H, 22, 2), device=dev, dtype=torch.int16)
+    part2 = torch.empty((B, 64, H, 6, 2), device=dev)
+    ds_c, gs_c = torch.empty(B * 64, device=dev), torch.empty(B * 64, device=dev)
+    _hip.call("mx_ln_prelu_bwd_gpool_f16", _hip.ptr(x_d), _hip.ptr(dx_sp), _hip.ptr(am2), _hip.ptr(stats), _hip.ptr(sl_d),
+              _hip.ptr(m12), _hip.ptr(sc3), B, H, W, _hip.ptr(fh), _hip.ptr(fl), _hip.ptr(fi), _hip.ptr(fp), _hip.ptr(part2),
+              _hip.ptr(ds_c), _hip.ptr(gs_c), st)
+    # the two-pass route on the same scale: G (g_b) -> pooled operand
+    rh, rl, ri, rp = torch.empty_like(fh), torch.empty_like(fl), torch.empty_like(fi), torch.empty_like(fp)
+    _hip.call("mx_conv_prep_gpool_cl_f16", _hip.ptr(g_b), _hip.ptr(am2), _hip.ptr(sc3), B, 2 * H, W, _hip.ptr(rh), _hip.ptr(rl),
+              _hip.ptr(ri), _hip.ptr(rp), st)
+    assert torch.equal(fi, ri) and torch.equal(fp, rp)
+    fused_pair, split_pair = fh.float() + fl.float(), rh.float() + rl.float()
+    assert rel(fused_pair, split_pair) < 2e-6
+    back = fused_pair.permute(0, 2, 4, 1, 3).reshape(B, 64, H, PITCH) / S3
+    assert rel(back.cpu()[..., :W], x_req.grad) < 1e-5 and bool((back[..., W:] == 0).all())
+    assert rel(ds_c, ds_b) < 2e-6 and rel(gs_c, gs_b) < 1e-5

@@ -80,7 +80,7 @@ def run(B=64):
             def dgr():
                 return lib.mx_conv_block_dgrad_sp_f16(vp(gc_hi.data_ptr()), vp(gc_lo.data_ptr()), vp(gc_idx.data_ptr()),
                                                       vp(w_hi.data_ptr()), vp(w_lo.data_ptr()), vp(scale.data_ptr()), i64(B), i64(H),
-                                                      i64(345), i32(T), vp(dx.data_ptr()), *ln_args, st)
+                                                      i64(345), i32(T), vp(dx.data_ptr()), *ln_args, vp(0), st)
             for fn, tag in ((wgr, "wgrad"), (dgr, "dgrad")):
                 if tag not in only:
                     continue
