@@ -692,8 +692,11 @@ def run_config5(args, env):
     kernels["flanger_kernel"]["avg_launch_ms_in_step"] = round(live["mx_flanger_fwd"], 4)
     mr = hbm_block("mr_stats_kernel + mr_grad_kernel + mr_fold_kernel x {512, 1024, 2048} (losses.py:155-156)",
                    B * N * 12.0, live["mx_mrstft_loss"],
-                   note="12 B/sample: x, y read once, d loss / d x written once; three STFT resolutions forward and backward in "
-                        "one entry point -- FFT butterflies in LDS dominate (VALU / LDS bound), HBM is the nominal roofline")
+                   note="12 B/sample algorithmic: x, y read once, d loss / d x written once; three STFT resolutions forward and "
+                        "backward in one entry point, 1.5 transforms per frame.  Pass A (one FFT of x + i y per frame, bins parked) is "
+                        "VALU-issue bound; pass B (one inverse FFT per PAIR of frames from the parked bins) moves 3.8 GB per launch "
+                        "and is HBM-bound at ~4.8 TB/s; ~25 GB per step actually cross the HBM interface (parked bins + gradient "
+                        "frames, written and read once), so the algorithmic fraction understates the kernel's HBM use by ~45x")
     kernels["mrstft_loss"] = mr
     audio_s = world * B * cfg["seconds"] * args.steps
     out = {

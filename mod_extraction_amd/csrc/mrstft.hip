@@ -425,6 +425,123 @@ __global__ __launch_bounds__(WF<N>::WAVES * 64) __attribute__((amdgpu_waves_per_
     }
 }
 
+// Pass B for 512 / 1024 with the overlap-add started in LDS.  A wavefront takes MR_SPAN_FRAMES CONSECUTIVE frames and adds
+// their windowed gradients into a wave-private span of (MR_SPAN_FRAMES - 1) hop + N samples (read - add - write in frame order:
+// no barrier, nothing shared between waves, deterministic); the span is what reaches HBM -- 1 864 instead of 8 192 floats per
+// eight 1024-point frames -- and the fold pass gathers one or two span values per sample instead of 8.5 frame values (fold
+// 0.35 -> 0.19 ms, this pass 0.78 -> 0.72 ms for 1024).  Two things measured on the way: the LDS fp32 atomic (ds_add_f32) in
+// place of the plain read - add - write made this pass 3x slower (2.4 ms); requesting the next pair's parked bins before the
+// current pair's transform (52 more registers) changed nothing (7.27 against 7.18 ms for the three resolutions).
+// 2048 keeps whole frames (mr_grad_kernel): its span would leave one wavefront per SIMD.
+#define MR_SPAN_FRAMES 8
+#define MR_SPAN_LEN(N, hop) ((MR_SPAN_FRAMES - 1) * (hop) + (N))
+#define MR_SPAN_MAX_HOP 128      // auraloss: 50 and 120; larger hops take the frame version
+template <int N>
+__global__ __launch_bounds__(WF<N>::WAVES * 64) __attribute__((amdgpu_waves_per_eu(2))) void mr_grad_span_kernel(
+    const float *__restrict__ park, const float *__restrict__ win, const float2 *__restrict__ tw, int n_frames, int hop, float eps,
+    const float *__restrict__ coef, float *__restrict__ scratch)
+{
+    constexpr int L = WF<N>::L, E = WF<N>::E, NB = WF<N>::NB, WAVES = WF<N>::WAVES, FW = WF<N>::FW, P = MR_PARK(N);
+    constexpr int ITERS = MR_SPAN_FRAMES / (2 * FW);
+    static_assert(NB == 4, "512 / 1024 only");
+    __shared__ cf xbuf[WAVES * FW][WF<N>::LEN];
+    __shared__ float2 tw_s[N];
+    extern __shared__ float span_s[];                                   // WAVES x S floats
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane / L, a_ = lane % L;
+    const int b = blockIdx.y;
+    const float c_sc = coef[0], c_log = coef[1];
+    cf *buf = xbuf[wave * FW + g];
+    const int S = MR_SPAN_LEN(N, hop);
+    float *span = span_s + wave * S;
+    stage_twiddles<N>(tw_s, tw);
+    const int fs = (blockIdx.x * WAVES + wave) * MR_SPAN_FRAMES;       // the wave's frames: fs .. fs + MR_SPAN_FRAMES - 1
+    if (fs >= n_frames) return;                                         // (behind the kernel's only workgroup barrier)
+    for (int j = lane; j < S; j += 64) span[j] = 0.0f;
+
+    float pk[2][2][NB][3], ny[2][2];                                    // parked bins of a frame pair: [frame][c][bq][Re X, Im X, Ym^2]
+    auto load_pair = [&](int it, int a) {
+        const int p = fs / 2 + it * FW + g, f0 = 2 * p, f1 = 2 * p + 1;
+        const float *s0 = park + ((size_t)b * n_frames + (f0 < n_frames ? f0 : n_frames - 1)) * P;
+        const float *s1 = park + ((size_t)b * n_frames + (f1 < n_frames ? f1 : n_frames - 1)) * P;
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int bq = 0; bq < NB; ++bq)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const int k = a + L * bq + (N / 4) * c;
+                    pk[0][c][bq][q] = s0[q * (N / 2) + k];
+                    pk[1][c][bq][q] = s1[q * (N / 2) + k];
+                }
+        ny[0][0] = s0[3 * N / 2]; ny[0][1] = s0[3 * N / 2 + 1];
+        ny[1][0] = s1[3 * N / 2]; ny[1][1] = s1[3 * N / 2 + 1];
+    };
+    for (int it = 0; it < ITERS; ++it) {
+        int a = a_;                                                      // opaque per iteration (see mr_grad_kernel)
+        asm volatile("" : "+v"(a));
+        load_pair(it, a);
+        const int p = fs / 2 + it * FW + g;
+        if (2 * (p - g) >= n_frames) break;                             // wave-uniform
+        const int f0 = 2 * p, f1 = 2 * p + 1;
+        const bool live0 = f0 < n_frames, live1 = f1 < n_frames;
+        const float m0 = live0 ? 1.0f : 0.0f, m1 = live1 ? 1.0f : 0.0f;
+        cf R[NB][4], Z[E];
+        // H = G~_a + i G~_b exactly as in mr_grad_kernel
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int bq = 0; bq < NB; ++bq) {
+                const int k = a + L * bq + (N / 4) * c;
+                cf ga = grad_bin(pk[0][c][bq][0], pk[0][c][bq][1], pk[0][c][bq][2], eps, c_sc, c_log);
+                cf gb = grad_bin(pk[1][c][bq][0], pk[1][c][bq][1], pk[1][c][bq][2], eps, c_sc, c_log);
+                ga = {m0 * ga.re, m0 * ga.im};
+                gb = {m1 * gb.re, m1 * gb.im};
+                const cf h = {0.5f * (ga.re - gb.im), 0.5f * (ga.im + gb.re)};
+                R[bq][c] = (bq == 0 && c == 0 && a == 0) ? cf{ga.re, gb.re} : h;
+                buf[N - k] = {0.5f * (ga.re + gb.im), 0.5f * (gb.re - ga.im)};
+            }
+        if (a == 0) {
+            const cf ga = grad_bin(ny[0][0], 0.0f, ny[0][1], eps, c_sc, c_log);
+            const cf gb = grad_bin(ny[1][0], 0.0f, ny[1][1], eps, c_sc, c_log);
+            buf[N / 2] = {m0 * ga.re, m1 * gb.re};
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int bq = 0; bq < NB; ++bq)
+#pragma unroll
+            for (int c = 2; c < 4; ++c) R[bq][c] = buf[a + L * bq + (N / 4) * c];
+        __builtin_amdgcn_wave_barrier();
+        wave_fft<N, true>(R, Z, buf, tw_s, a);
+        // frame order inside the wave: (half 0: f0, f1), then (half 1: f0, f1) -- two lanes of one ds_add never meet in one
+        // slot, and every slot receives its frames in ascending order
+        // (plain read - add - write, 16 values at a time: LDS operations of a wave execute in order; the LDS fp32 atomic
+        // ds_add_f32 is an order of magnitude slower than the three plain instructions)
+        float *sp0 = span + (f0 - fs) * hop;
+#pragma unroll
+        for (int h = 0; h < FW; ++h) {
+            if (g == h) {
+#pragma unroll
+                for (int fr = 0; fr < 2; ++fr) {
+                    float *sp = sp0 + fr * hop;
+                    const float mm = fr ? m1 : m0;
+                    float old[E];
+#pragma unroll
+                    for (int i = 0; i < E; ++i) old[i] = sp[pos_final<N>(i, a)];
+#pragma unroll
+                    for (int i = 0; i < E; ++i) {
+                        const int n = pos_final<N>(i, a);
+                        sp[n] = old[i] + mm * ((fr ? Z[i].im : Z[i].re) * win[n]);
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    float *out = scratch + ((size_t)b * (gridDim.x * WAVES) + (blockIdx.x * WAVES + wave)) * S;
+    for (int j = lane; j < S; j += 64) out[j] = span[j];
+}
+
 // ---- pass C -------------------------------------------------------------------------------------
 template <int N>
 __global__ __launch_bounds__(256) void mr_fold_kernel(const float *__restrict__ scratch, int T, int hop,
@@ -461,6 +578,35 @@ __global__ __launch_bounds__(256) void mr_fold_kernel(const float *__restrict__ 
     *o = accumulate ? *o + acc : acc;
 }
 
+// the same gather over the wave spans of mr_grad_span_kernel: span s holds frames [s F, s F + F) of its clip added up at padded
+// positions s F hop + j, j < (F - 1) hop + N, F = MR_SPAN_FRAMES
+template <int N>
+__global__ __launch_bounds__(256) void mr_fold_span_kernel(const float *__restrict__ scratch, int T, int hop,
+                                                           int n_frames, int n_spans, int accumulate,
+                                                           float *__restrict__ dx, long long ds)
+{
+    const int b = blockIdx.y;
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= T) return;
+    const int S = MR_SPAN_LEN(N, hop), FH = MR_SPAN_FRAMES * hop;
+    const float *sb = scratch + (size_t)b * n_spans * S;
+    int pos[3], np = 0;
+    pos[np++] = n + N / 2;
+    if (n >= 1 && n <= N / 2) pos[np++] = N / 2 - n;
+    if (n <= T - 2 && n >= T - 1 - N / 2) pos[np++] = N / 2 + 2 * (T - 1) - n;
+    float acc = 0.0f;
+    for (int i = 0; i < np; ++i) {
+        const int p = pos[i];
+        int f_hi = p / hop;
+        if (f_hi > n_frames - 1) f_hi = n_frames - 1;
+        int f_lo = (p - N + hop) / hop;                                 // ceil((p - N + 1) / hop)
+        if (p - N + 1 <= 0) f_lo = 0;
+        for (int sp = f_lo / MR_SPAN_FRAMES; sp <= f_hi / MR_SPAN_FRAMES; ++sp) acc += sb[(size_t)sp * S + (p - sp * FH)];
+    }
+    float *o = dx + (size_t)b * ds + n;
+    *o = accumulate ? *o + acc : acc;
+}
+
 __global__ void mr_total_kernel(float *__restrict__ terms, int n_res, float w_sc, float w_log)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -489,10 +635,33 @@ static int run_resolution(const float *x, long long xs, const float *y, long lon
     hipLaunchKernelGGL(mr_finish_kernel, dim3(1), dim3(256), 0, st, part, groups * B, count, w_sc, w_log, res_scale,
                        terms, coef);
     if (dx) {
-        hipLaunchKernelGGL((mr_grad_kernel<N>), dim3(groups, B), dim3(WF<N>::WAVES * 64), 0, st, park, win, tw, n_frames, eps,
-                           coef, scratch);
-        hipLaunchKernelGGL((mr_fold_kernel<N>), dim3((T + 255) / 256, B), dim3(256), 0, st, scratch, T, hop, n_frames,
-                           accumulate, dx, ds);
+        bool spans = false;
+        if constexpr (N != 2048) {
+            if (hop <= MR_SPAN_MAX_HOP) {
+                spans = true;
+                const int ggroups = (n_frames + MR_SPAN_FRAMES * WF<N>::WAVES - 1) / (MR_SPAN_FRAMES * WF<N>::WAVES);
+                const size_t span_bytes = (size_t)WF<N>::WAVES * MR_SPAN_LEN(N, hop) * sizeof(float);
+                static bool attr_set[64];                               // static + dynamic LDS exceeds 64 KB for 1024
+                int dev = 0;
+                (void)hipGetDevice(&dev);
+                if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mr_grad_span_kernel<N>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize,
+                                              (int)(WF<N>::WAVES * MR_SPAN_LEN(N, MR_SPAN_MAX_HOP) * sizeof(float)));
+                    if (dev >= 0 && dev < 64) attr_set[dev] = true;
+                }
+                hipLaunchKernelGGL((mr_grad_span_kernel<N>), dim3(ggroups, B), dim3(WF<N>::WAVES * 64), span_bytes, st, park, win,
+                                   tw, n_frames, hop, eps, coef, scratch);
+                hipLaunchKernelGGL((mr_fold_span_kernel<N>), dim3((T + 255) / 256, B), dim3(256), 0, st, scratch, T, hop,
+                                   n_frames, ggroups * WF<N>::WAVES, accumulate, dx, ds);
+            }
+        }
+        if (!spans) {
+            hipLaunchKernelGGL((mr_grad_kernel<N>), dim3(groups, B), dim3(WF<N>::WAVES * 64), 0, st, park, win, tw, n_frames, eps,
+                               coef, scratch);
+            hipLaunchKernelGGL((mr_fold_kernel<N>), dim3((T + 255) / 256, B), dim3(256), 0, st, scratch, T, hop, n_frames,
+                               accumulate, dx, ds);
+        }
     }
     return mx_launch_status();
 }
