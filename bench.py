@@ -674,7 +674,7 @@ def run_config5(args, env):
 
     def step():
         dry, wet, _, _ = bt.next_batch()
-        pred = (0.9 * wet + 0.1 * dry).requires_grad_(True)       # stand-in prediction: the loss path is what is measured
+        pred = torch.lerp(dry, wet, 0.9).requires_grad_(True)      # stand-in prediction (one pass): the loss path is what is measured
         loss = loss_fn(pred, wet)
         loss.backward()
         return loss.detach()        # (a live graph of the previous step changes the allocator's pattern: one 40 ms hipMalloc)
