@@ -9,19 +9,27 @@
 #define LOSS_MAXN 2048  // frames per row supported by the loss kernel
 
 // ---- head forward ----------------------------------------------------------------------------
+// Workgroup = (64-column tile, clip); thread = (column, group of C / 4 channels): every thread reduces its channels' rows,
+// writes their latents and leaves a partial logit per latent dimension in LDS; the first channel group adds the four
+// partials in a fixed order.  (One workgroup per clip with a serial loop over all 64 x 4 rows per thread took 0.22 ms for
+// 92 MB: a chain of dependent load batches.)
+#define HF_TW 64
 __global__ __launch_bounds__(256) void head_fwd_kernel(const float *__restrict__ p6,
                                                        const float *__restrict__ slope,
                                                        const float *__restrict__ wout,
                                                        const float *__restrict__ bout, int C, int Hl, int Wv,
                                                        int L, float *__restrict__ latent, float *__restrict__ out)
 {
-    const int b = blockIdx.x;
+    __shared__ float part[4][HL_MAXL][HF_TW];
+    const int b = blockIdx.y, wl = threadIdx.x & (HF_TW - 1), cg = threadIdx.x / HF_TW;
+    const int w = blockIdx.x * HF_TW + wl;
+    const int cpg = (C + 3) / 4, c0 = cg * cpg, c1 = min(C, c0 + cpg);
     const float inv_h = 1.0f / (float)Hl;
-    for (int w = threadIdx.x; w < Wv; w += 256) {
-        float logit[HL_MAXL];
+    float logit[HL_MAXL];
 #pragma unroll
-        for (int l = 0; l < HL_MAXL; ++l) logit[l] = 0.0f;
-        for (int c = 0; c < C; ++c) {
+    for (int l = 0; l < HL_MAXL; ++l) logit[l] = 0.0f;
+    if (w < Wv) {
+        for (int c = c0; c < c1; ++c) {
             const float sl = slope[c];
             const float *pc = p6 + (((size_t)b * C + c) * Hl) * CV_PITCH + w;
             float acc = 0.0f;
@@ -35,9 +43,17 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float *__restrict__
             for (int l = 0; l < HL_MAXL; ++l)
                 if (l < L) logit[l] = fmaf(wout[l * C + c], lat, logit[l]);
         }
+    }
+#pragma unroll
+    for (int l = 0; l < HL_MAXL; ++l) part[cg][l][wl] = logit[l];
+    __syncthreads();
+    if (cg == 0 && w < Wv) {
 #pragma unroll
         for (int l = 0; l < HL_MAXL; ++l)
-            if (l < L) out[((size_t)b * L + l) * Wv + w] = 1.0f / (1.0f + expf(-(logit[l] + bout[l])));
+            if (l < L) {
+                const float z = ((part[0][l][wl] + part[1][l][wl]) + part[2][l][wl]) + part[3][l][wl];
+                out[((size_t)b * L + l) * Wv + w] = 1.0f / (1.0f + expf(-(z + bout[l])));
+            }
     }
 }
 
@@ -45,9 +61,9 @@ MX_EXPORT int mx_head_fwd(const float *p6, const float *slope, const float *wout
                           int64_t C, int64_t Hl, int64_t Wv, int64_t L, float *latent, float *out, void *stream)
 {
     if (!p6 || !slope || !wout || !bout || !latent || !out || B <= 0) return MX_ERR_ARG;
-    if (L < 1 || L > HL_MAXL || Wv > CV_PITCH || C <= 0 || Hl <= 0) return MX_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(head_fwd_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, p6, slope, wout,
-                       bout, (int)C, (int)Hl, (int)Wv, (int)L, latent, out);
+    if (L < 1 || L > HL_MAXL || Wv > CV_PITCH || C <= 0 || Hl <= 0 || B > 65535) return MX_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(head_fwd_kernel, dim3((unsigned)((Wv + HF_TW - 1) / HF_TW), (unsigned)B), dim3(256), 0,
+                       (hipStream_t)stream, p6, slope, wout, bout, (int)C, (int)Hl, (int)Wv, (int)L, latent, out);
     return mx_launch_status();
 }
 
@@ -68,7 +84,10 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float *__restrict__
                                                        float *__restrict__ dslope_part)
 {
     __shared__ float dlogit[HL_MAXL][CV_PITCH];
+    // grid (clip, channel slice): a workgroup takes C / gridDim.y channels, one wave per channel at a time (a single workgroup
+    // per clip walked its 64 channels in 16 rounds: 0.19 ms for 92 MB read + 92 MB written)
     const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cps = (C + gridDim.y - 1) / gridDim.y, cbeg = blockIdx.y * cps, cend = min(C, cbeg + cps);
     for (int i = threadIdx.x; i < L * CV_PITCH; i += 256) {
         const int l = i / CV_PITCH, w = i % CV_PITCH;
         float v = 0.0f;
@@ -79,14 +98,14 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float *__restrict__
         dlogit[l][w] = v;
     }
     __syncthreads();
-    if (wave < L) {     // bias grads: one wave per latent dim
+    if (wave < L && blockIdx.y == 0) {     // bias grads: one wave per latent dim
         float s = 0.0f;
         for (int w = lane; w < Wv; w += 64) s += dlogit[wave][w];
         s = wave_sum_f32(s);
         if (lane == 0) dbout_part[(size_t)b * L + wave] = s;
     }
     const float inv_h = 1.0f / (float)Hl;
-    for (int c = wave; c < C; c += 4) {
+    for (int c = cbeg + wave; c < cend; c += 4) {
         const float sl = slope[c];
         float dw[HL_MAXL], ds = 0.0f;
 #pragma unroll
@@ -135,7 +154,7 @@ MX_EXPORT int mx_head_bwd(const float *p6, const float *slope, const float *wout
         B <= 0)
         return MX_ERR_ARG;
     if (L < 1 || L > HL_MAXL || Wv > CV_PITCH || C <= 0 || Hl <= 0) return MX_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(head_bwd_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, p6, slope, wout,
+    hipLaunchKernelGGL(head_bwd_kernel, dim3((unsigned)B, 4), dim3(256), 0, (hipStream_t)stream, p6, slope, wout,
                        latent, out, d_out, d_latent, (int)C, (int)Hl, (int)Wv, (int)L, G6, dwout_part, dbout_part,
                        dslope_part);
     return mx_launch_status();
