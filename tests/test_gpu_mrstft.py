@@ -79,3 +79,35 @@ def test_mrstft_identical_clip_among_different_ones(dev):
     xr = x0.clone().requires_grad_(True)
     loss_r = olosses.get_loss_func_by_name("mrstft")(xr, y)
     assert abs(float(loss) - float(loss_r)) < 1e-5 * abs(float(loss_r))
+
+
+def test_mrstft_other_hops_and_windows(dev):
+    """Hops above 128 take the whole-frame variant of the gradient pass for 512 / 1024 as well (the overlap-add spans are
+    sized for the auraloss hops), and full-length windows leave no zero positions: value and gradient against the oracle
+    restatement with the same resolutions, the fp64 evaluation arbitrating the gradient as above."""
+    from mod_extraction_amd import mrstft as amr
+    torch.manual_seed(5)
+    B, T = 2, 12000
+    cfg = dict(fft_sizes=(1024, 512, 2048), hop_sizes=(256, 100, 512), win_lengths=(1024, 512, 2048))
+    y = (torch.rand(B, 1, T) * 2 - 1) * 0.7
+    x = (0.6 * y + 0.3 * torch.roll(y, 3, -1)).requires_grad_(True)
+    ref = olosses.MultiResolutionSTFTLoss(**cfg)
+    loss_r = ref(x, y)
+    loss_r.backward()
+    mine = amr.MultiResolutionSTFTLoss(**cfg)
+    xd = x.detach().to(dev).requires_grad_(True)
+    loss_m = mine(xd, y.to(dev))
+    loss_m.backward()
+    assert abs(float(loss_m) - float(loss_r)) < 1e-5 * abs(float(loss_r)), (float(loss_m), float(loss_r))
+
+    class MR64(olosses.MultiResolutionSTFTLoss):
+        def _mag(self, v, n_fft, hop, win):
+            s = torch.stft(v.reshape(-1, v.size(-1)), n_fft, hop, win, torch.hann_window(win, dtype=torch.float64),
+                           return_complex=True)
+            return torch.sqrt(torch.clamp(s.real ** 2 + s.imag ** 2, min=self.eps))
+    x64 = x.detach().double().requires_grad_(True)
+    MR64(**cfg)(x64, y.double()).backward()
+    scale = x64.grad.abs().max()
+    e_mine = float((xd.grad.cpu().double() - x64.grad).abs().max() / scale)
+    e_oracle32 = float((x.grad.double() - x64.grad).abs().max() / scale)
+    assert e_mine < 2e-3 and e_mine < max(2.0 * e_oracle32, 1e-4), (e_mine, e_oracle32)
