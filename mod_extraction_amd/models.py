@@ -274,7 +274,8 @@ class _CNNStack(torch.autograd.Function):
             slope_prev = params[3 * (l - 1) + 2].contiguous() if l > 0 else None
             # bias gradient: sum of G over (b, h, w)
             if DEBUG_TAP is not None:
-                DEBUG_TAP[f"G{l}"] = G.clone()
+                if G is not None:                  # (with the fused LayerNorm backward dL/dp of blocks 2-4 never exists in fp32)
+                    DEBUG_TAP[f"G{l}"] = G.clone()
                 DEBUG_TAP[f"amax{l}"] = amax.clone()
                 DEBUG_TAP[f"p{l}"] = (p_last if l == n_blocks - 1 else saved[3 * (l + 1)]).clone()
             if bsum is None:
@@ -378,8 +379,7 @@ class _CNNStack(torch.autograd.Function):
                         # the epilogue also leaves the plane statistics of the LayerNorm backward below (x = xhat) and, when
                         # that pass writes the block below's pooled operand itself, max|dxhat| / max|xhat| for its scale
                         ln_part = torch.empty((B, 64, H, 2, 2), device=dev, dtype=torch.float32)
-                        fuse_g = (GPOOL_FUSED and DEBUG_TAP is None
-                                  and _pooled_only(l - 1, saved[3 * (l - 1)].size(1), dilations, precision, n_frames))
+                        fuse_g = GPOOL_FUSED and _pooled_only(l - 1, saved[3 * (l - 1)].size(1), dilations, precision, n_frames)
                         gx_bits = torch.zeros(2, device=dev, dtype=torch.int32) if fuse_g else None
                         _hip.call("mx_conv_block_dgrad_sp_f16", _hip.ptr(gc_hi), _hip.ptr(gc_lo), _hip.ptr(gc_idx),
                                   _hip.ptr(ws_hi), _hip.ptr(ws_lo), _hip.ptr(scale), B, H, n_frames, int(dilations[l]),

@@ -117,6 +117,18 @@ def test_cnn_forward_backward(dev, n_samples, n_mels, B, precision):
     run_pair(dev, ref, mine, audio(B, n_samples), (3, 11, 20, 41))
 
 
+@pytest.mark.parametrize("knob", ["GPOOL_FUSED", "STATS_FUSED", "LN_FUSED"])
+def test_cnn_forward_backward_with_a_fusion_switched_off(dev, knob, monkeypatch):
+    """The unfused routes stay available as A/B knobs (MODEX_GPOOL=split: LayerNorm backward and pooled-operand pass as two
+    kernels with the exact max|G| scale; MODEX_STATS=sweep: LayerNorm statistics by a sweep over the plane; MODEX_LN=sweep: the
+    LayerNorm backward's own statistics sweep) and meet the same tolerances."""
+    from mod_extraction_amd import models as amodels
+    monkeypatch.setattr(amodels, knob, False)
+    ref, mine = make_pair(dev, n_samples=22272, n_mels=64)
+    ref.eval(); mine.eval()
+    run_pair(dev, ref, mine, audio(3, 22272), (3, 11, 20, 41))
+
+
 def test_cnn_single_channel_input(dev):
     ref, mine = make_pair(dev, n_samples=22272, n_mels=64, in_ch=1)
     ref.eval(); mine.eval()
