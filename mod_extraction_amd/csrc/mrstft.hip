@@ -538,7 +538,10 @@ __global__ __launch_bounds__(WF<N>::WAVES * 64) __attribute__((amdgpu_waves_per_
         }
     }
     __builtin_amdgcn_wave_barrier();
-    float *out = scratch + ((size_t)b * (gridDim.x * WAVES) + (blockIdx.x * WAVES + wave)) * S;
+    // spans that hold a frame: ceil(n_frames / MR_SPAN_FRAMES) per clip -- with T > N / 2 (the reflect padding's condition) they
+    // never need more room than the n_frames x N floats of the whole-frame layout, behind which the parked bins start
+    const int n_spans = (n_frames + MR_SPAN_FRAMES - 1) / MR_SPAN_FRAMES;
+    float *out = scratch + ((size_t)b * n_spans + (blockIdx.x * WAVES + wave)) * S;
     for (int j = lane; j < S; j += 64) out[j] = span[j];
 }
 
@@ -653,7 +656,7 @@ static int run_resolution(const float *x, long long xs, const float *y, long lon
                 hipLaunchKernelGGL((mr_grad_span_kernel<N>), dim3(ggroups, B), dim3(WF<N>::WAVES * 64), span_bytes, st, park, win,
                                    tw, n_frames, hop, eps, coef, scratch);
                 hipLaunchKernelGGL((mr_fold_span_kernel<N>), dim3((T + 255) / 256, B), dim3(256), 0, st, scratch, T, hop,
-                                   n_frames, ggroups * WF<N>::WAVES, accumulate, dx, ds);
+                                   n_frames, (n_frames + MR_SPAN_FRAMES - 1) / MR_SPAN_FRAMES, accumulate, dx, ds);
             }
         }
         if (!spans) {
