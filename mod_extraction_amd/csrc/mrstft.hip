@@ -185,19 +185,26 @@ __device__ __forceinline__ int reflect_index(int s, int T)
     return s;
 }
 
-// frame f of x + i*y, windowed, centre / reflect padded, straight into the stage-A register layout
-template <int N>
+// frame f of x + i*y, windowed, centre / reflect padded, straight into the stage-A register layout.  INTERIOR (wave-uniform):
+// the frame does not touch either end of the clip, so no position needs the reflection arithmetic (two compares and selects per
+// load) and the loads are one base pointer + constant offsets; all but the first and last N / (2 hop) frames of a clip.
+template <int N, bool INTERIOR>
 __device__ __forceinline__ void load_frame(cf (&R)[WF<N>::NB][4], const float *xb, const float *yb, const float *win,
                                            int f, int hop, int T, int a)
 {
+    const float *xf = xb + (f * hop - N / 2 + a), *yf = yb + (f * hop - N / 2 + a);     // dereferenced only when INTERIOR
 #pragma unroll
     for (int b = 0; b < WF<N>::NB; ++b)
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const int n = a + WF<N>::L * b + (N / 4) * c;
-            const int s = reflect_index(f * hop + n - N / 2, T);
             const float w = win[n];
-            R[b][c] = {xb[s] * w, yb[s] * w};
+            if (INTERIOR) {
+                R[b][c] = {xf[WF<N>::L * b + (N / 4) * c] * w, yf[WF<N>::L * b + (N / 4) * c] * w};
+            } else {
+                const int s = reflect_index(f * hop + n - N / 2, T);
+                R[b][c] = {xb[s] * w, yb[s] * w};
+            }
         }
 }
 
@@ -243,7 +250,13 @@ __global__ __launch_bounds__(WF<N>::WAVES * 64) __attribute__((amdgpu_waves_per_
         if (f - g >= n_frames) break;                                   // wave-uniform (frames of a wave are f-g, f-g+1)
         const bool live = f < n_frames;
         cf R[WF<N>::NB][4], Z[E];
-        load_frame<N>(R, xb, yb, win, live ? f : n_frames - 1, hop, T, a);
+        {
+            // frames of this wave: f - g (and f - g + 1 for the two-frame layout of 512)
+            const int fa = f - g, fz = fa + FW - 1;
+            const bool interior = fa * hop - N / 2 >= 0 && fz * hop + N / 2 <= T && fz < n_frames;     // wave-uniform
+            if (interior) load_frame<N, true>(R, xb, yb, win, f, hop, T, a);
+            else load_frame<N, false>(R, xb, yb, win, live ? f : n_frames - 1, hop, T, a);
+        }
         // a frame whose windowed signals are bit-identical has identical spectra in the reference: keep that exact
         bool same_lane = true;
 #pragma unroll
