@@ -272,10 +272,12 @@ int mx_plane_sum(const float *x, int64_t planes, int64_t H, int64_t Wv, float *o
  * sigmoid.  p6 (B,C,Hl,352); latent (B,C,Wv) and out (B,L,Wv) dense.  L <= 4. */
 int mx_head_fwd(const float *p6, const float *slope, const float *wout, const float *bout, int64_t B,
                 int64_t C, int64_t Hl, int64_t Wv, int64_t L, float *latent, float *out, void *stream);
+/* gmax_bits (optional, zeroed by the caller): receives the bit pattern of max|G6| (atomic max) -- the f16x3 gradient scale of
+ * the last block without a sweep over G6 (mx_conv_prep_dgrad_f16 with amax_ready = 1). */
 int mx_head_bwd(const float *p6, const float *slope, const float *wout, const float *latent,
                 const float *out, const float *d_out, const float *d_latent, int64_t B, int64_t C,
                 int64_t Hl, int64_t Wv, int64_t L, float *G6, float *dwout_part, float *dbout_part,
-                float *dslope_part, void *stream);
+                float *dslope_part, uint32_t *gmax_bits, void *stream);
 
 /* ---- K8: LFO loss -- mod_extraction/lightning.py:33-62 + losses.py:70-102 (l1, fdl1, sdl1, mse,
  * 'mean' reductions).  y_hat, y (B,n), n <= 2048; part (B,4) workspace; losses (5,) = l1, fdl1,

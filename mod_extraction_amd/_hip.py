@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # MODEX_HIP_LIB: load another build of the same library (kernel experiments); there is no non-HIP fallback
 SO_PATH = os.environ.get("MODEX_HIP_LIB") or os.path.join(_HERE, "_lib", "libmodex_hip.so")
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 _ERR = {-1: "MX_ERR_ARG (bad argument)", -2: "MX_ERR_UNSUPPORTED (size not supported)",
         -3: "MX_ERR_LAUNCH (HIP launch error)"}
@@ -56,7 +56,7 @@ SIGNATURES = {
     "mx_reduce_rows": [_P, _I64, _I64, _I32, _P, _P],
     "mx_plane_sum": [_P, _I64, _I64, _I64, _P, _P],
     "mx_head_fwd": [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _P, _P, _P],
-    "mx_head_bwd": [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _P, _P, _P, _P, _P],
+    "mx_head_bwd": [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _P, _P, _P, _P, _P, _P],
     "mx_lfo_loss": [_P, _P, _I64, _I64, _F32, _F32, _F32, _F32, _P, _P, _P, _P],
     "mx_smoothen": [_P, _I64, _I64, _I64, _P, _P],
     "mx_find_corners": [_P, _I64, _I64, _P, _P, _P],

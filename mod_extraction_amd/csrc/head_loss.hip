@@ -81,9 +81,10 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float *__restrict__
                                                        int L, float *__restrict__ G6,
                                                        float *__restrict__ dwout_part,
                                                        float *__restrict__ dbout_part,
-                                                       float *__restrict__ dslope_part)
+                                                       float *__restrict__ dslope_part, unsigned *__restrict__ gmax_bits)
 {
     __shared__ float dlogit[HL_MAXL][CV_PITCH];
+    float gmax = 0.0f;                                          // max |G6| of this thread (the f16x3 scale of the last block)
     // grid (clip, channel slice): a workgroup takes C / gridDim.y channels, one wave per channel at a time (a single workgroup
     // per clip walked its 64 channels in 16 rounds: 0.19 ms for 92 MB read + 92 MB written)
     const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -131,6 +132,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float *__restrict__
                     g = pv > 0.0f ? dy : sl * dy;
                     if (!(pv > 0.0f)) ds = fmaf(dy, pv, ds);
                 }
+                gmax = fmaxf(gmax, fabsf(g));
                 G6[off] = g;
             }
         }
@@ -143,12 +145,16 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float *__restrict__
                 if (lane == 0) dwout_part[((size_t)b * L + l) * C + c] = t;
             }
     }
+    if (gmax_bits) {                                            // (order of non-negative floats = order of their bits)
+        gmax = wave_max_f32(gmax);
+        if (lane == 0) atomicMax(gmax_bits, __float_as_uint(gmax));
+    }
 }
 
 MX_EXPORT int mx_head_bwd(const float *p6, const float *slope, const float *wout, const float *latent,
                           const float *out, const float *d_out, const float *d_latent, int64_t B, int64_t C,
                           int64_t Hl, int64_t Wv, int64_t L, float *G6, float *dwout_part, float *dbout_part,
-                          float *dslope_part, void *stream)
+                          float *dslope_part, uint32_t *gmax_bits, void *stream)
 {
     if (!p6 || !slope || !wout || !latent || !out || !d_out || !G6 || !dwout_part || !dbout_part || !dslope_part ||
         B <= 0)
@@ -156,7 +162,7 @@ MX_EXPORT int mx_head_bwd(const float *p6, const float *slope, const float *wout
     if (L < 1 || L > HL_MAXL || Wv > CV_PITCH || C <= 0 || Hl <= 0) return MX_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(head_bwd_kernel, dim3((unsigned)B, 4), dim3(256), 0, (hipStream_t)stream, p6, slope, wout,
                        latent, out, d_out, d_latent, (int)C, (int)Hl, (int)Wv, (int)L, G6, dwout_part, dbout_part,
-                       dslope_part);
+                       dslope_part, gmax_bits);
     return mx_launch_status();
 }
 

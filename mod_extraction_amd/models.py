@@ -259,13 +259,16 @@ class _CNNStack(torch.autograd.Function):
         db_part = torch.empty((B, L), device=dev, dtype=torch.float32)
         ds_part = torch.empty((B, 64), device=dev, dtype=torch.float32)
         slope_last = params[3 * (n_blocks - 1) + 2].contiguous()
+        # max|G| of the last block's gradient for its f16x3 scale: taken while G is written (no sweep)
+        gmax_ws = (torch.zeros(1, device=dev, dtype=torch.int32)
+                   if _use_f16(saved[3 * (n_blocks - 1)].size(1), precision) else None)
         _hip.call("mx_head_bwd", _hip.ptr(p_last), _hip.ptr(slope_last), _hip.ptr(wout.contiguous()),
                   _hip.ptr(latent), _hip.ptr(out), _hip.ptr(d_out), _hip.ptr(d_latent), B, 64, Hl, n_frames, L,
-                  _hip.ptr(G), _hip.ptr(dw_part), _hip.ptr(db_part), _hip.ptr(ds_part), st)
+                  _hip.ptr(G), _hip.ptr(dw_part), _hip.ptr(db_part), _hip.ptr(ds_part), _hip.ptr(gmax_ws), st)
         grads[3 * n_blocks] = _reduce_rows(dw_part, B, L * 64).view_as(wout)
         grads[3 * n_blocks + 1] = _reduce_rows(db_part, B, L)
         grads[3 * (n_blocks - 1) + 2] = _reduce_rows(ds_part, B, 64)
-        bsum, gmax_ws = None, None       # by-products of mx_ln_prelu_bwd for the block below: bias partials, max|G| bits
+        bsum = None                      # by-product of mx_ln_prelu_bwd for the block below: bias partials (gmax_ws: max|G| bits)
         pooled = None                    # (gc_hi, gc_lo, gc_idx, gidx, scale) left for the block below by the fused LN backward
         for l in range(n_blocks - 1, -1, -1):
             x_in, stats, amax = saved[3 * l], saved[3 * l + 1], saved[3 * l + 2]
