@@ -430,7 +430,8 @@ def run_lfo_config(args, env, cfg_id):
             "achieved_executed": round(3 * dom["tflops"], 1), "frac_executed": round(3 * dom["tflops"] / F16_MFMA_PEAK_TFLOPS, 4),
             "x_fp32_mfma_peak": round(dom["tflops"] / FP32_MFMA_PEAK_TFLOPS, 3),
             "avg_launch_ms": dom["avg_ms"], "flops_per_launch": conv_flops(1, batch),
-            "traffic": measured_traffic(batch, "f16"), "traffic_unit": "bytes/launch (rocprofv3 PMC pass)"}
+            "traffic": measured_traffic(batch, "f16"),
+            "traffic_unit": "bytes/launch (rocprofv3 PMC pass measured at bs 64, scaled linearly to this batch)"}
     else:
         dom = kernels.get("conv_block_fwd[block2]", {"avg_ms": None, "tflops": None})
         roofline = {
@@ -444,7 +445,7 @@ def run_lfo_config(args, env, cfg_id):
         "metric": METRIC[cfg_id],
         "value": audio_s / dt, "unit": "audio-seconds/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32 (f16x3 products)" if f16 else "f32",
         "data": "synthetic",
         "config": {"workload": f"{cfg['name']}: 2D-CNN LFO extractor train step, bs={batch} x 2 s "
                                f"@44.1 kHz per GPU, {'/'.join(cfg['kinds'])} interleaved, fp32 parity (1e-5)",
@@ -833,12 +834,19 @@ def launch(args) -> int:
     if out is None:
         sys.stderr.write(f"bench worker failed (rc {rc})\n")
         return rc or 1
+    # a worker that printed its line and THEN crashed (e.g. at process teardown) is still a failed run: the code is on
+    # record in the line and becomes the launcher's exit code
+    out["worker_rc"] = rc
+    if rc != 0:
+        out["worker_stderr_tail"] = err[-400:]
+    worst = rc
     if args.gpus == 1 and args.config == 3 and not args.no_other_configs and not args.batch and not args.conv_precision:
         others = {}
         for c, steps in ((2, 30), (4, 5), (5, 20)):
             t0 = time.perf_counter()
             o, rc_c, err_c = _run_child([sys.executable, script, "--worker"] +
                                         _worker_cmd(args, c, steps, ["--no-cpu-baseline", "--no-fp32-leg"]), 900)
+            worst = worst or rc_c
             if o is None:
                 others[str(c)] = {"error": f"rc {rc_c}", "stderr_tail": err_c[-400:]}
                 continue
@@ -848,10 +856,13 @@ def launch(args) -> int:
                                       "avg_launch_ms_in_step", "final_loss", "loss_variants") if k in o}
             keep["config"] = o["config"]
             keep["process_wall_s"] = round(time.perf_counter() - t0, 1)
+            keep["worker_rc"] = rc_c
+            if rc_c != 0:
+                keep["worker_stderr_tail"] = err_c[-400:]
             others[str(c)] = keep
         out["other_configs"] = others
     print(json.dumps(out), flush=True)
-    return 0
+    return worst
 
 
 def main():
@@ -875,6 +886,13 @@ def main():
     else:
         out = run_config5(args, env)
     if env["rank"] == 0:
+        # how many ranks the collective library actually saw (a SCALE record must show it)
+        out["world_size"] = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
+        out["dist_backend"] = torch.distributed.get_backend() if torch.distributed.is_initialized() else None
+        try:
+            out["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:
+            out["rccl_version"] = None
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.barrier()

@@ -126,10 +126,12 @@ int mx_conv_pack_weights(const float *W, int64_t Cout, int64_t Cin, int32_t flip
 int mx_plane_stats(const float *x, const float *slope, int64_t B, int64_t C, int64_t H, int64_t Wv,
                    float eps, float *stats, void *stream);
 /* The same statistics from the per-row partial sums the f16x3 forward kernels below leave when given slope_out /
- * stats_part: part (B, H, C, 2) = {sum, sum of squares} of PReLU(out) over the Wv valid columns of one pooled row; fp64
- * across the rows.  The LayerNorm of models.py:186 of the NEXT block without re-reading the plane. */
-int mx_plane_stats_finish(const float *part, int64_t B, int64_t C, int64_t H, int64_t Wv, float eps, float *stats,
-                          void *stream);
+ * stats_part: part (B, H, C, 2) = {sum, sum of squares} of PReLU(out) - PReLU(bias_c) over the Wv valid columns of one
+ * pooled row (the shift keeps the fp32 row sums free of a common offset: no cancellation for near-constant planes);
+ * fp64 across the rows.  bias (C,) / slope (C,): the SAME bias and slope_out the forward kernel was given.
+ * The LayerNorm of models.py:186 of the NEXT block without re-reading the plane. */
+int mx_plane_stats_finish(const float *part, const float *bias, const float *slope, int64_t B, int64_t C, int64_t H,
+                          int64_t Wv, float eps, float *stats, void *stream);
 
 /* LayerNorm -> Conv2d(5x13, dilation (1,dilation), same) -> +bias -> MaxPool(2,1), fused.
  * in (B,Cin,H,352): log-mel (first_layer=1) or the previous block's pooled pre-activations (their

@@ -32,7 +32,7 @@ SIGNATURES = {
                       _I32, _I32, _P, _P],
     "mx_conv_pack_weights": [_P, _I64, _I64, _I32, _P, _P],
     "mx_plane_stats": [_P, _P, _I64, _I64, _I64, _I64, _F32, _P, _P],
-    "mx_plane_stats_finish": [_P, _I64, _I64, _I64, _I64, _F32, _P, _P],
+    "mx_plane_stats_finish": [_P, _P, _P, _I64, _I64, _I64, _I64, _F32, _P, _P],
     "mx_conv_block_fwd": [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I32, _I32, _P, _P, _P],
     "mx_conv_block_dgrad": [_P, _P, _P, _I64, _I64, _I64, _I32, _P, _P],
     "mx_conv_pack_weights_f16": [_P, _I32, _P, _P, _P],

@@ -32,6 +32,7 @@
 // gradients stay on the exact-fp32 kernels (conv2d.hip, wgrad.hip).
 #include "conv_common.h"
 #include <hip/hip_fp16.h>
+#include <cstdlib>
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 #define F16_WSCALE 256.0f
@@ -255,8 +256,8 @@ struct ConvF16Args {
     unsigned char *out_amax;       // forward
     int H, Wv;
     // forward, optional: the LayerNorm statistics of the NEXT block are those of PReLU(out) per (clip, channel) plane; with
-    // slope_out (64,) the epilogue leaves {sum, sum of squares} per (clip, pooled row, channel) in stats_part
-    // (B, H/2, 64, 2) and mx_plane_stats_finish turns them into mean / rstd: the plane is never re-read (norm.hip
+    // slope_out (64,) the epilogue leaves {sum, sum of squares} of PReLU(out) - PReLU(bias) per (clip, pooled row, channel) in
+    // stats_part (B, H/2, 64, 2) and mx_plane_stats_finish turns them into mean / rstd: the plane is never re-read (norm.hip
     // plane_stats_kernel swept 5.9 GB per step for them)
     const float *slope_out;
     float *stats_part;
@@ -265,8 +266,31 @@ struct ConvF16Args {
 // Epilogue shared by the conv kernels.  Wave = (output row, column half c); accumulator layout
 //   acc[2t + j], t < 5 : column tile c*6 + t, channel half j ^ c;      acc[10] : column tile 5, channel half c
 // OUTMODE 0: bias + max-pool over the row pair + argmax (rows exchanged through LDS), 1: plain rows * 1/S.
-template <int OUTMODE>
-__device__ __forceinline__ void conv_f16_epilogue(floatx16 (&acc)[CV_WT], const ConvF16Args &a, unsigned char *smem,
+// logical 32 x 32 tile i of a wave's accumulators -> [32 co][32 w] fp32 image (4 KB)
+//   floatx16[11] (v_mfma_f32_32x32x16_f16): tile i is acc[i]
+//   floatx4[44]  (v_mfma_f32_16x16x32_f16): tile i < 10 = 16-column tiles 2 (i >> 1) + dn, channel tiles 2 (i & 1) + dm of
+//                acc[nt * 4 + ct]; tile 10 = acc[40 + dn * 2 + dm]; element (lane, r): co = 4 (lane >> 4) + r, w = lane & 15
+__device__ __forceinline__ void store_tile32(const floatx16 (&acc)[CV_WT], int i, float *dst, int lane)
+{
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dst[mfma_row(r, lane) * 32 + (lane & 31)] = acc[i][r];
+}
+__device__ __forceinline__ void store_tile32(const floatx4 (&acc)[44], int i, float *dst, int lane)
+{
+#pragma unroll
+    for (int dn = 0; dn < 2; ++dn)
+#pragma unroll
+        for (int dm = 0; dm < 2; ++dm) {
+            const int u = i < 10 ? (2 * (i >> 1) + dn) * 4 + 2 * (i & 1) + dm : 40 + dn * 2 + dm;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dst[(dm * 16 + (lane >> 4) * 4 + r) * 32 + dn * 16 + (lane & 15)] = acc[u][r];
+        }
+}
+__device__ __forceinline__ float acc_elem(const floatx16 (&acc)[CV_WT], int i, int r) { return acc[i][r]; }
+__device__ __forceinline__ float acc_elem(const floatx4 (&acc)[44], int, int) { return 0.0f; }      // (plain rows: 32x32 layout only)
+
+template <int OUTMODE, typename ACC>
+__device__ __forceinline__ void conv_f16_epilogue(ACC &acc, const ConvF16Args &a, unsigned char *smem,
                                                   int b, int h0, int row, int c, int lane)
 {
     const int l32 = lane & 31;
@@ -281,7 +305,7 @@ __device__ __forceinline__ void conv_f16_epilogue(floatx16 (&acc)[CV_WT], const 
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = cb0 + mfma_row(r, lane);
-                a.out[(((size_t)b * CV_CO + co) * a.H + h) * CV_PITCH + w] = w < a.Wv ? acc[i][r] * inv : 0.0f;
+                a.out[(((size_t)b * CV_CO + co) * a.H + h) * CV_PITCH + w] = w < a.Wv ? acc_elem(acc, i, r) * inv : 0.0f;
             }
         }
     } else {
@@ -303,12 +327,17 @@ __device__ __forceinline__ void conv_f16_epilogue(floatx16 (&acc)[CV_WT], const 
             for (int q = 0; q < 4; ++q) bias_t[j][q] = a.bias[j * 32 + q * 8 + co_l];
         const bool want_stats = a.stats_part != nullptr;               // workgroup-uniform
         float slope_t[2][4];
+        // The row sums are taken of t - shift_c with shift_c = PReLU(bias_c), the value of a plane whose convolution sum is
+        // zero (silent clip, dead channel): sum and sum of squares in fp32 then carry no large common offset and
+        // var = E[d^2] - E[d]^2 does not cancel for near-constant planes (mx_plane_stats_finish adds shift_c back).
+        float shift_t[2][4];
         float st_s[2][4], st_q[2][4];                                   // [j = channel half ^ c][q]: sums over this lane's columns
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 slope_t[j][q] = want_stats ? a.slope_out[j * 32 + q * 8 + co_l] : 1.0f;
+                shift_t[j][q] = bias_t[j][q] > 0.0f ? bias_t[j][q] : slope_t[j][q] * bias_t[j][q];
                 st_s[j][q] = 0.0f;
                 st_q[j][q] = 0.0f;
             }
@@ -321,8 +350,7 @@ __device__ __forceinline__ void conv_f16_epilogue(floatx16 (&acc)[CV_WT], const 
             for (int s6 = 0; s6 < 6; ++s6) {
                 const int i = s6 < 3 ? 3 * round + s6 : 6 + 3 * round + (s6 - 3);
                 if (i >= CV_WT) continue;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) mine[s6 * 1024 + mfma_row(r, lane) * 32 + l32] = acc[i][r];
+                store_tile32(acc, i, mine + s6 * 1024, lane);
             }
             __syncthreads();
             const float *top = xch + (size_t)((c * 2 + 0) * 6) * 1024, *bot = xch + (size_t)((c * 2 + 1) * 6) * 1024;
@@ -341,6 +369,7 @@ __device__ __forceinline__ void conv_f16_epilogue(floatx16 (&acc)[CV_WT], const 
                     const floatx4 bv = *reinterpret_cast<const floatx4 *>(bot + s6 * 1024 + col * 32 + w4);
                     const float bsum = chh ? bias_t[1][q] : bias_t[0][q];
                     const float sl = chh ? slope_t[1][q] : slope_t[0][q];
+                    const float sh = chh ? shift_t[1][q] : shift_t[0][q];
                     floatx4 m;
                     unsigned am = 0;
                     float ts = 0.0f, tq = 0.0f;
@@ -350,9 +379,10 @@ __device__ __forceinline__ void conv_f16_epilogue(floatx16 (&acc)[CV_WT], const 
                         const float v = (take_bot ? bv[e] : tv[e]) * inv + bsum;
                         m[e] = w + e < a.Wv ? v : 0.0f;
                         am |= (take_bot ? 1u : 0u) << (8 * e);
-                        const float t = m[e] > 0.0f ? m[e] : sl * m[e];  // PReLU(0) = 0: pad columns add nothing
-                        ts += t;
-                        tq += t * t;
+                        const float t = m[e] > 0.0f ? m[e] : sl * m[e];
+                        const float dlt = w + e < a.Wv ? t - sh : 0.0f;  // pad columns add nothing
+                        ts += dlt;
+                        tq += dlt * dlt;
                     }
                     // accumulator index j = channel half ^ c = i & 1 (tile 10: 0), the same for both rows' tiles of a slot:
                     // a compile-time constant after unrolling
@@ -784,6 +814,257 @@ __global__ __launch_bounds__(256, 1) void conv_f16x3_dma_kernel(ConvF16Args a)
     conv_f16_epilogue<OUTMODE>(acc, a, smem, b, h0, row, c, lane);
 }
 
+// ---- LDS-DMA version on v_mfma_f32_16x16x32_f16 (forward, T <= 4) -------------------------------------------------
+// Same workgroup tile, wave tile (64 channels x 5.5 column tiles = 176 accumulator registers), operand images, LDS-DMA
+// staging and epilogue as conv_f16x3_dma_kernel; only the matrix instruction differs.  Why: these kernels are power
+// limited (matrix pipes ~84 % busy at 1.6-1.7 GHz), and at equal cycles per FLOP the chip holds a higher clock on the
+// 16x16x32 shape than on 32x32x16 -- tools/probe/ubench_mfma_shape.hip at this wave tile, random fp16 operands re-read
+// from LDS: 1 880 against 1 653 TFLOP/s (1.87 against 1.65 GHz, loop cycles equal within 0.2 %).
+//   K = 32 of one instruction = a PAIR of taps x 16 input channels: lane group g = lane >> 4 holds (tap parity g >> 1,
+//   8-channel half g & 1), so both operands are still ONE ds_read_b128 per fragment out of the unchanged images
+//   (weights [split][tap][khalf][co][8], patch [split][row][khalf][pos][8]); a 32 x 32 output tile is 2 x 2
+//   accumulators and its four instructions share two A and two B fragments: the same LDS bytes per FLOP.
+//   13 taps = 6 pairs + tap 12 paired with a zero tap (an eighth, zero-filled tap slot behind W1's seven that the DMA
+//   never writes): 14 / 13 of the matrix work.
+//   Phases: A = taps 0..5 from W0 (3 pairs), B = taps 6..12 (+ zero) from W1 (4 pairs).
+//   Instruction order inside a pair: column tile by column tile (12 instructions = 3 terms x 4 channel tiles, one
+//   accumulator every 4th instruction); a tile's two B fragments are dead after its 12 instructions, so the patch
+//   fragments live in a RING of six tiles read four tiles ahead of their use (across pair boundaries), and only the 8 A
+//   fragments are double buffered: 12 + 16 fragment vectors (112 registers; a full double buffer would be 256 and pushed
+//   accumulators out of the AGPRs: ~90 v_accvgpr moves per stage in the first version).
+template <int T>
+__global__ __launch_bounds__(256, 1) void conv_f16x3_dma16_kernel(ConvF16Args a)
+{
+    constexpr int NCB = 4, NKH = CV_KH;
+    constexpr int PWP = CV_PITCH + 12 * T;
+    constexpr int WSL = CV_KW * 64 * 16;
+    constexpr int PLANE = PWP * 16;
+    constexpr int P_SLOTS = 8 * PWP;
+    constexpr int P_PIECES = (P_SLOTS + 63) / 64;
+    constexpr int P_BYTES = P_PIECES * 1024;
+    constexpr int PPW = (P_PIECES + 3) / 4;
+    constexpr int W0_SPLIT = 6 * 2048, W0_BYTES = 2 * W0_SPLIT;       // taps 0..5
+    constexpr int W1_SPLIT = 8 * 2048, W1_BYTES = 2 * W1_SPLIT;       // taps 6..12 + the zero tap
+    constexpr int ROWB = NCB * CV_PITCH * 32;
+    constexpr int N_STAGE = NCB * NKH;
+    static_assert(PPW >= 12 && PPW <= 13, "DMA schedule");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char *const W0 = smem, *const W1 = smem + W0_BYTES, *const P0 = smem + W0_BYTES + W1_BYTES;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int row = wave >> 1, c = wave & 1, g = lane >> 4, l16 = lane & 15, tp = g >> 1, khf = g & 1;
+    int tile_id = blockIdx.y * gridDim.x + blockIdx.x;
+    {
+        const int n_tiles = gridDim.x * gridDim.y;
+        if ((n_tiles & 7) == 0) tile_id = (tile_id & 7) * (n_tiles >> 3) + (tile_id >> 3);
+    }
+    const int b = tile_id / gridDim.x, h0 = (tile_id - b * gridDim.x) * 2;
+
+    // the zero tap of W1 (both splits, both channel halves: 4 planes of 1 KB)
+    for (int i = tid; i < 4 * 64; i += 256) {
+        const int pl = i >> 6, sp = pl >> 1, kh2 = pl & 1;
+        *reinterpret_cast<floatx4 *>(W1 + sp * W1_SPLIT + (7 * 2 + kh2) * 1024 + (i & 63) * 16) = floatx4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    floatx4 acc[44];
+#pragma unroll
+    for (int i = 0; i < 44; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[i][r] = 0.0f;
+
+    int desc[PPW];
+#pragma unroll
+    for (int k = 0; k < PPW; ++k) {
+        const int i = (wave + 4 * k) * 64 + lane;
+        const int plane = i / PWP, pos = i - plane * PWP, w = pos - 6 * T;
+        const int split = plane >> 2, r = (plane >> 1) & 1, part = plane & 1;
+        desc[k] = (i < P_SLOTS && w >= 0 && w < CV_PITCH) ? ((split << 30) | (r << 29) | (r * ROWB + w * 32 + part * 16)) : -1;
+    }
+    const unsigned long long zero_src = (unsigned long long)k_zero_slot, xh = (unsigned long long)a.x_hi,
+                             xl = (unsigned long long)a.x_lo, wh = (unsigned long long)a.w_hi, wlo = (unsigned long long)a.w_lo;
+    const int H = a.H;
+
+    struct DmaSlot { unsigned long long src; unsigned lds; };
+    // weights of (stage, taps [t0, t0 + nt)) -> Wb with `wsplit` bytes per split; piece pw covers one (split, tap, khalf) plane
+    auto slot_w = [&](int st, int t0, int nt, unsigned char *Wb, int wsplit, int j) {
+        const int pw = wave + 4 * j, per = 2 * nt;
+        const int split = pw / per, rem = pw - split * per;
+        DmaSlot d;
+        d.src = (split ? wlo : wh) + ((unsigned long long)st * WSL + (t0 * 2 + rem) * 512 + lane * 8) * 2;
+        d.lds = lds0 + (unsigned)(Wb - smem) + split * wsplit + rem * 1024;
+        return d;
+    };
+    auto slot_p = [&](int st, unsigned char *Pb, int k) {
+        const bool in_range = wave + 4 * k < P_PIECES;
+        const int pp = in_range ? wave + 4 * k : wave + 4 * (k - 1);
+        const int d = in_range ? desc[k] : desc[k > 0 ? k - 1 : 0];
+        const int cb = st / NKH, kh = st - cb * NKH, hx0 = h0 + kh - NKH / 2;
+        const bool v0 = hx0 >= 0 && hx0 < H, v1 = hx0 + 1 >= 0 && hx0 + 1 < H;
+        const long long st_off = (((long long)b * H + hx0) * NCB + cb) * (CV_PITCH * 32);
+        const unsigned long long base_h = xh + st_off, base_l = xl + st_off;
+        const bool ok = d >= 0 && ((d & (1 << 29)) ? v1 : v0);
+        const unsigned long long src = ((d & (1 << 30)) ? base_l : base_h) + (unsigned)(d & 0xFFFFF);
+        DmaSlot r;
+        r.src = ok ? src : zero_src;
+        r.lds = lds0 + (unsigned)(Pb - smem) + pp * 1024;
+        return r;
+    };
+    auto slot_issue = [&](const DmaSlot &d) { glds16(d.src, d.lds); };
+
+    // prologue: taps 0..5 of stage 0 and its patch
+#pragma unroll
+    for (int j = 0; j < 6; ++j) slot_issue(slot_w(0, 0, 6, W0, W0_SPLIT, j));
+#pragma unroll
+    for (int k = 0; k < PPW; ++k)
+        if (wave + 4 * k < P_PIECES) slot_issue(slot_p(0, P0, k));
+    DMA_WAIT();
+    __syncthreads();
+
+    // lane parts of the fragment addresses: A = weights of channel half hh ^ c (hh relative to the wave), B = patch
+    const int a_lane0 = (tp * 2 + khf) * 1024 + (c * 32 + l16) * 16, a_lane1 = (tp * 2 + khf) * 1024 + ((c ^ 1) * 32 + l16) * 16;
+    const int b_lane = (row * 2 + khf) * PLANE + (c * 6 * 32 + l16 + tp * T) * 16;
+    const int bm_lane = (row * 2 + khf) * PLANE + (5 * 32 + l16 + tp * T) * 16;
+
+#pragma unroll 1
+    for (int s = 0; s < N_STAGE; ++s) {
+        unsigned char *const Pc = P0 + (s & 1) * P_BYTES, *const Pn = P0 + ((s + 1) & 1) * P_BYTES;
+        const bool more = s + 1 < N_STAGE;
+        const int sn = more ? s + 1 : s;
+        const unsigned char *const a_p0 = smem + a_lane0, *const a_p1 = smem + a_lane1;       // + buffer offset + split + tap * 2048 + (ct & 1) * 256
+        const unsigned char *const b_p = Pc + b_lane, *const bm_p = Pc + bm_lane;            // + nt * 256 + kw * T * 16 + split * 4 * PLANE
+        // fragments: A double buffered [buf][ctr * 2 + split] (ctr = channel tile relative to the wave: 0, 1 = half c), B single [nt][split]
+        half8 FA[2][8], FB[6][2];                                   // B: ring slot of column tile nt = nt % 6 (tiles 10, 11: 4, 5)
+        // WOFF = byte offset of the weight buffer, WS = its bytes per split, TL = first tap of the pair inside the buffer
+        auto rdA = [&](int buf, int woff, int ws, int tl, int q) {
+            const int ctr = q >> 1, sp = q & 1;
+            FA[buf][q] = *reinterpret_cast<const half8 *>(((ctr >> 1) ? a_p1 : a_p0) + woff + sp * ws + tl * 2048 + (ctr & 1) * 256);
+        };
+        auto rdB = [&](int kw, int nt, int sp) {
+            FB[nt < 10 ? nt % 6 : nt - 6][sp] = *reinterpret_cast<const half8 *>((nt < 10 ? b_p + nt * 256 : bm_p + (nt - 10) * 256) + kw * T * 16 + sp * 4 * PLANE);
+        };
+        // instruction m (0..11) of group gi of a pair; gi < 10: column tile gi x 4 channel tiles; gi == 10: tiles 10, 11 x 2
+        // channel tiles; term-major, so one accumulator every 4th instruction.  Written as inline assembly with the
+        // accumulator TIED (dest = src C, AGPR): the builtin leaves dest and src C of this 4-pass shape independent, the
+        // allocator renamed a third of them and paid for it with ~90 v_accvgpr moves per stage at the loop edge.  Inline
+        // assembly is opaque to the scheduler, so the MFMA / ds_read interleave below is pinned by sched_barrier fences in
+        // source order; the waits for the fragment reads are still the compiler's (register operands of the asm).
+        auto mma1 = [&](int buf, int gi, int m) {
+            const int term = m >> 2, q = m & 3;
+            const int nt = gi < 10 ? gi : 10 + (q >> 1), ctr = gi < 10 ? q : (q & 1);
+            const int u = gi < 10 ? gi * 4 + q : 40 + q;
+            const half8 av = FA[buf][ctr * 2 + (term == 0 ? 1 : 0)];
+            const half8 bv = FB[nt < 10 ? nt % 6 : nt - 6][term == 1 ? 1 : 0];
+            asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[u]) : "v"(av), "v"(bv));
+        };
+        // One pair of taps: 132 instructions on A buffer BUF, patch taps (KW, KW + 1).  Reads in its shadow, four tiles ahead:
+        //   groups 0..5: column tile gi + 4 of this pair;  group 6: its tiles 10, 11;  groups 7..10: tile gi - 7 of the NEXT
+        //   pair (taps KWN..) if NB;  groups 0..7: A fragment gi of the next pair (buffer offset WOFFN, first tap TLN) if NA.
+        // DMA slots after groups 2, 5, 8, 10 (NS pieces each, <= 2).
+#define DMA16_GROUP(BUF, GI, KW, NA, WOFFN, WSN, TLN, NB, KWN, NS, SLOT_1, SLOT_2)                   \
+    {                                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                             \
+        const DmaSlot s1_ = SLOT_1, s2_ = SLOT_2;                                                      \
+        constexpr int nb_ = (GI) < 6 ? 2 : (GI) == 6 ? 4 : (NB) ? 2 : 0;      /* patch reads, then the A read */ \
+        constexpr int nr_ = nb_ + (((NA) && (GI) < 8) ? 1 : 0);                                        \
+        constexpr int every_ = nr_ == 0 ? 99 : nr_ == 1 ? 6 : nr_ == 2 ? 4 : nr_ == 3 ? 3 : 2;         \
+        _Pragma("unroll") for (int m_ = 0; m_ < 12; ++m_) {                                            \
+            mma1(BUF, GI, m_);                                                                         \
+            __builtin_amdgcn_sched_barrier(0);                                                         \
+            if ((m_ + 1) % every_ == 0 && (m_ + 1) / every_ <= nr_) {                                  \
+                const int j_ = (m_ + 1) / every_ - 1;                                                  \
+                if (j_ < nb_) {                                                                        \
+                    if ((GI) < 6) rdB(KW, (GI) + 4, j_);                                               \
+                    else if ((GI) == 6) rdB(KW, 10 + (j_ >> 1), j_ & 1);                               \
+                    else rdB(KWN, (GI) - 7, j_);                                                       \
+                } else                                                                                 \
+                    rdA((BUF) ^ 1, WOFFN, WSN, TLN, GI);                                               \
+                __builtin_amdgcn_sched_barrier(0);                                                     \
+            }                                                                                          \
+        }                                                                                              \
+        if ((NS) >= 1) slot_issue(s1_);                                                                \
+        if ((NS) >= 2) slot_issue(s2_);                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                             \
+    }
+        // groups 2, 5, 8, 10 of a pair carry its DMA slots SBASE + 0..3; the others none
+#define DMA16_G_(BUF, GI, KW, NA, WOFFN, WSN, TLN, NB, KWN) DMA16_GROUP(BUF, GI, KW, NA, WOFFN, WSN, TLN, NB, KWN, 0, DmaSlot{}, DmaSlot{})
+#define DMA16_S_(BUF, GI, KW, NA, WOFFN, WSN, TLN, NB, KWN, SLOTN, SLOT_A, SLOT_B, SL) \
+    DMA16_GROUP(BUF, GI, KW, NA, WOFFN, WSN, TLN, NB, KWN, SLOTN(SL), SLOT_A(SL), SLOT_B(SL))
+#define DMA16_PAIR(BUF, KW, NA, WOFFN, WSN, TLN, NB, KWN, SLOTN, SLOT_A, SLOT_B, SBASE)                        \
+    DMA16_G_(BUF, 0, KW, NA, WOFFN, WSN, TLN, NB, KWN)                                                         \
+    DMA16_G_(BUF, 1, KW, NA, WOFFN, WSN, TLN, NB, KWN)                                                         \
+    DMA16_S_(BUF, 2, KW, NA, WOFFN, WSN, TLN, NB, KWN, SLOTN, SLOT_A, SLOT_B, (SBASE) + 0)                     \
+    DMA16_G_(BUF, 3, KW, NA, WOFFN, WSN, TLN, NB, KWN)                                                         \
+    DMA16_G_(BUF, 4, KW, NA, WOFFN, WSN, TLN, NB, KWN)                                                         \
+    DMA16_S_(BUF, 5, KW, NA, WOFFN, WSN, TLN, NB, KWN, SLOTN, SLOT_A, SLOT_B, (SBASE) + 1)                     \
+    DMA16_G_(BUF, 6, KW, NA, WOFFN, WSN, TLN, NB, KWN)                                                         \
+    DMA16_G_(BUF, 7, KW, NA, WOFFN, WSN, TLN, NB, KWN)                                                         \
+    DMA16_S_(BUF, 8, KW, NA, WOFFN, WSN, TLN, NB, KWN, SLOTN, SLOT_A, SLOT_B, (SBASE) + 2)                     \
+    DMA16_G_(BUF, 9, KW, NA, WOFFN, WSN, TLN, NB, KWN)                                                         \
+    DMA16_S_(BUF, 10, KW, NA, WOFFN, WSN, TLN, NB, KWN, SLOTN, SLOT_A, SLOT_B, (SBASE) + 3)
+        // DMA schedule (slot = 0..11 in phase A, 0..15 in phase B):
+        //   phase A: W1 <- this stage's taps 6..12 in slots 0..6, then patch pieces 0..4 of the next stage; its end waits with
+        //            vmcnt(5): the seven weight pieces, not the five patch pieces behind them
+        //   phase B: W0 <- the next stage's taps 0..5 in slots 0..5 with patch pieces 5..10 riding along, pieces 11, 12 in
+        //            slots 6, 7; the last eight slots are empty
+#define A_SLOTN(J) 1
+#define A_SLOT1(J) ((J) < 7 ? slot_w(s, 6, 7, W1, W1_SPLIT, (J)) : slot_p(sn, Pn, (J) - 7))
+#define A_SLOT2(J) A_SLOT1(J)
+#define B_SLOTN(J) (((J) < 6 ? 1 : 0) + ((J) + 5 < PPW && (J) < 8 ? 1 : 0))
+#define B_SLOT1(J) ((J) < 6 ? slot_w(sn, 0, 6, W0, W0_SPLIT, (J)) : slot_p(sn, Pn, (J) + 5 < PPW ? (J) + 5 : PPW - 1))
+#define B_SLOT2(J) slot_p(sn, Pn, (J) + 5 < PPW ? (J) + 5 : PPW - 1)
+        constexpr int W0_OFF = 0, W1_OFF = W0_BYTES;
+        // ---- phase A: pairs (0,1) (2,3) (4,5) from W0
+#pragma unroll
+        for (int q = 0; q < 8; ++q) rdA(0, W0_OFF, W0_SPLIT, 0, q);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) { rdB(0, nt, 0); rdB(0, nt, 1); }
+        DMA16_PAIR(0, 0, 1, W0_OFF, W0_SPLIT, 2, 1, 2, A_SLOTN, A_SLOT1, A_SLOT2, 0)
+        DMA16_PAIR(1, 2, 1, W0_OFF, W0_SPLIT, 4, 1, 4, A_SLOTN, A_SLOT1, A_SLOT2, 4)
+        DMA16_PAIR(0, 4, 0, W0_OFF, W0_SPLIT, 0, 1, 6, A_SLOTN, A_SLOT1, A_SLOT2, 8)          // next pair's weights are not there yet
+        asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        __syncthreads();
+        // ---- phase B: pairs (6,7) (8,9) (10,11) (12, zero) from W1
+#pragma unroll
+        for (int q = 0; q < 8; ++q) rdA(1, W1_OFF, W1_SPLIT, 0, q);
+        DMA16_PAIR(1, 6, 1, W1_OFF, W1_SPLIT, 2, 1, 8, B_SLOTN, B_SLOT1, B_SLOT2, 0)
+        DMA16_PAIR(0, 8, 1, W1_OFF, W1_SPLIT, 4, 1, 10, B_SLOTN, B_SLOT1, B_SLOT2, 4)
+        DMA16_PAIR(1, 10, 1, W1_OFF, W1_SPLIT, 6, 1, 12, B_SLOTN, B_SLOT1, B_SLOT2, 8)
+        DMA16_PAIR(0, 12, 0, W1_OFF, W1_SPLIT, 0, 0, 0, B_SLOTN, B_SLOT1, B_SLOT2, 12)
+        DMA_WAIT();
+        __syncthreads();
+#undef DMA16_GROUP
+#undef DMA16_PAIR
+#undef DMA16_G_
+#undef DMA16_S_
+#undef A_SLOTN
+#undef A_SLOT1
+#undef A_SLOT2
+#undef B_SLOTN
+#undef B_SLOT1
+#undef B_SLOT2
+    }
+    asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");           // the asm MFMAs are invisible to the hazard recogniser: results settled before the epilogue reads them
+    conv_f16_epilogue<0>(acc, a, smem, b, h0, row, c, lane);
+}
+
+template <int T>
+static int launch_f16_dma16(const ConvF16Args &a, int B, hipStream_t st)
+{
+    constexpr int PWP = CV_PITCH + 12 * T;
+    constexpr size_t lds = 2 * 6 * 2048 + 2 * 8 * 2048 + 2 * (size_t)((8 * PWP + 63) / 64) * 1024 + 256;   // + slack: the zero tap's patch reads run T positions past a plane
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void *)conv_f16x3_dma16_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+            hipSuccess)
+            return MX_ERR_LAUNCH;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((conv_f16x3_dma16_kernel<T>), dim3(a.H / 2, B), dim3(256), lds, st, a);
+    return mx_launch_status();
+}
+
 template <int T, int OUTMODE, int NCB = 4, int NKH = CV_KH>
 static int launch_f16_dma(const ConvF16Args &a, int B, hipStream_t st)
 {
@@ -820,6 +1101,13 @@ static int launch_f16(const ConvF16Args &a, int B, hipStream_t st)
 static int dispatch_f16(int T, int outmode, const ConvF16Args &a, int B, hipStream_t st)
 {
     if (outmode == 0) {
+        // MODEX_MFMA_SHAPE=32 selects the v_mfma_f32_32x32x16_f16 forward kernels (same-box A/B, profiles/r04)
+        static const bool shape16 = !(getenv("MODEX_MFMA_SHAPE") && atoi(getenv("MODEX_MFMA_SHAPE")) == 32);
+        if (shape16) {
+            if (T == 1) return launch_f16_dma16<1>(a, B, st);
+            if (T == 2) return launch_f16_dma16<2>(a, B, st);
+            if (T == 4) return launch_f16_dma16<4>(a, B, st);
+        }
         if (T == 1) return launch_f16_dma<1, 0>(a, B, st);
         if (T == 2) return launch_f16_dma<2, 0>(a, B, st);
         if (T == 4) return launch_f16_dma<4, 0>(a, B, st);

@@ -82,7 +82,8 @@ MX_EXPORT int mx_plane_stats(const float *x, const float *slope, int64_t B, int6
 // The same statistics from the per-row partial sums a forward convolution's epilogue leaves (conv_f16.hip, stats_part
 // (B, H, C, 2): {sum, sum of squares} of PReLU(out) over the valid columns of one pooled row, fp32 over <= 352 terms);
 // fp64 across the rows.
-__global__ __launch_bounds__(256) void plane_stats_finish_kernel(const float *__restrict__ part, int n_planes, int C, int H,
+__global__ __launch_bounds__(256) void plane_stats_finish_kernel(const float *__restrict__ part, const float *__restrict__ bias,
+                                                                 const float *__restrict__ slope, int n_planes, int C, int H,
                                                                  int Wv, float eps, float *__restrict__ stats)
 {
     const int plane = blockIdx.x * 256 + threadIdx.x;
@@ -96,21 +97,24 @@ __global__ __launch_bounds__(256) void plane_stats_finish_kernel(const float *__
         s += (double)v[0];
         ss += (double)v[1];
     }
+    // the sums are those of t - shift_c, shift_c = PReLU(bias_c) evaluated exactly as in the convolution's epilogue: the
+    // variance is shift invariant, the mean gets the shift back
+    const float bc = bias[c], shift = bc > 0.0f ? bc : slope[c] * bc;
     const double n = (double)H * (double)Wv;
-    const double mean = s / n;
-    double var = ss / n - mean * mean;
+    const double md = s / n;
+    double var = ss / n - md * md;
     var = var > 0.0 ? var : 0.0;
-    stats[plane * 2] = (float)mean;
+    stats[plane * 2] = (float)((double)shift + md);
     stats[plane * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
 }
 
-MX_EXPORT int mx_plane_stats_finish(const float *part, int64_t B, int64_t C, int64_t H, int64_t Wv, float eps, float *stats,
-                                    void *stream)
+MX_EXPORT int mx_plane_stats_finish(const float *part, const float *bias, const float *slope, int64_t B, int64_t C, int64_t H,
+                                    int64_t Wv, float eps, float *stats, void *stream)
 {
-    if (!part || !stats || B <= 0 || C <= 0 || H <= 0 || Wv <= 0 || Wv > CV_PITCH) return MX_ERR_ARG;
+    if (!part || !bias || !slope || !stats || B <= 0 || C <= 0 || H <= 0 || Wv <= 0 || Wv > CV_PITCH) return MX_ERR_ARG;
     const int n = (int)(B * C);
-    hipLaunchKernelGGL(plane_stats_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, part, n,
-                       (int)C, (int)H, (int)Wv, eps, stats);
+    hipLaunchKernelGGL(plane_stats_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, part, bias,
+                       slope, n, (int)C, (int)H, (int)Wv, eps, stats);
     return mx_launch_status();
 }
 

@@ -199,6 +199,7 @@ class TBPTTLFOEffectModeling(BaseLightingModule):
         # only nn.L1Loss weighted (every shipped config): the BPTT kernel evaluates its gradient itself
         self._fused_l1 = all(w <= 0 or name == "l1" for name, w in self.loss_dict.items())
         self._mrstft = None
+        self._extra_losses = {}           # loss modules outside effect_loss_terms (mrstft, ...), built once, by name
         self.warmup_n_samples, self.step_n_samples = warmup_n_samples, step_n_samples
         self.effect_model = effect_model
         self.lfo_model_weights_path = lfo_model_weights_path
@@ -361,10 +362,7 @@ class TBPTTLFOEffectModeling(BaseLightingModule):
                     if self._fused_l1:
                         em.bptt_l1_chunk(x, lat, y, tgt, stash, h0, c0, w_l1 / (B * S), optimizer.flat_grad)
                     else:       # lightning.py:380-382 with any loss_dict: d loss / d y from the loss kernels, then BPTT
-                        if "mrstft" in self.loss_dict and self._mrstft is None:
-                            from .mrstft import MultiResolutionSTFTLoss
-                            self._mrstft = MultiResolutionSTFTLoss()
-                        dy = effect_loss_grad(y, tgt, self.loss_dict, mrstft=self._mrstft)
+                        dy = effect_loss_grad(y, tgt, self.loss_dict, mrstft=self._loss_module("mrstft") if "mrstft" in self.loss_dict else None)
                         em.bptt_chunk(x, lat, y, dy, stash, h0, c0, optimizer.flat_grad)
                     optimizer.step(grad_scale=allreduce_flat_grad(optimizer.flat_grad, world_size))
                     em.detach_hidden()
@@ -382,7 +380,7 @@ class TBPTTLFOEffectModeling(BaseLightingModule):
             terms = effect_loss_terms(wet_hat, wet_c)
             for name in self.loss_dict:
                 if name not in terms:
-                    terms[name] = L.get_loss_func_by_name(name)(wet_hat, wet_c)
+                    terms[name] = self._loss_module(name)(wet_hat, wet_c)
             loss = None
             for name, w in self.loss_dict.items():
                 self.log(f"{prefix}/{name}", terms[name])
@@ -393,6 +391,16 @@ class TBPTTLFOEffectModeling(BaseLightingModule):
         if mod_sig is not None:
             data_dict["mod_sig"] = mod_sig
         return loss, data_dict, batch[3]
+
+    def _loss_module(self, name: str):
+        """One module per loss name for the lifetime of the step object (the MR-STFT module owns window / twiddle tables on
+        the device: building it per batch re-uploaded them); `mrstft` is the same object for the gradient and for logging."""
+        mod = self._extra_losses.get(name)
+        if mod is None:
+            mod = self._extra_losses[name] = L.get_loss_func_by_name(name)
+            if name == "mrstft":
+                self._mrstft = mod
+        return mod
 
     def training_step(self, batch, batch_idx: int = 0, optimizer=None, world_size: int = 1, prep=None):
         assert optimizer is not None, "manual optimisation: pass the FlatAdamW optimizer"

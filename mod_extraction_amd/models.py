@@ -169,6 +169,7 @@ class _CNNStack(torch.autograd.Function):
         st = _hip.stream()
         cur, slope = logmel, None
         stats_part = None                 # {sum, sum of squares} per pooled row left by the previous block's forward epilogue
+        prev_bias = None                  # ... taken of PReLU(out) - PReLU(bias): the finish pass needs that bias
         saved: List[T] = []
         # the fp16 operand pairs of the 64-channel blocks are kept for the weight gradient when a backward pass
         # will follow (5.9 GB at 256 clips x 2 s: cheaper than re-deriving them from the saved activations)
@@ -178,7 +179,8 @@ class _CNNStack(torch.autograd.Function):
             w, b, a = params[3 * l], params[3 * l + 1], params[3 * l + 2]
             stats = torch.empty((B, cin, 2), device=dev, dtype=torch.float32)
             if stats_part is not None:
-                _hip.call("mx_plane_stats_finish", _hip.ptr(stats_part), B, cin, H, n_frames, LN_EPS, _hip.ptr(stats), st)
+                _hip.call("mx_plane_stats_finish", _hip.ptr(stats_part), _hip.ptr(prev_bias), _hip.ptr(slope), B, cin, H,
+                          n_frames, LN_EPS, _hip.ptr(stats), st)
             else:
                 _hip.call("mx_plane_stats", _hip.ptr(cur), _hip.ptr(slope), B, cin, H, n_frames, LN_EPS,
                           _hip.ptr(stats), st)
@@ -226,7 +228,7 @@ class _CNNStack(torch.autograd.Function):
                           _hip.ptr(b.contiguous()), B, cin, H, n_frames, int(dilations[l]), 1 if l == 0 else 0,
                           _hip.ptr(p), _hip.ptr(amax), st)
             saved += [cur, stats, amax]
-            cur, slope, cin, H = p, a_out, 64, H // 2
+            cur, slope, cin, H, prev_bias = p, a_out, 64, H // 2, b.contiguous()
         wout, bout = params[3 * n_blocks], params[3 * n_blocks + 1]
         L = wout.size(0)
         latent = torch.empty((B, 64, n_frames), device=dev, dtype=torch.float32)

@@ -22,7 +22,9 @@ def _windows(fft_sizes: Sequence[int], win_lengths: Sequence[int], device) -> T:
 
 
 def mrstft_value_and_grad(mod: "MultiResolutionSTFTLoss", a: T, t: T, need_grad: bool = True, scale: float = 1.0):
-    """a, t: (B, T) rows (unit inner stride).  Returns (scale * loss as a device scalar, d (scale * loss) / d a or None)."""
+    """a, t: (B, T) rows (unit inner stride).  Returns (scale * loss as a device scalar, d (scale * loss) / d a or None).
+    ``mod.last_terms`` afterwards holds the per-resolution terms of THIS call: [sc_0, logmag_0, ..., total] with the
+    total (only) carrying ``scale`` -- the sc / logmag entries are the raw, unweighted terms."""
     assert a.shape == t.shape and a.ndim == 2 and a.stride(1) == 1 and t.stride(1) == 1
     B, Tn = a.shape
     dev = a.device

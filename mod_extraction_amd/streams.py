@@ -21,13 +21,39 @@ side stream made the step 14 % SLOWER (75.9 -> 86.5 ms): a masked queue next to 
 two.  With BOTH streams created through hipExtStreamCreateWithCUMask (tools/exp_cumask_headline.py): main on every CU +
 side on one word 74.6 ms against 75.1 with the default streams -- 0.7 %, not adopted.
 """
+import atexit
 import ctypes
 import os
-from typing import Dict, Optional, Tuple
+from typing import Dict, List, Optional, Tuple
 
 import torch
 
 _cache: Dict[Tuple[int, int], Tuple[torch.cuda.Stream, torch.cuda.Stream]] = {}
+_raw: List[Tuple[int, int]] = []            # (device index, hipStream_t) of every masked stream this module created
+
+
+def _destroy_masked_streams() -> None:
+    """The masked streams are created behind torch's back (ExternalStream does not own them), so nobody destroys them:
+    left alive until HIP's own teardown they crashed the process at exit (config 4 under the profiler: rc 139 after the
+    result line was printed, profiles/r03/notes.txt).  Drain and destroy them while the runtime is still up."""
+    if not _raw:
+        return
+    try:
+        hip = ctypes.CDLL("libamdhip64.so")
+        hip.hipStreamSynchronize.argtypes = [ctypes.c_void_p]
+        hip.hipStreamDestroy.argtypes = [ctypes.c_void_p]
+        hip.hipSetDevice.argtypes = [ctypes.c_int]
+        for idx, handle in _raw:
+            hip.hipSetDevice(idx)
+            hip.hipStreamSynchronize(ctypes.c_void_p(handle))
+            hip.hipStreamDestroy(ctypes.c_void_p(handle))
+    except Exception:                        # interpreter shutdown: never turn a clean exit into a traceback
+        pass
+    _raw.clear()
+    _cache.clear()
+
+
+atexit.register(_destroy_masked_streams)
 
 
 def _masked_stream(hip, words, device) -> torch.cuda.Stream:
@@ -36,6 +62,7 @@ def _masked_stream(hip, words, device) -> torch.cuda.Stream:
     rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(st), len(words), arr)
     if rc != 0:
         raise RuntimeError(f"hipExtStreamCreateWithCUMask failed ({rc})")
+    _raw.append((device.index if device.index is not None else torch.cuda.current_device(), st.value))
     return torch.cuda.ExternalStream(st.value, device=device)
 
 

@@ -306,7 +306,10 @@ class CheckpointKeeper:
 
     def state(self, current: Optional[float] = None) -> Dict[str, Any]:
         last = os.path.join(self.dirpath, "last.ckpt")
-        return {self.STATE_KEY: {"monitor": "val/loss", "best_model_score": None if self.best_path is None else torch.tensor(self.best),
+        # the best SCORE is written whenever one exists, also when its file belongs to an earlier run (best_path None after
+        # a resume into a new directory): a resume of that resume must still know what it has to beat
+        have = self.best != float("inf")
+        return {self.STATE_KEY: {"monitor": "val/loss", "best_model_score": torch.tensor(self.best) if have else None,
                                  "best_model_path": self.best_path or "", "current_score": None if current is None else torch.tensor(current),
                                  "dirpath": self.dirpath, "best_k_models": {} if self.best_path is None else {self.best_path: torch.tensor(self.best)},
                                  "kth_best_model_path": self.best_path or "", "kth_value": torch.tensor(self.best),
@@ -320,13 +323,20 @@ class CheckpointKeeper:
         return os.path.commonpath([mine, os.path.realpath(path)]) == mine
 
     def load_state(self, callbacks: Dict[str, Any]) -> None:
-        """Resume: the best SCORE always carries over; the best PATH only when the checkpoint was written into this
-        keeper's own directory.  The CLI resumes into a fresh `version_N+1/checkpoints`, and Lightning 2.0.2's
-        ModelCheckpoint likewise drops `best_k_models` / `kth_best_model_path` when `dirpath` changed -- the earlier
-        run's files (often the very `ckpt_path` being resumed) are never this run's to delete."""
+        """Resume: the best SCORE always carries over (from `best_model_score`, else from a finite `kth_value`); the best
+        PATH only when the checkpoint was written into this keeper's own directory.  The CLI resumes into a fresh
+        `version_N+1/checkpoints`; the earlier run's files (often the very `ckpt_path` being resumed) are never this
+        run's to delete.  Lightning 2.0.2's ModelCheckpoint differs both ways when `dirpath` changed -- it keeps
+        `best_model_path` and drops `best_model_score` / `best_k_models`, so its resumed run saves its first epoch as
+        "best" whatever the score; keeping the score is the deliberate deviation here."""
         for key, st in callbacks.items():
-            if str(key).startswith("ModelCheckpoint") and st.get("best_model_score") is not None:
-                self.best = float(st["best_model_score"])
+            if not str(key).startswith("ModelCheckpoint"):
+                continue
+            score = st.get("best_model_score")
+            if score is None and st.get("kth_value") is not None and float(st["kth_value"]) != float("inf"):
+                score = st["kth_value"]
+            if score is not None:
+                self.best = float(score)
                 path = st.get("best_model_path") or None
                 same_dir = os.path.realpath(str(st.get("dirpath") or "")) == os.path.realpath(self.dirpath)
                 self.best_path = path if (same_dir and self._owns(path)) else None

@@ -145,3 +145,29 @@ def test_resume_never_deletes_the_previous_runs_checkpoints(tmp_path):
     k3 = trainer.CheckpointKeeper(str(run2), "lfo_2dcnn", "synth")
     k3.load_state(torch.load(run2 / "last.ckpt", weights_only=False)["callbacks"])
     assert k3.best_path is not None and os.path.basename(k3.best_path) == "lfo_2dcnn__synth__epoch_3_step_40.ckpt"
+
+
+def test_resume_of_a_resume_keeps_the_best_score(tmp_path):
+    """run 2 resumes run 1 into a new directory and never improves, so it has no best FILE of its own; its
+    last.ckpt must still carry the score to beat, or run 3 (resuming run 2) would save its first epoch as 'best'."""
+    torch.manual_seed(5)
+    m = small_module()
+    runs = [tmp_path / f"version_{i}" / "checkpoints" for i in range(3)]
+    k1 = trainer.CheckpointKeeper(str(runs[0]), "lfo_2dcnn", "synth")
+    k1.update(m, None, epoch=0, step=10, metrics={"val/loss": 0.5})
+    t2 = trainer.Trainer(max_epochs=3, log_fn=None, checkpoints=trainer.CheckpointKeeper(str(runs[1]), "lfo_2dcnn", "synth"))
+    trainer.resume_from_checkpoint(str(runs[0] / "last.ckpt"), m, None, t2)
+    t2.checkpoints.update(m, None, epoch=1, step=20, metrics={"val/loss": 0.7})       # worse: only last.ckpt
+    cb = torch.load(runs[1] / "last.ckpt", weights_only=False)["callbacks"]
+    st = cb[trainer.CheckpointKeeper.STATE_KEY]
+    assert float(st["best_model_score"]) == 0.5 and st["best_model_path"] == ""
+    t3 = trainer.Trainer(max_epochs=3, log_fn=None, checkpoints=trainer.CheckpointKeeper(str(runs[2]), "lfo_2dcnn", "synth"))
+    trainer.resume_from_checkpoint(str(runs[1] / "last.ckpt"), m, None, t3)
+    k3 = t3.checkpoints
+    assert k3.best == 0.5 and k3.best_path is None
+    k3.update(m, None, epoch=2, step=30, metrics={"val/loss": 0.6})                   # still worse than run 1
+    assert sorted(os.listdir(runs[2])) == ["last.ckpt"]
+    # a checkpoint written by an older build (score None, finite kth_value) resumes through kth_value
+    k4 = trainer.CheckpointKeeper(str(tmp_path / "v4"), "lfo_2dcnn", "synth")
+    k4.load_state({trainer.CheckpointKeeper.STATE_KEY: {"best_model_score": None, "kth_value": torch.tensor(0.25), "dirpath": "/elsewhere"}})
+    assert k4.best == 0.25 and k4.best_path is None

@@ -137,7 +137,8 @@ def test_block_f16x3_kernels(dev, T, W, H):
     assert rel(p.cpu()[..., :W], p_r.detach()) < 1e-5
     stats_swept, stats_fused = torch.empty((B, 64, 2), device=dev), torch.empty((B, 64, 2), device=dev)
     _hip.call("mx_plane_stats", _hip.ptr(p), _hip.ptr(sl_out), B, 64, H // 2, W, 1e-5, _hip.ptr(stats_swept), st)
-    _hip.call("mx_plane_stats_finish", _hip.ptr(st_part), B, 64, H // 2, W, 1e-5, _hip.ptr(stats_fused), st)
+    _hip.call("mx_plane_stats_finish", _hip.ptr(st_part), _hip.ptr(b.detach().to(dev)), _hip.ptr(sl_out), B, 64, H // 2, W, 1e-5,
+              _hip.ptr(stats_fused), st)
     y_r = torch.where(p_r.detach() > 0, p_r.detach(), sl_out.cpu().view(1, 64, 1, 1) * p_r.detach())
     mean_r, var_r = y_r.double().mean(dim=(2, 3)), y_r.double().var(dim=(2, 3), unbiased=False)
     # mean against the plane's standard deviation, rstd relatively: both at fp32 rounding level
@@ -285,3 +286,44 @@ def test_block_f16x3_kernels(dev, T, W, H):
     back = fused_pair.permute(0, 2, 4, 1, 3).reshape(B, 64, H, PITCH) / S3
     assert rel(back.cpu()[..., :W], x_req.grad) < 1e-5 and bool((back[..., W:] == 0).all())
     assert rel(ds_c, ds_b) < 2e-6 and rel(gs_c, gs_b) < 1e-5
+
+
+def test_fused_plane_stats_large_offset_tiny_variance(dev):
+    """the LayerNorm statistics the forward epilogue leaves (fp32 row sums) must not cancel for planes with
+    |mean| >> std -- near-constant planes of silent clips or dead channels, where out ~ bias.  The row sums are taken of
+    PReLU(out) - PReLU(bias), so the variance keeps its digits; checked against an fp64 evaluation of the stored plane and
+    against the fp64 sweep (mx_plane_stats), for positive and negative biases of magnitude ~20 over a std of ~1e-3, and
+    for an exactly constant plane (zero weights: rstd = 1 / sqrt(eps))."""
+    from mod_extraction_amd import _hip, models as am
+    torch.manual_seed(11)
+    B, H, W, T = 2, 8, 345, 1
+    st = _hip.stream()
+    x_d = to_planes(torch.randn(B, 64, H, W), dev)
+    sl_d = (torch.rand(64) * 0.4 + 0.05).to(dev)
+    stats = torch.empty((B, 64, 2), device=dev)
+    _hip.call("mx_plane_stats", _hip.ptr(x_d), _hip.ptr(sl_d), B, 64, H, W, 1e-5, _hip.ptr(stats), st)
+    x_hi = torch.empty((B, H, 4, PITCH, 16), device=dev, dtype=torch.float16)
+    x_lo = torch.empty_like(x_hi)
+    _hip.call("mx_conv_prep_fwd_f16", _hip.ptr(x_d), _hip.ptr(stats), _hip.ptr(sl_d), B, H, W, _hip.ptr(x_hi), _hip.ptr(x_lo), st)
+    bias = (20.0 + torch.randn(64)) * torch.where(torch.arange(64) % 2 == 0, 1.0, -1.0)
+    sl_out = (torch.rand(64) * 0.4 + 0.05).to(dev)
+    for wscale in (1e-4, 0.0):
+        w = torch.randn(64, 64, 5, 13) * wscale
+        w_hi, w_lo = am._pack_f16(w.to(dev), 0)
+        p = torch.empty((B, 64, H // 2, PITCH), device=dev)
+        amax = torch.empty((B, 64, H // 2, PITCH), device=dev, dtype=torch.uint8)
+        st_part = torch.empty((B, H // 2, 64, 2), device=dev)
+        _hip.call("mx_conv_block_fwd_f16", _hip.ptr(x_hi), _hip.ptr(x_lo), _hip.ptr(w_hi), _hip.ptr(w_lo), _hip.ptr(bias.to(dev)),
+                  B, H, W, T, _hip.ptr(p), _hip.ptr(amax), _hip.ptr(sl_out), _hip.ptr(st_part), st)
+        fused, swept = torch.empty((B, 64, 2), device=dev), torch.empty((B, 64, 2), device=dev)
+        _hip.call("mx_plane_stats_finish", _hip.ptr(st_part), _hip.ptr(bias.to(dev)), _hip.ptr(sl_out), B, 64, H // 2, W, 1e-5,
+                  _hip.ptr(fused), st)
+        _hip.call("mx_plane_stats", _hip.ptr(p), _hip.ptr(sl_out), B, 64, H // 2, W, 1e-5, _hip.ptr(swept), st)
+        pv = p.cpu()[..., :W].double()
+        y = torch.where(pv > 0, pv, sl_out.cpu().double().view(1, 64, 1, 1) * pv)
+        mean_r, var_r = y.mean(dim=(2, 3)), y.var(dim=(2, 3), unbiased=False)
+        if wscale:
+            assert float(var_r.sqrt().max()) < 0.1 and float(mean_r.abs().min()) > 0.5       # the regime under test
+        assert float(((fused[..., 0].cpu().double() - mean_r).abs() / mean_r.abs()).max()) < 2e-7
+        assert float((fused[..., 1].cpu().double() * (var_r + 1e-5).sqrt() - 1).abs().max()) < 1e-4
+        assert float((fused[..., 1] / swept[..., 1] - 1).abs().max()) < 1e-4
