@@ -824,14 +824,18 @@ __global__ __launch_bounds__(256, 1) void conv_f16x3_dma_kernel(ConvF16Args a)
 //   8-channel half g & 1), so both operands are still ONE ds_read_b128 per fragment out of the unchanged images
 //   (weights [split][tap][khalf][co][8], patch [split][row][khalf][pos][8]); a 32 x 32 output tile is 2 x 2
 //   accumulators and its four instructions share two A and two B fragments: the same LDS bytes per FLOP.
-//   13 taps = 6 pairs + tap 12 paired with a zero tap (an eighth, zero-filled tap slot behind W1's seven that the DMA
-//   never writes): 14 / 13 of the matrix work.
-//   Phases: A = taps 0..5 from W0 (3 pairs), B = taps 6..12 (+ zero) from W1 (4 pairs).
+//   13 taps per stage is odd.  Padding tap 12 with a zero tap (first version: 14 / 13 of the matrix work) ate the gain:
+//   isolated 12.9 -> 12.2 ms, inside the train step 12.64 -> 12.84 ms.  So stages run in (even, odd) couples of 26 taps =
+//   13 pairs: the even stage runs taps 0..11 and leaves tap 12; the odd stage starts with the STRADDLING pair (tap 12
+//   of the even stage, tap 0 of the odd one) -- at that moment both stages' weights and patches are resident (the
+//   double buffers) -- then taps 1..12.  The straddling pair's lanes address two different buffers (per-lane bases).
+//   Its operands must be read before the odd stage's DMA overwrites the even stage's patch: W1's tap-12 slot is never
+//   written in an odd stage, the patch pieces are issued only after a workgroup barrier behind the straddling pair.
+//   Buffers (7 tap slots each):   even stage: W0 = taps 0..5, W1 = taps 6..12;   odd stage: W0 = taps 0..6, W1 = taps 7..12.
 //   Instruction order inside a pair: column tile by column tile (12 instructions = 3 terms x 4 channel tiles, one
 //   accumulator every 4th instruction); a tile's two B fragments are dead after its 12 instructions, so the patch
 //   fragments live in a RING of six tiles read four tiles ahead of their use (across pair boundaries), and only the 8 A
-//   fragments are double buffered: 12 + 16 fragment vectors (112 registers; a full double buffer would be 256 and pushed
-//   accumulators out of the AGPRs: ~90 v_accvgpr moves per stage in the first version).
+//   fragments are double buffered: 12 + 16 fragment vectors (112 registers).
 template <int T>
 __global__ __launch_bounds__(256, 1) void conv_f16x3_dma16_kernel(ConvF16Args a)
 {
@@ -843,13 +847,12 @@ __global__ __launch_bounds__(256, 1) void conv_f16x3_dma16_kernel(ConvF16Args a)
     constexpr int P_PIECES = (P_SLOTS + 63) / 64;
     constexpr int P_BYTES = P_PIECES * 1024;
     constexpr int PPW = (P_PIECES + 3) / 4;
-    constexpr int W0_SPLIT = 6 * 2048, W0_BYTES = 2 * W0_SPLIT;       // taps 0..5
-    constexpr int W1_SPLIT = 8 * 2048, W1_BYTES = 2 * W1_SPLIT;       // taps 6..12 + the zero tap
+    constexpr int W_SPLIT = 7 * 2048, W_BYTES = 2 * W_SPLIT;
     constexpr int ROWB = NCB * CV_PITCH * 32;
     constexpr int N_STAGE = NCB * NKH;
-    static_assert(PPW >= 12 && PPW <= 13, "DMA schedule");
+    static_assert(PPW >= 12 && PPW <= 13 && N_STAGE % 2 == 0, "DMA schedule");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char *const W0 = smem, *const W1 = smem + W0_BYTES, *const P0 = smem + W0_BYTES + W1_BYTES;
+    constexpr int W0_OFF = 0, W1_OFF = W_BYTES, P0_OFF = 2 * W_BYTES, P1_OFF = 2 * W_BYTES + P_BYTES;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -860,12 +863,6 @@ __global__ __launch_bounds__(256, 1) void conv_f16x3_dma16_kernel(ConvF16Args a)
         if ((n_tiles & 7) == 0) tile_id = (tile_id & 7) * (n_tiles >> 3) + (tile_id >> 3);
     }
     const int b = tile_id / gridDim.x, h0 = (tile_id - b * gridDim.x) * 2;
-
-    // the zero tap of W1 (both splits, both channel halves: 4 planes of 1 KB)
-    for (int i = tid; i < 4 * 64; i += 256) {
-        const int pl = i >> 6, sp = pl >> 1, kh2 = pl & 1;
-        *reinterpret_cast<floatx4 *>(W1 + sp * W1_SPLIT + (7 * 2 + kh2) * 1024 + (i & 63) * 16) = floatx4{0.f, 0.f, 0.f, 0.f};
-    }
 
     floatx4 acc[44];
 #pragma unroll
@@ -886,16 +883,16 @@ __global__ __launch_bounds__(256, 1) void conv_f16x3_dma16_kernel(ConvF16Args a)
     const int H = a.H;
 
     struct DmaSlot { unsigned long long src; unsigned lds; };
-    // weights of (stage, taps [t0, t0 + nt)) -> Wb with `wsplit` bytes per split; piece pw covers one (split, tap, khalf) plane
-    auto slot_w = [&](int st, int t0, int nt, unsigned char *Wb, int wsplit, int j) {
+    // weights of (stage, taps [t0, t0 + nt)) -> tap slots 0.. of the buffer at woff; piece pw covers one (split, tap, khalf) plane
+    auto slot_w = [&](int st, int t0, int nt, int woff, int j) {
         const int pw = wave + 4 * j, per = 2 * nt;
         const int split = pw / per, rem = pw - split * per;
         DmaSlot d;
         d.src = (split ? wlo : wh) + ((unsigned long long)st * WSL + (t0 * 2 + rem) * 512 + lane * 8) * 2;
-        d.lds = lds0 + (unsigned)(Wb - smem) + split * wsplit + rem * 1024;
+        d.lds = lds0 + woff + split * W_SPLIT + rem * 1024;
         return d;
     };
-    auto slot_p = [&](int st, unsigned char *Pb, int k) {
+    auto slot_p = [&](int st, int poff, int k) {
         const bool in_range = wave + 4 * k < P_PIECES;
         const int pp = in_range ? wave + 4 * k : wave + 4 * (k - 1);
         const int d = in_range ? desc[k] : desc[k > 0 ? k - 1 : 0];
@@ -907,61 +904,70 @@ __global__ __launch_bounds__(256, 1) void conv_f16x3_dma16_kernel(ConvF16Args a)
         const unsigned long long src = ((d & (1 << 30)) ? base_l : base_h) + (unsigned)(d & 0xFFFFF);
         DmaSlot r;
         r.src = ok ? src : zero_src;
-        r.lds = lds0 + (unsigned)(Pb - smem) + pp * 1024;
+        r.lds = lds0 + poff + pp * 1024;
         return r;
     };
     auto slot_issue = [&](const DmaSlot &d) { glds16(d.src, d.lds); };
 
     // prologue: taps 0..5 of stage 0 and its patch
 #pragma unroll
-    for (int j = 0; j < 6; ++j) slot_issue(slot_w(0, 0, 6, W0, W0_SPLIT, j));
+    for (int j = 0; j < 6; ++j) slot_issue(slot_w(0, 0, 6, W0_OFF, j));
 #pragma unroll
     for (int k = 0; k < PPW; ++k)
-        if (wave + 4 * k < P_PIECES) slot_issue(slot_p(0, P0, k));
+        if (wave + 4 * k < P_PIECES) slot_issue(slot_p(0, P0_OFF, k));
     DMA_WAIT();
     __syncthreads();
 
-    // lane parts of the fragment addresses: A = weights of channel half hh ^ c (hh relative to the wave), B = patch
-    const int a_lane0 = (tp * 2 + khf) * 1024 + (c * 32 + l16) * 16, a_lane1 = (tp * 2 + khf) * 1024 + ((c ^ 1) * 32 + l16) * 16;
-    const int b_lane = (row * 2 + khf) * PLANE + (c * 6 * 32 + l16 + tp * T) * 16;
-    const int bm_lane = (row * 2 + khf) * PLANE + (5 * 32 + l16 + tp * T) * 16;
+    // lane parts of the fragment addresses.  A = weights of channel half hh ^ c (hh relative to the wave), B = patch.
+    //   regular pair : + buffer offset + split * W_SPLIT + first tap slot * 2048 + (ct & 1) * 256   /   + patch offset + nt * 256 + kw * T * 16 + split * 4 * PLANE
+    //   straddling   : parity-0 lanes -> tap slot 6 of W1 / tap 12 of P0 (the even stage), parity-1 lanes -> tap slot 0 of W0 / tap 0 of P1
+    const int a_k = khf * 1024 + l16 * 16, b_k = (row * 2 + khf) * PLANE + l16 * 16;
+    const unsigned char *const a_p0 = smem + a_k + tp * 2048 + c * 512, *const a_p1 = smem + a_k + tp * 2048 + (c ^ 1) * 512;
+    // (one pointer per patch buffer: P1 lies beyond the 64 KB reach of a ds_read's immediate offset)
+    const unsigned char *const b_pE = smem + P0_OFF + b_k + (c * 6 * 32 + tp * T) * 16, *const bm_pE = smem + P0_OFF + b_k + (5 * 32 + tp * T) * 16;
+    const unsigned char *const b_pO = b_pE + P_BYTES, *const bm_pO = bm_pE + P_BYTES;
+    const int sa_off = tp ? W0_OFF : W1_OFF + 6 * 2048, sb_off = tp ? P1_OFF : P0_OFF + 12 * T * 16;
+    const unsigned char *const as_p0 = smem + a_k + sa_off + c * 512, *const as_p1 = smem + a_k + sa_off + (c ^ 1) * 512;
+    const unsigned char *const bs_p = smem + b_k + sb_off + c * 6 * 32 * 16, *const bsm_p = smem + b_k + sb_off + 5 * 32 * 16;
 
-#pragma unroll 1
-    for (int s = 0; s < N_STAGE; ++s) {
-        unsigned char *const Pc = P0 + (s & 1) * P_BYTES, *const Pn = P0 + ((s + 1) & 1) * P_BYTES;
-        const bool more = s + 1 < N_STAGE;
-        const int sn = more ? s + 1 : s;
-        const unsigned char *const a_p0 = smem + a_lane0, *const a_p1 = smem + a_lane1;       // + buffer offset + split + tap * 2048 + (ct & 1) * 256
-        const unsigned char *const b_p = Pc + b_lane, *const bm_p = Pc + bm_lane;            // + nt * 256 + kw * T * 16 + split * 4 * PLANE
-        // fragments: A double buffered [buf][ctr * 2 + split] (ctr = channel tile relative to the wave: 0, 1 = half c), B single [nt][split]
-        half8 FA[2][8], FB[6][2];                                   // B: ring slot of column tile nt = nt % 6 (tiles 10, 11: 4, 5)
-        // WOFF = byte offset of the weight buffer, WS = its bytes per split, TL = first tap of the pair inside the buffer
-        auto rdA = [&](int buf, int woff, int ws, int tl, int q) {
-            const int ctr = q >> 1, sp = q & 1;
-            FA[buf][q] = *reinterpret_cast<const half8 *>(((ctr >> 1) ? a_p1 : a_p0) + woff + sp * ws + tl * 2048 + (ctr & 1) * 256);
-        };
-        auto rdB = [&](int kw, int nt, int sp) {
-            FB[nt < 10 ? nt % 6 : nt - 6][sp] = *reinterpret_cast<const half8 *>((nt < 10 ? b_p + nt * 256 : bm_p + (nt - 10) * 256) + kw * T * 16 + sp * 4 * PLANE);
-        };
-        // instruction m (0..11) of group gi of a pair; gi < 10: column tile gi x 4 channel tiles; gi == 10: tiles 10, 11 x 2
-        // channel tiles; term-major, so one accumulator every 4th instruction.  Written as inline assembly with the
-        // accumulator TIED (dest = src C, AGPR): the builtin leaves dest and src C of this 4-pass shape independent, the
-        // allocator renamed a third of them and paid for it with ~90 v_accvgpr moves per stage at the loop edge.  Inline
-        // assembly is opaque to the scheduler, so the MFMA / ds_read interleave below is pinned by sched_barrier fences in
-        // source order; the waits for the fragment reads are still the compiler's (register operands of the asm).
-        auto mma1 = [&](int buf, int gi, int m) {
-            const int term = m >> 2, q = m & 3;
-            const int nt = gi < 10 ? gi : 10 + (q >> 1), ctr = gi < 10 ? q : (q & 1);
-            const int u = gi < 10 ? gi * 4 + q : 40 + q;
-            const half8 av = FA[buf][ctr * 2 + (term == 0 ? 1 : 0)];
-            const half8 bv = FB[nt < 10 ? nt % 6 : nt - 6][term == 1 ? 1 : 0];
-            asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[u]) : "v"(av), "v"(bv));
-        };
-        // One pair of taps: 132 instructions on A buffer BUF, patch taps (KW, KW + 1).  Reads in its shadow, four tiles ahead:
-        //   groups 0..5: column tile gi + 4 of this pair;  group 6: its tiles 10, 11;  groups 7..10: tile gi - 7 of the NEXT
-        //   pair (taps KWN..) if NB;  groups 0..7: A fragment gi of the next pair (buffer offset WOFFN, first tap TLN) if NA.
-        // DMA slots after groups 2, 5, 8, 10 (NS pieces each, <= 2).
-#define DMA16_GROUP(BUF, GI, KW, NA, WOFFN, WSN, TLN, NB, KWN, NS, SLOT_1, SLOT_2)                   \
+    // fragments: A double buffered [buf][ctr * 2 + split] (ctr = channel tile relative to the wave: 0, 1 = half c), B ring [slot][split]
+    // with slot = nt % 6 for column tile nt < 10 and 4, 5 for the middle tile's halves 10, 11
+    half8 FA[2][8], FB[6][2];
+    auto rdA = [&](int buf, int woff, int tl, int q) {
+        const int ctr = q >> 1, sp = q & 1;
+        FA[buf][q] = *reinterpret_cast<const half8 *>(((ctr >> 1) ? a_p1 : a_p0) + woff + sp * W_SPLIT + tl * 2048 + (ctr & 1) * 256);
+    };
+    auto rdB = [&](int odd, int kw, int nt, int sp) {
+        FB[nt < 10 ? nt % 6 : nt - 6][sp] = *reinterpret_cast<const half8 *>(
+            (nt < 10 ? (odd ? b_pO : b_pE) + nt * 256 : (odd ? bm_pO : bm_pE) + (nt - 10) * 256) + kw * T * 16 + sp * 4 * PLANE);
+    };
+    auto rdA_str = [&](int buf, int q) {
+        const int ctr = q >> 1, sp = q & 1;
+        FA[buf][q] = *reinterpret_cast<const half8 *>(((ctr >> 1) ? as_p1 : as_p0) + sp * W_SPLIT + (ctr & 1) * 256);
+    };
+    auto rdB_str = [&](int nt, int sp) {
+        FB[nt < 10 ? nt % 6 : nt - 6][sp] =
+            *reinterpret_cast<const half8 *>((nt < 10 ? bs_p + nt * 256 : bsm_p + (nt - 10) * 256) + sp * 4 * PLANE);
+    };
+    // instruction m (0..11) of group gi of a pair; gi < 10: column tile gi x 4 channel tiles; gi == 10: tiles 10, 11 x 2
+    // channel tiles; term-major, so one accumulator every 4th instruction.  Written as inline assembly with the
+    // accumulator TIED (dest = src C, AGPR): the builtin leaves dest and src C of this 4-pass shape independent, the
+    // allocator renamed a third of them and paid for it with ~90 v_accvgpr moves per stage at the loop edge.  Inline
+    // assembly is opaque to the scheduler, so the MFMA / ds_read interleave below is pinned by sched_barrier fences in
+    // source order; the waits for the fragment reads are still the compiler's (register operands of the asm).
+    auto mma1 = [&](int buf, int gi, int m) {
+        const int term = m >> 2, q = m & 3;
+        const int nt = gi < 10 ? gi : 10 + (q >> 1), ctr = gi < 10 ? q : (q & 1);
+        const int u = gi < 10 ? gi * 4 + q : 40 + q;
+        const half8 av = FA[buf][ctr * 2 + (term == 0 ? 1 : 0)];
+        const half8 bv = FB[nt < 10 ? nt % 6 : nt - 6][term == 1 ? 1 : 0];
+        asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[u]) : "v"(av), "v"(bv));
+    };
+    // One group = 12 instructions on A buffer BUF.  Reads in its shadow, four tiles ahead:
+    //   groups 0..5: column tile gi + 4 of THIS pair (RDB_CUR(nt, split));  group 6: its tiles 10, 11;
+    //   groups 7..10: tile gi - 7 of the NEXT pair (RDB_NXT) if NB;  groups 0..7: A fragment gi of the next pair (RDA_NXT(buf, q)) if NA.
+    // then NS (<= 2) DMA pieces.
+#define DMA16_GROUP(BUF, GI, RDB_CUR, NA, RDA_NXT, NB, RDB_NXT, NS, SLOT_1, SLOT_2)                  \
     {                                                                                                  \
         __builtin_amdgcn_sched_barrier(0);                                                             \
         const DmaSlot s1_ = SLOT_1, s2_ = SLOT_2;                                                      \
@@ -974,11 +980,12 @@ __global__ __launch_bounds__(256, 1) void conv_f16x3_dma16_kernel(ConvF16Args a)
             if ((m_ + 1) % every_ == 0 && (m_ + 1) / every_ <= nr_) {                                  \
                 const int j_ = (m_ + 1) / every_ - 1;                                                  \
                 if (j_ < nb_) {                                                                        \
-                    if ((GI) < 6) rdB(KW, (GI) + 4, j_);                                               \
-                    else if ((GI) == 6) rdB(KW, 10 + (j_ >> 1), j_ & 1);                               \
-                    else rdB(KWN, (GI) - 7, j_);                                                       \
-                } else                                                                                 \
-                    rdA((BUF) ^ 1, WOFFN, WSN, TLN, GI);                                               \
+                    if ((GI) < 6) { RDB_CUR((GI) + 4, j_); }                                           \
+                    else if ((GI) == 6) { RDB_CUR(10 + (j_ >> 1), j_ & 1); }                           \
+                    else { RDB_NXT((GI) - 7, j_); }                                                    \
+                } else {                                                                               \
+                    RDA_NXT((BUF) ^ 1, GI);                                                            \
+                }                                                                                      \
                 __builtin_amdgcn_sched_barrier(0);                                                     \
             }                                                                                          \
         }                                                                                              \
@@ -986,64 +993,107 @@ __global__ __launch_bounds__(256, 1) void conv_f16x3_dma16_kernel(ConvF16Args a)
         if ((NS) >= 2) slot_issue(s2_);                                                                \
         __builtin_amdgcn_sched_barrier(0);                                                             \
     }
-        // groups 2, 5, 8, 10 of a pair carry its DMA slots SBASE + 0..3; the others none
-#define DMA16_G_(BUF, GI, KW, NA, WOFFN, WSN, TLN, NB, KWN) DMA16_GROUP(BUF, GI, KW, NA, WOFFN, WSN, TLN, NB, KWN, 0, DmaSlot{}, DmaSlot{})
-#define DMA16_S_(BUF, GI, KW, NA, WOFFN, WSN, TLN, NB, KWN, SLOTN, SLOT_A, SLOT_B, SL) \
-    DMA16_GROUP(BUF, GI, KW, NA, WOFFN, WSN, TLN, NB, KWN, SLOTN(SL), SLOT_A(SL), SLOT_B(SL))
-#define DMA16_PAIR(BUF, KW, NA, WOFFN, WSN, TLN, NB, KWN, SLOTN, SLOT_A, SLOT_B, SBASE)                        \
-    DMA16_G_(BUF, 0, KW, NA, WOFFN, WSN, TLN, NB, KWN)                                                         \
-    DMA16_G_(BUF, 1, KW, NA, WOFFN, WSN, TLN, NB, KWN)                                                         \
-    DMA16_S_(BUF, 2, KW, NA, WOFFN, WSN, TLN, NB, KWN, SLOTN, SLOT_A, SLOT_B, (SBASE) + 0)                     \
-    DMA16_G_(BUF, 3, KW, NA, WOFFN, WSN, TLN, NB, KWN)                                                         \
-    DMA16_G_(BUF, 4, KW, NA, WOFFN, WSN, TLN, NB, KWN)                                                         \
-    DMA16_S_(BUF, 5, KW, NA, WOFFN, WSN, TLN, NB, KWN, SLOTN, SLOT_A, SLOT_B, (SBASE) + 1)                     \
-    DMA16_G_(BUF, 6, KW, NA, WOFFN, WSN, TLN, NB, KWN)                                                         \
-    DMA16_G_(BUF, 7, KW, NA, WOFFN, WSN, TLN, NB, KWN)                                                         \
-    DMA16_S_(BUF, 8, KW, NA, WOFFN, WSN, TLN, NB, KWN, SLOTN, SLOT_A, SLOT_B, (SBASE) + 2)                     \
-    DMA16_G_(BUF, 9, KW, NA, WOFFN, WSN, TLN, NB, KWN)                                                         \
-    DMA16_S_(BUF, 10, KW, NA, WOFFN, WSN, TLN, NB, KWN, SLOTN, SLOT_A, SLOT_B, (SBASE) + 3)
-        // DMA schedule (slot = 0..11 in phase A, 0..15 in phase B):
-        //   phase A: W1 <- this stage's taps 6..12 in slots 0..6, then patch pieces 0..4 of the next stage; its end waits with
-        //            vmcnt(5): the seven weight pieces, not the five patch pieces behind them
-        //   phase B: W0 <- the next stage's taps 0..5 in slots 0..5 with patch pieces 5..10 riding along, pieces 11, 12 in
-        //            slots 6, 7; the last eight slots are empty
-#define A_SLOTN(J) 1
-#define A_SLOT1(J) ((J) < 7 ? slot_w(s, 6, 7, W1, W1_SPLIT, (J)) : slot_p(sn, Pn, (J) - 7))
-#define A_SLOT2(J) A_SLOT1(J)
-#define B_SLOTN(J) (((J) < 6 ? 1 : 0) + ((J) + 5 < PPW && (J) < 8 ? 1 : 0))
-#define B_SLOT1(J) ((J) < 6 ? slot_w(sn, 0, 6, W0, W0_SPLIT, (J)) : slot_p(sn, Pn, (J) + 5 < PPW ? (J) + 5 : PPW - 1))
-#define B_SLOT2(J) slot_p(sn, Pn, (J) + 5 < PPW ? (J) + 5 : PPW - 1)
-        constexpr int W0_OFF = 0, W1_OFF = W0_BYTES;
-        // ---- phase A: pairs (0,1) (2,3) (4,5) from W0
+    // groups 2, 5, 8, 10 of a pair carry its DMA slots SBASE + 0..3; the others none
+#define DMA16_G_(BUF, GI, RC, NA, RA, NB, RN) DMA16_GROUP(BUF, GI, RC, NA, RA, NB, RN, 0, DmaSlot{}, DmaSlot{})
+#define DMA16_S_(BUF, GI, RC, NA, RA, NB, RN, SLOTN, SLOT_A, SLOT_B, SL) DMA16_GROUP(BUF, GI, RC, NA, RA, NB, RN, SLOTN(SL), SLOT_A(SL), SLOT_B(SL))
+#define DMA16_PAIR(BUF, RC, NA, RA, NB, RN, SLOTN, SLOT_A, SLOT_B, SBASE)                 \
+    DMA16_G_(BUF, 0, RC, NA, RA, NB, RN)                                                  \
+    DMA16_G_(BUF, 1, RC, NA, RA, NB, RN)                                                  \
+    DMA16_S_(BUF, 2, RC, NA, RA, NB, RN, SLOTN, SLOT_A, SLOT_B, (SBASE) + 0)              \
+    DMA16_G_(BUF, 3, RC, NA, RA, NB, RN)                                                  \
+    DMA16_G_(BUF, 4, RC, NA, RA, NB, RN)                                                  \
+    DMA16_S_(BUF, 5, RC, NA, RA, NB, RN, SLOTN, SLOT_A, SLOT_B, (SBASE) + 1)              \
+    DMA16_G_(BUF, 6, RC, NA, RA, NB, RN)                                                  \
+    DMA16_G_(BUF, 7, RC, NA, RA, NB, RN)                                                  \
+    DMA16_S_(BUF, 8, RC, NA, RA, NB, RN, SLOTN, SLOT_A, SLOT_B, (SBASE) + 2)              \
+    DMA16_G_(BUF, 9, RC, NA, RA, NB, RN)                                                  \
+    DMA16_S_(BUF, 10, RC, NA, RA, NB, RN, SLOTN, SLOT_A, SLOT_B, (SBASE) + 3)
+    // fragment readers of the schedule below: patch of the even stage in P0, of the odd stage in P1
+#define RB_E(KW) [&](int nt_, int sp_) { rdB(0, KW, nt_, sp_); }
+#define RB_O(KW) [&](int nt_, int sp_) { rdB(1, KW, nt_, sp_); }
+#define RB_S [&](int nt_, int sp_) { rdB_str(nt_, sp_); }
+#define RA_(WOFF, TL) [&](int buf_, int q_) { rdA(buf_, WOFF, TL, q_); }
+#define R_NONE [&](int, int) {}
+#define NO_SLOTN(J) 0
+#define NO_SLOT(J) DmaSlot{}
+
+#pragma unroll 1
+    for (int s = 0; s < N_STAGE; s += 2) {
+        const int so = s + 1, sn = s + 2 < N_STAGE ? s + 2 : s + 1;      // odd stage; the stage after it (last couple: harmless repeats)
+        // ================= even stage s: taps 0..11 (patch P0; W0 = taps 0..5, W1 = taps 6..12) =================
+        // DMA phase A (12 slots): W1 <- taps 6..12 of s in slots 0..6, patch pieces 0..4 of stage s + 1 -> P1; ends on vmcnt(5)
+        //     phase B (12 slots): W0 <- taps 0..6 of s + 1 in slots 0..6 with patch pieces 5.. riding along (piece 12 in slot 7)
+#define EA_SLOTN(J) 1
+#define EA_SLOT1(J) ((J) < 7 ? slot_w(s, 6, 7, W1_OFF, (J)) : slot_p(so, P1_OFF, (J) - 7))
+#define EB_SLOTN(J) (((J) < 7 ? 1 : 0) + ((J) + 5 < PPW ? 1 : 0))
+#define EB_SLOT1(J) ((J) < 7 ? slot_w(so, 0, 7, W0_OFF, (J)) : slot_p(so, P1_OFF, (J) + 5 < PPW ? (J) + 5 : PPW - 1))
+#define EB_SLOT2(J) slot_p(so, P1_OFF, (J) + 5 < PPW ? (J) + 5 : PPW - 1)
 #pragma unroll
-        for (int q = 0; q < 8; ++q) rdA(0, W0_OFF, W0_SPLIT, 0, q);
+        for (int q = 0; q < 8; ++q) rdA(0, W0_OFF, 0, q);
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) { rdB(0, nt, 0); rdB(0, nt, 1); }
-        DMA16_PAIR(0, 0, 1, W0_OFF, W0_SPLIT, 2, 1, 2, A_SLOTN, A_SLOT1, A_SLOT2, 0)
-        DMA16_PAIR(1, 2, 1, W0_OFF, W0_SPLIT, 4, 1, 4, A_SLOTN, A_SLOT1, A_SLOT2, 4)
-        DMA16_PAIR(0, 4, 0, W0_OFF, W0_SPLIT, 0, 1, 6, A_SLOTN, A_SLOT1, A_SLOT2, 8)          // next pair's weights are not there yet
+        for (int nt = 0; nt < 4; ++nt) { rdB(0, 0, nt, 0); rdB(0, 0, nt, 1); }
+        DMA16_PAIR(0, RB_E(0), 1, RA_(W0_OFF, 2), 1, RB_E(2), EA_SLOTN, EA_SLOT1, EA_SLOT1, 0)
+        DMA16_PAIR(1, RB_E(2), 1, RA_(W0_OFF, 4), 1, RB_E(4), EA_SLOTN, EA_SLOT1, EA_SLOT1, 4)
+        DMA16_PAIR(0, RB_E(4), 0, R_NONE, 1, RB_E(6), EA_SLOTN, EA_SLOT1, EA_SLOT1, 8)          // W1 is not there yet
         asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
         __syncthreads();
-        // ---- phase B: pairs (6,7) (8,9) (10,11) (12, zero) from W1
 #pragma unroll
-        for (int q = 0; q < 8; ++q) rdA(1, W1_OFF, W1_SPLIT, 0, q);
-        DMA16_PAIR(1, 6, 1, W1_OFF, W1_SPLIT, 2, 1, 8, B_SLOTN, B_SLOT1, B_SLOT2, 0)
-        DMA16_PAIR(0, 8, 1, W1_OFF, W1_SPLIT, 4, 1, 10, B_SLOTN, B_SLOT1, B_SLOT2, 4)
-        DMA16_PAIR(1, 10, 1, W1_OFF, W1_SPLIT, 6, 1, 12, B_SLOTN, B_SLOT1, B_SLOT2, 8)
-        DMA16_PAIR(0, 12, 0, W1_OFF, W1_SPLIT, 0, 0, 0, B_SLOTN, B_SLOT1, B_SLOT2, 12)
+        for (int q = 0; q < 8; ++q) rdA(1, W1_OFF, 0, q);
+        DMA16_PAIR(1, RB_E(6), 1, RA_(W1_OFF, 2), 1, RB_E(8), EB_SLOTN, EB_SLOT1, EB_SLOT2, 0)
+        DMA16_PAIR(0, RB_E(8), 1, RA_(W1_OFF, 4), 1, RB_E(10), EB_SLOTN, EB_SLOT1, EB_SLOT2, 4)
+        DMA16_PAIR(1, RB_E(10), 0, R_NONE, 0, R_NONE, EB_SLOTN, EB_SLOT1, EB_SLOT2, 8)          // the next pair straddles: its operands land with the barrier
         DMA_WAIT();
         __syncthreads();
+        // ================= odd stage s + 1: the straddling pair, then taps 1..12 (patch P1; W0 = taps 0..6, W1 = taps 7..12) =====
+        // DMA phase A (16 slots): W1 <- taps 7..12 of s + 1 in slots 0..5 (tap slot 6 of W1 keeps the even stage's tap 12);
+        //                         after the barrier behind the straddling pair: patch pieces 0..5 of stage s + 2 -> P0 in slots 6..11;
+        //                         ends on vmcnt(6)
+        //     phase B (12 slots): W0 <- taps 0..5 of s + 2 in slots 0..5 with patch pieces 6.. riding along
+#define OA_SLOTN(J) ((J) < 12 ? 1 : 0)
+#define OA_SLOT1(J) ((J) < 6 ? slot_w(so, 7, 6, W1_OFF, (J)) : slot_p(sn, P0_OFF, (J) < 12 ? (J) - 6 : 5))
+#define OB_SLOTN(J) (((J) < 6 ? 1 : 0) + ((J) + 6 < PPW ? 1 : 0))
+#define OB_SLOT1(J) ((J) < 6 ? slot_w(sn, 0, 6, W0_OFF, (J)) : slot_p(sn, P0_OFF, (J) + 6 < PPW ? (J) + 6 : PPW - 1))
+#define OB_SLOT2(J) slot_p(sn, P0_OFF, (J) + 6 < PPW ? (J) + 6 : PPW - 1)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) rdA_str(0, q);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) { rdB_str(nt, 0); rdB_str(nt, 1); }
+        DMA16_PAIR(0, RB_S, 1, RA_(W0_OFF, 1), 1, RB_O(1), OA_SLOTN, OA_SLOT1, OA_SLOT1, 0)     // slots 0..3: weights only
+        __builtin_amdgcn_s_barrier();                 // every wave holds the straddling pair's operands: P0 may be overwritten from here on
+        DMA16_PAIR(1, RB_O(1), 1, RA_(W0_OFF, 3), 1, RB_O(3), OA_SLOTN, OA_SLOT1, OA_SLOT1, 4)
+        DMA16_PAIR(0, RB_O(3), 1, RA_(W0_OFF, 5), 1, RB_O(5), OA_SLOTN, OA_SLOT1, OA_SLOT1, 8)
+        DMA16_PAIR(1, RB_O(5), 0, R_NONE, 1, RB_O(7), OA_SLOTN, OA_SLOT1, OA_SLOT1, 12)
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 8; ++q) rdA(0, W1_OFF, 0, q);
+        DMA16_PAIR(0, RB_O(7), 1, RA_(W1_OFF, 2), 1, RB_O(9), OB_SLOTN, OB_SLOT1, OB_SLOT2, 0)
+        DMA16_PAIR(1, RB_O(9), 1, RA_(W1_OFF, 4), 1, RB_O(11), OB_SLOTN, OB_SLOT1, OB_SLOT2, 4)
+        DMA16_PAIR(0, RB_O(11), 0, R_NONE, 0, R_NONE, OB_SLOTN, OB_SLOT1, OB_SLOT2, 8)
+        DMA_WAIT();
+        __syncthreads();
+    }
 #undef DMA16_GROUP
-#undef DMA16_PAIR
 #undef DMA16_G_
 #undef DMA16_S_
-#undef A_SLOTN
-#undef A_SLOT1
-#undef A_SLOT2
-#undef B_SLOTN
-#undef B_SLOT1
-#undef B_SLOT2
-    }
+#undef DMA16_PAIR
+#undef RB_E
+#undef RB_O
+#undef RB_S
+#undef RA_
+#undef R_NONE
+#undef NO_SLOTN
+#undef NO_SLOT
+#undef EA_SLOTN
+#undef EA_SLOT1
+#undef EB_SLOTN
+#undef EB_SLOT1
+#undef EB_SLOT2
+#undef OA_SLOTN
+#undef OA_SLOT1
+#undef OB_SLOTN
+#undef OB_SLOT1
+#undef OB_SLOT2
     asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");           // the asm MFMAs are invisible to the hazard recogniser: results settled before the epilogue reads them
     conv_f16_epilogue<0>(acc, a, smem, b, h0, row, c, lane);
 }
@@ -1052,7 +1102,7 @@ template <int T>
 static int launch_f16_dma16(const ConvF16Args &a, int B, hipStream_t st)
 {
     constexpr int PWP = CV_PITCH + 12 * T;
-    constexpr size_t lds = 2 * 6 * 2048 + 2 * 8 * 2048 + 2 * (size_t)((8 * PWP + 63) / 64) * 1024 + 256;   // + slack: the zero tap's patch reads run T positions past a plane
+    constexpr size_t lds = 2 * (2 * 7 * 2048) + 2 * (size_t)((8 * PWP + 63) / 64) * 1024;
     static_assert(lds <= 160 * 1024, "LDS budget");
     static bool attr_done = false;
     if (!attr_done) {
