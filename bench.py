@@ -691,13 +691,15 @@ def run_config5(args, env):
     torch.cuda.synchronize()
     kernels = fx_blocks(bt, params, fx_floor_pass(bt, params))
     kernels["flanger_kernel"]["avg_launch_ms_in_step"] = round(live["mx_flanger_fwd"], 4)
-    mr = hbm_block("mr_stats_kernel + mr_grad_kernel + mr_fold_kernel x {512, 1024, 2048} (losses.py:155-156)",
+    mr = hbm_block("mr_onepass_kernel x {512, 1024, 2048} + mr_fold_all_kernel (losses.py:155-156)",
                    B * N * 12.0, live["mx_mrstft_loss"],
                    note="12 B/sample algorithmic: x, y read once, d loss / d x written once; three STFT resolutions forward and "
-                        "backward in one entry point, 1.5 transforms per frame.  Pass A (one FFT of x + i y per frame, bins parked) is "
-                        "VALU-issue bound; pass B (one inverse FFT per PAIR of frames from the parked bins) moves 3.8 GB per launch "
-                        "and is HBM-bound at ~4.8 TB/s; ~25 GB per step actually cross the HBM interface (parked bins + gradient "
-                        "frames, written and read once), so the algorithmic fraction understates the kernel's HBM use by ~45x")
+                        "backward in one entry point.  One pass per resolution: per frame one forward FFT of x + i y, the loss sums and "
+                        "the two linear gradient components G1, G2 (dL/dX = alpha G1 + G2, alpha = the only global scalar); per PAIR "
+                        "of frames two inverse FFTs (G1 of both frames, G2 of both), overlap-added in LDS rings; a last gather forms "
+                        "alpha g1 + g2.  Nothing per bin reaches memory (the two-pass version parked 12 B per bin: ~25 GB per step, 46x "
+                        "the algorithmic bytes; now ~3.5 GB: run sums written and read once).  The kernels are VALU-issue bound "
+                        "(FFT butterflies on packed-fp32 instructions), which is why the HBM fraction stays small")
     kernels["mrstft_loss"] = mr
     audio_s = world * B * cfg["seconds"] * args.steps
     out = {

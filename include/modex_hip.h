@@ -386,9 +386,11 @@ int mx_effect_loss_grad(const float *y_hat, int64_t y_hat_stride, const float *y
  * pointers of this ABI.  windows (n_res, 2048) device: row r = n_fft_r-long analysis window (hann of
  * win_length centred in the frame).  twiddle (2048,2) device = exp(-2 pi i m/2048).
  * terms (2*n_res+1) device: [sc_0, logmag_0, ..., total].  dx: d total / d y_hat rows (stride dx_stride)
- * or NULL.  Workspaces (device): part >= 3*B*max_r ceil(frames_r/8) doubles, coef 2 floats,
- * scratch >= B*max_r(frames_r*(5*n_fft_r/2 + 4)) floats (needed only when dx != NULL: the frames' time-domain gradients
- * and the bins the forward pass parks for the gradient pass); frames_r = 1 + T/hop_r. */
+ * or NULL.  Workspaces (device): part >= 3*B*max_r ceil(frames_r/8) doubles, coef n_res floats (the scalar alpha_r =
+ * w_sc / (n_res ||Y-X||_F ||Y||_F) of each resolution), scratch (needed only when dx != NULL) >= sum_r 2*B*(frames_r*hop_r +
+ * runs_r*max(n_fft_r - hop_r, 0)) floats with frames_r = 1 + T/hop_r, runs_r = ceil(frames_r/F_r), F_r = max(32,
+ * ceil(n_fft_r/hop_r)) rounded up to even: the two linear components g1_r, g2_r of the time-domain gradient
+ * (d total / d y_hat = sum_r alpha_r g1_r + g2_r) as per-run overlap-add sums plus one tail per run; nothing per bin is stored. */
 int mx_mrstft_loss(const float *y_hat, int64_t y_hat_stride, const float *y, int64_t y_stride, int64_t B,
                    int64_t T, int32_t n_res, const int32_t *fft_sizes, const int32_t *hops,
                    const float *windows, const float *twiddle, float w_sc, float w_log, float eps,

@@ -6,45 +6,93 @@
 // frame, centre=True reflect padding, mag = sqrt(clamp(re^2 + im^2, eps)),
 // loss = mean over resolutions of [ ||Y - X||_F / ||Y||_F  +  mean |log X - log Y| ]).
 //
-// Three passes per resolution (12 B/sample algorithmic: x, y in, grad out):
-//   A  stats : per frame, ONE complex FFT of x + i*y (one frame per wavefront, register-staged radix-4 Stockham, see
-//              below) -> both spectra by Hermitian separation -> per-workgroup partial sums of
-//              (Ym - Xm)^2, Ym^2, |log Xm - log Ym|; when a gradient will follow, (Re X, Im X, Ym^2) of every bin is left in
-//              a workspace (12 B per bin: the transform is the expensive part, not the bytes)
-//   B  grad  : per-bin dL/dX from the global norms and the parked bins -- no second forward transform --, and ONE
-//              inverse FFT per PAIR of frames: the one-sided gradient spectra of frames 2p and 2p + 1 are completed to
-//              Hermitian spectra G~ (G~[k] = G[k] / 2, G~[N - k] = conj G[k] / 2, DC and Nyquist real) and transformed
-//              as G~_a + i G~_b, whose real / imaginary parts are the two frames' time-domain gradients; window, store to
-//              scratch (frames x n_fft)
-//   C  fold  : overlap-add as a GATHER (each sample sums the frames that cover it, incl. the reflect-
-//              padded positions) -> deterministic, no atomics
-// Transforms per frame: 1.5 (it was 3: forward in A, forward again and a zero-padded inverse in B).
+// Value + gradient: ONE pass over the frames per resolution, no per-bin workspace (12 B/sample algorithmic: x, y in, grad out).
+//   dL/dX of a bin = alpha_r * G1 + G2 with  G1 = (|X| - |Y|) X / |X|,  G2 = c_log sign(log|X| - log|Y|) / |X| * X / |X|,
+//   c_log = w_log / (n_res * count) known up front and alpha_r = w_sc / (n_res ||Y - X||_F ||Y||_F) the ONLY global quantity --
+//   a scalar multiplier.  Window, inverse transform, overlap-add and the reflect-padding fold are linear, so the kernel
+//   that holds a frame's bins carries G1 and G2 to the time domain separately and a small last pass forms
+//   alpha_r g1_r + g2_r:  nothing per bin is written to memory (the two-pass version parked 12 B per bin and re-read
+//   them once the norms were known: 25 GB per 256 x 4 s step, 46x the algorithmic bytes).
+//   onepass : a STREAM (64 lanes; 32 for N = 512, two streams per wavefront) walks a RUN of F consecutive frames of one
+//             clip, two frames at a time: forward FFT of x + i*y per frame (register-staged radix-4 Stockham, see below)
+//             -> both spectra by Hermitian separation -> loss sums and the frame's G1, G2; the pair's G1 spectra are
+//             completed to Hermitian ones and go through ONE inverse FFT as G1~_a + i G1~_b (real / imaginary part = the
+//             two frames' time-domain gradients), likewise G2: two transforms per frame (it was 1.5, plus 24 B per bin
+//             of traffic).  The windowed frames are overlap-added in two stream-private LDS rings of N floats; after a
+//             frame is added its first `hop` positions are final (within the run) and leave for memory; at the end of the
+//             run the ring's remaining N - hop positions leave as the run's TAIL.
+//   finish  : loss terms and alpha_r from the per-workgroup partial sums
+//   fold    : dx[n] = sum_r sum_{padded positions p of n} ( alpha_r g1_r[p] + g2_r[p] ),  g[p] = run sums + the tails of the
+//             (<= 2) earlier runs that reach p -- a gather: deterministic, no atomics
+// Value only (dx == NULL): pass A (mr_stats_kernel) + finish.
 // Measured per 256 clips x 4 s (all three resolutions, value + gradient): 19.2 ms (frame spread over 256 threads, an LDS
-// round trip and a __syncthreads per pass, twiddles from global memory) -> 14.9 (twiddles staged in LDS) -> 11.4 ms
-// (this file).  The FFT passes are VALU-issue bound: ~1 800 vector instructions per 1024-point frame.
+// round trip and a __syncthreads per pass, twiddles from global memory) -> 14.9 (twiddles staged in LDS) -> 11.4 ms (one frame
+// per wavefront) -> 7.0 ms (parked bins, paired inverse, hardware transcendentals, LDS spans) -> this file.
+// The FFT passes are VALU-issue bound.
 #include "common.h"
 
 #define MR_MAXN 2048
-#define MR_FPG 16        // frames per workgroup (passes A and B); the partial-sum workspace is sized for >= 8
-// parked bins of one frame: Re X[0..N/2), Im X[0..N/2), Ym^2[0..N/2), then Re X[N/2], Ym^2[N/2] (Im X[N/2] == 0), padded to 16 B
-#define MR_PARK(N) (3 * (N) / 2 + 4)
+#define MR_FPG 16        // frames per workgroup (value-only pass); the partial-sum workspace is sized for >= 8
+#ifndef MR_RUN_MIN
+#define MR_RUN_MIN 32    // frames per run of the one-pass kernel (at least ceil(N / hop): a position then lies in at most two earlier runs' tails)
+#endif
+#define MR_OPW 4         // wavefronts per workgroup of the one-pass kernel
+#ifndef MR_OP_EU
+#define MR_OP_EU 2       // waves per SIMD the 512 / 1024 one-pass kernels are compiled for (2048: 1, its LDS leaves one workgroup per CU)
+#endif
 
-struct cf { float re, im; };
-// Complex multiply with the second product of each component fused (2 mul + 2 fma instead of 4 mul + 2 add; the file is
-// compiled with -ffp-contract=off, so this is the only contraction): 10.95 -> 9.95 ms for the three resolutions when it
-// was first measured.  It costs a property the unfused arithmetic had for free: the loss packs the two real signals as
-// x + i y into ONE transform, and the spectra separate EXACTLY for x == y only while the arithmetic is symmetric under the
-// index mirror k -> N - k, which maps a butterfly's twiddle w to -i conj(w) and thereby SWAPS the two products of a complex
-// multiply -- an FMA rounds one of them and not the other, whichever way it is written.  The reference gives loss == 0 and
-// gradient == 0 exactly for identical signals (two identical STFTs), so pass A detects frames whose windowed x and y are
-// bit-identical and takes Y := X for them (tests/test_gpu_mrstft.py::test_mrstft_identical_signals, also with only some
-// clips identical).
-__device__ __forceinline__ cf cmulf(cf a, cf b)
+typedef float cf __attribute__((ext_vector_type(2)));          // complex: x = re, y = im (an aligned register pair: the packed-fp32 unit)
+// Complex arithmetic on the packed-fp32 instructions, two instructions per multiply, one per add -- written as inline
+// assembly because the compiler does not fold "swap the halves and negate ONE of them" into the source modifiers that do
+// exactly that (op_sel / neg_lo / neg_hi of v_pk_mul_f32, v_pk_fma_f32, v_pk_add_f32): from C++ a complex multiply was
+// 6 instructions (v_xor + v_mov to build (-w.im, w.re), a broadcast, v_pk_mul, v_pk_add, v_pk_fma) and a rotation by -+i
+// two more, and together with the address arithmetic below the transforms ran ~670 instructions per 1024-point frame
+// and lane against ~300 for the butterflies themselves.
+//   a * w      = (a.x w.x - a.y w.y,  a.x w.y + a.y w.x):  t = a.yy * (-w.y, w.x);  r = a.xx * w + t
+//   a * conj w = (a.x w.x + a.y w.y, -a.x w.y + a.y w.x):  t = a.yy * ( w.y, w.x);  r = a.xx * (w.x, -w.y) + t
+// The second product of each component is fused (2 mul + 2 fma).  That costs a property the unfused arithmetic had for
+// free: the loss packs the two real signals as x + i y into ONE transform, and the spectra separate EXACTLY for x == y only
+// while the arithmetic is symmetric under the index mirror k -> N - k, which maps a butterfly's twiddle w to -i conj(w) and
+// thereby SWAPS the two products of a complex multiply -- an FMA rounds one of them and not the other.  The reference gives
+// loss == 0 and gradient == 0 exactly for identical signals, so the kernels detect frames whose windowed x and y are
+// bit-identical and take Y := X for them (tests/test_gpu_mrstft.py::test_mrstft_identical_signals).
+template <bool INV> __device__ __forceinline__ cf cmul_v(cf a, cf w)        // twiddle in vector registers
 {
-    return {__builtin_fmaf(a.re, b.re, -(a.im * b.im)), __builtin_fmaf(a.re, b.im, a.im * b.re)};
+    cf t, r;
+    if (!INV) {
+        asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(t) : "v"(a), "v"(w));
+        asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(r) : "v"(a), "v"(w), "v"(t));
+    } else {
+        asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "v"(w));
+        asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1] neg_hi:[0,1,0]" : "=v"(r) : "v"(a), "v"(w), "v"(t));
+    }
+    return r;
 }
-__device__ __forceinline__ cf caddf(cf a, cf b) { return {a.re + b.re, a.im + b.im}; }
-__device__ __forceinline__ cf csubf(cf a, cf b) { return {a.re - b.re, a.im - b.im}; }
+template <bool INV> __device__ __forceinline__ cf cmul_s(cf a, cf w)        // wave-uniform twiddle in scalar registers
+{
+    cf t, r;
+    if (!INV) {
+        asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(t) : "v"(a), "s"(w));
+        asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(r) : "v"(a), "s"(w), "v"(t));
+    } else {
+        asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "s"(w));
+        asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1] neg_hi:[0,1,0]" : "=v"(r) : "v"(a), "s"(w), "v"(t));
+    }
+    return r;
+}
+// a + (-i) d = (a.x + d.y, a.y - d.x)   /   a + i d = (a.x - d.y, a.y + d.x)
+__device__ __forceinline__ cf add_mi(cf a, cf d)
+{
+    cf r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(d));
+    return r;
+}
+__device__ __forceinline__ cf add_pi(cf a, cf d)
+{
+    cf r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(d));
+    return r;
+}
 
 // ---- the FFT: one frame per wavefront (two per wavefront for N = 512), passes fused in registers -----------------
 // A frame of N points is held by L lanes, E = N / L complex values per lane.  Radix-4 Stockham passes p = 0.. with
@@ -55,6 +103,14 @@ __device__ __forceinline__ cf csubf(cf a, cf b) { return {a.re - b.re, a.im - b.
 // workgroup barrier (first version: the frame spread over 256 threads, one LDS round trip and one __syncthreads per
 // pass, twiddles from global memory: 19.2 ms per 256 x 4 s; twiddles in LDS: 14.9 ms).  The index algebra was
 // checked against numpy.fft for the three sizes, both directions, before it was written down here.
+// Every exchange-buffer slot and twiddle index is (a function of the lane) + (a compile-time constant) -- the forms below
+// are checked against the plain algebra (position -> padded slot, butterfly -> twiddle step) by
+// tools/probe/check_fft_addr.py -- so each LDS access is one instruction with an immediate offset; the lane parts
+// (FftLane) are set up once per kernel:
+//   exchange 1 (after passes 0, 1; slot = q + (q >> 4)):   write 17 a + (17 L be + r + 4 r2),   read a + (a >> 4) + const(b, c)
+//   exchange 2 (after passes 2, 3; slot = q + 16 (q >> 8)): write 272 (a >> 4) + (a & 15) + (17 L be + 16 r + 64 r2),  read a + const(b, c)
+//   twiddles: pass 1: r N / 16 (wave-uniform: nine constants in scalar registers);  pass 2: (a & 15) N / 64 (lane only: three values
+//   in registers);  pass 3: (a & 15) N / 256 + r N / 16;  pass 4: a + 64 b (1024), 2 a + 128 (b & 3) (2048);  radix-2: a + const
 template <int N> struct WF {
     static constexpr int L = (N == 512) ? 32 : 64;     // lanes per frame
     static constexpr int E = N / L;                    // complex values per lane: 16, 16, 32
@@ -65,63 +121,48 @@ template <int N> struct WF {
     static constexpr int FW = 64 / L;                  // frames a wavefront works on at a time
 };
 
-template <int N, bool INV, int P>
-__device__ __forceinline__ void bfly4(int j, const cf &i0, const cf &i1, const cf &i2, const cf &i3, cf (&o)[4],
-                                      const float2 *tw_s)
+template <int N> struct FftLane {
+    cf *w1, *w2;                                       // exchange write bases (lane part applied)
+    const cf *r1, *r2;                                 // exchange read bases
+    cf t2[3];                                          // pass-2 twiddles w, w^2, w^3 of this lane
+    const cf *t3[3];                                   // pass-3 twiddle bases: tw_s + m (a & 15) N / 256
+    const cf *t4[3];                                   // last radix-4 pass: tw_s + m a (1024), tw_s + 2 m a (2048); unused for 512
+    const cf *t5;                                      // radix-2 pass of 512 / 2048: tw_s + a
+    cf c1[3][3];                                       // pass-1 twiddles [r - 1][m - 1] = exp(-2 pi i m r / 16): wave-uniform
+};
+template <int N>
+__device__ __forceinline__ void fft_lane_setup(FftLane<N> &fl, cf *buf, const cf *tw_s, const float2 *__restrict__ tw, int a)
 {
-    constexpr int Ns = 1 << (2 * P);
-    cf v0 = i0, v1 = i1, v2 = i2, v3 = i3;
-    if (P > 0) {
-        const int step = (j & (Ns - 1)) * (N / (Ns * 4));
-        float2 w1 = tw_s[step], w2 = tw_s[2 * step], w3 = tw_s[3 * step];
-        if (INV) { w1.y = -w1.y; w2.y = -w2.y; w3.y = -w3.y; }
-        v1 = cmulf(v1, {w1.x, w1.y});
-        v2 = cmulf(v2, {w2.x, w2.y});
-        v3 = cmulf(v3, {w3.x, w3.y});
-    }
-    const cf a0 = caddf(v0, v2), a1 = csubf(v0, v2), a2 = caddf(v1, v3), d = csubf(v1, v3);
-    const cf a3 = INV ? cf{-d.im, d.re} : cf{d.im, -d.re};              // (+/-) i (v1 - v3)
-    o[0] = caddf(a0, a2);
-    o[1] = caddf(a1, a3);
-    o[2] = csubf(a0, a2);
-    o[3] = csubf(a1, a3);
-}
-template <int P> __device__ __forceinline__ int out_pos4(int j, int r)
-{
-    constexpr int Ns = 1 << (2 * P);
-    const int k = j & (Ns - 1);
-    return ((j - k) << 2) + k + r * Ns;
-}
-
-// passes P and P + 1 on the registers of one lane: R[b][c] = value at position a + L b + (N/4) c on entry, the
-// pass-(P+1) outputs go to the exchange buffer through PAD (position -> padded slot), and R is re-read in the same
-// layout from the buffer
-template <int N, bool INV, int P, typename PAD>
-__device__ __forceinline__ void fused_pair(cf (&R)[WF<N>::NB][4], cf *buf, const float2 *tw_s, int a, PAD pad)
-{
-    constexpr int L = WF<N>::L, NB = WF<N>::NB, NBQ = WF<N>::NBQ;
-    cf O[NB][4];
+    fl.w1 = buf + 17 * a;
+    fl.r1 = buf + a + (a >> 4);
+    fl.w2 = buf + 272 * (a >> 4) + (a & 15);
+    fl.r2 = buf + a;
 #pragma unroll
-    for (int b = 0; b < NB; ++b) bfly4<N, INV, P>(a + L * b, R[b][0], R[b][1], R[b][2], R[b][3], O[b], tw_s);
+    for (int m = 1; m <= 3; ++m) {
+        const float2 w = tw[(m * (a & 15) * (N / 64)) * (MR_MAXN / N)];
+        fl.t2[m - 1] = {w.x, w.y};
+        fl.t3[m - 1] = tw_s + m * (a & 15) * (N / 256);
+        fl.t4[m - 1] = tw_s + m * a * (N / 1024);
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int be = 0; be < NBQ; ++be) {
-            const int jn = out_pos4<P>(a, r) + 4 * L * be;                 // butterfly of pass P + 1 held by this lane
-            cf Pq[4];
-            bfly4<N, INV, P + 1>(jn, O[be][r], O[NBQ + be][r], O[2 * NBQ + be][r], O[3 * NBQ + be][r], Pq, tw_s);
-#pragma unroll
-            for (int r2 = 0; r2 < 4; ++r2) buf[pad(out_pos4<P + 1>(jn, r2))] = Pq[r2];
+        for (int r = 1; r <= 3; ++r) {
+            const float2 c = tw[(m * r * (N / 16)) * (MR_MAXN / N)];      // uniform address: scalar loads
+            fl.c1[r - 1][m - 1] = {c.x, c.y};
         }
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int b = 0; b < NB; ++b)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) R[b][c] = buf[pad(a + L * b + (N / 4) * c)];
-    __builtin_amdgcn_wave_barrier();
+    }
+    fl.t5 = tw_s + a;
 }
 
-// Full transform of the lane-resident frame R (layout above).  Results: Z[i] = bin pos_final<N>(i, a).
+// radix-4 butterfly on (already twiddled) v0..v3
+template <bool INV> __device__ __forceinline__ void bfly4_core(cf v0, cf v1, cf v2, cf v3, cf (&o)[4])
+{
+    const cf a0 = v0 + v2, a1 = v0 - v2, a2 = v1 + v3, d = v1 - v3;
+    o[0] = a0 + a2;
+    o[2] = a0 - a2;
+    o[1] = INV ? add_pi(a1, d) : add_mi(a1, d);               // a1 +- (-+ i) d
+    o[3] = INV ? add_mi(a1, d) : add_pi(a1, d);
+}
+
+// Full transform of the lane-resident frame R (R[b][c] = value at position a + L b + (N/4) c).  Results: Z[i] = bin pos_final<N>(i, a).
 template <int N> __device__ __forceinline__ int pos_final(int i, int a)
 {
     if (N == 1024) return a + 64 * (i >> 2) + 256 * (i & 3);                      // i = 4 b + r
@@ -129,52 +170,98 @@ template <int N> __device__ __forceinline__ int pos_final(int i, int a)
     return a + 32 * ((i >> 2) + 4 * (i & 1)) + 256 * ((i >> 1) & 1);            // 512: i = 4 b + cl + 2 h
 }
 template <int N, bool INV>
-__device__ __forceinline__ void wave_fft(cf (&R)[WF<N>::NB][4], cf (&Z)[WF<N>::E], cf *buf, const float2 *tw_s, int a)
+__device__ __forceinline__ void wave_fft(cf (&R)[WF<N>::NB][4], cf (&Z)[WF<N>::E], const FftLane<N> &fl)
 {
-    constexpr int L = WF<N>::L, NB = WF<N>::NB;
-    fused_pair<N, INV, 0>(R, buf, tw_s, a, [](int q) { return q + (q >> 4); });
-    fused_pair<N, INV, 2>(R, buf, tw_s, a, [](int q) { return q + 16 * (q >> 8); });
+    constexpr int L = WF<N>::L, NB = WF<N>::NB, NBQ = WF<N>::NBQ;
+    cf O[NB][4];
+    // ---- passes 0 (no twiddles) and 1 (uniform twiddles), exchange 1
+#pragma unroll
+    for (int b = 0; b < NB; ++b) bfly4_core<INV>(R[b][0], R[b][1], R[b][2], R[b][3], O[b]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int be = 0; be < NBQ; ++be) {
+            cf v1 = O[NBQ + be][r], v2 = O[2 * NBQ + be][r], v3 = O[3 * NBQ + be][r], Pq[4];
+            if (r > 0) {
+                v1 = cmul_s<INV>(v1, fl.c1[r - 1][0]);
+                v2 = cmul_s<INV>(v2, fl.c1[r - 1][1]);
+                v3 = cmul_s<INV>(v3, fl.c1[r - 1][2]);
+            }
+            bfly4_core<INV>(O[be][r], v1, v2, v3, Pq);
+#pragma unroll
+            for (int r2 = 0; r2 < 4; ++r2) fl.w1[17 * L * be + r + 4 * r2] = Pq[r2];
+        }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) R[b][c] = fl.r1[L * b + (N / 4) * c + ((L * b + (N / 4) * c) >> 4)];
+    __builtin_amdgcn_wave_barrier();
+    // ---- passes 2 (lane twiddles, in registers) and 3, exchange 2
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+        bfly4_core<INV>(R[b][0], cmul_v<INV>(R[b][1], fl.t2[0]), cmul_v<INV>(R[b][2], fl.t2[1]), cmul_v<INV>(R[b][3], fl.t2[2]), O[b]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const cf w1 = fl.t3[0][r * (N / 16)], w2 = fl.t3[1][2 * r * (N / 16)], w3 = fl.t3[2][3 * r * (N / 16)];
+#pragma unroll
+        for (int be = 0; be < NBQ; ++be) {
+            cf Pq[4];
+            bfly4_core<INV>(O[be][r], cmul_v<INV>(O[NBQ + be][r], w1), cmul_v<INV>(O[2 * NBQ + be][r], w2),
+                            cmul_v<INV>(O[3 * NBQ + be][r], w3), Pq);
+#pragma unroll
+            for (int r2 = 0; r2 < 4; ++r2) fl.w2[17 * L * be + 16 * r + 64 * r2] = Pq[r2];
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) R[b][c] = fl.r2[L * b + (N / 4) * c + 16 * ((L * b + (N / 4) * c) >> 8)];
+    __builtin_amdgcn_wave_barrier();
+    // ---- the last pass(es)
     if (N == 1024) {
 #pragma unroll
-        for (int b = 0; b < NB; ++b) {
+        for (int b = 0; b < NB; ++b) {                                      // pass 4: twiddle step a + 64 b
             cf o[4];
-            bfly4<N, INV, 4>(a + L * b, R[b][0], R[b][1], R[b][2], R[b][3], o, tw_s);
+            bfly4_core<INV>(R[b][0], cmul_v<INV>(R[b][1], fl.t4[0][64 * b]), cmul_v<INV>(R[b][2], fl.t4[1][2 * 64 * b]),
+                            cmul_v<INV>(R[b][3], fl.t4[2][3 * 64 * b]), o);
 #pragma unroll
             for (int r = 0; r < 4; ++r) Z[4 * b + r] = o[r];
         }
     } else if (N == 2048) {
-        cf O[NB][4];
 #pragma unroll
-        for (int b = 0; b < NB; ++b) bfly4<N, INV, 4>(a + L * b, R[b][0], R[b][1], R[b][2], R[b][3], O[b], tw_s);
+        for (int b = 0; b < NB; ++b)                                        // pass 4: twiddle step 2 a + 128 (b & 3)
+            bfly4_core<INV>(R[b][0], cmul_v<INV>(R[b][1], fl.t4[0][128 * (b & 3)]), cmul_v<INV>(R[b][2], fl.t4[1][2 * 128 * (b & 3)]),
+                            cmul_v<INV>(R[b][3], fl.t4[2][3 * 128 * (b & 3)]), O[b]);
 #pragma unroll
         for (int b = 0; b < 4; ++b)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {                                   // radix-2, Ns = 1024: j = a + 64 b + 256 r
-                float2 w = tw_s[a + 64 * b + 256 * r];
-                if (INV) w.y = -w.y;
-                const cf v = cmulf(O[(b + 4) % NB][r], {w.x, w.y});
-                Z[4 * b + r] = caddf(O[b][r], v);
-                Z[16 + 4 * b + r] = csubf(O[b][r], v);
+                const cf v = cmul_v<INV>(O[(b + 4) % NB][r], fl.t5[64 * b + 256 * r]);
+                Z[4 * b + r] = O[b][r] + v;
+                Z[16 + 4 * b + r] = O[b][r] - v;
             }
     } else {
 #pragma unroll
         for (int b = 0; b < 4; ++b)
 #pragma unroll
             for (int cl = 0; cl < 2; ++cl) {                                // radix-2, Ns = 256: j = a + 32 (b + 4 cl)
-                float2 w = tw_s[a + 32 * (b + 4 * cl)];
-                if (INV) w.y = -w.y;
-                const cf v = cmulf(R[b % NB][cl + 2], {w.x, w.y});
-                Z[4 * b + cl] = caddf(R[b % NB][cl], v);
-                Z[4 * b + cl + 2] = csubf(R[b % NB][cl], v);
+                const cf v = cmul_v<INV>(R[b % NB][cl + 2], fl.t5[32 * (b + 4 * cl)]);
+                Z[4 * b + cl] = R[b % NB][cl] + v;
+                Z[4 * b + cl + 2] = R[b % NB][cl] - v;
             }
     }
 }
 
 // tw_s[m] = exp(-2 pi i m / N) from the 2048-point table in global memory, once per workgroup
 template <int N>
-__device__ __forceinline__ void stage_twiddles(float2 *tw_s, const float2 *__restrict__ tw)
+__device__ __forceinline__ void stage_twiddles(cf *tw_s, const float2 *__restrict__ tw)
 {
-    for (int m = threadIdx.x; m < N; m += WF<N>::WAVES * 64) tw_s[m] = tw[m * (MR_MAXN / N)];
+    for (int m = threadIdx.x; m < N; m += WF<N>::WAVES * 64) {
+        const float2 w = tw[m * (MR_MAXN / N)];
+        tw_s[m] = {w.x, w.y};
+    }
     __syncthreads();
 }
 
@@ -208,14 +295,34 @@ __device__ __forceinline__ void load_frame(cf (&R)[WF<N>::NB][4], const float *x
         }
 }
 
+// the same with the lane's window values in registers (wv[m] = win[a + L m]; stage-A register (b, c) sits at m = b + (N/4/L) c)
+template <int N, bool INTERIOR>
+__device__ __forceinline__ void load_frame_w(cf (&R)[WF<N>::NB][4], const float *xb, const float *yb, const float (&wv)[WF<N>::E],
+                                             int f, int hop, int T, int a)
+{
+    const float *xf = xb + (f * hop - N / 2 + a), *yf = yb + (f * hop - N / 2 + a);     // dereferenced only when INTERIOR
+#pragma unroll
+    for (int b = 0; b < WF<N>::NB; ++b)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float w = wv[b + (N / 4 / WF<N>::L) * c];
+            if (INTERIOR) {
+                R[b][c] = {xf[WF<N>::L * b + (N / 4) * c] * w, yf[WF<N>::L * b + (N / 4) * c] * w};
+            } else {
+                const int s = reflect_index(f * hop + a + WF<N>::L * b + (N / 4) * c - N / 2, T);
+                R[b][c] = {xb[s] * w, yb[s] * w};
+            }
+        }
+}
+
 // spectra of the two real signals from Z = FFT(x + i y):  X[k] = (Z[k] + conj Z[N-k]) / 2,
 // Y[k] = (Z[k] - conj Z[N-k]) / (2 i)
 template <int N>
 __device__ __forceinline__ void split_bins(const cf *Z, int k, cf &X, cf &Y)
 {
     const cf z = Z[k], zc = Z[(N - k) & (N - 1)];
-    X = {0.5f * (z.re + zc.re), 0.5f * (z.im - zc.im)};
-    Y = {0.5f * (z.im + zc.im), -0.5f * (z.re - zc.re)};
+    X = {0.5f * (z.x + zc.x), 0.5f * (z.y - zc.y)};
+    Y = {0.5f * (z.y + zc.y), -0.5f * (z.x - zc.x)};
 }
 
 // the lane's frame slot of iteration `it`: frame index within the workgroup's MR_FPG frames
@@ -225,23 +332,25 @@ template <int N> __device__ __forceinline__ int frame_slot(int it, int wave, int
 }
 
 // ---- pass A -------------------------------------------------------------------------------------
-template <int N, bool PARK>
+template <int N>
 __global__ __launch_bounds__(WF<N>::WAVES * 64) __attribute__((amdgpu_waves_per_eu(2))) void mr_stats_kernel(const float *__restrict__ x, long long xs,
                                                                      const float *__restrict__ y, long long ys,
                                                                      const float *__restrict__ win,
                                                                      const float2 *__restrict__ tw, int T, int hop,
                                                                      int n_frames, float eps,
-                                                                     double *__restrict__ part, float *__restrict__ park)
+                                                                     double *__restrict__ part)
 {
     constexpr int L = WF<N>::L, E = WF<N>::E, WAVES = WF<N>::WAVES, FW = WF<N>::FW;
     __shared__ cf xbuf[WAVES * FW][WF<N>::LEN];
-    __shared__ float2 tw_s[N];
+    __shared__ cf tw_s[N];
     __shared__ double red[WAVES][3];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane / L, a_ = lane % L;
     const int b = blockIdx.y;
     const float *xb = x + (size_t)b * xs, *yb = y + (size_t)b * ys;
     cf *buf = xbuf[wave * FW + g];
     stage_twiddles<N>(tw_s, tw);
+    FftLane<N> fl;
+    fft_lane_setup<N>(fl, buf, tw_s, tw, a_);
     double s_d = 0.0, s_y = 0.0, s_l = 0.0;
     for (int it = 0; it < MR_FPG / (WAVES * FW); ++it) {
         int a = a_;                                                      // opaque per iteration: see mr_grad_kernel
@@ -262,10 +371,10 @@ __global__ __launch_bounds__(WF<N>::WAVES * 64) __attribute__((amdgpu_waves_per_
 #pragma unroll
         for (int bq = 0; bq < WF<N>::NB; ++bq)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) same_lane = same_lane && R[bq][c].re == R[bq][c].im;
+            for (int c = 0; c < 4; ++c) same_lane = same_lane && R[bq][c].x == R[bq][c].y;
         const unsigned long long same_mask = __ballot(same_lane);
         const bool same = L == 64 ? same_mask == ~0ull : ((same_mask >> (32 * g)) & 0xffffffffull) == 0xffffffffull;
-        wave_fft<N, false>(R, Z, buf, tw_s, a);
+        wave_fft<N, false>(R, Z, fl);
 #pragma unroll
         for (int i = 0; i < E; ++i) buf[pos_final<N>(i, a)] = Z[i];
         __builtin_amdgcn_wave_barrier();
@@ -273,25 +382,20 @@ __global__ __launch_bounds__(WF<N>::WAVES * 64) __attribute__((amdgpu_waves_per_
             // Bin pass.  Hardware square root / log2 (1 ulp; the library versions' range fix-ups were 40 % of this kernel's
             // instructions), log Xm - log Ym = ln2 / 2 * (log2 max(|X|^2, eps) - log2 max(|Y|^2, eps)), Ym^2 = max(|Y|^2, eps),
             // and the frame's <= 9 terms per lane summed in fp32 before they enter the fp64 accumulators.
-            float *pk = PARK ? park + ((size_t)b * n_frames + f) * MR_PARK(N) : nullptr;
             float fd = 0.0f, fy = 0.0f, fl = 0.0f;
-            auto bin = [&](int k, bool last) {
+            auto bin = [&](int k) {
                 cf X, Y;
                 split_bins<N>(buf, k, X, Y);
                 if (same) Y = X;
-                const float cx = fmaxf(X.re * X.re + X.im * X.im, eps), cy = fmaxf(Y.re * Y.re + Y.im * Y.im, eps);
+                const float cx = fmaxf(X.x * X.x + X.y * X.y, eps), cy = fmaxf(Y.x * Y.x + Y.y * Y.y, eps);
                 const float d = __builtin_amdgcn_sqrtf(cy) - __builtin_amdgcn_sqrtf(cx);
                 fd += d * d;
                 fy += cy;
                 fl += fabsf(__builtin_amdgcn_logf(cx) - __builtin_amdgcn_logf(cy));
-                if (PARK) {
-                    if (!last) { pk[k] = X.re; pk[N / 2 + k] = X.im; pk[N + k] = cy; }
-                    else { pk[3 * N / 2] = X.re; pk[3 * N / 2 + 1] = cy; }
-                }
             };
 #pragma unroll
-            for (int j = 0; j < N / 2 / L; ++j) bin(a + L * j, false);
-            if (a == 0) bin(N / 2, true);
+            for (int j = 0; j < N / 2 / L; ++j) bin(a + L * j);
+            if (a == 0) bin(N / 2);
             s_d += (double)fd;
             s_y += (double)fy;
             s_l += (double)(0.5f * 0.69314718055994531f * fl);
@@ -327,297 +431,282 @@ __global__ __launch_bounds__(256) void mr_finish_kernel(const double *__restrict
     const double nd = sqrt(s_d), ny = sqrt(s_y);
     terms[0] = (float)(nd / ny);
     terms[1] = (float)(s_l / (double)count);
-    // d sc / d Xm = (Xm - Ym) / (||Y-X|| * ||Y||);  d logmag / d Xm = sign(log Xm - log Ym) / (count * Xm)
+    // d sc / d Xm = (Xm - Ym) / (||Y-X|| * ||Y||): the scalar alpha of this resolution (0 for identical signals: the exact-zero
+    // gradient of the reference's 0 / 0-free path); d logmag / d Xm = sign(log Xm - log Ym) / (count * Xm) went into G2 already
     coef[0] = nd > 0.0 ? (float)((double)res_scale * w_sc / (nd * ny)) : 0.0f;
-    coef[1] = (float)((double)res_scale * w_log / (double)count);
 }
 
-// ---- pass B -------------------------------------------------------------------------------------
-// d loss / d X of one bin from the parked (Re X, Im X, Ym^2):  d sc / d Xm and d logmag / d Xm as in mr_finish_kernel, times
-// d Xm / d X = X / Xm; the clamp passes no gradient below eps
-__device__ __forceinline__ cf grad_bin(float xr, float xi, float cy, float eps, float c_sc, float c_log)
+// ---- the one-pass value + gradient kernel ------------------------------------------------------------------------
+// s1, s2 with G1 = s1 X, G2 = s2 X (see the file header) and the bin's three loss terms; branch-free; hardware square
+// root / reciprocal / log2 (1 ulp each, no range fix-ups: the library sqrtf, two logf and two divisions were 70 of ~90
+// instructions per bin); Xm and Ym by the same formula, so that X == Y gives exactly 0; the clamp passes no gradient below eps
+struct BinOut { float s1, s2; };
+__device__ __forceinline__ BinOut bin_terms(const cf &X, const cf &Y, float eps, float c_log, float &fd, float &fy, float &fl)
 {
-    // branch-free (a divergent branch per bin would also serialise the bins' loads behind one another); hardware square
-    // root / reciprocal / log2 (1 ulp each, no range fix-ups: the library sqrtf, two logf and two divisions were 70 of
-    // this function's ~90 instructions and most of the kernel); Xm and Ym by the same formula, so that X == Y gives 0
-    const float px = xr * xr + xi * xi;
-    const float cx = fmaxf(px, eps);
+    const float px = X.x * X.x + X.y * X.y;
+    const float cx = fmaxf(px, eps), cy = fmaxf(Y.x * Y.x + Y.y * Y.y, eps);
     const float xm = __builtin_amdgcn_sqrtf(cx), ym = __builtin_amdgcn_sqrtf(cy);
+    const float d = ym - xm;
+    const float dl = __builtin_amdgcn_logf(cx) - __builtin_amdgcn_logf(cy);       // 2 / ln 2 * (log Xm - log Ym)
+    fd += d * d;
+    fy += cy;
+    fl += fabsf(dl);
     const float rx = __builtin_amdgcn_rcpf(xm);
-    const float dl = __builtin_amdgcn_logf(cx) - __builtin_amdgcn_logf(cy);         // sign of log Xm - log Ym
     const float sg = dl > 0.0f ? c_log : (dl < 0.0f ? -c_log : 0.0f);
-    const float dxm = c_sc * (xm - ym) + sg * rx;
-    const float sc = px > eps ? dxm * rx : 0.0f;
-    return {sc * xr, sc * xi};                                          // dL/dRe X, dL/dIm X
+    const bool pass = px > eps;
+    return {pass ? (xm - ym) * rx : 0.0f, pass ? sg * rx * rx : 0.0f};
 }
 
-#ifndef MR_GRAD2048_EU
-#define MR_GRAD2048_EU 2
-#endif
+template <int N> struct OP {
+    static constexpr int L = WF<N>::L, E = WF<N>::E, NB = WF<N>::NB, FW = WF<N>::FW;
+    static constexpr int STREAMS = MR_OPW * FW;                  // runs a workgroup works on
+    static constexpr int NBIN = N / 2 / L;                      // bins per lane (plus the Nyquist bin on lane 0): 8, 8, 16
+    static constexpr size_t lds_bytes() { return (size_t)N * 8 + (size_t)STREAMS * WF<N>::LEN * 8 + (size_t)STREAMS * 2 * N * 4 + MR_OPW * 3 * 8; }
+};
+// window position index m of a lane: position a + L m.  Stage-A register (b, c) and final result i sit at these m:
+template <int N> __device__ __forceinline__ constexpr int m_of_in(int b, int c) { return b + (N / 4 / WF<N>::L) * c; }
+template <int N> __device__ __forceinline__ constexpr int m_of_out(int i) { return (pos_final<N>(i, 0)) / WF<N>::L; }
+
 template <int N>
-__global__ __launch_bounds__(WF<N>::WAVES * 64) __attribute__((amdgpu_waves_per_eu(N == 2048 ? MR_GRAD2048_EU : 2))) void mr_grad_kernel(const float *__restrict__ park,
-                                                                    const float *__restrict__ win,
-                                                                    const float2 *__restrict__ tw, int n_frames, float eps,
-                                                                    const float *__restrict__ coef,
-                                                                    float *__restrict__ scratch)
+__global__ __launch_bounds__(MR_OPW * 64) __attribute__((amdgpu_waves_per_eu(N == 2048 ? 1 : MR_OP_EU))) void mr_onepass_kernel(
+    const float *__restrict__ x, long long xs, const float *__restrict__ y, long long ys, const float *__restrict__ win,
+    const float2 *__restrict__ tw, int T, int hop, int n_frames, int F, int n_runs, float eps, float c_log,
+    double *__restrict__ part, float *__restrict__ main1, float *__restrict__ main2, float *__restrict__ tails)
 {
-    constexpr int L = WF<N>::L, E = WF<N>::E, NB = WF<N>::NB, WAVES = WF<N>::WAVES, FW = WF<N>::FW, P = MR_PARK(N);
-    __shared__ cf xbuf[WAVES * FW][WF<N>::LEN];
-    __shared__ float2 tw_s[N];
+    constexpr int L = OP<N>::L, E = OP<N>::E, NB = OP<N>::NB, FW = OP<N>::FW, STREAMS = OP<N>::STREAMS, NBIN = OP<N>::NBIN;
+    extern __shared__ __attribute__((aligned(16))) unsigned char op_smem[];
+    cf *tw_s = reinterpret_cast<cf *>(op_smem);
+    cf *xbuf = reinterpret_cast<cf *>(op_smem + (size_t)N * 8);
+    float *rings = reinterpret_cast<float *>(op_smem + (size_t)N * 8 + (size_t)STREAMS * WF<N>::LEN * 8);
+    double *red = reinterpret_cast<double *>(op_smem + (size_t)N * 8 + (size_t)STREAMS * WF<N>::LEN * 8 + (size_t)STREAMS * 2 * N * 4);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane / L, a_ = lane % L;
-    const int b = blockIdx.y;
-    const float c_sc = coef[0], c_log = coef[1];
-    cf *buf = xbuf[wave * FW + g];
-    stage_twiddles<N>(tw_s, tw);
-    for (int it = 0; it < MR_FPG / (2 * WAVES * FW); ++it) {
-        // the lane's position is opaque to the optimiser in every iteration: otherwise each of the ~100 window / parked-bin /
-        // output addresses built from it is loop invariant, gets hoisted out of the frame loop and, for N = 2048 (all 256
-        // registers taken by the transform), lives in scratch memory (89 spilled registers)
-        int a = a_;
-        asm volatile("" : "+v"(a));
-        // frames 2 p and 2 p + 1 share a transform
-        const int p = blockIdx.x * (MR_FPG / 2) + (it * WAVES + wave) * FW + g;
-        if (2 * (p - g) >= n_frames) break;                             // wave-uniform (pairs of a wave are p - g, p - g + 1)
-        const int f0 = 2 * p, f1 = 2 * p + 1;
-        const bool live0 = f0 < n_frames, live1 = f1 < n_frames;
-        const float *s0 = park + ((size_t)b * n_frames + (live0 ? f0 : n_frames - 1)) * P;
-        const float *s1 = park + ((size_t)b * n_frames + (live1 ? f1 : n_frames - 1)) * P;
-        const float m0 = live0 ? 1.0f : 0.0f, m1 = live1 ? 1.0f : 0.0f;
-        cf R[NB][4], Z[E];
-        // H = G~_a + i G~_b at the positions this lane feeds into the inverse transform (a + L b + (N/4) c): the lower half
-        // (c < 2) from the lane's own bins, which also leave their mirror images (conj G_a + i conj G_b) / 2 in the wave's
-        // exchange buffer for the lanes that feed the upper half
+    const int b = blockIdx.y, sidx = wave * FW + g;
+    const float *xb = x + (size_t)b * xs, *yb = y + (size_t)b * ys;
+    cf *buf = xbuf + (size_t)sidx * WF<N>::LEN;
+    float *ring1 = rings + (size_t)sidx * 2 * N, *ring2 = ring1 + N;
+    for (int m = threadIdx.x; m < N; m += MR_OPW * 64) {
+        const float2 w = tw[m * (MR_MAXN / N)];
+        tw_s[m] = {w.x, w.y};
+    }
+    for (int j = a_; j < 2 * N; j += L) ring1[j] = 0.0f;
+    __syncthreads();
+    FftLane<N> fl;
+    fft_lane_setup<N>(fl, buf, tw_s, tw, a_);
+
+    const int run = blockIdx.x * STREAMS + sidx;
+    const int f_begin = run * F, f_end = min(f_begin + F, n_frames);          // (an idle stream: f_begin >= f_end)
+    const int tail_len = N > hop ? N - hop : 0;
+    float wv[E];                                                              // the lane's window values: positions a + L m
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
+    for (int m = 0; m < E; ++m) wv[m] = win[a_ + L * m];
+    double s_d = 0.0, s_y = 0.0, s_l = 0.0;
+    int base = 0;                                                             // ring slot of the current frame's position 0
+
+    // windowed gradient frame -> ring (read - add - write, 16 / 32 values a lane; LDS operations of a wave execute in order),
+    // then the frame's first `hop` positions leave the ring for memory
+    auto add_and_flush = [&](float *ring, float *mainp, const cf (&Z)[E], bool imag, int f, bool live, int a, int bs) {
+        float old[E];
 #pragma unroll
-            for (int b0 = 0; b0 < NB; b0 += 4) {
-                float v0[4][3], v1[4][3];                                // the loads of four bin pairs first: 24 requests in flight
-#pragma unroll
-                for (int bq = 0; bq < 4; ++bq)
-#pragma unroll
-                    for (int q = 0; q < 3; ++q) {
-                        const int k = a + L * (b0 + bq) + (N / 4) * c;
-                        v0[bq][q] = s0[q * (N / 2) + k];
-                        v1[bq][q] = s1[q * (N / 2) + k];
-                    }
-#pragma unroll
-                for (int bq = 0; bq < 4; ++bq) {
-                    const int k = a + L * (b0 + bq) + (N / 4) * c;
-                    cf ga = grad_bin(v0[bq][0], v0[bq][1], v0[bq][2], eps, c_sc, c_log);
-                    cf gb = grad_bin(v1[bq][0], v1[bq][1], v1[bq][2], eps, c_sc, c_log);
-                    ga = {m0 * ga.re, m0 * ga.im};
-                    gb = {m1 * gb.re, m1 * gb.im};
-                    const cf h = {0.5f * (ga.re - gb.im), 0.5f * (ga.im + gb.re)};
-                    R[b0 + bq][c] = (b0 + bq == 0 && c == 0 && a == 0) ? cf{ga.re, gb.re} : h;   // DC: real, not halved
-                    buf[N - k] = {0.5f * (ga.re + gb.im), 0.5f * (gb.re - ga.im)};  // (k = 0 lands in the pad: never read)
-                }
-            }
-        if (a == 0) {                                                    // Nyquist: real, not halved
-            const cf ga = grad_bin(s0[3 * N / 2], 0.0f, s0[3 * N / 2 + 1], eps, c_sc, c_log);
-            const cf gb = grad_bin(s1[3 * N / 2], 0.0f, s1[3 * N / 2 + 1], eps, c_sc, c_log);
-            buf[N / 2] = {m0 * ga.re, m1 * gb.re};
-        }
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int bq = 0; bq < NB; ++bq)
-#pragma unroll
-            for (int c = 2; c < 4; ++c) R[bq][c] = buf[a + L * bq + (N / 4) * c];
-        __builtin_amdgcn_wave_barrier();
-        // dx_a[n] + i dx_b[n] = sum_k H[k] e^{+2 pi i k n / N}: the adjoint of the one-sided DFT for both frames at once
-        wave_fft<N, true>(R, Z, buf, tw_s, a);
-        // (overlap-adding a workgroup's 16 frames in LDS and writing one span instead was measured: the fold pass
-        // fell from 1.7 to 0.6 ms but this kernel lost 1.5-2 ms to the read-modify-writes and the lower occupancy)
-        float *out0 = scratch + ((size_t)b * n_frames + f0) * N, *out1 = out0 + N;
+        for (int i = 0; i < E; ++i) old[i] = ring[(bs + pos_final<N>(i, a)) & (N - 1)];
 #pragma unroll
         for (int i = 0; i < E; ++i) {
-            const int n = pos_final<N>(i, a);
-            const float w = win[n];
-            if (live0) out0[n] = Z[i].re * w;
-            if (live1) out1[n] = Z[i].im * w;
+            const float v = (imag ? Z[i].y : Z[i].x) * wv[m_of_out<N>(i)];
+            ring[(bs + pos_final<N>(i, a)) & (N - 1)] = live ? old[i] + v : old[i];
         }
-    }
-}
+        __builtin_amdgcn_wave_barrier();
+        if (live) {
+            float *o = mainp + (size_t)f * hop;
+            for (int j = a; j < hop; j += L) {
+                float v = 0.0f;
+                if (j < N) {
+                    v = ring[(bs + j) & (N - 1)];
+                    ring[(bs + j) & (N - 1)] = 0.0f;
+                }
+                o[j] = v;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
 
-// Pass B for 512 / 1024 with the overlap-add started in LDS.  A wavefront takes MR_SPAN_FRAMES CONSECUTIVE frames and adds
-// their windowed gradients into a wave-private span of (MR_SPAN_FRAMES - 1) hop + N samples (read - add - write in frame order:
-// no barrier, nothing shared between waves, deterministic); the span is what reaches HBM -- 1 864 instead of 8 192 floats per
-// eight 1024-point frames -- and the fold pass gathers one or two span values per sample instead of 8.5 frame values (fold
-// 0.35 -> 0.19 ms, this pass 0.78 -> 0.72 ms for 1024).  Two things measured on the way: the LDS fp32 atomic (ds_add_f32) in
-// place of the plain read - add - write made this pass 3x slower (2.4 ms); requesting the next pair's parked bins before the
-// current pair's transform (52 more registers) changed nothing (7.27 against 7.18 ms for the three resolutions).
-// 2048 keeps whole frames (mr_grad_kernel): its span would leave one wavefront per SIMD.
-#define MR_SPAN_FRAMES 8
-#define MR_SPAN_LEN(N, hop) ((MR_SPAN_FRAMES - 1) * (hop) + (N))
-#define MR_SPAN_MAX_HOP 128      // auraloss: 50 and 120; larger hops take the frame version
-template <int N>
-__global__ __launch_bounds__(WF<N>::WAVES * 64) __attribute__((amdgpu_waves_per_eu(2))) void mr_grad_span_kernel(
-    const float *__restrict__ park, const float *__restrict__ win, const float2 *__restrict__ tw, int n_frames, int hop, float eps,
-    const float *__restrict__ coef, float *__restrict__ scratch)
-{
-    constexpr int L = WF<N>::L, E = WF<N>::E, NB = WF<N>::NB, WAVES = WF<N>::WAVES, FW = WF<N>::FW, P = MR_PARK(N);
-    constexpr int ITERS = MR_SPAN_FRAMES / (2 * FW);
-    static_assert(NB == 4, "512 / 1024 only");
-    __shared__ cf xbuf[WAVES * FW][WF<N>::LEN];
-    __shared__ float2 tw_s[N];
-    extern __shared__ float span_s[];                                   // WAVES x S floats
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane / L, a_ = lane % L;
-    const int b = blockIdx.y;
-    const float c_sc = coef[0], c_log = coef[1];
-    cf *buf = xbuf[wave * FW + g];
-    const int S = MR_SPAN_LEN(N, hop);
-    float *span = span_s + wave * S;
-    stage_twiddles<N>(tw_s, tw);
-    const int fs = (blockIdx.x * WAVES + wave) * MR_SPAN_FRAMES;       // the wave's frames: fs .. fs + MR_SPAN_FRAMES - 1
-    if (fs >= n_frames) return;                                         // (behind the kernel's only workgroup barrier)
-    for (int j = lane; j < S; j += 64) span[j] = 0.0f;
-
-    float pk[2][2][NB][3], ny[2][2];                                    // parked bins of a frame pair: [frame][c][bq][Re X, Im X, Ym^2]
-    auto load_pair = [&](int it, int a) {
-        const int p = fs / 2 + it * FW + g, f0 = 2 * p, f1 = 2 * p + 1;
-        const float *s0 = park + ((size_t)b * n_frames + (f0 < n_frames ? f0 : n_frames - 1)) * P;
-        const float *s1 = park + ((size_t)b * n_frames + (f1 < n_frames ? f1 : n_frames - 1)) * P;
+    float *m1 = main1 + (size_t)b * n_frames * hop, *m2 = main2 + (size_t)b * n_frames * hop;
+    for (int fp = 0; fp < F; fp += 2) {
+        // the lane's position is made opaque to the optimiser again before every transform: the ~100 twiddle / exchange /
+        // window addresses built from it would otherwise be shared by the iteration's four transforms (and hoisted out of the
+        // frame loop) and live in scratch memory (21 / 30 spilled registers for N = 1024 / 2048)
+#ifndef MR_NO_OPAQUE
+#define MR_OPAQUE(v) asm volatile("" : "+v"(v))
+#else
+#define MR_OPAQUE(v)
+#endif
+        int a = a_;
+        asm volatile("" : "+v"(a));
+        const int f0 = f_begin + fp, f1 = f0 + 1;
+        if (__ballot(f0 < f_end) == 0ull) break;                               // every stream of the wavefront is done
+        const bool live0 = f0 < f_end, live1 = f1 < f_end;
+        cf ga1[NBIN], ga2[NBIN];                                               // G1, G2 of frame f0 at the lane's bins
+        float ny1a = 0.0f, ny2a = 0.0f;                                        // ... and at the Nyquist bin (real; lane 0)
+        cf R[NB][4], Z[E];
+        cf h2[NBIN], h2m[NBIN];                                                // second transform's input: lower half, mirrored upper half
+        float h2ny_re = 0.0f, h2ny_im = 0.0f;
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
+        for (int u = 0; u < 2; ++u) {
+            const int f = u ? f1 : f0;
+            const bool live = u ? live1 : live0;
+            const int fl_ = live ? f : (n_frames - 1);                         // dead slots transform a valid frame and contribute nothing
+            {
+                // interior (decided for the whole wavefront: a per-position test would put every load in a basic block of its own):
+                // no position of the frame needs the reflection arithmetic, the loads are one base pointer + constant offsets
+                const bool inter_lane = fl_ * hop - N / 2 >= 0 && fl_ * hop + N / 2 <= T;
+                if (__ballot(!inter_lane) == 0ull) load_frame_w<N, true>(R, xb, yb, wv, fl_, hop, T, a);
+                else load_frame_w<N, false>(R, xb, yb, wv, fl_, hop, T, a);
+            }
+            bool same_lane = true;
 #pragma unroll
             for (int bq = 0; bq < NB; ++bq)
 #pragma unroll
-                for (int q = 0; q < 3; ++q) {
-                    const int k = a + L * bq + (N / 4) * c;
-                    pk[0][c][bq][q] = s0[q * (N / 2) + k];
-                    pk[1][c][bq][q] = s1[q * (N / 2) + k];
+                for (int c = 0; c < 4; ++c) same_lane = same_lane && R[bq][c].x == R[bq][c].y;
+            const unsigned long long same_mask = __ballot(same_lane);
+            const bool same = L == 64 ? same_mask == ~0ull : ((same_mask >> (32 * g)) & 0xffffffffull) == 0xffffffffull;
+            wave_fft<N, false>(R, Z, fl);
+#pragma unroll
+            for (int i = 0; i < E; ++i) buf[pos_final<N>(i, a)] = Z[i];
+            __builtin_amdgcn_wave_barrier();
+            float fd = 0.0f, fy = 0.0f, fl = 0.0f;
+            const float lm = live ? 1.0f : 0.0f;
+#pragma unroll
+            for (int j = 0; j < NBIN; ++j) {
+                const int k = a + L * j;
+                cf X, Y;
+                split_bins<N>(buf, k, X, Y);
+                if (same) Y = X;
+                const BinOut t = bin_terms(X, Y, eps, c_log, fd, fy, fl);
+                const float s1 = lm * t.s1, s2 = lm * t.s2;
+                const cf g1 = {s1 * X.x, s1 * X.y}, g2 = {s2 * X.x, s2 * X.y};
+                if (u == 0) {
+                    ga1[j] = g1;
+                    ga2[j] = g2;
+                } else {
+                    // H = G~_a + i G~_b of the pair at position k (lower half) and its mirror image at N - k: G~[k] = G[k] / 2,
+                    // G~[N - k] = conj G[k] / 2, DC real and not halved
+                    const cf p1 = ga1[j], p2 = ga2[j];
+                    const bool dc = (j == 0) && (a == 0);
+                    R[j % NB][j / NB] = dc ? cf{p1.x, g1.x} : cf{0.5f * (p1.x - g1.y), 0.5f * (p1.y + g1.x)};
+                    buf[N - k] = {0.5f * (p1.x + g1.y), 0.5f * (g1.x - p1.y)};      // (k = 0 lands in the pad: never read)
+                    h2[j] = dc ? cf{p2.x, g2.x} : cf{0.5f * (p2.x - g2.y), 0.5f * (p2.y + g2.x)};
+                    h2m[j] = {0.5f * (p2.x + g2.y), 0.5f * (g2.x - p2.y)};
                 }
-        ny[0][0] = s0[3 * N / 2]; ny[0][1] = s0[3 * N / 2 + 1];
-        ny[1][0] = s1[3 * N / 2]; ny[1][1] = s1[3 * N / 2 + 1];
-    };
-    for (int it = 0; it < ITERS; ++it) {
-        int a = a_;                                                      // opaque per iteration (see mr_grad_kernel)
-        asm volatile("" : "+v"(a));
-        load_pair(it, a);
-        const int p = fs / 2 + it * FW + g;
-        if (2 * (p - g) >= n_frames) break;                             // wave-uniform
-        const int f0 = 2 * p, f1 = 2 * p + 1;
-        const bool live0 = f0 < n_frames, live1 = f1 < n_frames;
-        const float m0 = live0 ? 1.0f : 0.0f, m1 = live1 ? 1.0f : 0.0f;
-        cf R[NB][4], Z[E];
-        // H = G~_a + i G~_b exactly as in mr_grad_kernel
-#pragma unroll
-        for (int c = 0; c < 2; ++c)
-#pragma unroll
-            for (int bq = 0; bq < NB; ++bq) {
-                const int k = a + L * bq + (N / 4) * c;
-                cf ga = grad_bin(pk[0][c][bq][0], pk[0][c][bq][1], pk[0][c][bq][2], eps, c_sc, c_log);
-                cf gb = grad_bin(pk[1][c][bq][0], pk[1][c][bq][1], pk[1][c][bq][2], eps, c_sc, c_log);
-                ga = {m0 * ga.re, m0 * ga.im};
-                gb = {m1 * gb.re, m1 * gb.im};
-                const cf h = {0.5f * (ga.re - gb.im), 0.5f * (ga.im + gb.re)};
-                R[bq][c] = (bq == 0 && c == 0 && a == 0) ? cf{ga.re, gb.re} : h;
-                buf[N - k] = {0.5f * (ga.re + gb.im), 0.5f * (gb.re - ga.im)};
             }
-        if (a == 0) {
-            const cf ga = grad_bin(ny[0][0], 0.0f, ny[0][1], eps, c_sc, c_log);
-            const cf gb = grad_bin(ny[1][0], 0.0f, ny[1][1], eps, c_sc, c_log);
-            buf[N / 2] = {m0 * ga.re, m1 * gb.re};
+            if (a == 0) {                                                       // Nyquist bin: real, not halved
+                cf X, Y;
+                split_bins<N>(buf, N / 2, X, Y);
+                if (same) Y = X;
+                X.y = 0.0f;
+                Y.y = 0.0f;
+                const BinOut t = bin_terms(X, Y, eps, c_log, fd, fy, fl);
+                const float n1 = lm * t.s1 * X.x, n2 = lm * t.s2 * X.x;
+                if (u == 0) { ny1a = n1; ny2a = n2; }
+                else { buf[N / 2] = {ny1a, n1}; h2ny_re = ny2a; h2ny_im = n2; }
+            }
+            if (live) {
+                s_d += (double)fd;
+                s_y += (double)fy;
+                s_l += (double)(0.5f * 0.69314718055994531f * fl);
+            }
+            __builtin_amdgcn_wave_barrier();
         }
+        // ---- G1 of both frames: one inverse transform, overlap-add
+#pragma unroll
+        for (int bq = 0; bq < NB; ++bq)
+#pragma unroll
+            for (int c = 2; c < 4; ++c) R[bq][c] = buf[a + L * bq + (N / 4) * c];
+        __builtin_amdgcn_wave_barrier();
+        wave_fft<N, true>(R, Z, fl);
+        MR_OPAQUE(a);
+        add_and_flush(ring1, m1, Z, false, f0, live0, a, base);
+        add_and_flush(ring1, m1, Z, true, f1, live1, a, (base + hop) & (N - 1));
+        // ---- G2
+#pragma unroll
+        for (int j = 0; j < NBIN; ++j) {
+            R[j % NB][j / NB] = h2[j];
+            buf[N - (a + L * j)] = h2m[j];
+        }
+        if (a == 0) buf[N / 2] = {h2ny_re, h2ny_im};
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int bq = 0; bq < NB; ++bq)
 #pragma unroll
             for (int c = 2; c < 4; ++c) R[bq][c] = buf[a + L * bq + (N / 4) * c];
         __builtin_amdgcn_wave_barrier();
-        wave_fft<N, true>(R, Z, buf, tw_s, a);
-        // frame order inside the wave: (half 0: f0, f1), then (half 1: f0, f1) -- two lanes of one ds_add never meet in one
-        // slot, and every slot receives its frames in ascending order
-        // (plain read - add - write, 16 values at a time: LDS operations of a wave execute in order; the LDS fp32 atomic
-        // ds_add_f32 is an order of magnitude slower than the three plain instructions)
-        float *sp0 = span + (f0 - fs) * hop;
-#pragma unroll
-        for (int h = 0; h < FW; ++h) {
-            if (g == h) {
-#pragma unroll
-                for (int fr = 0; fr < 2; ++fr) {
-                    float *sp = sp0 + fr * hop;
-                    const float mm = fr ? m1 : m0;
-                    float old[E];
-#pragma unroll
-                    for (int i = 0; i < E; ++i) old[i] = sp[pos_final<N>(i, a)];
-#pragma unroll
-                    for (int i = 0; i < E; ++i) {
-                        const int n = pos_final<N>(i, a);
-                        sp[n] = old[i] + mm * ((fr ? Z[i].im : Z[i].re) * win[n]);
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                }
-            }
+        wave_fft<N, true>(R, Z, fl);
+        MR_OPAQUE(a);
+        add_and_flush(ring2, m2, Z, false, f0, live0, a, base);
+        add_and_flush(ring2, m2, Z, true, f1, live1, a, (base + hop) & (N - 1));
+        base = (base + 2 * hop) & (N - 1);
+    }
+    // the run's tail: positions [f_end * hop, f_end * hop + N - hop) as far as this run's frames reach them
+    if (f_begin < f_end) {
+        const int bs = ((f_end - f_begin) * hop) & (N - 1);
+        float *t1 = tails + ((size_t)b * n_runs + run) * 2 * tail_len, *t2 = t1 + tail_len;
+        for (int j = a_; j < tail_len; j += L) {
+            t1[j] = ring1[(bs + j) & (N - 1)];
+            t2[j] = ring2[(bs + j) & (N - 1)];
         }
     }
-    __builtin_amdgcn_wave_barrier();
-    // spans that hold a frame: ceil(n_frames / MR_SPAN_FRAMES) per clip -- with T > N / 2 (the reflect padding's condition) they
-    // never need more room than the n_frames x N floats of the whole-frame layout, behind which the parked bins start
-    const int n_spans = (n_frames + MR_SPAN_FRAMES - 1) / MR_SPAN_FRAMES;
-    float *out = scratch + ((size_t)b * n_spans + (blockIdx.x * WAVES + wave)) * S;
-    for (int j = lane; j < S; j += 64) out[j] = span[j];
+    s_d = wave_sum_f64(s_d); s_y = wave_sum_f64(s_y); s_l = wave_sum_f64(s_l);
+    if (lane == 0) { red[wave * 3] = s_d; red[wave * 3 + 1] = s_y; red[wave * 3 + 2] = s_l; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        double acc = 0.0;
+        for (int w = 0; w < MR_OPW; ++w) acc += red[w * 3 + threadIdx.x];
+        part[((size_t)b * gridDim.x + blockIdx.x) * 3 + threadIdx.x] = acc;
+    }
 }
 
-// ---- pass C -------------------------------------------------------------------------------------
-template <int N>
-__global__ __launch_bounds__(256) void mr_fold_kernel(const float *__restrict__ scratch, int T, int hop,
-                                                      int n_frames, int accumulate, float *__restrict__ dx,
-                                                      long long ds)
+// ---- fold ---------------------------------------------------------------------------------------------------------
+struct FoldRes {
+    const float *main1, *main2, *tails, *alpha;       // (B, n_frames * hop) x 2, (B, n_runs, 2, tail_len), scalar
+    int N, hop, n_frames, F, n_runs, tail_len;
+};
+struct FoldArgs { FoldRes r[4]; int n_res; };
+
+// g1, g2 of resolution r at padded position p of clip b: the run sums plus the tails of the runs that end before p and reach it
+__device__ __forceinline__ void fold_pos(const FoldRes &r, int b, int p, float &g1, float &g2)
+{
+    const int flushed = r.n_frames * r.hop;
+    if (p < flushed) {
+        g1 += r.main1[(size_t)b * flushed + p];
+        g2 += r.main2[(size_t)b * flushed + p];
+    }
+    if (r.tail_len == 0) return;
+    int rho = p / (r.F * r.hop);
+    if (rho > r.n_runs - 1) rho = r.n_runs - 1;
+    for (int q = rho; q >= 0 && q >= rho - 2; --q) {
+        int fe = (q + 1) * r.F;
+        if (fe > r.n_frames) fe = r.n_frames;
+        const int j = p - fe * r.hop;
+        if (j >= 0 && j < r.tail_len) {
+            const float *t = r.tails + ((size_t)b * r.n_runs + q) * 2 * r.tail_len;
+            g1 += t[j];
+            g2 += t[r.tail_len + j];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void mr_fold_all_kernel(FoldArgs fa, int T, int accumulate, float *__restrict__ dx, long long ds)
 {
     const int b = blockIdx.y;
     const int n = blockIdx.x * 256 + threadIdx.x;
     if (n >= T) return;
-    const float *sb = scratch + (size_t)b * n_frames * N;
-    // padded positions that map to sample n: the direct one and up to two reflected ones
-    int pos[3], np = 0;
-    pos[np++] = n + N / 2;
-    if (n >= 1 && n <= N / 2) pos[np++] = N / 2 - n;
-    if (n <= T - 2 && n >= T - 1 - N / 2) pos[np++] = N / 2 + 2 * (T - 1) - n;
     float acc = 0.0f;
-    for (int i = 0; i < np; ++i) {
-        const int p = pos[i];
-        int f_hi = p / hop;
-        if (f_hi > n_frames - 1) f_hi = n_frames - 1;
-        int f_lo = (p - N + hop) / hop;                                 // ceil((p - N + 1) / hop)
-        if (p - N + 1 <= 0) f_lo = 0;
-        // same summation order as a plain loop, four loads in flight
-        const float *q = sb + (size_t)f_lo * N + (p - f_lo * hop);
-        const int step = N - hop;
-        int f = f_lo;
-        for (; f + 3 <= f_hi; f += 4, q += 4 * (size_t)step) {
-            const float a0 = q[0], a1 = q[step], a2 = q[2 * (size_t)step], a3 = q[3 * (size_t)step];
-            acc += a0; acc += a1; acc += a2; acc += a3;
-        }
-        for (; f <= f_hi; ++f, q += step) acc += q[0];
-    }
-    float *o = dx + (size_t)b * ds + n;
-    *o = accumulate ? *o + acc : acc;
-}
-
-// the same gather over the wave spans of mr_grad_span_kernel: span s holds frames [s F, s F + F) of its clip added up at padded
-// positions s F hop + j, j < (F - 1) hop + N, F = MR_SPAN_FRAMES
-template <int N>
-__global__ __launch_bounds__(256) void mr_fold_span_kernel(const float *__restrict__ scratch, int T, int hop,
-                                                           int n_frames, int n_spans, int accumulate,
-                                                           float *__restrict__ dx, long long ds)
-{
-    const int b = blockIdx.y;
-    const int n = blockIdx.x * 256 + threadIdx.x;
-    if (n >= T) return;
-    const int S = MR_SPAN_LEN(N, hop), FH = MR_SPAN_FRAMES * hop;
-    const float *sb = scratch + (size_t)b * n_spans * S;
-    int pos[3], np = 0;
-    pos[np++] = n + N / 2;
-    if (n >= 1 && n <= N / 2) pos[np++] = N / 2 - n;
-    if (n <= T - 2 && n >= T - 1 - N / 2) pos[np++] = N / 2 + 2 * (T - 1) - n;
-    float acc = 0.0f;
-    for (int i = 0; i < np; ++i) {
-        const int p = pos[i];
-        int f_hi = p / hop;
-        if (f_hi > n_frames - 1) f_hi = n_frames - 1;
-        int f_lo = (p - N + hop) / hop;                                 // ceil((p - N + 1) / hop)
-        if (p - N + 1 <= 0) f_lo = 0;
-        for (int sp = f_lo / MR_SPAN_FRAMES; sp <= f_hi / MR_SPAN_FRAMES; ++sp) acc += sb[(size_t)sp * S + (p - sp * FH)];
+    for (int ri = 0; ri < fa.n_res; ++ri) {
+        const FoldRes &r = fa.r[ri];
+        const int N = r.N;
+        float g1 = 0.0f, g2 = 0.0f;
+        // padded positions that map to sample n: the direct one and up to two reflected ones
+        fold_pos(r, b, n + N / 2, g1, g2);
+        if (n >= 1 && n <= N / 2) fold_pos(r, b, N / 2 - n, g1, g2);
+        if (n <= T - 2 && n >= T - 1 - N / 2) fold_pos(r, b, N / 2 + 2 * (T - 1) - n, g1, g2);
+        acc += r.alpha[0] * g1 + g2;
     }
     float *o = dx + (size_t)b * ds + n;
     *o = accumulate ? *o + acc : acc;
@@ -631,55 +720,61 @@ __global__ void mr_total_kernel(float *__restrict__ terms, int n_res, float w_sc
     terms[2 * n_res] = tot / (float)n_res;
 }
 
+static int mr_run_frames(int N, int hop)
+{
+    int F = (N + hop - 1) / hop;
+    if (F < MR_RUN_MIN) F = MR_RUN_MIN;
+    return (F + 1) & ~1;
+}
+
+// value only
 template <int N>
-static int run_resolution(const float *x, long long xs, const float *y, long long ys, const float *win,
-                          const float2 *tw, int B, int T, int hop, float eps, float w_sc, float w_log,
-                          float res_scale, double *part, float *terms, float *coef, float *scratch, float *dx,
-                          long long ds, int accumulate, hipStream_t st)
+static int run_stats(const float *x, long long xs, const float *y, long long ys, const float *win, const float2 *tw, int B, int T,
+                     int hop, float eps, float w_sc, float w_log, float res_scale, double *part, float *terms, float *coef,
+                     hipStream_t st)
 {
     const int n_frames = 1 + T / hop;
     const int groups = (n_frames + MR_FPG - 1) / MR_FPG;
-    // scratch = [ time-domain gradient frames | parked bins ]
-    float *park = scratch ? scratch + (size_t)B * n_frames * N : nullptr;
-    if (dx)
-        hipLaunchKernelGGL((mr_stats_kernel<N, true>), dim3(groups, B), dim3(WF<N>::WAVES * 64), 0, st, x, xs, y, ys, win, tw,
-                           T, hop, n_frames, eps, part, park);
-    else
-        hipLaunchKernelGGL((mr_stats_kernel<N, false>), dim3(groups, B), dim3(WF<N>::WAVES * 64), 0, st, x, xs, y, ys, win,
-                           tw, T, hop, n_frames, eps, part, (float *)nullptr);
+    hipLaunchKernelGGL((mr_stats_kernel<N>), dim3(groups, B), dim3(WF<N>::WAVES * 64), 0, st, x, xs, y, ys, win, tw, T, hop,
+                       n_frames, eps, part);
     const long long count = (long long)B * n_frames * (N / 2 + 1);
-    hipLaunchKernelGGL(mr_finish_kernel, dim3(1), dim3(256), 0, st, part, groups * B, count, w_sc, w_log, res_scale,
-                       terms, coef);
-    if (dx) {
-        bool spans = false;
-        if constexpr (N != 2048) {
-            if (hop <= MR_SPAN_MAX_HOP) {
-                spans = true;
-                const int ggroups = (n_frames + MR_SPAN_FRAMES * WF<N>::WAVES - 1) / (MR_SPAN_FRAMES * WF<N>::WAVES);
-                const size_t span_bytes = (size_t)WF<N>::WAVES * MR_SPAN_LEN(N, hop) * sizeof(float);
-                static bool attr_set[64];                               // static + dynamic LDS exceeds 64 KB for 1024
-                int dev = 0;
-                (void)hipGetDevice(&dev);
-                if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-                    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mr_grad_span_kernel<N>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize,
-                                              (int)(WF<N>::WAVES * MR_SPAN_LEN(N, MR_SPAN_MAX_HOP) * sizeof(float)));
-                    if (dev >= 0 && dev < 64) attr_set[dev] = true;
-                }
-                hipLaunchKernelGGL((mr_grad_span_kernel<N>), dim3(ggroups, B), dim3(WF<N>::WAVES * 64), span_bytes, st, park, win,
-                                   tw, n_frames, hop, eps, coef, scratch);
-                hipLaunchKernelGGL((mr_fold_span_kernel<N>), dim3((T + 255) / 256, B), dim3(256), 0, st, scratch, T, hop,
-                                   n_frames, (n_frames + MR_SPAN_FRAMES - 1) / MR_SPAN_FRAMES, accumulate, dx, ds);
-            }
-        }
-        if (!spans) {
-            hipLaunchKernelGGL((mr_grad_kernel<N>), dim3(groups, B), dim3(WF<N>::WAVES * 64), 0, st, park, win, tw, n_frames, eps,
-                               coef, scratch);
-            hipLaunchKernelGGL((mr_fold_kernel<N>), dim3((T + 255) / 256, B), dim3(256), 0, st, scratch, T, hop, n_frames,
-                               accumulate, dx, ds);
-        }
-    }
+    hipLaunchKernelGGL(mr_finish_kernel, dim3(1), dim3(256), 0, st, part, groups * B, count, w_sc, w_log, res_scale, terms, coef);
     return mx_launch_status();
+}
+
+// value + the two time-domain gradient components of one resolution; fr describes what the fold pass needs
+template <int N>
+static int run_onepass(const float *x, long long xs, const float *y, long long ys, const float *win, const float2 *tw, int B, int T,
+                       int hop, float eps, float w_sc, float w_log, float res_scale, double *part, float *terms, float *alpha,
+                       float *ws, FoldRes &fr, hipStream_t st)
+{
+    const int n_frames = 1 + T / hop;
+    const int F = mr_run_frames(N, hop), n_runs = (n_frames + F - 1) / F, tail_len = N > hop ? N - hop : 0;
+    const int groups = (n_runs + OP<N>::STREAMS - 1) / OP<N>::STREAMS;
+    float *main1 = ws, *main2 = main1 + (size_t)B * n_frames * hop, *tails = main2 + (size_t)B * n_frames * hop;
+    const long long count = (long long)B * n_frames * (N / 2 + 1);
+    const float c_log = (float)((double)res_scale * w_log / (double)count);
+    static bool attr_set[64];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&mr_onepass_kernel<N>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)OP<N>::lds_bytes()) != hipSuccess)
+            return MX_ERR_LAUNCH;
+        if (dev >= 0 && dev < 64) attr_set[dev] = true;
+    }
+    hipLaunchKernelGGL((mr_onepass_kernel<N>), dim3(groups, B), dim3(MR_OPW * 64), OP<N>::lds_bytes(), st, x, xs, y, ys, win, tw, T,
+                       hop, n_frames, F, n_runs, eps, c_log, part, main1, main2, tails);
+    hipLaunchKernelGGL(mr_finish_kernel, dim3(1), dim3(256), 0, st, part, groups * B, count, w_sc, w_log, res_scale, terms, alpha);
+    fr = FoldRes{main1, main2, tails, alpha, N, hop, n_frames, F, n_runs, tail_len};
+    return mx_launch_status();
+}
+
+// floats of workspace one resolution needs for the gradient (mirrored by mod_extraction_amd/mrstft.py)
+static size_t mr_ws_floats(int B, int T, int N, int hop)
+{
+    const int n_frames = 1 + T / hop, F = mr_run_frames(N, hop), n_runs = (n_frames + F - 1) / F, tail_len = N > hop ? N - hop : 0;
+    return 2 * (size_t)B * ((size_t)n_frames * hop + (size_t)n_runs * tail_len);
 }
 
 // y_hat, y: B rows of T samples (row strides); n_res resolutions with fft_sizes in {512,1024,2048} and hops
@@ -687,8 +782,9 @@ static int run_resolution(const float *x, long long xs, const float *y, long lon
 // windows (n_res, 2048): row r holds the n_fft-long window of resolution r (win_length hann, centred);
 // twiddle (2048,2) = exp(-2 pi i m / 2048).  terms (2*n_res + 1): [sc_0, logmag_0, ..., total].
 // dx (B rows, stride dx_stride) = d total / d y_hat, or NULL.  Workspaces: part (doubles) >= 3 * B *
-// max_r ceil(frames_r / 8); coef (2,) floats; scratch (floats) >= B * max_r(frames_r * (5 * n_fft_r / 2 + 4)) (only
-// when dx != NULL: the frames' time-domain gradients and the parked bins).
+// max_r ceil(frames_r / 8); coef (n_res,) floats (alpha_r); scratch (floats, only when dx != NULL) >= sum_r 2 * B *
+// (frames_r * hop_r + runs_r * max(n_fft_r - hop_r, 0)) with runs_r = ceil(frames_r / F_r), F_r = max(32, ceil(n_fft_r / hop_r))
+// rounded up to even: the two time-domain gradient components of every resolution (run sums + run tails).
 MX_EXPORT int mx_mrstft_loss(const float *y_hat, int64_t y_hat_stride, const float *y, int64_t y_stride, int64_t B,
                              int64_t T, int32_t n_res, const int32_t *fft_sizes, const int32_t *hops,
                              const float *windows, const float *twiddle, float w_sc, float w_log, float eps,
@@ -701,21 +797,35 @@ MX_EXPORT int mx_mrstft_loss(const float *y_hat, int64_t y_hat_stride, const flo
     if (B > 65535 || T >= (1ll << 30)) return MX_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     const float res_scale = 1.0f / (float)n_res;
+    FoldArgs fa;
+    fa.n_res = 0;
+    int folded = 0;
+    float *ws = scratch;
     for (int r = 0; r < n_res; ++r) {
         const int N = fft_sizes[r], hop = hops[r];
         if (T <= N / 2 || hop <= 0) return MX_ERR_UNSUPPORTED;
         const float *win = windows + (size_t)r * MR_MAXN;
         int rc;
-#define MR_RUN(NN)                                                                                                   \
-    rc = run_resolution<NN>(y_hat, (long long)y_hat_stride, y, (long long)y_stride, win, (const float2 *)twiddle,    \
-                            (int)B, (int)T, hop, eps, w_sc, w_log, res_scale, part, terms + 2 * r, coef, scratch, dx, \
-                            (long long)dx_stride, r > 0, st)
+#define MR_RUN(NN)                                                                                                              \
+    rc = dx ? run_onepass<NN>(y_hat, (long long)y_hat_stride, y, (long long)y_stride, win, (const float2 *)twiddle, (int)B,     \
+                              (int)T, hop, eps, w_sc, w_log, res_scale, part, terms + 2 * r, coef + r, ws, fa.r[fa.n_res], st) \
+            : run_stats<NN>(y_hat, (long long)y_hat_stride, y, (long long)y_stride, win, (const float2 *)twiddle, (int)B,      \
+                            (int)T, hop, eps, w_sc, w_log, res_scale, part, terms + 2 * r, coef + r, st)
         if (N == 512) MR_RUN(512);
         else if (N == 1024) MR_RUN(1024);
         else if (N == 2048) MR_RUN(2048);
         else return MX_ERR_UNSUPPORTED;
 #undef MR_RUN
         if (rc != MX_OK) return rc;
+        if (dx) {
+            ws += mr_ws_floats((int)B, (int)T, N, hop);
+            if (++fa.n_res == 4 || r == n_res - 1) {
+                hipLaunchKernelGGL(mr_fold_all_kernel, dim3((unsigned)((T + 255) / 256), (unsigned)B), dim3(256), 0, st, fa, (int)T,
+                                   folded, dx, (long long)dx_stride);
+                folded = 1;
+                fa.n_res = 0;
+            }
+        }
     }
     hipLaunchKernelGGL(mr_total_kernel, dim3(1), dim3(64), 0, st, terms, (int)n_res, w_sc, w_log);
     return mx_launch_status();

@@ -21,6 +21,15 @@ def _windows(fft_sizes: Sequence[int], win_lengths: Sequence[int], device) -> T:
     return w.to(device)
 
 
+def scratch_floats(B: int, Tn: int, n_fft: int, hop: int) -> int:
+    """Workspace floats of one resolution for the gradient (mirrors mr_ws_floats in csrc/mrstft.hip)."""
+    frames = 1 + Tn // hop
+    run = max(32, -(-n_fft // hop))
+    run += run & 1
+    runs = -(-frames // run)
+    return 2 * B * (frames * hop + runs * max(n_fft - hop, 0))
+
+
 def mrstft_value_and_grad(mod: "MultiResolutionSTFTLoss", a: T, t: T, need_grad: bool = True, scale: float = 1.0):
     """a, t: (B, T) rows (unit inner stride).  Returns (scale * loss as a device scalar, d (scale * loss) / d a or None).
     ``mod.last_terms`` afterwards holds the per-resolution terms of THIS call: [sc_0, logmag_0, ..., total] with the
@@ -31,10 +40,11 @@ def mrstft_value_and_grad(mod: "MultiResolutionSTFTLoss", a: T, t: T, need_grad:
     n_res = len(mod.fft_sizes)
     frames = [1 + Tn // h for h in mod.hop_sizes]
     part = torch.empty(3 * B * max(-(-f // 8) for f in frames), device=dev, dtype=torch.float64)
-    coef = torch.empty(2, device=dev, dtype=torch.float32)
+    coef = torch.empty(n_res, device=dev, dtype=torch.float32)
     terms = torch.empty(2 * n_res + 1, device=dev, dtype=torch.float32)
-    # per frame: n_fft samples of time-domain gradient + the parked bins (Re X, Im X, Ym) the gradient pass re-uses
-    scratch = torch.empty(B * max(f * (5 * n // 2 + 4) for f, n in zip(frames, mod.fft_sizes)), device=dev,
+    # the two time-domain gradient components of every resolution: per clip frames * hop run sums + one tail of n_fft - hop
+    # positions per run of F frames (include/modex_hip.h, mx_mrstft_loss)
+    scratch = torch.empty(sum(scratch_floats(B, Tn, n, h) for n, h in zip(mod.fft_sizes, mod.hop_sizes)), device=dev,
                           dtype=torch.float32) if need_grad else None
     dx = torch.empty((B, Tn), device=dev, dtype=torch.float32) if need_grad else None
     ffts = (ctypes.c_int32 * n_res)(*mod.fft_sizes)

@@ -83,8 +83,8 @@ def test_mrstft_identical_clip_among_different_ones(dev):
 
 @pytest.mark.parametrize("T", [300, 411, 1000])
 def test_mrstft_one_resolution_on_very_short_clips(dev, T):
-    """Only the 512-point resolution, clips barely longer than its reflect padding: one or two overlap-add spans per clip,
-    which must fit in front of the parked bins in the shared scratch."""
+    """Only the 512-point resolution, clips barely longer than its reflect padding: one run of a handful of frames per clip,
+    most of the gradient arriving through the run's tail."""
     from mod_extraction_amd import mrstft as amr
     torch.manual_seed(T)
     cfg = dict(fft_sizes=(512,), hop_sizes=(50,), win_lengths=(240,))
