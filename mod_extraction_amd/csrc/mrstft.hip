@@ -437,24 +437,49 @@ __global__ __launch_bounds__(256) void mr_finish_kernel(const double *__restrict
 }
 
 // ---- the one-pass value + gradient kernel ------------------------------------------------------------------------
-// s1, s2 with G1 = s1 X, G2 = s2 X (see the file header) and the bin's three loss terms; branch-free; hardware square
-// root / reciprocal / log2 (1 ulp each, no range fix-ups: the library sqrtf, two logf and two divisions were 70 of ~90
-// instructions per bin); Xm and Ym by the same formula, so that X == Y gives exactly 0; the clamp passes no gradient below eps
-struct BinOut { float s1, s2; };
-__device__ __forceinline__ BinOut bin_terms(const cf &X, const cf &Y, float eps, float c_log, float &fd, float &fy, float &fl)
+// One bin of one frame.  Works on the DOUBLED spectra straight from the Hermitian separation of Z = FFT(x + i y),
+//   X2 = Z[k] + conj Z[N-k] = 2 X,   D = Z[k] - conj Z[N-k]  with |D| = 2 |Y|  (only |Y| enters the loss),
+// two packed adds; every constant factor is folded into the scalars: the three loss sums come out 4x (d^2, Ym^2) or unscaled
+// (the log difference) and are rescaled once per frame, and the function returns s1', s2' such that s' X2 = G / 2 -- the
+// Hermitian-completed gradient spectrum G~[k] = G[k] / 2 the inverse transform wants (DC and Nyquist: G itself = 2 s' X2).
+// With G1 = (Xm - Ym) X / Xm and G2 = c_log sign(log Xm - log Ym) X / Xm^2:  s1' = (Xm2 - Ym2) / (4 Xm2),  s2' = +-c_log / Xm2^2
+// (Xm2 = 2 Xm).  Branch-free; hardware square root / reciprocal / log2 (1 ulp each, no range fix-ups: the library sqrtf, two logf
+// and two divisions were 70 of ~90 instructions per bin); Xm and Ym by the same formula, so that X == Y gives exactly 0; the clamp
+// passes no gradient below eps.
+__device__ __forceinline__ cf add_conj(cf a, cf b)          // (a.x + b.x, a.y - b.y)
 {
-    const float px = X.x * X.x + X.y * X.y;
-    const float cx = fmaxf(px, eps), cy = fmaxf(Y.x * Y.x + Y.y * Y.y, eps);
+    cf r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ cf sub_conj(cf a, cf b)          // (a.x - b.x, a.y + b.y)
+{
+    cf r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ cf mirror_h(cf ga, cf gb)        // conj(ga) + i conj(gb) = (ga.x + gb.y, gb.x - ga.y)
+{
+    cf r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[1,0]" : "=v"(r) : "v"(ga), "v"(gb));
+    return r;
+}
+struct BinOut { float s1, s2; };
+__device__ __forceinline__ BinOut bin_terms(const cf &X2, const cf &D, bool same, float eps4, float c_log, float &fd, float &fy, float &fl)
+{
+    const float px = __builtin_fmaf(X2.x, X2.x, X2.y * X2.y);
+    const float py = same ? px : __builtin_fmaf(D.x, D.x, D.y * D.y);
+    const float cx = fmaxf(px, eps4), cy = fmaxf(py, eps4);
     const float xm = __builtin_amdgcn_sqrtf(cx), ym = __builtin_amdgcn_sqrtf(cy);
-    const float d = ym - xm;
+    const float d = xm - ym;
     const float dl = __builtin_amdgcn_logf(cx) - __builtin_amdgcn_logf(cy);       // 2 / ln 2 * (log Xm - log Ym)
-    fd += d * d;
+    fd = __builtin_fmaf(d, d, fd);
     fy += cy;
     fl += fabsf(dl);
     const float rx = __builtin_amdgcn_rcpf(xm);
     const float sg = dl > 0.0f ? c_log : (dl < 0.0f ? -c_log : 0.0f);
-    const bool pass = px > eps;
-    return {pass ? (xm - ym) * rx : 0.0f, pass ? sg * rx * rx : 0.0f};
+    const bool pass = px > eps4;
+    return {pass ? 0.25f * d * rx : 0.0f, pass ? sg * rx * rx : 0.0f};
 }
 
 template <int N> struct OP {
@@ -475,9 +500,10 @@ __global__ __launch_bounds__(MR_OPW * 64) __attribute__((amdgpu_waves_per_eu(N =
 {
     constexpr int L = OP<N>::L, E = OP<N>::E, NB = OP<N>::NB, FW = OP<N>::FW, STREAMS = OP<N>::STREAMS, NBIN = OP<N>::NBIN;
     extern __shared__ __attribute__((aligned(16))) unsigned char op_smem[];
-    cf *tw_s = reinterpret_cast<cf *>(op_smem);
-    cf *xbuf = reinterpret_cast<cf *>(op_smem + (size_t)N * 8);
-    float *rings = reinterpret_cast<float *>(op_smem + (size_t)N * 8 + (size_t)STREAMS * WF<N>::LEN * 8);
+    // rings first: ring c of stream s starts at byte (2 s + c) 4 N, so that a slot's address is (position bytes & (4 N - 1)) | base
+    float *rings = reinterpret_cast<float *>(op_smem);
+    cf *tw_s = reinterpret_cast<cf *>(op_smem + (size_t)STREAMS * 2 * N * 4);
+    cf *xbuf = reinterpret_cast<cf *>(op_smem + (size_t)STREAMS * 2 * N * 4 + (size_t)N * 8);
     double *red = reinterpret_cast<double *>(op_smem + (size_t)N * 8 + (size_t)STREAMS * WF<N>::LEN * 8 + (size_t)STREAMS * 2 * N * 4);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane / L, a_ = lane % L;
     const int b = blockIdx.y, sidx = wave * FW + g;
@@ -502,31 +528,47 @@ __global__ __launch_bounds__(MR_OPW * 64) __attribute__((amdgpu_waves_per_eu(N =
     double s_d = 0.0, s_y = 0.0, s_l = 0.0;
     int base = 0;                                                             // ring slot of the current frame's position 0
 
-    // windowed gradient frame -> ring (read - add - write, 16 / 32 values a lane; LDS operations of a wave execute in order),
-    // then the frame's first `hop` positions leave the ring for memory
-    auto add_and_flush = [&](float *ring, float *mainp, const cf (&Z)[E], bool imag, int f, bool live, int a, int bs) {
-        float old[E];
+    // The pair's windowed gradient frames (real part: frame f0 at ring position bs, imaginary part: frame f1 at bs + hop) ->
+    // ring: read - add - write, 16 / 32 values a lane (LDS operations of a wave execute in order); after each frame its first
+    // `hop` positions are final within the run and leave the ring for memory.  A slot's byte address is
+    // ((position bytes) & (4 N - 1)) | ring base: two vector instructions per value.
+    auto add_and_flush = [&](unsigned ring_b, float *mainp, const cf (&Z)[E], int f0, bool live0, bool live1, int a, int bs) {
+        unsigned char *const lds = op_smem;
+        cf Zw[E];
 #pragma unroll
-        for (int i = 0; i < E; ++i) old[i] = ring[(bs + pos_final<N>(i, a)) & (N - 1)];
+        for (int i = 0; i < E; ++i) Zw[i] = Z[i] * wv[m_of_out<N>(i)];
 #pragma unroll
-        for (int i = 0; i < E; ++i) {
-            const float v = (imag ? Z[i].y : Z[i].x) * wv[m_of_out<N>(i)];
-            ring[(bs + pos_final<N>(i, a)) & (N - 1)] = live ? old[i] + v : old[i];
-        }
-        __builtin_amdgcn_wave_barrier();
-        if (live) {
-            float *o = mainp + (size_t)f * hop;
-            for (int j = a; j < hop; j += L) {
-                float v = 0.0f;
-                if (j < N) {
-                    v = ring[(bs + j) & (N - 1)];
-                    ring[(bs + j) & (N - 1)] = 0.0f;
-                }
-                o[j] = v;
+        for (int u = 0; u < 2; ++u) {
+            const int f = f0 + u;
+            const bool live = u ? live1 : live0;
+            const unsigned tb = (unsigned)(((u ? bs + hop : bs) + a) * 4);
+            if (live) {
+                float old[E];
+#pragma unroll
+                for (int i = 0; i < E; ++i)
+                    old[i] = *reinterpret_cast<const float *>(lds + (((tb + 4u * (unsigned)pos_final<N>(i, 0)) & (4u * N - 1u)) | ring_b));
+#pragma unroll
+                for (int i = 0; i < E; ++i)
+                    *reinterpret_cast<float *>(lds + (((tb + 4u * (unsigned)pos_final<N>(i, 0)) & (4u * N - 1u)) | ring_b)) =
+                        old[i] + (u ? Zw[i].y : Zw[i].x);
             }
+            __builtin_amdgcn_wave_barrier();
+            if (live) {
+                float *o = mainp + (size_t)f * hop;
+                for (int j = a; j < hop; j += L) {
+                    float v = 0.0f;
+                    if (j < N) {
+                        float *slot = reinterpret_cast<float *>(lds + (((tb + 4u * (unsigned)(j - a)) & (4u * N - 1u)) | ring_b));
+                        v = *slot;
+                        *slot = 0.0f;
+                    }
+                    o[j] = v;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
         }
-        __builtin_amdgcn_wave_barrier();
     };
+    const unsigned ring1_b = (unsigned)(sidx * 2) * 4u * N, ring2_b = ring1_b + 4u * N;
 
     float *m1 = main1 + (size_t)b * n_frames * hop, *m2 = main2 + (size_t)b * n_frames * hop;
     for (int fp = 0; fp < F; fp += 2) {
@@ -576,40 +618,35 @@ __global__ __launch_bounds__(MR_OPW * 64) __attribute__((amdgpu_waves_per_eu(N =
 #pragma unroll
             for (int j = 0; j < NBIN; ++j) {
                 const int k = a + L * j;
-                cf X, Y;
-                split_bins<N>(buf, k, X, Y);
-                if (same) Y = X;
-                const BinOut t = bin_terms(X, Y, eps, c_log, fd, fy, fl);
-                const float s1 = lm * t.s1, s2 = lm * t.s2;
-                const cf g1 = {s1 * X.x, s1 * X.y}, g2 = {s2 * X.x, s2 * X.y};
+                const cf z = buf[k], zc = buf[(N - k) & (N - 1)];
+                const cf X2 = add_conj(z, zc), D = sub_conj(z, zc);
+                const BinOut t = bin_terms(X2, D, same, 4.0f * eps, c_log, fd, fy, fl);
+                const bool dc = (j == 0) && (a == 0);                          // DC: real, not halved
+                const float s1 = (dc ? 2.0f * lm : lm) * t.s1, s2 = (dc ? 2.0f * lm : lm) * t.s2;
+                const cf g1 = X2 * s1, g2 = X2 * s2;
                 if (u == 0) {
                     ga1[j] = g1;
                     ga2[j] = g2;
                 } else {
-                    // H = G~_a + i G~_b of the pair at position k (lower half) and its mirror image at N - k: G~[k] = G[k] / 2,
-                    // G~[N - k] = conj G[k] / 2, DC real and not halved
+                    // H = G~_a + i G~_b of the pair at position k (lower half) and its mirror image conj G~_a + i conj G~_b at N - k
                     const cf p1 = ga1[j], p2 = ga2[j];
-                    const bool dc = (j == 0) && (a == 0);
-                    R[j % NB][j / NB] = dc ? cf{p1.x, g1.x} : cf{0.5f * (p1.x - g1.y), 0.5f * (p1.y + g1.x)};
-                    buf[N - k] = {0.5f * (p1.x + g1.y), 0.5f * (g1.x - p1.y)};      // (k = 0 lands in the pad: never read)
-                    h2[j] = dc ? cf{p2.x, g2.x} : cf{0.5f * (p2.x - g2.y), 0.5f * (p2.y + g2.x)};
-                    h2m[j] = {0.5f * (p2.x + g2.y), 0.5f * (g2.x - p2.y)};
+                    R[j % NB][j / NB] = dc ? cf{p1.x, g1.x} : add_pi(p1, g1);
+                    buf[N - k] = mirror_h(p1, g1);                              // (k = 0 lands in the pad: never read)
+                    h2[j] = dc ? cf{p2.x, g2.x} : add_pi(p2, g2);
+                    h2m[j] = mirror_h(p2, g2);
                 }
             }
             if (a == 0) {                                                       // Nyquist bin: real, not halved
-                cf X, Y;
-                split_bins<N>(buf, N / 2, X, Y);
-                if (same) Y = X;
-                X.y = 0.0f;
-                Y.y = 0.0f;
-                const BinOut t = bin_terms(X, Y, eps, c_log, fd, fy, fl);
-                const float n1 = lm * t.s1 * X.x, n2 = lm * t.s2 * X.x;
+                const cf z = buf[N / 2];
+                const cf X2 = {2.0f * z.x, 0.0f}, D = {0.0f, 2.0f * z.y};
+                const BinOut t = bin_terms(X2, D, same, 4.0f * eps, c_log, fd, fy, fl);
+                const float n1 = 2.0f * lm * t.s1 * X2.x, n2 = 2.0f * lm * t.s2 * X2.x;
                 if (u == 0) { ny1a = n1; ny2a = n2; }
                 else { buf[N / 2] = {ny1a, n1}; h2ny_re = ny2a; h2ny_im = n2; }
             }
             if (live) {
-                s_d += (double)fd;
-                s_y += (double)fy;
+                s_d += (double)(0.25f * fd);
+                s_y += (double)(0.25f * fy);
                 s_l += (double)(0.5f * 0.69314718055994531f * fl);
             }
             __builtin_amdgcn_wave_barrier();
@@ -622,8 +659,7 @@ __global__ __launch_bounds__(MR_OPW * 64) __attribute__((amdgpu_waves_per_eu(N =
         __builtin_amdgcn_wave_barrier();
         wave_fft<N, true>(R, Z, fl);
         MR_OPAQUE(a);
-        add_and_flush(ring1, m1, Z, false, f0, live0, a, base);
-        add_and_flush(ring1, m1, Z, true, f1, live1, a, (base + hop) & (N - 1));
+        add_and_flush(ring1_b, m1, Z, f0, live0, live1, a, base);
         // ---- G2
 #pragma unroll
         for (int j = 0; j < NBIN; ++j) {
@@ -639,8 +675,7 @@ __global__ __launch_bounds__(MR_OPW * 64) __attribute__((amdgpu_waves_per_eu(N =
         __builtin_amdgcn_wave_barrier();
         wave_fft<N, true>(R, Z, fl);
         MR_OPAQUE(a);
-        add_and_flush(ring2, m2, Z, false, f0, live0, a, base);
-        add_and_flush(ring2, m2, Z, true, f1, live1, a, (base + hop) & (N - 1));
+        add_and_flush(ring2_b, m2, Z, f0, live0, live1, a, base);
         base = (base + 2 * hop) & (N - 1);
     }
     // the run's tail: positions [f_end * hop, f_end * hop + N - hop) as far as this run's frames reach them
