@@ -244,21 +244,30 @@ __global__ __launch_bounds__(256, 1) void dgrad_sp_f16x3_kernel(DgradSpArgs a)
     const int h = h0 + row;
     float s1a[2][16], s2a[2][16];                               // [weight fragment j: ci tile j ^ c][channel hh*16 + i]
     float mxd = 0.0f, mxx = 0.0f;                               // running max |dxhat|, max |xhat| of this lane
-    half8 xh[LN ? CV_WT : 1][2], xl[LN ? CV_WT : 1][2];         // all of the wave's xhat vectors, requested up front: one
-    if (LN) {                                                   // memory round trip per workgroup instead of eleven
+    // the wave's xhat vectors: a ring of XSLOTS tiles, the first XSLOTS requested up front, tile u + XSLOTS as soon as tile u
+    // is done (its data is then XSLOTS - 1 tiles of work away) -- one exposed memory round trip per workgroup instead of
+    // eleven, and 16 XSLOTS registers instead of 176 (all eleven tiles at once spilled 56 registers to scratch memory
+    // beside the 176 accumulators)
+#ifndef DS_XSLOTS
+#define DS_XSLOTS 3
+#endif
+    constexpr int XSLOTS = DS_XSLOTS;
+    half8 xh[LN ? XSLOTS : 1][2], xl[LN ? XSLOTS : 1][2];
+    auto load_x = [&](int u) {
+        const int ptile = u < 10 ? c * 6 + (u >> 1) : 5, cit = (u < 10 ? (u & 1) : 0) ^ c;
+        const size_t xo = ((((size_t)b * H + h) * 4 + cit * 2 + hh) * CV_PITCH + ptile * 32 + l32) * 16;
+        xh[u % XSLOTS][0] = *reinterpret_cast<const half8 *>(a.x_hi + xo);
+        xh[u % XSLOTS][1] = *reinterpret_cast<const half8 *>(a.x_hi + xo + 8);
+        xl[u % XSLOTS][0] = *reinterpret_cast<const half8 *>(a.x_lo + xo);
+        xl[u % XSLOTS][1] = *reinterpret_cast<const half8 *>(a.x_lo + xo + 8);
+    };
+    if (LN) {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int i = 0; i < 16; ++i) { s1a[j][i] = 0.0f; s2a[j][i] = 0.0f; }
 #pragma unroll
-        for (int u = 0; u < CV_WT; ++u) {
-            const int ptile = u < 10 ? c * 6 + (u >> 1) : 5, cit = (u < 10 ? (u & 1) : 0) ^ c;
-            const size_t xo = ((((size_t)b * H + h) * 4 + cit * 2 + hh) * CV_PITCH + ptile * 32 + l32) * 16;
-            xh[u][0] = *reinterpret_cast<const half8 *>(a.x_hi + xo);
-            xh[u][1] = *reinterpret_cast<const half8 *>(a.x_hi + xo + 8);
-            xl[u][0] = *reinterpret_cast<const half8 *>(a.x_lo + xo);
-            xl[u][1] = *reinterpret_cast<const half8 *>(a.x_lo + xo + 8);
-        }
+        for (int u = 0; u < XSLOTS; ++u) load_x(u);
     }
 #pragma unroll
     for (int u = 0; u < CV_WT; ++u) {
@@ -275,7 +284,7 @@ __global__ __launch_bounds__(256, 1) void dgrad_sp_f16x3_kernel(DgradSpArgs a)
             const float v = w < a.Wv ? scr[cil * 33 + l32] : 0.0f;
             a.out[(((size_t)b * CV_CO + cit * 32 + cil) * H + h) * CV_PITCH + w] = v;
             if (LN) {
-                const float xv = (float)xh[u][i >> 3][i & 7] + (float)xl[u][i >> 3][i & 7];
+                const float xv = (float)xh[u % XSLOTS][i >> 3][i & 7] + (float)xl[u % XSLOTS][i >> 3][i & 7];
                 s1a[jf][i] += v;
                 s2a[jf][i] += v * xv;
                 mxd = fmaxf(mxd, fabsf(v));
@@ -283,6 +292,7 @@ __global__ __launch_bounds__(256, 1) void dgrad_sp_f16x3_kernel(DgradSpArgs a)
             }
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);
+        if (LN && u + XSLOTS < CV_WT) load_x(u + XSLOTS);
     }
     if (LN && a.gx_bits) {                                      // (order of non-negative floats = order of their bits)
         mxd = wave_max_f32(mxd);

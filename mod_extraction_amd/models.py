@@ -134,6 +134,7 @@ BLOCK1_F16 = os.environ.get("MODEX_BLOCK1", "f16x3") != "f32"
 WGRAD_SPARSE = os.environ.get("MODEX_WGRAD", "sparse") != "dense"
 WGRAD_SPARSE_MAX_T = int(os.environ.get("MODEX_WGRAD_SP_MAXT", "4"))     # dilations above it: dense kernel (no shared fragment blocks)
 DGRAD_SPARSE = os.environ.get("MODEX_DGRAD", "sparse") != "dense"
+DIRECT_GRADS = os.environ.get("MODEX_DIRECT_GRADS", "1") != "0"   # parameter gradients written straight into FlatAdamW's flat buffer
 STATS_FUSED = os.environ.get("MODEX_STATS", "fused") != "sweep"   # next block's LayerNorm statistics from the forward epilogue
 # LayerNorm / PReLU backward written straight into the pooled operand of the block below (blocks whose two gradients both run
 # on the sparse instruction): dL/dp never exists in fp32.  "split" keeps the two passes (A/B knob).
@@ -145,10 +146,34 @@ def _use_f16(cin: int, precision: str) -> bool:
     return precision == "f16x3" and cin == 64
 
 
-def _reduce_rows(part: T, rows: int, cols: int) -> T:
-    out = torch.empty(cols, device=part.device, dtype=torch.float32)
+def _reduce_rows(part: T, rows: int, cols: int, out: Optional[T] = None) -> T:
+    if out is None:
+        out = torch.empty(cols, device=part.device, dtype=torch.float32)
     _hip.call("mx_reduce_rows", _hip.ptr(part), rows, cols, 0, _hip.ptr(out), _hip.stream())
     return out
+
+
+def _direct_grad_views(params) -> Optional[List[T]]:
+    """The parameters' ``.grad`` tensors when the backward pass may write its results straight into them: all of them are
+    contiguous views of ONE flat gradient buffer (optim.FlatAdamW) that was zeroed since the last backward
+    (``_modex_fresh`` on the buffer, set by ``FlatAdamW.zero_grad`` and consumed here).  autograd then gets ``None`` for
+    those inputs and skips its 20 ``grad += g`` launches per step; any other situation -- no flat buffer, a second backward
+    into the same buffer (sub-batches), plain ``torch.optim`` -- keeps the ordinary accumulate path."""
+    views = []
+    base = None
+    for p in params:
+        g = getattr(p, "grad", None)
+        if g is None or not g.is_contiguous() or g._base is None or g.dtype != torch.float32 or not p.requires_grad:
+            return None
+        if base is None:
+            base = g._base
+        elif g._base is not base:
+            return None
+        views.append(g)
+    if base is None or not getattr(base, "_modex_fresh", False):
+        return None
+    base._modex_fresh = False
+    return views
 
 
 def _pooled_only(l: int, cin: int, dilations, precision: str, n_frames: int) -> bool:
@@ -236,6 +261,7 @@ class _CNNStack(torch.autograd.Function):
         _hip.call("mx_head_fwd", _hip.ptr(cur), _hip.ptr(slope), _hip.ptr(wout.contiguous()),
                   _hip.ptr(bout.contiguous()), B, 64, H, n_frames, L, _hip.ptr(latent), _hip.ptr(out), st)
         ctx.save_for_backward(*saved, cur, latent, out, *params)
+        ctx.param_objs = params               # the Parameter objects themselves: their .grad views are looked up in backward
         ctx.meta = (n_frames, tuple(dilations), n_blocks, precision)
         return out, latent
 
@@ -251,6 +277,10 @@ class _CNNStack(torch.autograd.Function):
         B, L = out.size(0), out.size(1)
         wout = params[3 * n_blocks]
         grads: List[Optional[T]] = [None] * len(params)
+        direct = _direct_grad_views(ctx.param_objs) if DIRECT_GRADS else None
+
+        def gout(i: int) -> Optional[T]:          # where parameter i's gradient is written: its .grad view, or a fresh tensor
+            return direct[i].view(-1) if direct is not None else None
         if d_out is None:
             d_out = torch.zeros_like(out)
         d_out = d_out.contiguous()
@@ -267,9 +297,9 @@ class _CNNStack(torch.autograd.Function):
         _hip.call("mx_head_bwd", _hip.ptr(p_last), _hip.ptr(slope_last), _hip.ptr(wout.contiguous()),
                   _hip.ptr(latent), _hip.ptr(out), _hip.ptr(d_out), _hip.ptr(d_latent), B, 64, Hl, n_frames, L,
                   _hip.ptr(G), _hip.ptr(dw_part), _hip.ptr(db_part), _hip.ptr(ds_part), _hip.ptr(gmax_ws), st)
-        grads[3 * n_blocks] = _reduce_rows(dw_part, B, L * 64).view_as(wout)
-        grads[3 * n_blocks + 1] = _reduce_rows(db_part, B, L)
-        grads[3 * (n_blocks - 1) + 2] = _reduce_rows(ds_part, B, 64)
+        grads[3 * n_blocks] = _reduce_rows(dw_part, B, L * 64, gout(3 * n_blocks)).view_as(wout)
+        grads[3 * n_blocks + 1] = _reduce_rows(db_part, B, L, gout(3 * n_blocks + 1))
+        grads[3 * (n_blocks - 1) + 2] = _reduce_rows(ds_part, B, 64, gout(3 * (n_blocks - 1) + 2))
         bsum = None                      # by-product of mx_ln_prelu_bwd for the block below: bias partials (gmax_ws: max|G| bits)
         pooled = None                    # (gc_hi, gc_lo, gc_idx, gidx, scale) left for the block below by the fused LN backward
         for l in range(n_blocks - 1, -1, -1):
@@ -287,12 +317,12 @@ class _CNNStack(torch.autograd.Function):
                 assert G is not None
                 bsum = torch.empty((B, 64), device=dev, dtype=torch.float32)
                 _hip.call("mx_plane_sum", _hip.ptr(G), B * 64, H // 2, n_frames, _hip.ptr(bsum), st)
-            grads[3 * l + 1] = _reduce_rows(bsum, B, 64)
+            grads[3 * l + 1] = _reduce_rows(bsum, B, 64, gout(3 * l + 1))
             bsum = None
             # weight gradient (+ data gradient below) -- f16x3 path: both share the prepared operand pairs
             rows = B * H
             f16 = _use_f16(cin, precision)
-            dW = torch.empty_like(w)
+            dW = direct[3 * l] if direct is not None else torch.empty_like(w)
             if f16:
                 dz_hi = dz_lo = None
                 ready = gmax_ws is not None
@@ -434,7 +464,9 @@ class _CNNStack(torch.autograd.Function):
                     _hip.call("mx_ln_prelu_bwd", _hip.ptr(x_in), _hip.ptr(dxhat), _hip.ptr(stats), _hip.ptr(slope_prev),
                               B, 64, H, n_frames, _hip.ptr(ds_part), _hip.ptr(bsum), _hip.ptr(gmax_ws), _hip.ptr(ln_part), st)
                     G = dxhat
-                grads[3 * (l - 1) + 2] = _reduce_rows(ds_part, B, 64)
+                grads[3 * (l - 1) + 2] = _reduce_rows(ds_part, B, 64, gout(3 * (l - 1) + 2))
+        if direct is not None:                      # already in place: autograd has nothing to accumulate
+            grads = [None] * len(params)
         return (None, None, None, None, *grads)
 
 

@@ -43,6 +43,7 @@ class FlatAdamW:
 
     def zero_grad(self, set_to_none: bool = False) -> None:
         self.flat_grad.zero_()
+        self.flat_grad._modex_fresh = True      # a backward pass may write its parameter gradients in place once (models._direct_grad_views)
         off = 0
         for p in self.params:          # re-attach views if something replaced .grad
             k = p.numel()

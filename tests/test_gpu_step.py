@@ -295,6 +295,75 @@ def test_bench_launches_its_own_ranks():
     assert out["value"] > 0 and "other_configs" not in out
 
 
+def test_bench_eight_ranks_sharing_the_gpu_over_gloo():
+    """The driver's N = 8 form once, end to end: `python bench.py --gpus 8` starts EIGHT rank processes through
+    torch.distributed.run on a free port (here all on this box's one GPU, collectives over gloo, two clips per rank), every
+    rank joins the barriers / the max-over-ranks timing / the flat-gradient all-reduce, and rank 0's one line -- relayed by
+    the launcher -- says how many ranks the collective library saw.  (The launcher, the port logic, the rank-0 relay and the
+    eight-way rendezvous are exactly the code the 8-GPU scaling run executes; only the transport and the device differ.)"""
+    out = _run_bench(["--gpus", "8", "--steps", "1", "--warmup", "1", "--batch", "2"],
+                     env={"MODEX_SHARE_GPU": "1", "MODEX_DIST_BACKEND": "gloo"}, timeout=1500)
+    assert out["n_gpus"] == 8 and out["world_size"] == 8 and out["dist_backend"] == "gloo"
+    assert out["config"]["global_batch"] == 16 and out["config"]["parallelism"] == "dp8"
+    assert out["value"] > 0 and out["worker_rc"] == 0 and "cpu_baseline" not in out
+
+
+def test_tbptt_step_through_rccl_with_the_cu_partition_installed(dev):
+    """Config 4 under DDP issues one 70 KB all-reduce per optimizer step (83 per batch) on the CU-MASKED main stream that
+    Trainer.fit installs.  With ONE rank on backend "nccl" (= RCCL) the collective is the identity, so the run must land on
+    exactly the parameters of the same steps without a process group -- and it must get through RCCL's kernels on a stream
+    created by hipExtStreamCreateWithCUMask, which is what the 8-GPU run of that config will do."""
+    import socket
+    import torch.distributed as dist
+    from mod_extraction_amd import lightning as al, models as am, optim, streams, trainer
+    from oracle import modulations as omod
+
+    n, W, S, B = 1024 + 6 * 1024, 1024, 1024, 4
+
+    def run(with_pg):
+        torch.manual_seed(21)
+        dry = torch.rand(B, 1, n) * 1.6 - 0.8
+        wet = (0.7 * dry + 0.2 * torch.roll(dry, 5, -1)).clamp(-1, 1)
+        lfo = torch.stack([omod.make_mod_signal(64, 64 / (n / 44100.0), 5.0 + i, 0.3 * i, "cos") for i in range(B)])
+        em = am.LSTMEffectModel()
+        mod = al.TBPTTLFOEffectModeling(W, S, em, lfo_model=None, model_smooth_n_frames=0, should_stretch=False,
+                                        discard_invalid_lfos=False, loss_dict={"l1": 1.0, "esr": 0.0, "dc": 0.0}).to(dev).train()
+        opt = optim.FlatAdamW(mod.parameters(), lr=1e-3, betas=(0.8, 0.99))
+        part = streams.cu_partition(dev, main_workgroups=B)
+        assert part is not None, "this test needs the CU partition (256-CU part, MODEX_CU_PARTITION unset)"
+        main = part[0]
+        main.wait_stream(torch.cuda.current_stream(dev))
+        calls = []
+        real = trainer.allreduce_flat_grad
+
+        def counted(flat_grad, world_size):
+            calls.append(flat_grad.numel())
+            if with_pg:
+                dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)      # 1-rank group: the identity, through RCCL on the masked stream
+            return 1.0
+        trainer.allreduce_flat_grad = counted
+        try:
+            with torch.cuda.stream(main):
+                mod.common_step((dry.to(dev), wet.to(dev), lfo.to(dev), None), is_training=True, optimizer=opt, world_size=2)
+            torch.cuda.current_stream(dev).wait_stream(main)
+            torch.cuda.synchronize()
+        finally:
+            trainer.allreduce_flat_grad = real
+        return opt.flat_param.clone(), len(calls), opt.step_count
+
+    base = run(False)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        with_pg = run(True)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+    assert base[1] == with_pg[1] == base[2] == (n - W) // S            # one collective per optimizer step
+    assert torch.equal(base[0], with_pg[0])
+
+
 def test_bench_single_gpu_line_carries_every_config():
     """N = 1: the headline line carries `roofline`, and configs 2 / 4 / 5 measured in their own processes at their
     BASELINE sizes under `other_configs` (CPU legs skipped here to keep the test short)."""
@@ -346,3 +415,36 @@ def test_two_rank_step_equals_the_single_process_step_on_the_joined_batch(tmp_pa
     if mode == "tbptt":
         assert a["steps"] == b["steps"] == 4
     assert abs(a["loss"] - b["loss"]) < 0.5                      # rank 0 reports its own half's loss: same order of magnitude
+
+
+def test_parameter_gradients_written_in_place_equal_the_accumulated_ones(dev):
+    """FlatAdamW.zero_grad marks the flat gradient buffer fresh; the first CNN backward after it writes every parameter
+    gradient straight into its `.grad` view and hands autograd `None` (20 `grad += g` launches less per step).  The flat
+    gradient must be bit-identical to the ordinary accumulate path, and a SECOND backward into the same buffer (sub-batches)
+    must still accumulate."""
+    from mod_extraction_amd import data_modules, lightning, models, optim
+
+    def grads(direct, twice):
+        torch.manual_seed(5); np.random.seed(5)
+        cfg = dict(in_ch=2, n_samples=22272, sr=44100, n_fft=1024, hop_len=256, n_mels=64, kernel_size=(5, 13),
+                   out_channels=[64] * 6, temp_dilations=[1, 1, 2, 4, 8, 16], pool_size=(2, 1), latent_dim=1,
+                   freq_mask_amount=0.0, time_mask_amount=0.0, use_ln=True)
+        module = lightning.LFOExtraction(models.Spectral2DCNN(**cfg), sr=44100, model_smooth_n_frames=0,
+                                         loss_dict={"l1": 1.0, "fdl1": 5.0, "sdl1": 10.0, "mse": 0.0}).to(dev).train()
+        opt = optim.FlatAdamW(module.parameters(), lr=1e-4, betas=(0.8, 0.99))
+        bt = data_modules.SyntheticFxBatcher(4, 22272, 44100, ("flanger", "chorus"), dev, audio_seed=3)
+        batch = bt.next_batch()
+        models.DIRECT_GRADS = direct
+        try:
+            opt.zero_grad()
+            module.training_step(batch, 0).backward()
+            if twice:
+                module.training_step(batch, 0).backward()
+        finally:
+            models.DIRECT_GRADS = True
+        return opt.flat_grad.clone()
+
+    g_direct, g_plain = grads(True, False), grads(False, False)
+    assert float(g_plain.abs().max()) > 0 and torch.equal(g_direct, g_plain)
+    g2 = grads(True, True)                                                 # first backward in place, second accumulated
+    assert float((g2 - 2 * g_plain).abs().max()) <= 1e-6 * float(g_plain.abs().max())
