@@ -289,7 +289,8 @@ __device__ __forceinline__ void store_tile32(const floatx4 (&acc)[44], int i, fl
 __device__ __forceinline__ float acc_elem(const floatx16 (&acc)[CV_WT], int i, int r) { return acc[i][r]; }
 __device__ __forceinline__ float acc_elem(const floatx4 (&acc)[44], int, int) { return 0.0f; }      // (plain rows: 32x32 layout only)
 
-template <int OUTMODE, typename ACC>
+// HALF = tiles a wave finishes per exchange round (3: two rounds through 96 KB of LDS; 1: six rounds through 32 KB)
+template <int OUTMODE, typename ACC, int HALF = 3>
 __device__ __forceinline__ void conv_f16_epilogue(ACC &acc, const ConvF16Args &a, unsigned char *smem,
                                                   int b, int h0, int row, int c, int lane)
 {
@@ -342,22 +343,23 @@ __device__ __forceinline__ void conv_f16_epilogue(ACC &acc, const ConvF16Args &a
                 st_q[j][q] = 0.0f;
             }
         __syncthreads();                                                // the K loop's LDS images are dead
+        constexpr int ROUNDS = 6 / HALF, SLOTS = 2 * HALF;
 #pragma unroll
-        for (int round = 0; round < 2; ++round) {
-            // slot s of a wave = tile i: s < 3 -> i = 3 round + s (row-0 finishes), s >= 3 -> i = 6 + 3 round + (s - 3)
-            float *mine = xch + (size_t)((c * 2 + row) * 6) * 1024;
+        for (int round = 0; round < ROUNDS; ++round) {
+            // slot s of a wave = tile i: s < HALF -> i = HALF round + s (row-0 finishes), s >= HALF -> i = 6 + HALF round + (s - HALF)
+            float *mine = xch + (size_t)((c * 2 + row) * SLOTS) * 1024;
 #pragma unroll
-            for (int s6 = 0; s6 < 6; ++s6) {
-                const int i = s6 < 3 ? 3 * round + s6 : 6 + 3 * round + (s6 - 3);
+            for (int s6 = 0; s6 < SLOTS; ++s6) {
+                const int i = s6 < HALF ? HALF * round + s6 : 6 + HALF * round + (s6 - HALF);
                 if (i >= CV_WT) continue;
                 store_tile32(acc, i, mine + s6 * 1024, lane);
             }
             __syncthreads();
-            const float *top = xch + (size_t)((c * 2 + 0) * 6) * 1024, *bot = xch + (size_t)((c * 2 + 1) * 6) * 1024;
+            const float *top = xch + (size_t)((c * 2 + 0) * SLOTS) * 1024, *bot = xch + (size_t)((c * 2 + 1) * SLOTS) * 1024;
 #pragma unroll
-            for (int s3 = 0; s3 < 3; ++s3) {
-                const int s6 = row * 3 + s3;
-                const int i = row == 0 ? 3 * round + s3 : 6 + 3 * round + s3;
+            for (int s3 = 0; s3 < HALF; ++s3) {
+                const int s6 = row * HALF + s3;
+                const int i = row == 0 ? HALF * round + s3 : 6 + HALF * round + s3;
                 if (i >= CV_WT) continue;
                 const int wt = i == 10 ? 5 : c * 6 + (i >> 1);           // column tile
                 const int chh = i == 10 ? c : (i & 1) ^ c;              // channel half
@@ -386,14 +388,14 @@ __device__ __forceinline__ void conv_f16_epilogue(ACC &acc, const ConvF16Args &a
                     }
                     // accumulator index j = channel half ^ c = i & 1 (tile 10: 0), the same for both rows' tiles of a slot:
                     // a compile-time constant after unrolling
-                    st_s[(3 * round + s3) & 1][q] += ts;
-                    st_q[(3 * round + s3) & 1][q] += tq;
+                    st_s[(HALF * round + s3) & 1][q] += ts;
+                    st_q[(HALF * round + s3) & 1][q] += tq;
                     const size_t off = (((size_t)b * CV_CO + chh * 32 + col) * Hp + hp) * CV_PITCH + w;
                     *reinterpret_cast<floatx4 *>(a.out + off) = m;
                     *reinterpret_cast<unsigned *>(a.out_amax + off) = am;
                 }
             }
-            if (round == 0) __syncthreads();                            // round 1 overwrites the images
+            if (round + 1 < ROUNDS) __syncthreads();                    // the next round overwrites the images
         }
         if (want_stats) {
             // [wave][j][q][lane] partial sums -> thread co < 64 adds the 4 waves x 8 column lanes of its channel in a fixed order
@@ -812,6 +814,163 @@ __global__ __launch_bounds__(256, 1) void conv_f16x3_dma_kernel(ConvF16Args a)
 #undef DMA_NB
     }
     conv_f16_epilogue<OUTMODE>(acc, a, smem, b, h0, row, c, lane);
+}
+
+// ---- first block, persistent (2 input channels as a k-vector operand: ONE K stage of 13 taps per output row pair) --------
+// On conv_f16x3_dma_kernel<1, 0, 1, 1> a workgroup's life was: fetch weights + patch (nothing to overlap with), 13 taps of
+// matrix work, an epilogue that stores 112 KB -- strictly one after the other, one workgroup per CU (LDS): 36 us per row pair
+// for 8 us of matrix work.  Here a workgroup keeps the block's 53 KB of weights in LDS and walks a contiguous range of row
+// pairs: the next row pair's patch arrives by LDS-DMA during the taps, the pooled rows of the previous one are still
+// draining to memory meanwhile, and the max-pool exchange runs through the patch buffer the taps have just finished with
+// (six rounds of 32 KB).  Measured: 2.31 -> 2.15 ms per 256 clips x 256 mel bins (17 -> 16.5 us per row pair), i.e. the fetch
+// was NOT what the row pair waited for: 8 us are the 429 MFMAs and ~7 us the epilogue's own work on the vector unit and
+// the LDS (176 ds_write_b32 + ~1 400 vector instructions + 12 barriers per wave: pooling select, bias, argmax bytes, PReLU,
+// LayerNorm partial sums, bounds) -- with one workgroup per CU nothing overlaps the two.  Starting every other workgroup
+// half a row pair late (so that one half of the chip stores while the other computes) changed nothing either: 2.12-2.15 ms.
+// Floors at these sizes: 5.2 GB at ~4.7 TB/s = 1.1 ms, 1.8 PFLOP at 1.7 GHz = 1.0 ms.
+//   LDS = W (13 taps x 2 splits: 52 KB) | P[2] (46 KB each)
+__global__ __launch_bounds__(256, 1) void conv1_f16x3_persist_kernel(ConvF16Args a, int n_tiles, int tiles_per_wg)
+{
+    constexpr int T = 1;
+    constexpr int PWP = CV_PITCH + 12 * T;
+    constexpr int PLANE = PWP * 16;
+    constexpr int P_SLOTS = 8 * PWP;
+    constexpr int P_PIECES = (P_SLOTS + 63) / 64;
+    constexpr int P_BYTES = P_PIECES * 1024;
+    constexpr int PPW = (P_PIECES + 3) / 4;                      // 12
+    constexpr int W_SPLIT = CV_KW * 2048, W_BYTES = 2 * W_SPLIT;
+    constexpr int ROWB = CV_PITCH * 32;
+    static_assert(PPW == 12, "DMA schedule");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char *const Wl = smem, *const P0 = smem + W_BYTES;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int row = wave >> 1, c = wave & 1, half = lane >> 5, l32 = lane & 31;
+    // XCD-contiguous ranges of row pairs (workgroups go to the 8 XCDs round-robin in launch order)
+    int wg = blockIdx.x;
+    if ((gridDim.x & 7) == 0) wg = (wg & 7) * (gridDim.x >> 3) + (wg >> 3);
+    const int t_begin = wg * tiles_per_wg, t_end = min(t_begin + tiles_per_wg, n_tiles);
+    if (t_begin >= t_end) return;
+    const int Hp = a.H >> 1, H = a.H;
+    int desc[PPW];
+#pragma unroll
+    for (int k = 0; k < PPW; ++k) {
+        const int i = (wave + 4 * k) * 64 + lane;
+        const int plane = i / PWP, pos = i - plane * PWP, w = pos - 6 * T;
+        const int split = plane >> 2, r = (plane >> 1) & 1, part = plane & 1;
+        desc[k] = (i < P_SLOTS && w >= 0 && w < CV_PITCH) ? ((split << 30) | (r << 29) | (r * ROWB + w * 32 + part * 16)) : -1;
+    }
+    const unsigned long long zero_src = (unsigned long long)k_zero_slot, xh = (unsigned long long)a.x_hi,
+                             xl = (unsigned long long)a.x_lo, wh = (unsigned long long)a.w_hi, wlo = (unsigned long long)a.w_lo;
+    struct DmaSlot { unsigned long long src; unsigned lds; };
+    // patch piece k of row pair `tile` -> patch buffer pb (the operand row h carries its five kernel rows as channels: no halo rows)
+    auto slot_p = [&](int tile, int pb, int k) {
+        const bool in_range = wave + 4 * k < P_PIECES;
+        const int pp = in_range ? wave + 4 * k : wave + 4 * (k - 1);
+        const int d = in_range ? desc[k] : desc[k > 0 ? k - 1 : 0];
+        const int tb = tile / Hp, th0 = (tile - tb * Hp) * 2;
+        const long long st_off = ((long long)tb * H + th0) * (CV_PITCH * 32);
+        const bool ok = d >= 0;                                   // both rows of a pair are inside the image (H is even)
+        const unsigned long long src = ((d & (1 << 30)) ? xl : xh) + st_off + (unsigned)(d & 0xFFFFF);
+        DmaSlot r;
+        r.src = ok ? src : zero_src;
+        r.lds = lds0 + W_BYTES + pb * P_BYTES + pp * 1024;
+        return r;
+    };
+    auto slot_issue = [&](const DmaSlot &d) { glds16(d.src, d.lds); };
+
+    // prologue: all 13 taps of the weights (52 pieces: 13 per wave), the first row pair's patch
+#pragma unroll
+    for (int j = 0; j < CV_KW; ++j) {
+        const int pw = wave + 4 * j, split = pw / (2 * CV_KW), rem = pw - split * (2 * CV_KW);
+        glds16((split ? wlo : wh) + ((unsigned long long)rem * 512 + lane * 8) * 2, lds0 + split * W_SPLIT + rem * 1024);
+    }
+#pragma unroll
+    for (int k = 0; k < PPW; ++k)
+        if (wave + 4 * k < P_PIECES) slot_issue(slot_p(t_begin, 0, k));
+    DMA_WAIT();
+    __syncthreads();
+
+#pragma unroll 1
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        const int pb = (tile - t_begin) & 1;
+        unsigned char *const Pc = P0 + pb * P_BYTES;
+        const int tn = tile + 1 < t_end ? tile + 1 : tile;       // the row pair whose patch the DMA slots fetch (last: a harmless repeat)
+        const int b = tile / Hp, h0 = (tile - b * Hp) * 2;
+        floatx16 acc[CV_WT];
+#pragma unroll
+        for (int i = 0; i < CV_WT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+        const unsigned char *b_p = Pc + (row * 2 + half) * PLANE + (c * 6 * 32 + l32) * 16;
+        const unsigned char *bm_p = Pc + (row * 2 + half) * PLANE + (5 * 32 + l32) * 16;
+        half8 FA[2][4], FBH[2][6], FBL[2][6];
+        auto rd = [&](int f, int kw, int r) {
+            if (r < 4) {
+                const int ch = (r >> 1) ? (c ^ 1) : c;
+                FA[f][r] = *reinterpret_cast<const half8 *>(Wl + (r & 1) * W_SPLIT + (kw * 2 + half) * 1024 + (ch * 32 + l32) * 16);
+            } else {
+                const int tl = (r - 4) >> 1, lo = (r - 4) & 1;
+                const unsigned char *p = (tl < 5 ? b_p + tl * 32 * 16 : bm_p) + lo * 4 * PLANE + kw * T * 16;
+                if (lo) FBL[f][tl] = *reinterpret_cast<const half8 *>(p);
+                else FBH[f][tl] = *reinterpret_cast<const half8 *>(p);
+            }
+        };
+        auto mma = [&](int f, int i) {
+            const int term = i / 11, u = i - term * 11;
+            const int tl = u < 10 ? (u >> 1) : 5, j = u < 10 ? (u & 1) : 0;
+            const half8 av = FA[f][2 * j + (term == 0 ? 1 : 0)];
+            const half8 bv = term == 1 ? FBL[f][tl] : FBH[f][tl];
+            acc[u] = mfma16(av, bv, acc[u]);
+        };
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rd(0, 0, r);
+#pragma unroll
+        for (int t = 0; t < CV_KW; ++t) {
+            // one tap: 33 MFMAs on fragment set t & 1, the next tap's 16 reads into the other set (one read per two MFMAs),
+            // and -- taps 0..5 -- two DMA pieces of the next row pair's patch
+            const int f = t & 1;
+            __builtin_amdgcn_sched_barrier(0);
+            const DmaSlot sa = slot_p(tn, pb ^ 1, t < 6 ? 2 * t : 0), sb = slot_p(tn, pb ^ 1, t < 6 ? 2 * t + 1 : 0);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) mma(f, i);
+            if (t + 1 < CV_KW) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) rd(f ^ 1, t + 1, r);
+#pragma unroll
+                for (int g = 0; g < 8; ++g) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (t < 6) slot_issue(sa);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 16; i < 33; ++i) mma(f, i);
+            if (t + 1 < CV_KW) {
+#pragma unroll
+                for (int r = 8; r < 16; ++r) rd(f ^ 1, t + 1, r);
+#pragma unroll
+                for (int g = 0; g < 8; ++g) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (t < 6) slot_issue(sb);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // the next patch has landed (its pieces were issued seven taps ago; the previous row pair's stores have retired long
+        // since) BEFORE this row pair's stores are issued: a wait behind them would expose their latency
+        DMA_WAIT();
+        // bias + max-pool + argmax (+ LayerNorm partial sums) through the patch buffer the taps are done with; the barrier at
+        // its head also publishes the next patch
+        conv_f16_epilogue<0, floatx16[CV_WT], 1>(acc, a, Pc, b, h0, row, c, lane);
+        __syncthreads();                                        // the exchange images are dead: the next DMA may overwrite them
+    }
 }
 
 // ---- LDS-DMA version on v_mfma_f32_16x16x32_f16 (forward, T <= 4) -------------------------------------------------
@@ -1279,5 +1438,22 @@ MX_EXPORT int mx_conv_block1_fwd_f16(const void *xk_hi, const void *xk_lo, const
     if (B <= 0 || B > 65535 || H < 2 || (H & 1) || Wv <= 0 || Wv > CV_PITCH) return MX_ERR_UNSUPPORTED;
     ConvF16Args a{(const _Float16 *)xk_hi, (const _Float16 *)xk_lo, (const _Float16 *)w_hi, (const _Float16 *)w_lo, bias,
                   nullptr, out, out_amax, (int)H, (int)Wv, slope_out, stats_part};
-    return launch_f16_dma<1, 0, 1, 1>(a, (int)B, (hipStream_t)stream);
+    // MODEX_BLOCK1_PERSIST=0 selects the one-row-pair-per-workgroup kernel (same-box A/B)
+    static const bool persist = !(getenv("MODEX_BLOCK1_PERSIST") && atoi(getenv("MODEX_BLOCK1_PERSIST")) == 0);
+    if (!persist) return launch_f16_dma<1, 0, 1, 1>(a, (int)B, (hipStream_t)stream);
+    constexpr size_t lds = 2 * CV_KW * 2048 + 2 * (size_t)((8 * (CV_PITCH + 12) + 63) / 64) * 1024;
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void *)conv1_f16x3_persist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return MX_ERR_LAUNCH;
+        attr_done = true;
+    }
+    const int n_tiles = (int)(B * (H / 2));
+    int grid = 1024;                                            // 4 workgroups per CU over the launch: contiguous ranges, a short tail
+    if (grid > n_tiles) grid = n_tiles;
+    const int per = (n_tiles + grid - 1) / grid;
+    grid = (n_tiles + per - 1) / per;
+    hipLaunchKernelGGL(conv1_f16x3_persist_kernel, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, a, n_tiles, per);
+    return mx_launch_status();
 }
