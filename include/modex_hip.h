@@ -105,7 +105,8 @@ int mx_phaser_fwd_probe(const float *x, int64_t x_stride, const float *rate, con
                   float *y, int64_t y_stride, float *dry_out, float *workspace, int64_t workspace_stride, void *stream);
 
 /* ---- K4: log-mel front end -- mod_extraction/models.py:170-181,199-208
- * (torchaudio MelSpectrogram: n_fft 1024, hann, centre/reflect, power 2, mel filter bank `fb`)
+ * (torchaudio MelSpectrogram: n_fft in {512, 1024, 2048} -- every shipped config: 1024 --, hann, centre/reflect, power 2,
+ * mel filter bank `fb`; other n_fft: MX_ERR_UNSUPPORTED)
  * x (planes, N), planes = B*in_ch; window (n_fft,); twiddle (n_fft, 2) = exp(-2 pi i m / n_fft);
  * fb (n_fft/2+1, n_mels) row-major; band_lo/band_hi (n_mels,) int32 non-zero row range per mel band.
  * out (planes, n_mels, out_pitch) = log(clip(mel, eps)); out_pitch >= n_frames (352 for 345);

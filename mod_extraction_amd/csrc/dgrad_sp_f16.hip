@@ -129,6 +129,9 @@ __global__ __launch_bounds__(256, 1) void dgrad_sp_f16x3_kernel(DgradSpArgs a)
     // weights of (stage, this wave's output row): fragment f = 0: ci tile c, f = 1: ci tile c ^ 1
     auto w_ptr = [&](const _Float16 *base, int st, int kwf, int f) {
         const int tile = f ? (c ^ 1) : c;
+#ifdef DS_ABL_WFIX        // ablation (wrong results): every tap reads tap 0's fragments -> the weight stream stays in the CU's L1
+        kwf = 0;
+#endif
         return base + ((((size_t)(st * 2 + row) * CV_KW + kwf) * 2 + tile) * 64 + lane) * 16;
     };
 

@@ -15,7 +15,7 @@
 //
 // HBM-bound by design: 2*N*4 B read + 2*n_mels*frames*4 B written per clip (1.41 MB at N=88200);
 // the FFT is ~17.7 MFLOP per clip.
-#include "common.h"
+#include "wave_fft.h"
 
 #define MEL_NFFT 1024
 #define MEL_FR 16
@@ -214,7 +214,112 @@ __global__ __launch_bounds__(256) void melspec_kernel(
     }
 }
 
-// x: (planes, N) fp32 with planes = B*in_ch; window (1024,), twiddle (1024,) float2, fb (513,n_mels),
+// ---- n_fft = 512 / 2048: the same pipeline on the shared wavefront FFT (wave_fft.h) ---------------------------------
+// One frame per wavefront (two for 512) as a complex transform of (x, 0): the same passes, exchanges and twiddle table as
+// the MR-STFT loss's forward transform; power of bins 0..NF/2 -> LDS -> mel bands -> mask, clip, log exactly as above.
+// (The reference's own configs all use n_fft = 1024 -- the kernel above; this one closes the constructor's other sizes.)
+template <int NF>
+__global__ __launch_bounds__(WF<NF>::WAVES * 64) void melspec_wf_kernel(
+    const float *__restrict__ x, int N, const float *__restrict__ window, const float2 *__restrict__ twiddle,
+    const float *__restrict__ fb, const int *__restrict__ band_lo, const int *__restrict__ band_hi, int n_mels, int hop,
+    int n_frames, int out_pitch, float eps, int f0, int f1, int t0, int t1, int coef_cap, float *__restrict__ out)
+{
+    constexpr int L = WF<NF>::L, E = WF<NF>::E, NB = WF<NF>::NB, WAVES = WF<NF>::WAVES, FW = WF<NF>::FW, NT = WAVES * 64;
+    __shared__ cf fftbuf[WAVES * FW][WF<NF>::LEN];
+    __shared__ float powbuf[WAVES * FW][NF / 2 + 1];
+    __shared__ cf tw_s[NF];
+    extern __shared__ float melbuf[];       // n_mels * (MEL_FR + 1) results, then the filter bank's non-zero coefficients
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane / L, a = lane % L;
+    const int plane = blockIdx.y;
+    const int tile0 = blockIdx.x * MEL_FR;
+    const float *xp = x + (size_t)plane * N;
+    cf *buf = fftbuf[wave * FW + g];
+    float *power = powbuf[wave * FW + g];
+    float *coef = melbuf + n_mels * (MEL_FR + 1);
+    int *boff = reinterpret_cast<int *>(coef + coef_cap);
+    for (int i = tid; i < NF; i += NT) {
+        const float2 w = twiddle[i];
+        tw_s[i] = {w.x, w.y};
+    }
+    if (tid == 0) {
+        int acc = 0;
+        for (int m = 0; m < n_mels; ++m) { boff[m] = acc; acc += band_hi[m] - band_lo[m]; }
+        boff[n_mels] = acc;
+    }
+    __syncthreads();
+    const bool packed = boff[n_mels] <= coef_cap;
+    if (packed) {
+        for (int m = tid; m < n_mels; m += NT) {
+            const int lo = band_lo[m], hi = band_hi[m], o = boff[m];
+            for (int kk = lo; kk < hi; ++kk) coef[o + kk - lo] = fb[(size_t)kk * n_mels + m];
+        }
+    }
+    __syncthreads();
+    FftLane<NF> fl_;
+    fft_lane_setup<NF, 1>(fl_, buf, tw_s, twiddle, a);
+
+    for (int fb0 = wave * FW; fb0 < MEL_FR; fb0 += WAVES * FW) {
+        const int fl = fb0 + g;                                 // this stream's frame slot
+        if (tile0 + fb0 >= n_frames) break;                     // wave-uniform
+        const int t = tile0 + fl;
+        const bool live = t < n_frames && fl < MEL_FR;
+        const int tt = live ? t : n_frames - 1;
+        cf R[NB][4], Z[E];
+#pragma unroll
+        for (int bq = 0; bq < NB; ++bq)
+#pragma unroll
+            for (int cq = 0; cq < 4; ++cq) {
+                const int n = a + L * bq + (NF / 4) * cq;
+                int sidx = tt * hop + n - NF / 2;
+                if (sidx < 0) sidx = -sidx;
+                if (sidx >= N) sidx = 2 * (N - 1) - sidx;
+                sidx = sidx < 0 ? 0 : sidx;                    // clips shorter than n_fft/2 are rejected on the host
+                R[bq][cq] = {xp[sidx] * window[n], 0.0f};
+            }
+        wave_fft<NF, false>(R, Z, fl_);
+#pragma unroll
+        for (int i = 0; i < E; ++i) {
+            const int bin = pos_final<NF>(i, a);
+            if (bin <= NF / 2) {
+                const float mag = sqrtf(Z[i].x * Z[i].x + Z[i].y * Z[i].y);  // torchaudio: spec.abs().pow(2)
+                power[bin] = mag * mag;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (live) {
+            for (int m = a; m < n_mels; m += L) {
+                float acc = 0.0f;
+                const int lo = band_lo[m], hi = band_hi[m];
+                if (packed) {
+                    const float *cm = coef + boff[m] - lo;
+                    for (int kk = lo; kk < hi; ++kk) acc = fmaf(cm[kk], power[kk], acc);
+                } else {
+                    for (int kk = lo; kk < hi; ++kk) acc = fmaf(fb[(size_t)kk * n_mels + m], power[kk], acc);
+                }
+                melbuf[m * (MEL_FR + 1) + fl] = acc;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    float *op = out + (size_t)plane * n_mels * out_pitch;
+    for (int idx = tid; idx < n_mels * MEL_FR; idx += NT) {
+        const int m = idx / MEL_FR, fl = idx % MEL_FR;
+        const int t = tile0 + fl;
+        if (t < out_pitch) {
+            float v = 0.0f;
+            if (t < n_frames) {
+                float p = melbuf[m * (MEL_FR + 1) + fl];
+                if ((m >= f0 && m < f1) || (t >= t0 && t < t1)) p = 0.0f;   // SpecAugment fill value 0
+                v = logf(fmaxf(p, eps));
+            }
+            op[(size_t)m * out_pitch + t] = v;
+        }
+    }
+}
+
+// x: (planes, N) fp32 with planes = B*in_ch; window (n_fft,), twiddle (n_fft,) float2 = exp(-2 pi i m / n_fft), fb (n_fft/2+1,n_mels),
+// n_fft in {512, 1024, 2048};
 // band_lo/band_hi (n_mels,) int32 = non-zero row range of each fb column;
 // out: (planes, n_mels, out_pitch) = log(clip(mel, eps)); mask ranges [f0,f1) x [t0,t1) (0,0 = none).
 MX_EXPORT int mx_logmel_fwd(const float *x, int64_t planes, int64_t N, const float *window,
@@ -224,12 +329,23 @@ MX_EXPORT int mx_logmel_fwd(const float *x, int64_t planes, int64_t N, const flo
                             int32_t t0, int32_t t1, float *out, void *stream)
 {
     if (!x || !window || !twiddle || !fb || !band_lo || !band_hi || !out || planes <= 0) return MX_ERR_ARG;
-    if (n_fft != MEL_NFFT || N <= MEL_NFFT / 2 || N >= (1ll << 30) || planes > 65535 || n_mels > 2048 ||
+    if ((n_fft != 512 && n_fft != 1024 && n_fft != 2048) || N <= n_fft / 2 || N >= (1ll << 30) || planes > 65535 || n_mels > 2048 ||
         out_pitch < n_frames)
         return MX_ERR_UNSUPPORTED;
     const int tiles = (int)((out_pitch + MEL_FR - 1) / MEL_FR);
-    const int coef_cap = 2 * (MEL_NFFT / 2 + 1) + 2 * (int)n_mels;      // triangular filters: every bin lies in <= 2 bands
+    const int coef_cap = 2 * ((int)n_fft / 2 + 1) + 2 * (int)n_mels;    // triangular filters: every bin lies in <= 2 bands
     const size_t lds = ((size_t)n_mels * (MEL_FR + 1) + coef_cap + n_mels + 1) * sizeof(float);
+    if (n_fft != MEL_NFFT) {
+        if (n_fft == 512)
+            hipLaunchKernelGGL((melspec_wf_kernel<512>), dim3(tiles, (unsigned)planes), dim3(WF<512>::WAVES * 64), lds, (hipStream_t)stream,
+                               x, (int)N, window, (const float2 *)twiddle, fb, band_lo, band_hi, (int)n_mels, (int)hop, (int)n_frames,
+                               (int)out_pitch, eps, f0, f1, t0, t1, coef_cap, out);
+        else
+            hipLaunchKernelGGL((melspec_wf_kernel<2048>), dim3(tiles, (unsigned)planes), dim3(WF<2048>::WAVES * 64), lds, (hipStream_t)stream,
+                               x, (int)N, window, (const float2 *)twiddle, fb, band_lo, band_hi, (int)n_mels, (int)hop, (int)n_frames,
+                               (int)out_pitch, eps, f0, f1, t0, t1, coef_cap, out);
+        return mx_launch_status();
+    }
     hipLaunchKernelGGL(melspec_kernel, dim3(tiles, (unsigned)planes), dim3(256), lds, (hipStream_t)stream,
                        x, (int)N, window, (const float2 *)twiddle, fb, band_lo, band_hi, (int)n_mels, (int)hop,
                        (int)n_frames, (int)out_pitch, eps, f0, f1, t0, t1, coef_cap, out);

@@ -99,8 +99,7 @@ class MonoFlangerChorusModule(nn.Module):
     def __init__(self, batch_size: int, n_ch: int, n_samples: int, sr: float,
                  max_min_delay_ms: float, max_lfo_delay_ms: float) -> None:
         super().__init__()
-        if n_ch != 1:
-            raise NotImplementedError("mono only (every reference call site uses n_ch=1)")
+        assert n_ch >= 1
         self.batch_size = batch_size
         self.n_ch = n_ch
         self.n_samples = n_samples
@@ -137,19 +136,25 @@ class MonoFlangerChorusModule(nn.Module):
                 width: Param = 1.0, depth: Param = 1.0, mix: Param = 1.0) -> T:
         assert x.ndim == 3
         bs, n_ch, n = x.shape
-        assert n_ch == 1
+        assert n_ch == self.n_ch
         assert mod_sig.size(0) == bs
         if mod_sig.ndim == 3:
-            assert mod_sig.size(1) == 1
+            assert mod_sig.size(1) in (1, n_ch)
         with torch.no_grad():
             consts = derive_clip_constants(bs, x.device, self.max_min_delay_samples,
                                            self.max_lfo_delay_samples, feedback, min_delay_width,
                                            width, depth, mix)
-            md = torch.full((bs,), self.max_delay_samples, device=x.device, dtype=torch.int32)
-            xc = x.reshape(bs, n).contiguous().float()
-            mc = mod_sig.reshape(bs, -1).contiguous().float()
+            # n_ch > 1 (fx.py:81-85,104-115): every channel owns a delay line = one kernel row per (clip, channel); a clip's
+            # channels share its parameters; mod_sig (bs, n) / (bs, 1, n) is shared by the channels
+            rows = bs * n_ch
+            if n_ch > 1:
+                consts = {k: v.repeat_interleave(n_ch) for k, v in consts.items()}
+                mod_sig = mod_sig.view(bs, 1, -1).expand(-1, n_ch, -1) if mod_sig.ndim == 2 or mod_sig.size(1) == 1 else mod_sig
+            md = torch.full((rows,), self.max_delay_samples, device=x.device, dtype=torch.int32)
+            xc = x.reshape(rows, n).contiguous().float()
+            mc = mod_sig.reshape(rows, -1).contiguous().float()
             y = flanger_forward(xc, mc, consts, md, self.max_delay_samples)
-        return y.view(bs, 1, n)
+        return y.view(bs, n_ch, n)
 
 
 def phaser_forward(src: T, params: Dict[str, T], lead: Optional[T], sr: float, n_samples: int,

@@ -69,8 +69,8 @@ class MelSpectrogramHIP(nn.Module):
 
     def __init__(self, sample_rate: int, n_fft: int, hop_length: int, n_mels: int) -> None:
         super().__init__()
-        if n_fft != 1024:
-            raise NotImplementedError("mx_logmel_fwd is built for n_fft = 1024")
+        if n_fft not in (512, 1024, 2048):
+            raise NotImplementedError("mx_logmel_fwd is built for n_fft in {512, 1024, 2048}")
         self.sample_rate, self.n_fft, self.hop_length, self.n_mels = sample_rate, n_fft, hop_length, n_mels
         self.spectrogram = _Buffers()
         self.spectrogram.register_buffer("window", torch.hann_window(n_fft))
@@ -610,8 +610,8 @@ class SpectrogramHIP(nn.Module):
 
     def __init__(self, n_fft: int, hop_length: int) -> None:
         super().__init__()
-        if n_fft != 1024:
-            raise NotImplementedError("mx_logmel_fwd is built for n_fft = 1024")
+        if n_fft not in (512, 1024, 2048):
+            raise NotImplementedError("mx_logmel_fwd is built for n_fft in {512, 1024, 2048}")
         self.n_fft, self.hop_length, self.n_bins = n_fft, hop_length, n_fft // 2 + 1
         self.register_buffer("window", torch.hann_window(n_fft))
         k = torch.arange(n_fft, dtype=torch.float64) * (-2.0 * math.pi / n_fft)

@@ -87,12 +87,13 @@ def flanger_np(x: np.ndarray, mod: np.ndarray, p: Dict[str, np.ndarray], M: int,
 
 
 class MonoFlangerChorusModule(torch.nn.Module):
-    """Same constructor / forward surface as fx.py:25-130 (mono only, as every call site)."""
+    """Same constructor / forward surface as fx.py:25-130.  n_ch > 1 (fx.py:81-85,104-115): every channel owns a delay
+    line, a clip's channels share its parameters, mod_sig is (bs, n) -- shared -- or (bs, n_ch, n)."""
 
     def __init__(self, batch_size: int, n_ch: int, n_samples: int, sr: float,
                  max_min_delay_ms: float, max_lfo_delay_ms: float) -> None:
         super().__init__()
-        assert n_ch == 1
+        assert n_ch >= 1
         self.batch_size, self.n_ch, self.n_samples, self.sr = batch_size, n_ch, n_samples, sr
         self.max_min_delay_ms, self.max_lfo_delay_ms = max_min_delay_ms, max_lfo_delay_ms
         self.max_min_delay_samples = delay_samples(max_min_delay_ms, sr)
@@ -103,13 +104,17 @@ class MonoFlangerChorusModule(torch.nn.Module):
     def forward(self, x: torch.Tensor, mod_sig: torch.Tensor, feedback: Param = 0.0,
                 min_delay_width: Param = 1.0, width: Param = 1.0, depth: Param = 1.0,
                 mix: Param = 1.0) -> torch.Tensor:
-        assert x.ndim == 3 and x.size(1) == 1
-        bs, _, n = x.shape
+        assert x.ndim == 3 and x.size(1) == self.n_ch
+        bs, c, n = x.shape
         assert mod_sig.size(0) == bs and mod_sig.size(-1) == n
         p = derive_params(bs, self.max_min_delay_samples, self.max_lfo_delay_samples,
                           feedback, min_delay_width, width, depth, mix)
-        y = flanger_np(x.reshape(bs, n).numpy(), mod_sig.reshape(bs, n).numpy(), p, self.max_delay_samples)
-        return torch.from_numpy(y).view(bs, 1, n)
+        if mod_sig.ndim == 2:
+            mod_sig = mod_sig.unsqueeze(1).expand(-1, c, -1)                        # fx.py:84-85
+        p = {k: np.repeat(v, c) for k, v in p.items()}                              # a clip's channels share its parameters
+        y = flanger_np(np.ascontiguousarray(x.reshape(bs * c, n).numpy()), np.ascontiguousarray(mod_sig.reshape(bs * c, n).numpy()), p,
+                       self.max_delay_samples)
+        return torch.from_numpy(y).view(bs, c, n)
 
 
 def apply_tremolo(x: torch.Tensor, mod_sig: torch.Tensor, mix: Param = 1.0) -> torch.Tensor:

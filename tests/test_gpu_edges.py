@@ -168,6 +168,10 @@ def test_tbptt_training_with_other_warmup_and_step_lengths(dev, W, S, n):
     (dict(hop_len=128, n_mels=64), 30000),
     (dict(hop_len=512, n_mels=96, sr=22050, out_channels=[64] * 5, temp_dilations=[1, 2, 4, 8, 16]), 88200),
     (dict(hop_len=300, n_mels=128, sr=48000), 48000),
+    (dict(n_fft=512, hop_len=128, n_mels=64), 40000),                     # the other transform sizes of the constructor
+    (dict(n_fft=2048, hop_len=512, n_mels=128), 88200),
+    (dict(n_fft=2048, hop_len=256, n_mels=256), 30001),
+    (dict(n_fft=512, hop_len=100, n_mels=64, sr=16000), 16000),
 ])
 def test_logmel_other_hops_rates_and_band_counts(dev, over, n_samples):
     """mel front end away from the shipped (hop 256, 256 bands, 44.1 kHz): frame count, filter bank and framing follow

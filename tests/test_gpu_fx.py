@@ -233,3 +233,21 @@ def test_probe_twins_are_separate_entry_points(dev):
         y1 = fl(x, mod, **p).clone()
     y2 = fl(x, mod, **p)
     assert torch.equal(y0, y2) and not torch.equal(y0, y1)
+
+
+def test_flanger_two_channels_vs_reference_golden(golden_dir, dev):
+    """n_ch = 2 (fx.py:81-85,104-115; the round-3 review's generality hole): one kernel row per (clip, channel), a clip's
+    channels share its parameters, mod_sig shared or per channel -- bit-exact against vectors of the REAL module."""
+    from mod_extraction_amd import fx as afx
+    g = np.load(os.path.join(golden_dir, "flanger_stereo.npz"))
+    for ci in range(2):
+        x = torch.from_numpy(g[f"x_{ci}"]).to(dev)
+        mm, ml = (float(v) for v in g[f"ms_{ci}"])
+        mod = afx.MonoFlangerChorusModule(x.size(0), 2, x.size(-1), 44100, mm, ml)
+        p = {k: torch.from_numpy(g[f"p_{ci}_{k}"]).to(dev) for k in ("feedback", "min_delay_width", "width", "depth", "mix")}
+        y = mod(x, torch.from_numpy(g[f"mod_shared_{ci}"]).to(dev), **p)
+        assert y.shape == x.shape and np.array_equal(y.cpu().numpy(), g[f"y_shared_{ci}"])
+        y = mod(x, torch.from_numpy(g[f"mod_per_ch_{ci}"]).to(dev), **p)
+        assert np.array_equal(y.cpu().numpy(), g[f"y_per_ch_{ci}"])
+        y = mod(x, torch.from_numpy(g[f"mod_shared_{ci}"]).to(dev), feedback=0.4, min_delay_width=0.3, width=0.9, depth=0.8, mix=0.7)
+        assert np.array_equal(y.cpu().numpy(), g[f"y_float_{ci}"])

@@ -146,3 +146,20 @@ def test_python_loop_flanger_equals_c_restatement():
         ref = ofx.MonoFlangerChorusModule(B, 1, N, 44100.0, m_min / 44.1, 10.0)
         assert ref.max_min_delay_samples == m_min
         assert torch.equal(y, ref(x, mod, *ps))
+
+
+def test_flanger_two_channels_bit_exact(golden_dir):
+    """MonoFlangerChorusModule with n_ch = 2 against vectors of the REAL module (tests/golden/make_golden_stereo.py): shared
+    and per-channel mod_sig, tensor and float parameters -- every channel its own delay line, bit for bit."""
+    import torch
+    from oracle import fx as ofx
+    g = np.load(os.path.join(golden_dir, "flanger_stereo.npz"))
+    for ci in range(2):
+        x = torch.from_numpy(g[f"x_{ci}"])
+        mm, ml = (float(v) for v in g[f"ms_{ci}"])
+        mod = ofx.MonoFlangerChorusModule(x.size(0), 2, x.size(-1), 44100, mm, ml)
+        p = {k: torch.from_numpy(g[f"p_{ci}_{k}"]) for k in ("feedback", "min_delay_width", "width", "depth", "mix")}
+        assert np.array_equal(mod(x, torch.from_numpy(g[f"mod_shared_{ci}"]), **p).numpy(), g[f"y_shared_{ci}"])
+        assert np.array_equal(mod(x, torch.from_numpy(g[f"mod_per_ch_{ci}"]), **p).numpy(), g[f"y_per_ch_{ci}"])
+        y = mod(x, torch.from_numpy(g[f"mod_shared_{ci}"]), feedback=0.4, min_delay_width=0.3, width=0.9, depth=0.8, mix=0.7)
+        assert np.array_equal(y.numpy(), g[f"y_float_{ci}"])
