@@ -79,7 +79,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_kvec_f16_kernel(WgradKvecArgs a)
     constexpr int NA = 64 * (WK_CH / 4) / 256, NB = (2 * WK_BR * 2 + 255) / 256;
     floatx4 ga[NA], vb[NB];
     unsigned ama[NA];
-    auto issue = [&](int rid, int w0) {
+    // G / argmax of the pooled row that rows rid, rid + 1 share (rid even): fetched ONCE and committed twice, once per row
+    // parity (the routed gradient of row 2 hp + p is G where argmax == p) -- the second fetch was a cache hit, but a load
+    // latency and 14 MB per clip of L2 traffic all the same
+    auto issue_g = [&](int rid, int w0) {
         const int b = rid / a.H, h = rid - b * a.H;
         const int npos = (CV_PITCH - w0 >= WK_CH) ? WK_CH : (CV_PITCH - w0);
 #pragma unroll
@@ -93,6 +96,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_kvec_f16_kernel(WgradKvecArgs a)
                 ama[q] = *reinterpret_cast<const unsigned *>(a.amax + off);
             }
         }
+    };
+    auto issue_x = [&](int rid, int w0) {
+        const int b = rid / a.H, h = rid - b * a.H;
+        const int npos = (CV_PITCH - w0 >= WK_CH) ? WK_CH : (CV_PITCH - w0);
 #pragma unroll
         for (int q = 0; q < NB; ++q) {
             const int i = tid + q * 256;
@@ -133,15 +140,25 @@ __global__ __launch_bounds__(256, 2) void wgrad_kvec_f16_kernel(WgradKvecArgs a)
         }
     };
 
+    // units in the order (row pair, chunk, row parity): rid = the unit's row; slabs start on even rows and hold an even
+    // number of rows (the entry point sees to it), so a pair never straddles two slabs
     int rid = row_begin, w0 = 0;
-    if (rid < row_end) issue(rid, w0);
+    if (rid < row_end) { issue_g(rid, w0); issue_x(rid, w0); }
     while (rid < row_end) {
         const int nks = (CV_PITCH - w0 >= WK_CH) ? WK_KS_MAX : (CV_PITCH - w0) / 32;     // 6 then 5
-        int nrid = rid, nw0 = w0 + WK_CH;
-        if (nw0 >= CV_PITCH) { nw0 = 0; ++nrid; }
+        int nrid, nw0 = w0;
+        if (!(rid & 1)) nrid = rid + 1;                     // the pair's odd row: same chunk, same G
+        else {
+            nrid = rid - 1;
+            nw0 = w0 + WK_CH;
+            if (nw0 >= CV_PITCH) { nw0 = 0; nrid = rid + 1; }
+        }
         __syncthreads();                                    // previous chunk's fragments are all read
         commit(rid, w0);
-        if (nrid < row_end) issue(nrid, nw0);               // in flight during the MFMAs below
+        if (nrid < row_end) {                               // in flight during the MFMAs below
+            if (!(nrid & 1)) issue_g(nrid, nw0);
+            issue_x(nrid, nw0);
+        }
         __syncthreads();
         {
             {
@@ -236,6 +253,7 @@ MX_EXPORT int mx_conv_block1_wgrad_f16(const float *G, const uint8_t *amax, cons
     if (!G || !amax || !amax_bits || !xk_hi || !xk_lo || !scale || !part || !dW || B <= 0 || rows_per_slab <= 0)
         return MX_ERR_ARG;
     if (H < 2 || (H & 1) || Wv <= 0 || Wv > CV_PITCH) return MX_ERR_UNSUPPORTED;
+    rows_per_slab += rows_per_slab & 1;                     // whole pooling pairs per slab (fewer slabs than the workspace was sized for)
     const int64_t n_slabs = (B * H + rows_per_slab - 1) / rows_per_slab;
     if (n_slabs > 1000000) return MX_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
