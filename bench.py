@@ -82,10 +82,10 @@ METRIC = {2: "44.1 kHz audio-seconds/sec (train step), phaser",
 
 def measured_traffic(batch: int, kind: str = "f32"):
     """HBM bytes per launch of the roofline kernel from the latest committed PMC pass (profiles/rNN/
-    pmc_conv_block2_fwd[_f16].json; FETCH_SIZE / WRITE_SIZE collected in separate rocprofv3 --pmc runs and
-    corrected as MI355X_MICROARCH.md prescribes), scaled linearly to this batch; None if absent."""
+    pmc_conv_block2_fwd[_f16].json, pmc_mrstft.json; FETCH_SIZE / WRITE_SIZE collected in separate rocprofv3 --pmc runs
+    and corrected as MI355X_MICROARCH.md prescribes), scaled linearly to this batch; None if absent."""
     import glob
-    name = "pmc_conv_block2_fwd_f16.json" if kind == "f16" else "pmc_conv_block2_fwd.json"
+    name = {"f16": "pmc_conv_block2_fwd_f16.json", "mrstft": "pmc_mrstft.json"}.get(kind, "pmc_conv_block2_fwd.json")
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", name)))
     if not files:
         return None
@@ -421,7 +421,8 @@ def run_lfo_config(args, env, cfg_id):
     if f16:                      # roofline kernel = the heaviest conv launch of the step: block-2 forward
         dom = kernels["conv_block_fwd_f16[block2]"]
         roofline = {
-            "bound": "mfma", "kernel": "conv_f16x3_dma_kernel<1,0> (block-2 forward: conv5x13+bias+maxpool on split-fp16 operands)",
+            "bound": "mfma", "kernel": "conv_f16x3_dma16_kernel<1> (block-2 forward: conv5x13+bias+maxpool on split-fp16 operands, "
+                                       "v_mfma_f32_16x16x32_f16)",
             "achieved": dom["tflops"], "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(dom["tflops"] / F16_MFMA_PEAK_TFLOPS, 4),
             "note": "achieved = ALGORITHMIC fp32-equivalent flops (2*64*64*65*128*345 per clip) / HIP-event launch time; "
@@ -700,6 +701,8 @@ def run_config5(args, env):
                         "alpha g1 + g2.  Nothing per bin reaches memory (the two-pass version parked 12 B per bin: ~25 GB per step, 46x "
                         "the algorithmic bytes; now ~3.5 GB: run sums written and read once).  The kernels are VALU-issue bound "
                         "(FFT butterflies on packed-fp32 instructions), which is why the HBM fraction stays small")
+    mr["traffic"] = measured_traffic(B, "mrstft")
+    mr["traffic_unit"] = "bytes/launch of mx_mrstft_loss (rocprofv3 PMC passes measured at bs 64, scaled linearly to this batch)"
     kernels["mrstft_loss"] = mr
     audio_s = world * B * cfg["seconds"] * args.steps
     out = {

@@ -446,7 +446,7 @@ __global__ __launch_bounds__(256, 1) void conv_f16x3_kernel(ConvF16Args a)
     _Float16 *wl = reinterpret_cast<_Float16 *>(smem);            // [split][kw][khalf][co][8]
     _Float16 *pl = wl + 2 * WSL;                                   // [split][row][khalf][q][8]
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: wave-uniform address parts stay off the vector unit
     // wave = (output row, column half c).  Each wave owns all 64 output channels of 5 whole column tiles plus ONE
     // channel half of the middle tile (tile 5): 11 accumulators like a (channel half x whole row) split, but every
     // patch fragment feeds two channel tiles, so a tap needs 12 + 4 fragment reads instead of 22 + 2 -- the LDS

@@ -67,7 +67,9 @@ __global__ __launch_bounds__(256, 1) void dgrad_sp_f16x3_kernel(DgradSpArgs a)
     constexpr int N_STAGE = 12;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // (wave index pinned to a scalar register: row / c are then wave-uniform for the compiler and the weight-fragment addresses
+    // -- base + a per-tap constant beyond the loads' immediate range -- become scalar adds instead of a 64-bit vector add per load)
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int row = wave >> 1, c = wave & 1, hh = lane >> 5, l32 = lane & 31;
     int tile_id = blockIdx.y * gridDim.x + blockIdx.x;
     {
@@ -132,7 +134,9 @@ __global__ __launch_bounds__(256, 1) void dgrad_sp_f16x3_kernel(DgradSpArgs a)
 #ifdef DS_ABL_WFIX        // ablation (wrong results): every tap reads tap 0's fragments -> the weight stream stays in the CU's L1
         kwf = 0;
 #endif
-        return base + ((((size_t)(st * 2 + row) * CV_KW + kwf) * 2 + tile) * 64 + lane) * 16;
+        // (wave-uniform part) + (32-bit lane offset): the loads take the scalar-base form, no vector address arithmetic
+        const _Float16 *ub = base + (((size_t)(st * 2 + row) * CV_KW + kwf) * 2 + tile) * (64 * 16);
+        return ub + (unsigned)(lane * 16);
     };
 
     int st = 0;

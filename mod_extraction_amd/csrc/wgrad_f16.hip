@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_f16x3_kernel(WgradF16Args a)
     _Float16 *dzl = reinterpret_cast<_Float16 *>(smem);               // [split][WF_CH][64]
     _Float16 *xl = dzl + 2 * WF_CH * 64;                               // [split][WIN][64]
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: wave-uniform address parts stay off the vector unit
     const int g = wave & 1, nt = wave >> 1;
     // workgroup id -> (kh, slab): the 5 kh of a slab get ids that differ by 8 (same XCD under round-robin
     // dispatch; a speed-only assumption, correctness does not depend on placement)

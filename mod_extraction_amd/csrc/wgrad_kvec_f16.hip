@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kvec_f16_kernel(WgradKvecArgs a)
 {
     __shared__ __attribute__((aligned(16))) _Float16 dzA[2 * 64 * WK_AP];      // [split][co][position]   51,200 B
     __shared__ __attribute__((aligned(16))) _Float16 xB[2 * WK_BR * 16];       // [split][position][16]   13,056 B
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: wave-uniform address parts stay off the vector unit
     const int mh = wave & 1, g = wave >> 1;
     const int m16 = lane & 15, kg = lane >> 4;
     const int slab = blockIdx.x;

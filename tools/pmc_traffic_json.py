@@ -1,0 +1,59 @@
+"""From the FETCH_SIZE / WRITE_SIZE summaries of tools/profile_round.sh (pmc_b64_{fetch,write}.txt for the headline step,
+pmc_c5_b64_{fetch,write}.txt for config 5) build the two files bench.py scales into `roofline.traffic`:
+    pmc_conv_block2_fwd_f16.json   HBM bytes per launch of the block-2 forward convolution at bs 64
+    pmc_mrstft.json                HBM bytes per mx_mrstft_loss call (all its kernels) at bs 64
+Counter units and the gfx950 correction as MI355X_MICROARCH.md's HBM / rocprofv3 section prescribes: FETCH_SIZE and WRITE_SIZE
+in KB of 1000 B; FETCH_SIZE x 2 for kernels whose reads are 16 B per lane (incl. LDS-DMA) -- the convolution; the MR-STFT
+kernels read 4 B per lane (x, y, run sums): no correction.
+    python tools/pmc_traffic_json.py profiles/r04
+"""
+import json
+import os
+import re
+import sys
+
+d = sys.argv[1]
+
+
+def per_launch(path, pattern, counter):
+    """sum over the kernels matching `pattern` of (counter per launch x launches per step)."""
+    out = {}
+    for line in open(path):
+        m = re.match(r"(.{60}) x\s*(\d+)\s+([\d.]+) ms/launch\s+(.*)", line)
+        if not m or not re.search(pattern, m.group(1)):
+            continue
+        vals = dict(kv.split("=") for kv in m.group(4).split())
+        out[m.group(1).strip()] = (int(m.group(2)), float(vals[counter]))
+    return out
+
+
+conv_f = per_launch(os.path.join(d, "pmc_b64_fetch.txt"), r"conv_f16x3_dma16_kernel<1>", "FETCH_SIZE")
+conv_w = per_launch(os.path.join(d, "pmc_b64_write.txt"), r"conv_f16x3_dma16_kernel<1>", "WRITE_SIZE")
+if conv_f and conv_w:
+    f = list(conv_f.values())[0][1]
+    w = list(conv_w.values())[0][1]
+    alg = 64 * (2 * 128 * 4 * 352 * 16 * 2 + 64 * 64 * 352 * 4 + 64 * 64 * 352 + 64 * 64 * 2 * 4)
+    json.dump({"kernel": "conv_f16x3_dma16_kernel<1>", "batch_measured": 64, "fetch_size_kb": f, "write_size_kb": w,
+               "fetch_correction": 2.0, "hbm_bytes_per_launch_b64": (2.0 * f + w) * 1000.0, "algorithmic_bytes_b64": alg,
+               "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (pmc_b64_fetch.txt, pmc_b64_write.txt), KB = 1000 B, "
+                       "gfx950 FETCH_SIZE x2 correction for 16 B/lane loads incl. LDS-DMA; algorithmic = operand pair read once + pooled "
+                       "fp32 output, argmax bytes and the per-row LayerNorm partial sums written once; scale linearly with batch"},
+              open(os.path.join(d, "pmc_conv_block2_fwd_f16.json"), "w"), indent=1)
+    print("conv:", (2.0 * f + w) * 1000.0 / alg, "x algorithmic")
+p5f, p5w = os.path.join(d, "pmc_c5_b64_fetch.txt"), os.path.join(d, "pmc_c5_b64_write.txt")
+if os.path.exists(p5f) and os.path.exists(p5w):
+    mf = per_launch(p5f, r"mr_", "FETCH_SIZE")
+    mw = per_launch(p5w, r"mr_", "WRITE_SIZE")
+    steps = 3                                            # bench.py --steps 2 --warmup 1: three calls of mx_mrstft_loss
+    fetch = sum(n * v for n, v in mf.values()) / steps
+    write = sum(n * v for n, v in mw.values()) / steps
+    alg = 64 * 176400 * 12
+    json.dump({"kernel": "mx_mrstft_loss (mr_onepass_kernel x 3 + mr_fold_all_kernel + finish)", "batch_measured": 64,
+               "fetch_size_kb": fetch, "write_size_kb": write, "fetch_correction": 1.0,
+               "hbm_bytes_per_launch_b64": (fetch + write) * 1000.0, "algorithmic_bytes_b64": alg,
+               "per_kernel_kb_per_launch": {k: {"launches": n, "fetch_kb": v, "write_kb": mw.get(k, (0, 0.0))[1]} for k, (n, v) in mf.items()},
+               "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over bench.py --config 5 --batch 64 (pmc_c5_b64_*.txt), "
+                       "KB = 1000 B, summed over the kernels of one mx_mrstft_loss call; 4 B/lane reads: no gfx950 fetch correction; "
+                       "algorithmic = 12 B per sample (x, y in, gradient out)"},
+              open(os.path.join(d, "pmc_mrstft.json"), "w"), indent=1)
+    print("mrstft:", (fetch + write) * 1000.0 / alg, "x algorithmic")

@@ -27,6 +27,16 @@ run_pmc fetch FETCH_SIZE
 python tools/pmc_summary.py $O/pmc_fetch > $O/pmc_b64_fetch.txt
 run_pmc write WRITE_SIZE
 python tools/pmc_summary.py $O/pmc_write > $O/pmc_b64_write.txt
+# the MR-STFT entry point of config 5 at bs 64 (FETCH_SIZE / WRITE_SIZE in separate passes) -> pmc_mrstft.json for bench.py's roofline.traffic
+run_pmc5() { n=$1; shift
+  timeout 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $O/pmc5_$n -- python3 bench.py --worker --config 5 --steps 2 --warmup 1 --batch 64 --no-cpu-baseline > $O/pmc5_$n.log 2>&1
+}
+run_pmc5 fetch FETCH_SIZE
+python tools/pmc_summary.py $O/pmc5_fetch mr_ > $O/pmc_c5_b64_fetch.txt
+run_pmc5 write WRITE_SIZE
+python tools/pmc_summary.py $O/pmc5_write mr_ > $O/pmc_c5_b64_write.txt
+python tools/pmc_traffic_json.py $O
+rm -rf $O/pmc5_fetch $O/pmc5_write
 # the sample-recurrent kernels of config 4 (LSTM forward / backward): issue and LDS counters
 rocprofv3 --kernel-trace --pmc SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_lstm -- python3 tools/bench_lstm.py > $O/pmc_lstm.log 2>&1
 python tools/pmc_summary.py $O/pmc_lstm lstm > $O/pmc_lstm_sq.txt
