@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # MODEX_HIP_LIB: load another build of the same library (kernel experiments); there is no non-HIP fallback
 SO_PATH = os.environ.get("MODEX_HIP_LIB") or os.path.join(_HERE, "_lib", "libmodex_hip.so")
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 _ERR = {-1: "MX_ERR_ARG (bad argument)", -2: "MX_ERR_UNSUPPORTED (size not supported)",
         -3: "MX_ERR_LAUNCH (HIP launch error)"}

@@ -162,8 +162,10 @@ def _direct_grad_views(params) -> Optional[List[T]]:
     views = []
     base = None
     for p in params:
-        g = getattr(p, "grad", None)
-        if g is None or not g.is_contiguous() or g._base is None or g.dtype != torch.float32 or not p.requires_grad:
+        if not (p.is_leaf and p.requires_grad):          # (.grad of a non-leaf tensor warns)
+            return None
+        g = p.grad
+        if g is None or not g.is_contiguous() or g._base is None or g.dtype != torch.float32:
             return None
         if base is None:
             base = g._base
