@@ -352,7 +352,7 @@ def fx_blocks(batcher, params, res):
         out["flanger_kernel"] = hbm_block(
             f"flanger_kernel ({n_fx} flanger/chorus clips x {N} samples, fx.py:104-115)", n_fx * N * 8.0,
             res[0]["mx_flanger_fwd"], res[1].get("mx_flanger_fwd"),
-            note="8 B/sample: x in, y out; the 882-point LFO is resampled in-kernel. One workgroup (4 producer waves + 1 consumer "
+            note="8 B/sample: x in, y out; the 882-point LFO is resampled in-kernel. One workgroup (8 producer waves + 1 consumer "
                  "wave) per clip, delay line in LDS; the launch lasts as long as its slowest clip's read-after-write chain, so "
                  "the serial floor, not HBM, is the governing roofline")
         try:                                                # the independent floor: lock-steps x measured LDS round trip

@@ -995,6 +995,9 @@ __global__ __launch_bounds__(256, 1) void conv1_f16x3_persist_kernel(ConvF16Args
 //   accumulator every 4th instruction); a tile's two B fragments are dead after its 12 instructions, so the patch
 //   fragments live in a RING of six tiles read four tiles ahead of their use (across pair boundaries), and only the 8 A
 //   fragments are double buffered: 12 + 16 fragment vectors (112 registers).
+#ifndef DMA16_ABL
+#define DMA16_ABL 0     // ablation knobs (wrong results): 1 = no LDS-DMA issue inside the loop, 2 = no barrier behind the straddling pair
+#endif
 template <int T>
 __global__ __launch_bounds__(256, 1) void conv_f16x3_dma16_kernel(ConvF16Args a)
 {
@@ -1074,6 +1077,13 @@ __global__ __launch_bounds__(256, 1) void conv_f16x3_dma16_kernel(ConvF16Args a)
 #pragma unroll
     for (int k = 0; k < PPW; ++k)
         if (wave + 4 * k < P_PIECES) slot_issue(slot_p(0, P0_OFF, k));
+    if (DMA16_ABL & 1) {                                     // ablation: every buffer holds valid operands once, nothing moves afterwards
+#pragma unroll
+        for (int j = 0; j < 7; ++j) slot_issue(slot_w(0, 6, 7, W1_OFF, j));
+#pragma unroll
+        for (int k = 0; k < PPW; ++k)
+            if (wave + 4 * k < P_PIECES) slot_issue(slot_p(1, P1_OFF, k));
+    }
     DMA_WAIT();
     __syncthreads();
 
@@ -1148,8 +1158,8 @@ __global__ __launch_bounds__(256, 1) void conv_f16x3_dma16_kernel(ConvF16Args a)
                 __builtin_amdgcn_sched_barrier(0);                                                     \
             }                                                                                          \
         }                                                                                              \
-        if ((NS) >= 1) slot_issue(s1_);                                                                \
-        if ((NS) >= 2) slot_issue(s2_);                                                                \
+        if ((NS) >= 1 && !(DMA16_ABL & 1)) slot_issue(s1_);                                            \
+        if ((NS) >= 2 && !(DMA16_ABL & 1)) slot_issue(s2_);                                            \
         __builtin_amdgcn_sched_barrier(0);                                                             \
     }
     // groups 2, 5, 8, 10 of a pair carry its DMA slots SBASE + 0..3; the others none
@@ -1218,7 +1228,7 @@ __global__ __launch_bounds__(256, 1) void conv_f16x3_dma16_kernel(ConvF16Args a)
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) { rdB_str(nt, 0); rdB_str(nt, 1); }
         DMA16_PAIR(0, RB_S, 1, RA_(W0_OFF, 1), 1, RB_O(1), OA_SLOTN, OA_SLOT1, OA_SLOT1, 0)     // slots 0..3: weights only
-        __builtin_amdgcn_s_barrier();                 // every wave holds the straddling pair's operands: P0 may be overwritten from here on
+        if (!(DMA16_ABL & 2)) __builtin_amdgcn_s_barrier();   // every wave holds the straddling pair's operands: P0 may be overwritten from here on
         DMA16_PAIR(1, RB_O(1), 1, RA_(W0_OFF, 3), 1, RB_O(3), OA_SLOTN, OA_SLOT1, OA_SLOT1, 4)
         DMA16_PAIR(0, RB_O(3), 1, RA_(W0_OFF, 5), 1, RB_O(5), OA_SLOTN, OA_SLOT1, OA_SLOT1, 8)
         DMA16_PAIR(1, RB_O(5), 0, R_NONE, 1, RB_O(7), OA_SLOTN, OA_SLOT1, OA_SLOT1, 12)

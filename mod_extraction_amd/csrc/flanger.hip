@@ -1,8 +1,8 @@
 // flanger.hip -- K2: mono flanger / chorus (reference: mod_extraction/fx.py:72-119).
 //
-// One workgroup = one clip = FIVE wavefronts; the circular delay line (M <= ~38k floats) lives in LDS.
-// The reference executes 88 200 dependent python iterations per batch.  Here the clip is walked in chunks of 256 samples
-// (4 rows of 64).  For every sample the fp32 index bookkeeping of fx.py:95-103 (write slot, fractional read position,
+// One workgroup = one clip = NINE wavefronts; the circular delay line (M <= ~34k floats) lives in LDS.
+// The reference executes 88 200 dependent python iterations per batch.  Here the clip is walked in chunks of 512 samples
+// (FL_V = 8 rows of 64).  For every sample the fp32 index bookkeeping of fx.py:95-103 (write slot, fractional read position,
 // prev / next slot) is evaluated with exactly the reference's rounding sequence (no FMA contraction: the build uses
 // -ffp-contract=off and explicit __f*_rn).  From the INTEGER slots follows, per sample k of a row, the newest sample
 // t[k] = k - (distance back to the write it reads) it depends on; a run of consecutive samples [a, b) has no internal
@@ -10,12 +10,13 @@
 // (all reads, then all writes: the reference's read-before-write order, fx.py:111-115).  Runs are maximal (greedy):
 // chorus (delay >= 485 samples) always runs 64 samples per step, a flanger near zero delay degrades gracefully down to
 // the reference's one-sample-at-a-time order.
-//   four PRODUCER waves (one chunk ahead, one row of the chunk each): input loads, the LFO (resampled in-kernel), the
+//   FL_V PRODUCER waves (one chunk ahead, one row of the chunk each): input loads, the LFO (resampled in-kernel), the
 //            index bookkeeping, the run boundaries of the row (a 64-bit mask), debug outputs -> a two-slot LDS ring of
 //            float4 records.
 //   CONSUMER wave: only the dependent chain -- per lock-step two ds_read_b32, five dependent fp32 operations, one
 //            ds_write_b32 -- and the dry / wet mix + store of the finished chunk.
-// One workgroup barrier per chunk.  Round 2 ran everything on one wave with one run length per 256-sample chunk:
+// One workgroup barrier per chunk (round 4: 8 rows per chunk instead of 4: the barrier and the consumer's per-chunk record
+// loads amortise over twice the rows, 0.58 -> 0.62 of the independent floor on the headline draw).  Round 2 ran everything on one wave with one run length per 256-sample chunk:
 // 1.40 ms for the slowest of 171 clips x 2 s, ~750 cycles per lock-step of which ~200 are the dependent chain.
 //
 // Results are bit-identical to the reference for identical mod_sig input.
@@ -23,9 +24,11 @@
 // resampled in-kernel (util.py:15-29).
 #include "common.h"
 
-#define FL_V 4                 // rows of 64 samples per chunk
+#ifndef FL_V
+#define FL_V 8                 // rows of 64 samples per chunk (4: 0.58 of the independent floor on config 3, 6: 0.60, 8: 0.62 -- the per-chunk barrier and the consumer's record loads amortise over more rows; 12 would need 132 consumer registers)
+#endif
 #define FL_CHUNK (64 * FL_V)
-#define FL_SLOT_FLOATS (FL_CHUNK * 6 + 2 * FL_V)          // 256 float4 records, 256 64-bit lane masks (run r of a row in lane r), 4 run counts
+#define FL_SLOT_FLOATS (FL_CHUNK * 6 + 2 * FL_V)          // FL_CHUNK float4 records, FL_CHUNK 64-bit lane masks (run r of a row in lane r), FL_V run counts
 #define FL_RING_FLOATS (2 * FL_SLOT_FLOATS)
 #define FL_MAX_M (40960 - FL_RING_FLOATS)                // 160 KB LDS = 40960 floats, minus the ring
 
