@@ -816,6 +816,192 @@ __global__ __launch_bounds__(256, 1) void conv_f16x3_dma_kernel(ConvF16Args a)
     conv_f16_epilogue<OUTMODE>(acc, a, smem, b, h0, row, c, lane);
 }
 
+// Epilogue of the first block's "pair-wave" layout: wave = (channel tile jt, column half c) holds BOTH rows of the pooling
+// pair -- acc[2t + r], t < 5: column tile c*6 + t, row r; acc[10]: column tile 5, row c -- so the max over the pair is taken
+// in registers and only the pooled tile (with its 16 argmax bits per lane packed into one word) goes through LDS for the
+// transposition to 16-byte stores, in a region private to the wave: 17 LDS writes + 5 reads per pooled tile instead of
+// 32 + 8, and no workgroup barrier.  Only the middle column tile, whose two rows sit in two waves, is exchanged: each of
+// the two waves finishes 16 of its 32 channels.  scr: 4 waves x 4 352 B + 2 x 2 x 4 KB, inside the patch buffer the taps
+// are done with.
+#ifdef C1_DIAG           // diagnostic build (tools/exp_block1.py): cycle stamps of wave 0 summed over workgroups and row pairs
+__device__ unsigned long long c1_diag[8];
+struct C1Diag { unsigned long long prev, sum[8]; };
+#define C1_STAMP(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); dg.sum[i] += t_ - dg.prev; dg.prev = t_; } while (0)
+#define C1_DIAG_PARAM , C1Diag &dg
+#define C1_DIAG_ARG , dg
+extern "C" __attribute__((visibility("default"))) int mx_diag_c1(unsigned long long *out, int reset)
+{
+    if (reset) { unsigned long long z[8] = {0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(c1_diag), z, sizeof z); }
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(c1_diag), 8 * sizeof(unsigned long long));
+}
+#else
+#define C1_STAMP(i) do { } while (0)
+#define C1_DIAG_PARAM
+#define C1_DIAG_ARG
+#endif
+struct PairwaveConsts { float bias[4], slope[4], nshift[4]; };       // of channel rows jt*32 + q*8 + (lane >> 3): loaded once per workgroup
+__device__ __forceinline__ PairwaveConsts pairwave_consts(const ConvF16Args &a, int jt, int lane)
+{
+    PairwaveConsts k;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        k.bias[q] = a.bias[jt * 32 + q * 8 + (lane >> 3)];
+        k.slope[q] = a.stats_part != nullptr ? a.slope_out[jt * 32 + q * 8 + (lane >> 3)] : 1.0f;
+        k.nshift[q] = -(k.bias[q] > 0.0f ? k.bias[q] : k.slope[q] * k.bias[q]);
+    }
+    return k;
+}
+__device__ __forceinline__ void conv1_pairwave_epilogue(floatx16 (&acc)[CV_WT], const ConvF16Args &a, const PairwaveConsts &kc,
+                                                        unsigned char *smem, int b, int h0, int jt, int c, int lane C1_DIAG_PARAM)
+{
+    const int l32 = lane & 31, wave = jt * 2 + c;
+    const float inv = 1.0f / F16_WSCALE;
+    const int hp = h0 >> 1, Hp = a.H >> 1;
+    const int co_l = lane >> 3, w4 = (lane & 7) * 4;                    // transposed role of the lane inside a tile
+    const int rbit0 = co_l & 3, fhalf = (co_l >> 2) & 1;               // co row q*8 + co_l = register q*4 + rbit0 of lane half fhalf
+    float *const img = reinterpret_cast<float *>(smem + wave * 4352);
+    unsigned *const flg = reinterpret_cast<unsigned *>(smem + wave * 4352 + 4096);
+    float *const mid = reinterpret_cast<float *>(smem + 4 * 4352);     // [jt][row][32 co][32 w]
+    const bool want_stats = a.stats_part != nullptr;                   // workgroup-uniform
+    // One wave per SIMD: the vector unit issues ~one instruction per 5 cycles, and this epilogue was as long as the 429
+    // matrix instructions before it (ablation, tools/exp_block1.py: 1.09 of 2.05 ms with the MFMAs removed, the same with its
+    // global stores removed too).  So the arithmetic is written on 4-vectors (packed fp32 instructions: x * 2^-k + bias is
+    // ONE rounding either way, the multiplication being exact), the pad-column masks exist only for the column tiles that
+    // reach past Wv (wave-uniform test), and a store's address is a scalar base + one 32-bit lane offset per channel row.
+    floatx4 st_s[4], st_q[4];
+    unsigned voff[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        st_s[q] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+        st_q[q] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+        voff[q] = (unsigned)((q * 8 + co_l) * Hp * CV_PITCH + w4);
+    }
+    const size_t sbase = (((size_t)b * CV_CO + jt * 32) * Hp + hp) * CV_PITCH;       // wave-uniform
+    float *const out_b = a.out + sbase;
+    unsigned char *const amax_b = a.out_amax + sbase;
+    __syncthreads();                                                    // every wave is done with the patch (and the next one is visible)
+    C1_STAMP(4);
+    store_tile32(acc, 10, mid + (jt * 2 + c) * 1024, lane);             // this wave's row of the middle tile
+    // one pooled tile: values tv (already the maximum of the pair), argmax bits in fl[e] bit (q*4 + rbit0)
+    auto finish = [&](int wt, int q, const floatx4 &tv, const uint4 &flw) {
+        const int w = wt * 32 + w4;
+        const unsigned fl[4] = {flw.x, flw.y, flw.z, flw.w};
+        const floatx4 invv = {inv, inv, inv, inv}, bv4 = {kc.bias[q], kc.bias[q], kc.bias[q], kc.bias[q]};
+        floatx4 m = __builtin_elementwise_fma(tv, invv, bv4);
+        unsigned am = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) am |= ((fl[e] >> (q * 4 + rbit0)) & 1u) << (8 * e);
+        const floatx4 slv = {kc.slope[q], kc.slope[q], kc.slope[q], kc.slope[q]};
+        const floatx4 shv = {kc.nshift[q], kc.nshift[q], kc.nshift[q], kc.nshift[q]};
+        const bool partial = wt * 32 + 32 > a.Wv;                       // wave-uniform: pad columns inside this tile
+        if (partial) {
+            asm volatile("" ::: "memory");                              // a real branch (if-converted it costs 16 selects per call)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) m[e] = w + e < a.Wv ? m[e] : 0.0f;
+        }
+        const floatx4 sm = m * slv;
+        floatx4 dlt;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dlt[e] = m[e] > 0.0f ? m[e] : sm[e];
+        dlt = dlt + shv;
+        if (partial) {
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dlt[e] = w + e < a.Wv ? dlt[e] : 0.0f;   // pad columns add nothing
+        }
+        st_s[q] += dlt;
+        st_q[q] += dlt * dlt;
+#if defined(C1_ABL) && (C1_ABL & 4)
+        if (m[0] + m[1] + m[2] + m[3] != 12345.0f && am != 77u) return;
+#endif
+        *reinterpret_cast<floatx4 *>(out_b + (voff[q] + (unsigned)(wt * 32))) = m;
+        *reinterpret_cast<unsigned *>(amax_b + (voff[q] + (unsigned)(wt * 32))) = am;
+    };
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+        unsigned flags = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const bool take_bot = acc[2 * t + 1][r] > acc[2 * t][r];     // ties keep the first row (torch)
+            img[mfma_row(r, lane) * 32 + l32] = take_bot ? acc[2 * t + 1][r] : acc[2 * t][r];
+            flags |= (take_bot ? 1u : 0u) << r;
+        }
+        flg[lane] = flags;
+        // the wave's own LDS operations execute in order: no barrier between its writes and its reads (compiler fences only)
+        asm volatile("" ::: "memory");
+#ifdef C1_DIAG2
+        C1_STAMP(5);                                                    // pooling + LDS writes (and their completion)
+#endif
+        const uint4 flw = *reinterpret_cast<const uint4 *>(flg + fhalf * 32 + w4);
+        floatx4 tvq[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) tvq[q] = *reinterpret_cast<const floatx4 *>(img + (q * 8 + co_l) * 32 + w4);
+#ifdef C1_DIAG2
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        C1_STAMP(6);                                                    // LDS reads
+#endif
+#pragma unroll
+        for (int q = 0; q < 4; ++q) finish(c * 6 + t, q, tvq[q], flw);
+        asm volatile("" ::: "memory");
+#ifdef C1_DIAG2
+        C1_STAMP(7);                                                    // arithmetic + stores
+#endif
+    }
+#ifndef C1_DIAG2
+    C1_STAMP(5);
+#endif
+    __syncthreads();                                                    // both rows of the middle tile are in LDS
+#ifndef C1_DIAG2
+    C1_STAMP(6);
+#endif
+    {
+        const float *top = mid + (jt * 2 + 0) * 1024, *bot = mid + (jt * 2 + 1) * 1024;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if ((q >> 1) != c) continue;                                // wave c finishes channel rows 16 c .. 16 c + 15 of the tile (q stays a constant)
+            const floatx4 tv = *reinterpret_cast<const floatx4 *>(top + (q * 8 + co_l) * 32 + w4);
+            const floatx4 bv = *reinterpret_cast<const floatx4 *>(bot + (q * 8 + co_l) * 32 + w4);
+            floatx4 mv;
+            unsigned fl[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bool take_bot = bv[e] > tv[e];
+                mv[e] = take_bot ? bv[e] : tv[e];
+                fl[e] = (take_bot ? 1u : 0u) << (q * 4 + rbit0);
+            }
+            finish(5, q, mv, uint4{fl[0], fl[1], fl[2], fl[3]});
+        }
+    }
+#ifndef C1_DIAG2
+    C1_STAMP(7);
+#endif
+    if (want_stats) {
+        // [wave][q][lane] partial sums -> thread co < 64 adds the 2 waves x 8 column lanes of its channel in a fixed order
+        float *xch = reinterpret_cast<float *>(smem + 4 * 4352 + 4 * 4096);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            xch[(wave * 4 + q) * 64 + lane] = (st_s[q][0] + st_s[q][1]) + (st_s[q][2] + st_s[q][3]);
+            xch[1024 + (wave * 4 + q) * 64 + lane] = (st_q[q][0] + st_q[q][1]) + (st_q[q][2] + st_q[q][3]);
+        }
+        __syncthreads();
+        const int co = threadIdx.x;
+        if (co < CV_CO) {
+            const int cjt = co >> 5, q = (co >> 3) & 3, col = co & 7;
+            float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    s1 += xch[((cjt * 2 + cc) * 4 + q) * 64 + col * 8 + e];
+                    s2 += xch[1024 + ((cjt * 2 + cc) * 4 + q) * 64 + col * 8 + e];
+                }
+            float *sp = a.stats_part + (((size_t)b * Hp + hp) * CV_CO + co) * 2;
+            sp[0] = s1;
+            sp[1] = s2;
+        }
+    }
+}
+
 // ---- first block, persistent (2 input channels as a k-vector operand: ONE K stage of 13 taps per output row pair) --------
 // On conv_f16x3_dma_kernel<1, 0, 1, 1> a workgroup's life was: fetch weights + patch (nothing to overlap with), 13 taps of
 // matrix work, an epilogue that stores 112 KB -- strictly one after the other, one workgroup per CU (LDS): 36 us per row pair
@@ -823,14 +1009,28 @@ __global__ __launch_bounds__(256, 1) void conv_f16x3_dma_kernel(ConvF16Args a)
 // pairs: the next row pair's patch arrives by LDS-DMA during the taps, the pooled rows of the previous one are still
 // draining to memory meanwhile, and the max-pool exchange runs through the patch buffer the taps have just finished with
 // (six rounds of 32 KB).  Measured: 2.31 -> 2.15 ms per 256 clips x 256 mel bins (17 -> 16.5 us per row pair), i.e. the fetch
-// was NOT what the row pair waited for: 8 us are the 429 MFMAs and ~7 us the epilogue's own work on the vector unit and
-// the LDS (176 ds_write_b32 + ~1 400 vector instructions + 12 barriers per wave: pooling select, bias, argmax bytes, PReLU,
-// LayerNorm partial sums, bounds) -- with one workgroup per CU nothing overlaps the two.  Starting every other workgroup
-// half a row pair late (so that one half of the chip stores while the other computes) changed nothing either: 2.12-2.15 ms.
+// was NOT what the row pair waited for.  Cycle stamps (C1_DIAG build, tools/exp_block1.py) per row pair and wave: 15.0 k
+// cycles of taps (429 MFMAs = 13.7 k), no wait for the next patch, 14.4 k of epilogue -- and the two simply add, one wave
+// per SIMD has nothing to overlap them with.  Inside the epilogue: pooling + LDS writes 3.5 k, waiting for the LDS reads
+// 0.5 k, arithmetic + stores 6.7 k, middle tile + statistics + barriers 3.7 k: a lone wave issues one vector instruction
+// per ~7 cycles (dependent chains), whatever the instruction.  What does NOT help (all measured, same box): half the LDS
+// traffic and 5 instead of 12 barriers (the pair-wave layout below: 2.07 -> 2.02 ms), half the vector instructions
+// (packed fp32, masks only on the tile that has pad columns: no change), no global stores at all (no change: they are free),
+// no transposition but dword + byte stores straight from the accumulator layout (2.15 ms: slower), staggered workgroups
+// (no change).  With the MFMAs removed the kernel runs at the HBM floor (1.1 ms).  What would: the epilogue's vector work
+// under the NEXT row pair's matrix instructions (pooled values carried in 94 registers: projected ~1.35 ms), or two waves
+// per SIMD at half the wave tile (projected ~1.55 ms) -- not built.
 // Floors at these sizes: 5.2 GB at ~4.7 TB/s = 1.1 ms, 1.8 PFLOP at 1.7 GHz = 1.0 ms.
 //   LDS = W (13 taps x 2 splits: 52 KB) | P[2] (46 KB each)
+// PW (pair-wave): wave = (channel tile, column half) with both rows of the pooling pair (conv1_pairwave_epilogue); a tap
+// then reads 2 weight + 22 patch fragments instead of 4 + 12.
+#ifndef C1_ABL
+#define C1_ABL 0        // ablation knobs (wrong results; tools/exp_block1.py): 1 no epilogue, 2 no MFMAs, 4 no global stores, 8 no DMA in the loop
+#endif
+template <int PWM>       // 0: wave = (row, column half), rows exchanged through LDS; 1: pair-wave (conv1_pairwave_epilogue)
 __global__ __launch_bounds__(256, 1) void conv1_f16x3_persist_kernel(ConvF16Args a, int n_tiles, int tiles_per_wg)
 {
+    constexpr bool PW = PWM != 0;
     constexpr int T = 1;
     constexpr int PWP = CV_PITCH + 12 * T;
     constexpr int PLANE = PWP * 16;
@@ -892,8 +1092,16 @@ __global__ __launch_bounds__(256, 1) void conv1_f16x3_persist_kernel(ConvF16Args
     DMA_WAIT();
     __syncthreads();
 
+    PairwaveConsts kc;
+    if (PWM == 1) kc = pairwave_consts(a, row, lane);
+#ifdef C1_DIAG
+    C1Diag dg;
+    dg.prev = __builtin_readcyclecounter();
+    for (int i = 0; i < 8; ++i) dg.sum[i] = 0;
+#endif
 #pragma unroll 1
     for (int tile = t_begin; tile < t_end; ++tile) {
+        C1_STAMP(0);                                            // loop overhead + the barrier at the end of the previous row pair
         const int pb = (tile - t_begin) & 1;
         unsigned char *const Pc = P0 + pb * P_BYTES;
         const int tn = tile + 1 < t_end ? tile + 1 : tile;       // the row pair whose patch the DMA slots fetch (last: a harmless repeat)
@@ -905,9 +1113,22 @@ __global__ __launch_bounds__(256, 1) void conv1_f16x3_persist_kernel(ConvF16Args
             for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
         const unsigned char *b_p = Pc + (row * 2 + half) * PLANE + (c * 6 * 32 + l32) * 16;
         const unsigned char *bm_p = Pc + (row * 2 + half) * PLANE + (5 * 32 + l32) * 16;
-        half8 FA[2][4], FBH[2][6], FBL[2][6];
+        // pair-wave: row (= wave >> 1) is the channel tile; patch rows r = 0, 1 at b_q + r * 2 * PLANE
+        const unsigned char *b_q = Pc + half * PLANE + (c * 6 * 32 + l32) * 16;
+        const unsigned char *bm_q = Pc + (c * 2 + half) * PLANE + (5 * 32 + l32) * 16;
+        constexpr int NFA = PW ? 2 : 4, NFB = PW ? 11 : 6, NRD = NFA + 2 * NFB;
+        half8 FA[2][NFA], FBH[2][NFB], FBL[2][NFB];
         auto rd = [&](int f, int kw, int r) {
-            if (r < 4) {
+            if (PW) {
+                if (r < 2) {
+                    FA[f][r] = *reinterpret_cast<const half8 *>(Wl + r * W_SPLIT + (kw * 2 + half) * 1024 + (row * 32 + l32) * 16);
+                } else {
+                    const int u = (r - 2) >> 1, lo = (r - 2) & 1;
+                    const unsigned char *p = (u < 10 ? b_q + (u & 1) * 2 * PLANE + (u >> 1) * 32 * 16 : bm_q) + lo * 4 * PLANE + kw * T * 16;
+                    if (lo) FBL[f][u] = *reinterpret_cast<const half8 *>(p);
+                    else FBH[f][u] = *reinterpret_cast<const half8 *>(p);
+                }
+            } else if (r < 4) {
                 const int ch = (r >> 1) ? (c ^ 1) : c;
                 FA[f][r] = *reinterpret_cast<const half8 *>(Wl + (r & 1) * W_SPLIT + (kw * 2 + half) * 1024 + (ch * 32 + l32) * 16);
             } else {
@@ -919,17 +1140,25 @@ __global__ __launch_bounds__(256, 1) void conv1_f16x3_persist_kernel(ConvF16Args
         };
         auto mma = [&](int f, int i) {
             const int term = i / 11, u = i - term * 11;
-            const int tl = u < 10 ? (u >> 1) : 5, j = u < 10 ? (u & 1) : 0;
-            const half8 av = FA[f][2 * j + (term == 0 ? 1 : 0)];
-            const half8 bv = term == 1 ? FBL[f][tl] : FBH[f][tl];
-            acc[u] = mfma16(av, bv, acc[u]);
+            if (C1_ABL & 2) {
+                if (i == 0) acc[0][0] += (float)FA[f][0][0] + (float)FBH[f][0][0];       // keep the reads alive
+            } else if (PW) {
+                acc[u] = mfma16(FA[f][term == 0 ? 1 : 0], term == 1 ? FBL[f][u] : FBH[f][u], acc[u]);
+            } else {
+                const int tl = u < 10 ? (u >> 1) : 5, j = u < 10 ? (u & 1) : 0;
+                const half8 av = FA[f][2 * j + (term == 0 ? 1 : 0)];
+                const half8 bv = term == 1 ? FBL[f][tl] : FBH[f][tl];
+                acc[u] = mfma16(av, bv, acc[u]);
+            }
         };
+        // reads of a tap's fragments behind the previous tap's MFMAs: R1 in the first segment (16 MFMAs), the rest in the second (17)
+        constexpr int R1 = PW ? 12 : 8;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) rd(0, 0, r);
+        for (int r = 0; r < NRD; ++r) rd(0, 0, r);
 #pragma unroll
         for (int t = 0; t < CV_KW; ++t) {
-            // one tap: 33 MFMAs on fragment set t & 1, the next tap's 16 reads into the other set (one read per two MFMAs),
-            // and -- taps 0..5 -- two DMA pieces of the next row pair's patch
+            // one tap: 33 MFMAs on fragment set t & 1, the next tap's reads into the other set and -- taps 0..5 -- two DMA
+            // pieces of the next row pair's patch
             const int f = t & 1;
             __builtin_amdgcn_sched_barrier(0);
             const DmaSlot sa = slot_p(tn, pb ^ 1, t < 6 ? 2 * t : 0), sb = slot_p(tn, pb ^ 1, t < 6 ? 2 * t + 1 : 0);
@@ -937,40 +1166,69 @@ __global__ __launch_bounds__(256, 1) void conv1_f16x3_persist_kernel(ConvF16Args
             for (int i = 0; i < 16; ++i) mma(f, i);
             if (t + 1 < CV_KW) {
 #pragma unroll
-                for (int r = 0; r < 8; ++r) rd(f ^ 1, t + 1, r);
+                for (int r = 0; r < R1; ++r) rd(f ^ 1, t + 1, r);
+                if (PW) {
 #pragma unroll
-                for (int g = 0; g < 8; ++g) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    for (int g = 0; g < 12; ++g) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                } else {
+#pragma unroll
+                    for (int g = 0; g < 8; ++g) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (t < 6) slot_issue(sa);
+            if (t < 6 && !(C1_ABL & 8)) slot_issue(sa);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 16; i < 33; ++i) mma(f, i);
             if (t + 1 < CV_KW) {
 #pragma unroll
-                for (int r = 8; r < 16; ++r) rd(f ^ 1, t + 1, r);
+                for (int r = R1; r < NRD; ++r) rd(f ^ 1, t + 1, r);
+                if (PW) {
 #pragma unroll
-                for (int g = 0; g < 8; ++g) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    for (int g = 0; g < 12; ++g) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x008, 5, 0);
+                } else {
+#pragma unroll
+                    for (int g = 0; g < 8; ++g) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 }
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (t < 6) slot_issue(sb);
+            if (t < 6 && !(C1_ABL & 8)) slot_issue(sb);
             __builtin_amdgcn_sched_barrier(0);
         }
         // the next patch has landed (its pieces were issued seven taps ago; the previous row pair's stores have retired long
         // since) BEFORE this row pair's stores are issued: a wait behind them would expose their latency
+        C1_STAMP(1);                                            // the 13 taps
         DMA_WAIT();
+        C1_STAMP(2);                                            // waiting for the next patch
         // bias + max-pool + argmax (+ LayerNorm partial sums) through the patch buffer the taps are done with; the barrier at
         // its head also publishes the next patch
-        conv_f16_epilogue<0, floatx16[CV_WT], 1>(acc, a, Pc, b, h0, row, c, lane);
+        if (C1_ABL & 1) {
+            if (acc[0][0] + acc[3][5] + acc[7][2] + acc[10][9] == 12345.0f) a.out[tile] = 1.0f;
+            __syncthreads();
+        } else if (PWM == 1) conv1_pairwave_epilogue(acc, a, kc, Pc, b, h0, row, c, lane C1_DIAG_ARG);
+        else conv_f16_epilogue<0, floatx16[CV_WT], 1>(acc, a, Pc, b, h0, row, c, lane);
+        C1_STAMP(3);                                            // the epilogue
         __syncthreads();                                        // the exchange images are dead: the next DMA may overwrite them
     }
+#ifdef C1_DIAG
+    if (threadIdx.x == 0)
+        for (int i = 0; i < 8; ++i) atomicAdd(&c1_diag[i], dg.sum[i]);
+#endif
 }
 
 // ---- LDS-DMA version on v_mfma_f32_16x16x32_f16 (forward, T <= 4) -------------------------------------------------
@@ -1449,13 +1707,15 @@ MX_EXPORT int mx_conv_block1_fwd_f16(const void *xk_hi, const void *xk_lo, const
     ConvF16Args a{(const _Float16 *)xk_hi, (const _Float16 *)xk_lo, (const _Float16 *)w_hi, (const _Float16 *)w_lo, bias,
                   nullptr, out, out_amax, (int)H, (int)Wv, slope_out, stats_part};
     // MODEX_BLOCK1_PERSIST=0 selects the one-row-pair-per-workgroup kernel (same-box A/B)
-    static const bool persist = !(getenv("MODEX_BLOCK1_PERSIST") && atoi(getenv("MODEX_BLOCK1_PERSIST")) == 0);
+    // (1: the persistent kernel with the row-exchanging epilogue; default 2: its pair-wave layout)
+    static const int persist = getenv("MODEX_BLOCK1_PERSIST") ? atoi(getenv("MODEX_BLOCK1_PERSIST")) : 2;
     if (!persist) return launch_f16_dma<1, 0, 1, 1>(a, (int)B, (hipStream_t)stream);
     constexpr size_t lds = 2 * CV_KW * 2048 + 2 * (size_t)((8 * (CV_PITCH + 12) + 63) / 64) * 1024;
     static_assert(lds <= 160 * 1024, "LDS budget");
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute((const void *)conv1_f16x3_persist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        if (hipFuncSetAttribute((const void *)conv1_f16x3_persist_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+            hipFuncSetAttribute((const void *)conv1_f16x3_persist_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return MX_ERR_LAUNCH;
         attr_done = true;
     }
@@ -1464,6 +1724,7 @@ MX_EXPORT int mx_conv_block1_fwd_f16(const void *xk_hi, const void *xk_lo, const
     if (grid > n_tiles) grid = n_tiles;
     const int per = (n_tiles + grid - 1) / grid;
     grid = (n_tiles + per - 1) / per;
-    hipLaunchKernelGGL(conv1_f16x3_persist_kernel, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, a, n_tiles, per);
+    if (persist == 1) hipLaunchKernelGGL(conv1_f16x3_persist_kernel<0>, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, a, n_tiles, per);
+    else hipLaunchKernelGGL(conv1_f16x3_persist_kernel<1>, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, a, n_tiles, per);
     return mx_launch_status();
 }

@@ -1,11 +1,12 @@
 #!/bin/bash
-# usage: ab_env.sh VAR N  -> alternate VAR=0 / VAR=1
-VAR=$1; N=${2:-2}
+# on the GPU box: alternate VAR=A / VAR=B N times on the current build; prints audio-s/s, ms/step, conv ms and the kernels named in $KEYS
+# usage: tools/ab_env.sh VAR A B [N]     (KEYS="conv_block1_fwd_f16[block1] ..." optional)
+VAR=$1; A=$2; B=$3; N=${4:-2}
 for i in $(seq $N); do
-  for v in 0 1; do
+  for v in $A $B; do
     export $VAR=$v
     echo -n "$VAR=$v "; timeout 300 python bench.py --worker --no-fp32-leg --steps 8 --warmup 2 --no-cpu-baseline 2>&1 | tail -1 | python -c "
-import json,sys
-d=json.loads(sys.stdin.read()); print(round(d['value']), round(d['ms_per_step'],2), d['conv_ms_per_step'])"
+import json,sys,os
+d=json.loads(sys.stdin.read()); print(round(d['value']), round(d['ms_per_step'],2), d['conv_ms_per_step'], {k: d['kernels'][k]['avg_ms'] for k in os.environ.get('KEYS','').split() if k in d['kernels']})"
   done
 done
