@@ -187,14 +187,18 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(ConvArgs a)
 
     // ---- epilogue ----
     if (OUTMODE == OUT_PLAIN) {
+        // store address = (wave-uniform base of the channel row: scalar registers) + (one 32-bit lane offset): written as a
+        // 64-bit offset per (tile, register) the 176 addresses spilled 37-53 registers to scratch memory
         const int h = h0 + row;
+        const unsigned vo = (unsigned)(half * 4 * a.H * CV_PITCH + l32);
 #pragma unroll
         for (int i = 0; i < CV_WT; ++i) {
             const int w = i * 32 + l32;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int co = mt * 32 + mfma_row(r, lane);
-                a.out[(((size_t)b * CV_CO + co) * a.H + h) * CV_PITCH + w] = w < a.Wv ? acc[i][r] : 0.0f;
+                const int co_u = mt * 32 + (r & 3) + 8 * (r >> 2);             // + 4 * half: in vo
+                float *rowp = a.out + (((size_t)b * CV_CO + co_u) * a.H + h) * CV_PITCH + i * 32;
+                rowp[vo] = w < a.Wv ? acc[i][r] : 0.0f;
             }
         }
     } else {
@@ -202,6 +206,7 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(ConvArgs a)
         // 4 w-tiles at a time (2 co tiles x 4 x 16 regs x 64 lanes x 4 B = 32 KB, fits the staging LDS)
         float *xch = lds;
         const int hp = h0 >> 1, Hp = a.H >> 1;
+        const unsigned vo = (unsigned)(half * 4 * Hp * CV_PITCH + l32);
         // this lane's 16 bias values, fetched before the store loop (a load between stores would make every
         // iteration wait for the previous stores: vmcnt retires in order)
         float bias_r[16];
@@ -223,14 +228,14 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(ConvArgs a)
                     const int w = i * 32 + l32;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const int co = mt * 32 + mfma_row(r, lane);
+                        const int co_u = mt * 32 + (r & 3) + 8 * (r >> 2);     // + 4 * half: in vo (scalar base + lane offset, as above)
                         const float top = acc[i][r];
                         const float bot = xch[((mt * 4 + (i - c0)) * 16 + r) * 64 + lane];
                         const bool take_bot = bot > top;                 // ties keep the first row (torch)
                         const float m = (take_bot ? bot : top) + bias_r[r];
-                        const size_t off = (((size_t)b * CV_CO + co) * Hp + hp) * CV_PITCH + w;
-                        a.out[off] = w < a.Wv ? m : 0.0f;
-                        a.out_amax[off] = take_bot ? 1 : 0;
+                        const size_t ro = (((size_t)b * CV_CO + co_u) * Hp + hp) * CV_PITCH + i * 32;
+                        (a.out + ro)[vo] = w < a.Wv ? m : 0.0f;
+                        (a.out_amax + ro)[vo] = take_bot ? 1 : 0;
                     }
                 }
             }
