@@ -18,6 +18,7 @@
 // conv_f16.hip; the patch (31 KB per stage) is register-staged into double-buffered LDS.  The epilogue transposes the
 // [position][ci] tiles through wave-private LDS and writes dxhat (B, 64, H, 352) rows coalesced.
 #include "conv_common.h"
+#include <type_traits>
 
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -251,6 +252,7 @@ __global__ __launch_bounds__(256, 1) void dgrad_sp_f16x3_kernel(DgradSpArgs a)
     const int h = h0 + row;
     float s1a[2][16], s2a[2][16];                               // [weight fragment j: ci tile j ^ c][channel hh*16 + i]
     float mxd = 0.0f, mxx = 0.0f;                               // running max |dxhat|, max |xhat| of this lane
+    const unsigned out_vo = (unsigned)(hh * 16 * H * CV_PITCH + l32);   // lane part of a dxhat element offset
     // the wave's xhat vectors: a ring of XSLOTS tiles, the first XSLOTS requested up front, tile u + XSLOTS as soon as tile u
     // is done (its data is then XSLOTS - 1 tiles of work away) -- one exposed memory round trip per workgroup instead of
     // eleven, and 16 XSLOTS registers instead of 176 (all eleven tiles at once spilled 56 registers to scratch memory
@@ -285,19 +287,29 @@ __global__ __launch_bounds__(256, 1) void dgrad_sp_f16x3_kernel(DgradSpArgs a)
 #pragma unroll
         for (int r = 0; r < 16; ++r) scr[l32 * 33 + mfma_row(r, lane)] = acc[u][r] * inv;      // [ci local][position local]
         __builtin_amdgcn_s_waitcnt(0xc07f);                      // lgkmcnt(0): the wave's own writes have landed
+        // pad columns exist in at most one column tile: the masks sit behind ONE wave-uniform test per tile (as selects per
+        // element they were an exec-mask save / restore around every LDS read)
+        const bool valid = w < a.Wv;
+        auto rows16 = [&](auto partial_tag) {
+            constexpr bool PARTIAL = decltype(partial_tag)::value;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int cil = hh * 16 + i;
-            const float v = w < a.Wv ? scr[cil * 33 + l32] : 0.0f;
-            a.out[(((size_t)b * CV_CO + cit * 32 + cil) * H + h) * CV_PITCH + w] = v;
-            if (LN) {
-                const float xv = (float)xh[u % XSLOTS][i >> 3][i & 7] + (float)xl[u % XSLOTS][i >> 3][i & 7];
-                s1a[jf][i] += v;
-                s2a[jf][i] += v * xv;
-                mxd = fmaxf(mxd, fabsf(v));
-                mxx = fmaxf(mxx, w < a.Wv ? fabsf(xv) : 0.0f);
+            for (int i = 0; i < 16; ++i) {
+                const int cil = hh * 16 + i;
+                float v = scr[cil * 33 + l32];
+                if (PARTIAL) v = valid ? v : 0.0f;
+                // (wave-uniform row base: scalar registers) + (32-bit lane offset): no 64-bit vector address arithmetic per store
+                (a.out + ((((size_t)b * CV_CO + cit * 32 + i) * H + h) * CV_PITCH + ptile * 32))[out_vo] = v;
+                if (LN) {
+                    const float xv = (float)xh[u % XSLOTS][i >> 3][i & 7] + (float)xl[u % XSLOTS][i >> 3][i & 7];
+                    s1a[jf][i] += v;
+                    s2a[jf][i] += v * xv;
+                    mxd = fmaxf(mxd, fabsf(v));
+                    mxx = fmaxf(mxx, (!PARTIAL || valid) ? fabsf(xv) : 0.0f);
+                }
             }
-        }
+        };
+        if (ptile * 32 + 32 > a.Wv) rows16(std::true_type{});
+        else rows16(std::false_type{});
         __builtin_amdgcn_s_waitcnt(0xc07f);
         if (LN && u + XSLOTS < CV_WT) load_x(u + XSLOTS);
     }
