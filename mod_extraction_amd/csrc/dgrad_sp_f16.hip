@@ -247,7 +247,8 @@ __global__ __launch_bounds__(256, 1) void dgrad_sp_f16x3_kernel(DgradSpArgs a)
     // value is in a register next to its position's 16 channels of xhat (one 32-byte vector of each operand half), so
     // the wave accumulates both sums per channel and writes one partial per (plane, row, position half).
     __syncthreads();                                            // the patch buffers are dead
-    float *scr = reinterpret_cast<float *>(smem) + wave * (32 * 33);
+    // two wave-private transposition images (32 ci x 33 floats each): tile u + 1 is written while tile u's rows are in flight
+    float *scr = reinterpret_cast<float *>(smem) + wave * (2 * 32 * 33);
     const float inv = a.scale[1] * (1.0f / DS_WSCALE);
     const int h = h0 + row;
     float s1a[2][16], s2a[2][16];                               // [weight fragment j: ci tile j ^ c][channel hh*16 + i]
@@ -278,15 +279,25 @@ __global__ __launch_bounds__(256, 1) void dgrad_sp_f16x3_kernel(DgradSpArgs a)
 #pragma unroll
         for (int u = 0; u < XSLOTS; ++u) load_x(u);
     }
+    // A wave's LDS operations execute in order, so its reads see its own earlier writes without a wait; the reads of tile u
+    // are issued BEFORE the writes of tile u + 1 (other image), whose 16 multiplications + writes hide their latency.
+    auto put_tile = [&](int u) {
+        float *d = scr + (u & 1) * (32 * 33);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) d[l32 * 33 + mfma_row(r, lane)] = acc[u][r] * inv;      // [ci local][position local]
+    };
+    put_tile(0);
 #pragma unroll
     for (int u = 0; u < CV_WT; ++u) {
         const int ptile = u < 10 ? c * 6 + (u >> 1) : 5;
         const int jf = u < 10 ? (u & 1) : 0;
         const int cit = jf ^ c;
         const int w = ptile * 32 + l32;
+        float tv[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) scr[l32 * 33 + mfma_row(r, lane)] = acc[u][r] * inv;      // [ci local][position local]
-        __builtin_amdgcn_s_waitcnt(0xc07f);                      // lgkmcnt(0): the wave's own writes have landed
+        for (int i = 0; i < 16; ++i) tv[i] = (scr + (u & 1) * (32 * 33))[(hh * 16 + i) * 33 + l32];
+        asm volatile("" ::: "memory");
+        if (u + 1 < CV_WT) put_tile(u + 1);
         // pad columns exist in at most one column tile: the masks sit behind ONE wave-uniform test per tile (as selects per
         // element they were an exec-mask save / restore around every LDS read)
         const bool valid = w < a.Wv;
@@ -294,8 +305,7 @@ __global__ __launch_bounds__(256, 1) void dgrad_sp_f16x3_kernel(DgradSpArgs a)
             constexpr bool PARTIAL = decltype(partial_tag)::value;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const int cil = hh * 16 + i;
-                float v = scr[cil * 33 + l32];
+                float v = tv[i];
                 if (PARTIAL) v = valid ? v : 0.0f;
                 // (wave-uniform row base: scalar registers) + (32-bit lane offset): no 64-bit vector address arithmetic per store
                 (a.out + ((((size_t)b * CV_CO + cit * 32 + i) * H + h) * CV_PITCH + ptile * 32))[out_vo] = v;
@@ -310,7 +320,6 @@ __global__ __launch_bounds__(256, 1) void dgrad_sp_f16x3_kernel(DgradSpArgs a)
         };
         if (ptile * 32 + 32 > a.Wv) rows16(std::true_type{});
         else rows16(std::false_type{});
-        __builtin_amdgcn_s_waitcnt(0xc07f);
         if (LN && u + XSLOTS < CV_WT) load_x(u + XSLOTS);
     }
     if (LN && a.gx_bits) {                                      // (order of non-negative floats = order of their bits)
@@ -323,9 +332,9 @@ __global__ __launch_bounds__(256, 1) void dgrad_sp_f16x3_kernel(DgradSpArgs a)
     }
     if (LN) {
         // sum over the 32 positions held by the lanes of each half (same hh), in a fixed order, through wave-private
-        // LDS (behind the four transposition tiles): lane (hh, l32) writes its 32 partials [q = j*16 + i] as column
-        // l32, then sums row q = l32
-        float *red = reinterpret_cast<float *>(smem) + 4 * (32 * 33) + wave * (2 * 32 * 33) + hh * (32 * 33);
+        // LDS (the wave's two transposition images, free now): lane (hh, l32) writes its 32 partials [q = j*16 + i] as
+        // column l32, then sums row q = l32
+        float *red = scr + hh * (32 * 33);
         float tot[2];
 #pragma unroll
         for (int kind = 0; kind < 2; ++kind) {
