@@ -421,7 +421,7 @@ def run_lfo_config(args, env, cfg_id):
     if f16:                      # roofline kernel = the heaviest conv launch of the step: block-2 forward
         dom = kernels["conv_block_fwd_f16[block2]"]
         roofline = {
-            "bound": "mfma", "kernel": "conv_f16x3_dma16_kernel<1> (block-2 forward: conv5x13+bias+maxpool on split-fp16 operands, "
+            "bound": "mfma", "kernel": "conv_f16x3_dma16_kernel<1, true> (block-2 forward: conv5x13+bias+maxpool on split-fp16 operands, "
                                        "v_mfma_f32_16x16x32_f16)",
             "achieved": dom["tflops"], "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(dom["tflops"] / F16_MFMA_PEAK_TFLOPS, 4),

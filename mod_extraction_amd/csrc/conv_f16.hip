@@ -1256,7 +1256,17 @@ __global__ __launch_bounds__(256, 1) void conv1_f16x3_persist_kernel(ConvF16Args
 #ifndef DMA16_ABL
 #define DMA16_ABL 0     // ablation knobs (wrong results): 1 = no LDS-DMA issue inside the loop, 2 = no barrier behind the straddling pair
 #endif
-template <int T>
+// RING: the patch lives in a ring of FOUR ROW SLOTS instead of two 2-row buffers.  Stage (cb, kh) reads input rows
+//   j = kh (for output row 0) and kh + 1 (output row 1) of the six rows j = 0..5 = h0 - 2 .. h0 + 3 of channel block cb;
+//   row number n = 6 cb + j lives in slot n & 3.  Consecutive kernel-row stages of a channel block share a row, so a stage
+//   fetches ONE new row for its successor (its row kh + 1), and a second one (row 0, in one burst behind the mid-stage
+//   barrier) only when the successor opens a channel block: 6 instead of 10 row fetches per channel block = 40 % fewer
+//   patch pieces, 19 % fewer LDS-DMA pieces in all (each one costs issue slots between 16-cycle matrix instructions and
+//   energy: the kernel is power limited).  The two rows in use and the one or two being fetched are always in different
+//   slots; the odd stage still issues its patch pieces only behind the barrier that follows the straddling pair.  The
+//   fragment bases become per-couple values (a dozen vector adds per 3 432 matrix instructions).
+//   Measured (one box, inside the train step): block 2 / 3 / 4 forward 12.24 -> 11.77 / 5.92 -> 5.72 / 2.96 -> 2.88 ms.
+template <int T, bool RING>
 __global__ __launch_bounds__(256, 1) void conv_f16x3_dma16_kernel(ConvF16Args a)
 {
     constexpr int NCB = 4, NKH = CV_KH;
@@ -1271,6 +1281,12 @@ __global__ __launch_bounds__(256, 1) void conv_f16x3_dma16_kernel(ConvF16Args a)
     constexpr int ROWB = NCB * CV_PITCH * 32;
     constexpr int N_STAGE = NCB * NKH;
     static_assert(PPW >= 12 && PPW <= 13 && N_STAGE % 2 == 0, "DMA schedule");
+    constexpr int R_PIECES = (4 * PWP + 63) / 64;                // RING: pieces of one patch row = 4 planes [split][khalf]
+    constexpr int SLOT_BYTES = R_PIECES * 1024;
+    constexpr int RPW = (R_PIECES + 3) / 4;                      //       per wave
+    static_assert(RPW >= 6 && RPW <= 7, "DMA schedule (ring)");
+    constexpr int NDESC = RING ? RPW : PPW;
+    constexpr int SP_STRIDE = RING ? 2 * PLANE : 4 * PLANE;      // bytes between the hi and lo images of a patch row
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int W0_OFF = 0, W1_OFF = W_BYTES, P0_OFF = 2 * W_BYTES, P1_OFF = 2 * W_BYTES + P_BYTES;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
@@ -1290,13 +1306,18 @@ __global__ __launch_bounds__(256, 1) void conv_f16x3_dma16_kernel(ConvF16Args a)
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[i][r] = 0.0f;
 
-    int desc[PPW];
+    int desc[NDESC];
 #pragma unroll
-    for (int k = 0; k < PPW; ++k) {
+    for (int k = 0; k < NDESC; ++k) {
         const int i = (wave + 4 * k) * 64 + lane;
         const int plane = i / PWP, pos = i - plane * PWP, w = pos - 6 * T;
-        const int split = plane >> 2, r = (plane >> 1) & 1, part = plane & 1;
-        desc[k] = (i < P_SLOTS && w >= 0 && w < CV_PITCH) ? ((split << 30) | (r << 29) | (r * ROWB + w * 32 + part * 16)) : -1;
+        if (RING) {
+            const int split = plane >> 1, part = plane & 1;
+            desc[k] = (i < 4 * PWP && w >= 0 && w < CV_PITCH) ? ((split << 30) | (w * 32 + part * 16)) : -1;
+        } else {
+            const int split = plane >> 2, r = (plane >> 1) & 1, part = plane & 1;
+            desc[k] = (i < P_SLOTS && w >= 0 && w < CV_PITCH) ? ((split << 30) | (r << 29) | (r * ROWB + w * 32 + part * 16)) : -1;
+        }
     }
     const unsigned long long zero_src = (unsigned long long)k_zero_slot, xh = (unsigned long long)a.x_hi,
                              xl = (unsigned long long)a.x_lo, wh = (unsigned long long)a.w_hi, wlo = (unsigned long long)a.w_lo;
@@ -1315,7 +1336,7 @@ __global__ __launch_bounds__(256, 1) void conv_f16x3_dma16_kernel(ConvF16Args a)
     auto slot_p = [&](int st, int poff, int k) {
         const bool in_range = wave + 4 * k < P_PIECES;
         const int pp = in_range ? wave + 4 * k : wave + 4 * (k - 1);
-        const int d = in_range ? desc[k] : desc[k > 0 ? k - 1 : 0];
+        const int d = in_range ? desc[k < NDESC ? k : 0] : desc[(k > 0 && k - 1 < NDESC) ? k - 1 : 0];
         const int cb = st / NKH, kh = st - cb * NKH, hx0 = h0 + kh - NKH / 2;
         const bool v0 = hx0 >= 0 && hx0 < H, v1 = hx0 + 1 >= 0 && hx0 + 1 < H;
         const long long st_off = (((long long)b * H + hx0) * NCB + cb) * (CV_PITCH * 32);
@@ -1327,15 +1348,39 @@ __global__ __launch_bounds__(256, 1) void conv_f16x3_dma16_kernel(ConvF16Args a)
         r.lds = lds0 + poff + pp * 1024;
         return r;
     };
+    // RING: piece k of input row j (= h0 - 2 + j) of channel block cb -> row slot (6 cb + j) & 3; cb == NCB: zeros (no next stage)
+    auto slot_row = [&](int cb, int j, int k) {
+        const bool in_range = wave + 4 * k < R_PIECES;
+        const int pp = in_range ? wave + 4 * k : wave + 4 * (k - 1);
+        const int d = in_range ? desc[k < NDESC ? k : 0] : desc[(k > 0 && k - 1 < NDESC) ? k - 1 : 0];
+        const int hx = h0 + j - NKH / 2;
+        const bool v = hx >= 0 && hx < H && cb < NCB;
+        const long long st_off = (((long long)b * H + hx) * NCB + cb) * (CV_PITCH * 32);
+        const unsigned long long src = ((d & (1 << 30)) ? xl : xh) + st_off + (unsigned)(d & 0xFFFFF);
+        DmaSlot r;
+        r.src = (d >= 0 && v) ? src : zero_src;
+        r.lds = lds0 + P0_OFF + ((cb * 6 + j) & 3) * SLOT_BYTES + pp * 1024;
+        return r;
+    };
     auto slot_issue = [&](const DmaSlot &d) { glds16(d.src, d.lds); };
+    auto row_burst = [&](int cb, int j) {                    // a whole row at once (the second new row of a stage that opens a channel block)
+#pragma unroll
+        for (int k = 0; k < RPW; ++k)
+            if (wave + 4 * k < R_PIECES) slot_issue(slot_row(cb, j, k));
+    };
 
     // prologue: taps 0..5 of stage 0 and its patch
 #pragma unroll
     for (int j = 0; j < 6; ++j) slot_issue(slot_w(0, 0, 6, W0_OFF, j));
+    if (RING) {
+        row_burst(0, 0);
+        row_burst(0, 1);
+    } else {
 #pragma unroll
-    for (int k = 0; k < PPW; ++k)
-        if (wave + 4 * k < P_PIECES) slot_issue(slot_p(0, P0_OFF, k));
-    if (DMA16_ABL & 1) {                                     // ablation: every buffer holds valid operands once, nothing moves afterwards
+        for (int k = 0; k < PPW; ++k)
+            if (wave + 4 * k < P_PIECES) slot_issue(slot_p(0, P0_OFF, k));
+    }
+    if ((DMA16_ABL & 1) && !RING) {                                     // ablation: every buffer holds valid operands once, nothing moves afterwards
 #pragma unroll
         for (int j = 0; j < 7; ++j) slot_issue(slot_w(0, 6, 7, W1_OFF, j));
 #pragma unroll
@@ -1348,14 +1393,15 @@ __global__ __launch_bounds__(256, 1) void conv_f16x3_dma16_kernel(ConvF16Args a)
     // lane parts of the fragment addresses.  A = weights of channel half hh ^ c (hh relative to the wave), B = patch.
     //   regular pair : + buffer offset + split * W_SPLIT + first tap slot * 2048 + (ct & 1) * 256   /   + patch offset + nt * 256 + kw * T * 16 + split * 4 * PLANE
     //   straddling   : parity-0 lanes -> tap slot 6 of W1 / tap 12 of P0 (the even stage), parity-1 lanes -> tap slot 0 of W0 / tap 0 of P1
-    const int a_k = khf * 1024 + l16 * 16, b_k = (row * 2 + khf) * PLANE + l16 * 16;
+    const int a_k = khf * 1024 + l16 * 16, b_k = RING ? khf * PLANE + l16 * 16 : (row * 2 + khf) * PLANE + l16 * 16;
     const unsigned char *const a_p0 = smem + a_k + tp * 2048 + c * 512, *const a_p1 = smem + a_k + tp * 2048 + (c ^ 1) * 512;
     // (one pointer per patch buffer: P1 lies beyond the 64 KB reach of a ds_read's immediate offset)
-    const unsigned char *const b_pE = smem + P0_OFF + b_k + (c * 6 * 32 + tp * T) * 16, *const bm_pE = smem + P0_OFF + b_k + (5 * 32 + tp * T) * 16;
-    const unsigned char *const b_pO = b_pE + P_BYTES, *const bm_pO = bm_pE + P_BYTES;
+    // (RING: re-based per stage couple below)
+    const unsigned char *b_pE = smem + P0_OFF + b_k + (c * 6 * 32 + tp * T) * 16, *bm_pE = smem + P0_OFF + b_k + (5 * 32 + tp * T) * 16;
+    const unsigned char *b_pO = b_pE + P_BYTES, *bm_pO = bm_pE + P_BYTES;
     const int sa_off = tp ? W0_OFF : W1_OFF + 6 * 2048, sb_off = tp ? P1_OFF : P0_OFF + 12 * T * 16;
     const unsigned char *const as_p0 = smem + a_k + sa_off + c * 512, *const as_p1 = smem + a_k + sa_off + (c ^ 1) * 512;
-    const unsigned char *const bs_p = smem + b_k + sb_off + c * 6 * 32 * 16, *const bsm_p = smem + b_k + sb_off + 5 * 32 * 16;
+    const unsigned char *bs_p = smem + b_k + sb_off + c * 6 * 32 * 16, *bsm_p = smem + b_k + sb_off + 5 * 32 * 16;
 
     // fragments: A double buffered [buf][ctr * 2 + split] (ctr = channel tile relative to the wave: 0, 1 = half c), B ring [slot][split]
     // with slot = nt % 6 for column tile nt < 10 and 4, 5 for the middle tile's halves 10, 11
@@ -1366,7 +1412,7 @@ __global__ __launch_bounds__(256, 1) void conv_f16x3_dma16_kernel(ConvF16Args a)
     };
     auto rdB = [&](int odd, int kw, int nt, int sp) {
         FB[nt < 10 ? nt % 6 : nt - 6][sp] = *reinterpret_cast<const half8 *>(
-            (nt < 10 ? (odd ? b_pO : b_pE) + nt * 256 : (odd ? bm_pO : bm_pE) + (nt - 10) * 256) + kw * T * 16 + sp * 4 * PLANE);
+            (nt < 10 ? (odd ? b_pO : b_pE) + nt * 256 : (odd ? bm_pO : bm_pE) + (nt - 10) * 256) + kw * T * 16 + sp * SP_STRIDE);
     };
     auto rdA_str = [&](int buf, int q) {
         const int ctr = q >> 1, sp = q & 1;
@@ -1374,7 +1420,7 @@ __global__ __launch_bounds__(256, 1) void conv_f16x3_dma16_kernel(ConvF16Args a)
     };
     auto rdB_str = [&](int nt, int sp) {
         FB[nt < 10 ? nt % 6 : nt - 6][sp] =
-            *reinterpret_cast<const half8 *>((nt < 10 ? bs_p + nt * 256 : bsm_p + (nt - 10) * 256) + sp * 4 * PLANE);
+            *reinterpret_cast<const half8 *>((nt < 10 ? bs_p + nt * 256 : bsm_p + (nt - 10) * 256) + sp * SP_STRIDE);
     };
     // instruction m (0..11) of group gi of a pair; gi < 10: column tile gi x 4 channel tiles; gi == 10: tiles 10, 11 x 2
     // channel tiles; term-major, so one accumulator every 4th instruction.  Written as inline assembly with the
@@ -1447,14 +1493,32 @@ __global__ __launch_bounds__(256, 1) void conv_f16x3_dma16_kernel(ConvF16Args a)
 #pragma unroll 1
     for (int s = 0; s < N_STAGE; s += 2) {
         const int so = s + 1, sn = s + 2 < N_STAGE ? s + 2 : s + 1;      // odd stage; the stage after it (last couple: harmless repeats)
+        // RING: the new rows of the odd stage (fetched during the even one) and of stage s + 2 (fetched during the odd one):
+        // row A = kernel row + 1 of the successor, always; row B = its row 0, only when it opens a channel block
+        const int cbo = so / NKH, kho = so - cbo * NKH, cbn = (s + 2) / NKH, khn = (s + 2) - cbn * NKH;
+        const bool two_e = RING && kho == 0, two_o = RING && khn == 0 && s + 2 < N_STAGE;
+        if (RING) {
+            const int n0e = (s / NKH) * 6 + s % NKH + row, n0o = cbo * 6 + kho + row;
+            const int oe = P0_OFF + (n0e & 3) * SLOT_BYTES, oo = P0_OFF + (n0o & 3) * SLOT_BYTES;
+            b_pE = smem + oe + b_k + (c * 6 * 32 + tp * T) * 16;
+            bm_pE = smem + oe + b_k + (5 * 32 + tp * T) * 16;
+            b_pO = smem + oo + b_k + (c * 6 * 32 + tp * T) * 16;
+            bm_pO = smem + oo + b_k + (5 * 32 + tp * T) * 16;
+            const int os = tp ? oo : oe + 12 * T * 16;
+            bs_p = smem + b_k + os + c * 6 * 32 * 16;
+            bsm_p = smem + b_k + os + 5 * 32 * 16;
+        }
         // ================= even stage s: taps 0..11 (patch P0; W0 = taps 0..5, W1 = taps 6..12) =================
         // DMA phase A (12 slots): W1 <- taps 6..12 of s in slots 0..6, patch pieces 0..4 of stage s + 1 -> P1; ends on vmcnt(5)
         //     phase B (12 slots): W0 <- taps 0..6 of s + 1 in slots 0..6 with patch pieces 5.. riding along (piece 12 in slot 7)
 #define EA_SLOTN(J) 1
-#define EA_SLOT1(J) ((J) < 7 ? slot_w(s, 6, 7, W1_OFF, (J)) : slot_p(so, P1_OFF, (J) - 7))
-#define EB_SLOTN(J) (((J) < 7 ? 1 : 0) + ((J) + 5 < PPW ? 1 : 0))
-#define EB_SLOT1(J) ((J) < 7 ? slot_w(so, 0, 7, W0_OFF, (J)) : slot_p(so, P1_OFF, (J) + 5 < PPW ? (J) + 5 : PPW - 1))
-#define EB_SLOT2(J) slot_p(so, P1_OFF, (J) + 5 < PPW ? (J) + 5 : PPW - 1)
+#define NPW_ (RING ? RPW : PPW)
+#define PATCH_E_(K) (RING ? slot_row(cbo, kho + 1, (K)) : slot_p(so, P1_OFF, (K)))
+#define PATCH_O_(K) (RING ? slot_row(cbn, khn + 1, (K)) : slot_p(sn, P0_OFF, (K)))
+#define EA_SLOT1(J) ((J) < 7 ? slot_w(s, 6, 7, W1_OFF, (J)) : PATCH_E_((J) - 7))
+#define EB_SLOTN(J) (((J) < 7 ? 1 : 0) + ((J) + 5 < NPW_ ? 1 : 0))
+#define EB_SLOT1(J) ((J) < 7 ? slot_w(so, 0, 7, W0_OFF, (J)) : PATCH_E_((J) + 5 < NPW_ ? (J) + 5 : NPW_ - 1))
+#define EB_SLOT2(J) PATCH_E_((J) + 5 < NPW_ ? (J) + 5 : NPW_ - 1)
 #pragma unroll
         for (int q = 0; q < 8; ++q) rdA(0, W0_OFF, 0, q);
 #pragma unroll
@@ -1466,6 +1530,7 @@ __global__ __launch_bounds__(256, 1) void conv_f16x3_dma16_kernel(ConvF16Args a)
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < 8; ++q) rdA(1, W1_OFF, 0, q);
+        if (two_e) row_burst(cbo, 0);
         DMA16_PAIR(1, RB_E(6), 1, RA_(W1_OFF, 2), 1, RB_E(8), EB_SLOTN, EB_SLOT1, EB_SLOT2, 0)
         DMA16_PAIR(0, RB_E(8), 1, RA_(W1_OFF, 4), 1, RB_E(10), EB_SLOTN, EB_SLOT1, EB_SLOT2, 4)
         DMA16_PAIR(1, RB_E(10), 0, R_NONE, 0, R_NONE, EB_SLOTN, EB_SLOT1, EB_SLOT2, 8)          // the next pair straddles: its operands land with the barrier
@@ -1477,10 +1542,10 @@ __global__ __launch_bounds__(256, 1) void conv_f16x3_dma16_kernel(ConvF16Args a)
         //                         ends on vmcnt(6)
         //     phase B (12 slots): W0 <- taps 0..5 of s + 2 in slots 0..5 with patch pieces 6.. riding along
 #define OA_SLOTN(J) ((J) < 12 ? 1 : 0)
-#define OA_SLOT1(J) ((J) < 6 ? slot_w(so, 7, 6, W1_OFF, (J)) : slot_p(sn, P0_OFF, (J) < 12 ? (J) - 6 : 5))
-#define OB_SLOTN(J) (((J) < 6 ? 1 : 0) + ((J) + 6 < PPW ? 1 : 0))
-#define OB_SLOT1(J) ((J) < 6 ? slot_w(sn, 0, 6, W0_OFF, (J)) : slot_p(sn, P0_OFF, (J) + 6 < PPW ? (J) + 6 : PPW - 1))
-#define OB_SLOT2(J) slot_p(sn, P0_OFF, (J) + 6 < PPW ? (J) + 6 : PPW - 1)
+#define OA_SLOT1(J) ((J) < 6 ? slot_w(so, 7, 6, W1_OFF, (J)) : PATCH_O_((J) < 12 ? (J) - 6 : 5))
+#define OB_SLOTN(J) (((J) < 6 ? 1 : 0) + ((J) + 6 < NPW_ ? 1 : 0))
+#define OB_SLOT1(J) ((J) < 6 ? slot_w(sn, 0, 6, W0_OFF, (J)) : PATCH_O_((J) + 6 < NPW_ ? (J) + 6 : NPW_ - 1))
+#define OB_SLOT2(J) PATCH_O_((J) + 6 < NPW_ ? (J) + 6 : NPW_ - 1)
 #pragma unroll
         for (int q = 0; q < 8; ++q) rdA_str(0, q);
 #pragma unroll
@@ -1494,6 +1559,7 @@ __global__ __launch_bounds__(256, 1) void conv_f16x3_dma16_kernel(ConvF16Args a)
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < 8; ++q) rdA(0, W1_OFF, 0, q);
+        if (two_o) row_burst(cbn, 0);
         DMA16_PAIR(0, RB_O(7), 1, RA_(W1_OFF, 2), 1, RB_O(9), OB_SLOTN, OB_SLOT1, OB_SLOT2, 0)
         DMA16_PAIR(1, RB_O(9), 1, RA_(W1_OFF, 4), 1, RB_O(11), OB_SLOTN, OB_SLOT1, OB_SLOT2, 4)
         DMA16_PAIR(0, RB_O(11), 0, R_NONE, 0, R_NONE, OB_SLOTN, OB_SLOT1, OB_SLOT2, 8)
@@ -1521,24 +1587,27 @@ __global__ __launch_bounds__(256, 1) void conv_f16x3_dma16_kernel(ConvF16Args a)
 #undef OB_SLOTN
 #undef OB_SLOT1
 #undef OB_SLOT2
+#undef NPW_
+#undef PATCH_E_
+#undef PATCH_O_
     asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");           // the asm MFMAs are invisible to the hazard recogniser: results settled before the epilogue reads them
     conv_f16_epilogue<0>(acc, a, smem, b, h0, row, c, lane);
 }
 
-template <int T>
+template <int T, bool RING>
 static int launch_f16_dma16(const ConvF16Args &a, int B, hipStream_t st)
 {
     constexpr int PWP = CV_PITCH + 12 * T;
-    constexpr size_t lds = 2 * (2 * 7 * 2048) + 2 * (size_t)((8 * PWP + 63) / 64) * 1024;
+    constexpr size_t lds = 2 * (2 * 7 * 2048) + (RING ? 4 * (size_t)((4 * PWP + 63) / 64) : 2 * (size_t)((8 * PWP + 63) / 64)) * 1024;
     static_assert(lds <= 160 * 1024, "LDS budget");
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute((const void *)conv_f16x3_dma16_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+        if (hipFuncSetAttribute((const void *)conv_f16x3_dma16_kernel<T, RING>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
             hipSuccess)
             return MX_ERR_LAUNCH;
         attr_done = true;
     }
-    hipLaunchKernelGGL((conv_f16x3_dma16_kernel<T>), dim3(a.H / 2, B), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((conv_f16x3_dma16_kernel<T, RING>), dim3(a.H / 2, B), dim3(256), lds, st, a);
     return mx_launch_status();
 }
 
@@ -1581,9 +1650,16 @@ static int dispatch_f16(int T, int outmode, const ConvF16Args &a, int B, hipStre
         // MODEX_MFMA_SHAPE=32 selects the v_mfma_f32_32x32x16_f16 forward kernels (same-box A/B, profiles/r04)
         static const bool shape16 = !(getenv("MODEX_MFMA_SHAPE") && atoi(getenv("MODEX_MFMA_SHAPE")) == 32);
         if (shape16) {
-            if (T == 1) return launch_f16_dma16<1>(a, B, st);
-            if (T == 2) return launch_f16_dma16<2>(a, B, st);
-            if (T == 4) return launch_f16_dma16<4>(a, B, st);
+            // MODEX_PATCH_RING=0: the two 2-row patch buffers instead of the four-row ring (same-box A/B)
+            static const bool ring = !(getenv("MODEX_PATCH_RING") && atoi(getenv("MODEX_PATCH_RING")) == 0);
+            if (ring) {
+                if (T == 1) return launch_f16_dma16<1, true>(a, B, st);
+                if (T == 2) return launch_f16_dma16<2, true>(a, B, st);
+                if (T == 4) return launch_f16_dma16<4, true>(a, B, st);
+            }
+            if (T == 1) return launch_f16_dma16<1, false>(a, B, st);
+            if (T == 2) return launch_f16_dma16<2, false>(a, B, st);
+            if (T == 4) return launch_f16_dma16<4, false>(a, B, st);
         }
         if (T == 1) return launch_f16_dma<1, 0>(a, B, st);
         if (T == 2) return launch_f16_dma<2, 0>(a, B, st);

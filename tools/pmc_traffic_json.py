@@ -29,13 +29,13 @@ def per_launch(path, pattern, counter):
     return out
 
 
-conv_f = per_launch(os.path.join(d, "pmc_b64_fetch.txt"), r"conv_f16x3_dma16_kernel<1>", "FETCH_SIZE")
-conv_w = per_launch(os.path.join(d, "pmc_b64_write.txt"), r"conv_f16x3_dma16_kernel<1>", "WRITE_SIZE")
+conv_f = per_launch(os.path.join(d, "pmc_b64_fetch.txt"), r"conv_f16x3_dma16_kernel<1, (true|false)>", "FETCH_SIZE")
+conv_w = per_launch(os.path.join(d, "pmc_b64_write.txt"), r"conv_f16x3_dma16_kernel<1, (true|false)>", "WRITE_SIZE")
 if conv_f and conv_w:
     f = list(conv_f.values())[0][1]
     w = list(conv_w.values())[0][1]
     alg = 64 * (2 * 128 * 4 * 352 * 16 * 2 + 64 * 64 * 352 * 4 + 64 * 64 * 352 + 64 * 64 * 2 * 4)
-    json.dump({"kernel": "conv_f16x3_dma16_kernel<1>", "batch_measured": 64, "fetch_size_kb": f, "write_size_kb": w,
+    json.dump({"kernel": "conv_f16x3_dma16_kernel<1, true>", "batch_measured": 64, "fetch_size_kb": f, "write_size_kb": w,
                "fetch_correction": 2.0, "hbm_bytes_per_launch_b64": (2.0 * f + w) * 1000.0, "algorithmic_bytes_b64": alg,
                "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (pmc_b64_fetch.txt, pmc_b64_write.txt), KB = 1000 B, "
                        "gfx950 FETCH_SIZE x2 correction for 16 B/lane loads incl. LDS-DMA; algorithmic = operand pair read once + pooled "
