@@ -1018,8 +1018,14 @@ __device__ __forceinline__ void conv1_pairwave_epilogue(floatx16 (&acc)[CV_WT], 
 // (packed fp32, masks only on the tile that has pad columns: no change), no global stores at all (no change: they are free),
 // no transposition but dword + byte stores straight from the accumulator layout (2.15 ms: slower), staggered workgroups
 // (no change).  With the MFMAs removed the kernel runs at the HBM floor (1.1 ms).  What would: the epilogue's vector work
-// under the NEXT row pair's matrix instructions (pooled values carried in 94 registers: projected ~1.35 ms), or two waves
-// per SIMD at half the wave tile (projected ~1.55 ms) -- not built.
+// under the NEXT row pair's matrix instructions in the SAME wave (pooled values carried in 94 registers: projected ~1.35 ms)
+// -- not built.  Two waves per SIMD at half the wave tile were built twice, parity-green, and are not faster: (a) half-row
+// workgroups of 256 registers / 78 KB, two per CU: 1.95-2.05 ms -- the two run IN phase (a start offset changes nothing) and
+// the single patch buffer that fits leaves every fetch exposed (11 k cycles per half row pair); (b) one 512-thread workgroup,
+// weights once, two wave groups half a period apart by construction (equal barrier counts in the tap and the epilogue
+// phase bodies): 5.1 ms, although its taps alone take 1.31 ms and its epilogue alone 1.09 ms -- the phase barrier makes the
+// tap group wait for the other group's store drain (vmcnt counts stores with the LDS-DMA loads) and its 78 spilled
+// registers; both removed again.
 // Floors at these sizes: 5.2 GB at ~4.7 TB/s = 1.1 ms, 1.8 PFLOP at 1.7 GHz = 1.0 ms.
 //   LDS = W (13 taps x 2 splits: 52 KB) | P[2] (46 KB each)
 // PW (pair-wave): wave = (channel tile, column half) with both rows of the pooling pair (conv1_pairwave_epilogue); a tap
