@@ -540,7 +540,9 @@ class Spectral2DCNN(nn.Module):
             if i == 0 and self.in_ch == 1:      # pad the single input channel to the 2-channel kernel
                 w = torch.cat([w, torch.zeros_like(w)], dim=1)
             ps += [w, conv.bias, prelu.weight]
-        ps += [self.output.weight.view(self.latent_dim, -1), self.output.bias]
+        # (the Conv1d's (latent_dim, 64, 1) weight itself, not a 2-D view of it: a view is not a leaf, and its gradient could
+        #  not be written in place -- _direct_grad_views; the kernels only need its pointer and first dimension)
+        ps += [self.output.weight, self.output.bias]
         return ps
 
     def draw_masks(self) -> Tuple[int, int, int, int]:
