@@ -97,7 +97,7 @@ def test_block_fwd_dgrad_wgrad(dev, T, W, H, cin):
 
 
 @pytest.mark.parametrize("T", [1, 2, 4, 8, 16])
-@pytest.mark.parametrize("W,H", [(345, 8), (88, 16)])
+@pytest.mark.parametrize("W,H", [(345, 8), (88, 16), (17, 2), (351, 4)])      # (17, 2): one row pair, every halo row outside the image
 def test_block_f16x3_kernels(dev, T, W, H):
     """The split-fp16 family, kernel by kernel, against torch CPU autograd at the fp32 tolerance (1e-5 of the tensor's
     max): operand preparation, forward (LDS-DMA kernel for T <= 4, register-staged for T >= 8), data gradient, and BOTH
