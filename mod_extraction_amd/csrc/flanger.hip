@@ -184,28 +184,32 @@ __global__ __launch_bounds__(FL_THREADS) void flanger_kernel(
                 // s_mov exec -> not-taken branch -> read.  The compiler's own versions of this loop (selects onto a private dummy
                 // slot, or an exec region per step) put 25-30 instructions there.  A lane is active in exactly one run of its
                 // row, so `it` keeps each lane's own interpolated value.
-                float it = 0.0f, pv, nv;
+                float it = 0.0f;
                 unsigned long long sv;
                 int k;
+// (the two independent products of fx.py:113 as ONE packed multiplication on fixed register pairs -- v[84:85] = {next, prev},
+//  v[86:87] = {frac, 1 - frac}: one instruction less on the dependent path of every lock-step; each product is still its own
+//  IEEE multiplication, so the waveform stays bit-identical)
 #define FL_LOCK_STEP                                                                                                   \
-    "ds_read_b32 %[pv], %[ap]\n"       /* fx.py:111 */                                                                 \
-    "ds_read_b32 %[nv], %[an]\n"       /* fx.py:112 */                                                                 \
+    "ds_read_b32 v85, %[ap]\n"        /* fx.py:111 */                                                                 \
+    "ds_read_b32 v84, %[an]\n"        /* fx.py:112 */                                                                 \
     "s_add_i32 %[k], %[k], 1\n"                                                                                        \
     "s_cmp_lt_i32 %[k], %[nr]\n"                                                                                       \
     "v_readlane_b32 vcc_lo, %[mlo], %[k]\n" /* lane nr (mod 64) after the last run: unused */                          \
     "v_readlane_b32 vcc_hi, %[mhi], %[k]\n"                                                                            \
     "s_waitcnt lgkmcnt(0)\n"                                                                                           \
-    "v_mul_f32 %[nv], %[frac], %[nv]\n"                                                                                \
-    "v_mul_f32 %[pv], %[omf], %[pv]\n"                                                                                 \
-    "v_add_f32 %[it], %[nv], %[pv]\n"  /* fx.py:113 */                                                                 \
-    "v_mul_f32 %[pv], %[fb], %[it]\n"                                                                                  \
-    "v_add_f32 %[pv], %[xs], %[pv]\n"                                                                                  \
-    "ds_write_b32 %[aw], %[pv]\n"      /* fx.py:114 */                                                                 \
+    "v_pk_mul_f32 v[84:85], v[86:87], v[84:85]\n"                                                                \
+    "v_add_f32 %[it], v84, v85\n"    /* fx.py:113 */                                                                 \
+    "v_mul_f32 v85, %[fb], %[it]\n"                                                                                   \
+    "v_add_f32 v85, %[xs], v85\n"                                                                                    \
+    "ds_write_b32 %[aw], v85\n"       /* fx.py:114 */                                                                 \
     "s_mov_b64 exec, vcc\n"
                 // four lock-steps per taken branch (a not-taken exit branch costs an issue slot, a taken one refills the
                 // instruction buffer on the dependent path)
                 asm volatile(
                     "s_mov_b64 %[sv], exec\n"
+                    "v_mov_b32 v86, %[frac]\n"
+                    "v_mov_b32 v87, %[omf]\n"
                     "s_mov_b32 %[k], 0\n"
                     "v_readlane_b32 vcc_lo, %[mlo], 0\n"
                     "v_readlane_b32 vcc_hi, %[mhi], 0\n"
@@ -219,10 +223,10 @@ __global__ __launch_bounds__(FL_THREADS) void flanger_kernel(
                     "Lfl_done_%=:\n"
                     "s_mov_b64 exec, %[sv]\n"
                     "s_waitcnt lgkmcnt(0)\n"
-                    : [it] "+v"(it), [pv] "=&v"(pv), [nv] "=&v"(nv), [sv] "=&s"(sv), [k] "=&s"(k)
+                    : [it] "+v"(it), [sv] "=&s"(sv), [k] "=&s"(k)
                     : [ap] "v"(a_prev), [an] "v"(a_next), [aw] "v"(a_w), [frac] "v"(frac), [omf] "v"(omf), [xs] "v"(xs), [fb] "s"(fb),
                       [mlo] "v"(m_lo), [mhi] "v"(m_hi), [nr] "s"(nr)
-                    : "memory", "scc", "vcc");
+                    : "memory", "scc", "vcc", "v84", "v85", "v86", "v87");
                 const float oj = __fadd_rn(xs, __fmul_rn(dp, it));                                   // fx.py:115
                 o[j] = oj;
             }
