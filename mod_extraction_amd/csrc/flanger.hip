@@ -204,7 +204,7 @@ __global__ __launch_bounds__(FL_THREADS) void flanger_kernel(
     "v_add_f32 v85, %[xs], v85\n"                                                                                    \
     "ds_write_b32 %[aw], v85\n"       /* fx.py:114 */                                                                 \
     "s_mov_b64 exec, vcc\n"
-                // four lock-steps per taken branch (a not-taken exit branch costs an issue slot, a taken one refills the
+                // eight lock-steps per taken branch (a not-taken exit branch costs an issue slot, a taken one refills the
                 // instruction buffer on the dependent path)
                 asm volatile(
                     "s_mov_b64 %[sv], exec\n"
@@ -216,6 +216,10 @@ __global__ __launch_bounds__(FL_THREADS) void flanger_kernel(
                     "s_nop 3\n"
                     "s_mov_b64 exec, vcc\n"
                     "Lfl_step_%=:\n"
+                    FL_LOCK_STEP "s_cbranch_scc0 Lfl_done_%=\n"
+                    FL_LOCK_STEP "s_cbranch_scc0 Lfl_done_%=\n"
+                    FL_LOCK_STEP "s_cbranch_scc0 Lfl_done_%=\n"
+                    FL_LOCK_STEP "s_cbranch_scc0 Lfl_done_%=\n"
                     FL_LOCK_STEP "s_cbranch_scc0 Lfl_done_%=\n"
                     FL_LOCK_STEP "s_cbranch_scc0 Lfl_done_%=\n"
                     FL_LOCK_STEP "s_cbranch_scc0 Lfl_done_%=\n"
