@@ -194,37 +194,47 @@ __global__ void pack_weights_f16_kernel(const float *__restrict__ W, int flip, _
 // x (B, 2, H, 352) fp32 log-mel, stats (B, 2, 2) -> xk_hi, xk_lo (B, H, 1, 352, 16): channel k = kh * 2 + ci (k < 10)
 // holds xhat[ci][h + kh - 2][w] = (x - mean) * rstd (0 outside the image), k >= 10 is 0.  One 16-deep MFMA k-step then
 // covers a whole tap COLUMN of the 5x13 kernel for both channels, and the K loop of the conv kernel is a single stage.
+// One workgroup = KV_ROWS consecutive output rows of a clip over the full width: the KV_ROWS + 4 input rows of both channels
+// are read ONCE (coalesced 16-byte loads), normalised into LDS, and every thread writes whole 16-byte vectors of the pair
+// (the first version -- 32 columns of one row per workgroup, 128 of 256 threads loading, 64 storing, every input row read five
+// times -- ran at a third of the HBM rate: 0.76 ms per 256 clips for 1.5 GB of output; this one 0.38 ms; 4 / 16 rows per workgroup: 0.52 / 0.46).
+#define KV_ROWS 8
 __global__ __launch_bounds__(256) void split_prep_kvec_kernel(const float *__restrict__ x, const float *__restrict__ stats,
                                                               int H, int Wv, _Float16 *__restrict__ out_hi,
                                                               _Float16 *__restrict__ out_lo)
 {
-    __shared__ float tile[16][33];
-    const int wt = blockIdx.x, h = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
-    for (int i = tid; i < 16 * 8; i += 256) {
-        const int k = i >> 3, c4 = i & 7, kh = k >> 1, ci = k & 1;
-        const int hx = h + kh - 2, w0 = wt * 32 + c4 * 4;
-        floatx4 v = {0.f, 0.f, 0.f, 0.f};
-        if (k < 2 * CV_KH && hx >= 0 && hx < H) {
-            v = *reinterpret_cast<const floatx4 *>(x + (((size_t)b * 2 + ci) * H + hx) * CV_PITCH + w0);
-            const float mean = stats[((size_t)b * 2 + ci) * 2], rstd = stats[((size_t)b * 2 + ci) * 2 + 1];
+    constexpr int NR = (KV_ROWS + 4) * 2, RS = CV_PITCH + 1;       // (input row, channel) images; odd stride: the 8 rows a thread reads fall in 8 banks
+    __shared__ float tile[NR * RS];
+    const int h0 = blockIdx.x * KV_ROWS, b = blockIdx.y, tid = threadIdx.x;
+    float mean[2], rstd[2];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = (w0 + e < Wv) ? (v[e] - mean) * rstd : 0.0f;
+    for (int ci = 0; ci < 2; ++ci) { mean[ci] = stats[((size_t)b * 2 + ci) * 2]; rstd[ci] = stats[((size_t)b * 2 + ci) * 2 + 1]; }
+    for (int i = tid; i < NR * (CV_PITCH / 4); i += 256) {
+        const int rw = i / (CV_PITCH / 4), c4 = i - rw * (CV_PITCH / 4), ci = rw & 1, hx = h0 - 2 + (rw >> 1), w0 = c4 * 4;
+        floatx4 v = {0.f, 0.f, 0.f, 0.f};
+        if (hx >= 0 && hx < H) {
+            v = *reinterpret_cast<const floatx4 *>(x + (((size_t)b * 2 + ci) * H + hx) * CV_PITCH + w0);
+            const float m = ci ? mean[1] : mean[0], r = ci ? rstd[1] : rstd[0];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (w0 + e < Wv) ? (v[e] - m) * r : 0.0f;
         }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) tile[k][c4 * 4 + e] = v[e];
+        for (int e = 0; e < 4; ++e) tile[rw * RS + w0 + e] = v[e];
     }
     __syncthreads();
-    if (tid < 64) {                                       // 32 positions x 2 groups of 8 channels
-        const int pos = tid >> 1, cg = tid & 1;
+    for (int i = tid; i < KV_ROWS * CV_PITCH * 2; i += 256) {       // (output row, position, group of 8 channels)
+        const int r = i / (CV_PITCH * 2), rem = i - r * (CV_PITCH * 2), pos = rem >> 1, cg = rem & 1, h = h0 + r;
+        if (h >= H) break;
         half8 hi, lo;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const float v = tile[cg * 8 + j][pos];
+            const int k = cg * 8 + j;                               // channel k = kh * 2 + ci: image (r + kh) * 2 + ci = 2 r + k
+            const float v = k < 2 * CV_KH ? tile[(2 * r + k) * RS + pos] : 0.0f;
             const _Float16 hh = (_Float16)v;
             hi[j] = hh;
             lo[j] = (_Float16)(v - (float)hh);
         }
-        const size_t o = (((size_t)b * H + h) * CV_PITCH + wt * 32 + pos) * 16 + cg * 8;
+        const size_t o = (((size_t)b * H + h) * CV_PITCH + pos) * 16 + cg * 8;
         *reinterpret_cast<half8 *>(out_hi + o) = hi;
         *reinterpret_cast<half8 *>(out_lo + o) = lo;
     }
@@ -1774,7 +1784,7 @@ MX_EXPORT int mx_conv_prep_fwd_kvec_f16(const float *x, const float *stats, int6
 {
     if (!x || !stats || !xk_hi || !xk_lo || B <= 0 || H <= 0 || Wv <= 0 || Wv > CV_PITCH) return MX_ERR_ARG;
     if (B > 65535 || H > 65535) return MX_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(split_prep_kvec_kernel, dim3(CV_PITCH / 32, (unsigned)H, (unsigned)B), dim3(256), 0,
+    hipLaunchKernelGGL(split_prep_kvec_kernel, dim3((unsigned)((H + KV_ROWS - 1) / KV_ROWS), (unsigned)B), dim3(256), 0,
                        (hipStream_t)stream, x, stats, (int)H, (int)Wv, (_Float16 *)xk_hi, (_Float16 *)xk_lo);
     return mx_launch_status();
 }
