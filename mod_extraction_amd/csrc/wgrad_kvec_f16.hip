@@ -11,8 +11,10 @@
 //       * S -> fp16 pair) into a [co][position] LDS image: a lane's 8 consecutive positions are one ds_read_b128.
 //   B = xk rows in a [position][16] image (32-byte rows): fragments by ds_read_b64_tr_b16 at row offset kw.
 // Workgroup = slab of (b, h) rows, 2 per CU (64 KB LDS each) so that one stages while the other multiplies; 4 waves =
-// (co half, tap group g): both 16-row co tiles of 6 taps 7g .. 7g+5 plus co tile g of the middle tap = 13 accumulators,
-// 39 MFMAs per 32 positions.  Partial results per slab, deterministic fp64 slab reduction (as the other wgrad kernels).
+// tap groups {0,1,2}, {3,4,5}, {7,8,9}, {10,11,12}, each with ALL FOUR 16-row co tiles of its three taps plus co tile
+// `wave` of the middle tap 6 = 13 accumulators, 39 MFMAs per 32 positions.  (First version: waves = (co half, tap group of
+// six): 28 transposed B reads + 6 A reads per wave and k-step against 16 + 10 now -- the LDS read port, shared by the
+// eight waves of a CU, is what this kernel waits for.)  Partial results per slab, deterministic fp64 slab reduction (as the other wgrad kernels).
 #include "conv_common.h"
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -54,7 +56,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kvec_f16_kernel(WgradKvecArgs a)
     __shared__ __attribute__((aligned(16))) _Float16 dzA[2 * 64 * WK_AP];      // [split][co][position]   51,200 B
     __shared__ __attribute__((aligned(16))) _Float16 xB[2 * WK_BR * 16];       // [split][position][16]   13,056 B
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: wave-uniform address parts stay off the vector unit
-    const int mh = wave & 1, g = wave >> 1;
+    const int tap0 = wave * 3 + (wave >> 1);                                    // first tap of the wave's group (tap 6 is shared)
     const int m16 = lane & 15, kg = lane >> 4;
     const int slab = blockIdx.x;
     const int Hp = a.H >> 1;
@@ -65,7 +67,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kvec_f16_kernel(WgradKvecArgs a)
     for (int i = 0; i < CV_KW; ++i) acc[i] = floatx4{0.f, 0.f, 0.f, 0.f};
 
     // fragment addressing (bytes)
-    const int a_lane = ((mh * 32 + m16) * WK_AP + 8 * kg) * 2;                  // + j*16*WK_AP*2 (co tile) + ks*64 (+ split)
+    const int a_lane = (m16 * WK_AP + 8 * kg) * 2;                              // + j*16*WK_AP*2 (co tile) + ks*64 (+ split)
     const int b_lane = (8 * kg + (m16 >> 2)) * 32 + (m16 & 3) * 8;              // + (ks*32 + kw)*32 (+ split)
     constexpr int A_SPLIT = 64 * WK_AP * 2, B_SPLIT = WK_BR * 32;
     const unsigned char *Ab = reinterpret_cast<const unsigned char *>(dzA);
@@ -165,28 +167,28 @@ __global__ __launch_bounds__(256, 2) void wgrad_kvec_f16_kernel(WgradKvecArgs a)
             // ---- nks k-steps of 32 positions: 39 MFMAs each
 #pragma unroll 1
             for (int ks = 0; ks < nks; ++ks) {
-                // A fragments: co tile 0, co tile 1, and co tile g once more for the middle tap (a separate read, not a
+                // A fragments: co tiles 0..3, and co tile `wave` once more for the middle tap (a separate read, not a
                 // register select: the optimizer would turn the select into a dynamically indexed private array)
-                half8 ah[3], al[3], bh[7], bl[7];
+                half8 ah[5], al[5], bh[4], bl[4];
 #pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    const int jt = j < 2 ? j : g;
+                for (int j = 0; j < 5; ++j) {
+                    const int jt = j < 4 ? j : wave;
                     ah[j] = *reinterpret_cast<const half8 *>(Ab + a_lane + jt * (16 * WK_AP * 2) + ks * 64);
                     al[j] = *reinterpret_cast<const half8 *>(Ab + A_SPLIT + a_lane + jt * (16 * WK_AP * 2) + ks * 64);
                 }
 #pragma unroll
-                for (int t = 0; t < 7; ++t) {
-                    const int kw = t < 6 ? 7 * g + t : 6;
+                for (int t = 0; t < 4; ++t) {
+                    const int kw = t < 3 ? tap0 + t : 6;
                     bh[t] = tr_frag16(Bb, b_lane, ks * 32 + kw);
                     bl[t] = tr_frag16(Bb + B_SPLIT, b_lane, ks * 32 + kw);
                 }
-                // three split products, every accumulator once per pass
+                // three split products, every accumulator once per pass: acc[4t + j] = tap tap0 + t, co tile j; acc[12] = tap 6, co tile `wave`
 #pragma unroll
-                for (int u = 0; u < 13; ++u) acc[u] = mfma_16x16x32(al[u < 12 ? (u & 1) : 2], bh[u < 12 ? (u >> 1) : 6], acc[u]);
+                for (int u = 0; u < 13; ++u) acc[u] = mfma_16x16x32(al[u < 12 ? (u & 3) : 4], bh[u < 12 ? (u >> 2) : 3], acc[u]);
 #pragma unroll
-                for (int u = 0; u < 13; ++u) acc[u] = mfma_16x16x32(ah[u < 12 ? (u & 1) : 2], bl[u < 12 ? (u >> 1) : 6], acc[u]);
+                for (int u = 0; u < 13; ++u) acc[u] = mfma_16x16x32(ah[u < 12 ? (u & 3) : 4], bl[u < 12 ? (u >> 2) : 3], acc[u]);
 #pragma unroll
-                for (int u = 0; u < 13; ++u) acc[u] = mfma_16x16x32(ah[u < 12 ? (u & 1) : 2], bh[u < 12 ? (u >> 1) : 6], acc[u]);
+                for (int u = 0; u < 13; ++u) acc[u] = mfma_16x16x32(ah[u < 12 ? (u & 3) : 4], bh[u < 12 ? (u >> 2) : 3], acc[u]);
             }
             }
         }
@@ -194,11 +196,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_kvec_f16_kernel(WgradKvecArgs a)
         w0 = nw0;
     }
     // partial tiles: part[slab][kw][co][k]; D: lane l, reg r -> co row 4 (l >> 4) + r, column k = l & 15
-    // acc[2t + j]: tap 7g + t, co tile j (rows mh*32 + j*16 ..); acc[12]: tap 6, co tile g
+    // acc[4t + j]: tap tap0 + t, co tile j (rows j*16 ..); acc[12]: tap 6, co tile `wave`
 #pragma unroll
     for (int u = 0; u < CV_KW; ++u) {
-        const int kw = u < 12 ? 7 * g + (u >> 1) : 6, j = u < 12 ? (u & 1) : g;
-        float *dst = a.part + (((size_t)slab * CV_KW + kw) * 64 + mh * 32 + j * 16) * 16;
+        const int kw = u < 12 ? tap0 + (u >> 2) : 6, j = u < 12 ? (u & 3) : wave;
+        float *dst = a.part + (((size_t)slab * CV_KW + kw) * 64 + j * 16) * 16;
 #pragma unroll
         for (int r = 0; r < 4; ++r) dst[(4 * kg + r) * 16 + m16] = acc[u][r];
     }
