@@ -95,6 +95,7 @@ class SyntheticFxBatcher:
         self.kind_id = torch.tensor([{"flanger": 0, "chorus": 1, "phaser": 2, "dry": 3}[k] for k in self.kinds])
         self.rows_fx = torch.nonzero(self.kind_id < 2).view(-1).to(torch.int32).to(device)
         self.rows_ph = torch.nonzero(self.kind_id == 2).view(-1).to(torch.int32).to(device)
+        self._is_ph_dev = (self.kind_id == 2).to(device)
         self.has_ph = bool((self.kind_id == 2).any())
         self.has_fx = bool((self.kind_id < 2).any())
         self.has_dry = bool((self.kind_id == 3).any())
@@ -230,10 +231,20 @@ class SyntheticFxBatcher:
         return p
 
     # ---- device-side rendering -------------------------------------------------------------------
-    def render(self, p: Dict[str, Any]) -> Tuple[T, T, T, Dict[str, Any]]:
-        dev, B, N = self.device, self.B, self.N
+    def to_device(self, p: Dict[str, Any]) -> Tuple[Dict[str, T], T]:
+        """The host-sampled parameters on the device.  These copies come from pageable host memory, so each of them blocks
+        the HOST until the stream it is issued on has reached it: issue them on a stream that is not waiting for anything
+        (``_launch_ahead`` does so BEFORE it makes the side stream wait for the train step in flight -- with the copies behind
+        that wait the host was held until the step had finished, once per step, and the main stream then idled ~0.85 ms
+        while the host caught up)."""
+        dev = self.device
         d = {k: v.to(dev) for k, v in p.items() if isinstance(v, torch.Tensor)}
         shape_id = torch.tensor([SHAPE_IDS[s] for s in p["shape"]], dtype=torch.int32, device=dev)
+        return d, shape_id
+
+    def render(self, p: Dict[str, Any], dev_params: Optional[Tuple[Dict[str, T], T]] = None) -> Tuple[T, T, T, Dict[str, Any]]:
+        dev, B, N = self.device, self.B, self.N
+        d, shape_id = self.to_device(p) if dev_params is None else dev_params
         if self.chunk_source is not None:
             # recorded audio: one non-silent chunk per clip (phaser clips: n + sr/rate samples, datasets.py:433-436)
             extra = p.get("proc_extra", torch.zeros(B, dtype=torch.int64))
@@ -253,7 +264,7 @@ class SyntheticFxBatcher:
         if self.has_ph:
             half_pi = torch.full((B,), math.pi / 2, device=dev)
             mod_ph = make_mod_signals(N, self.sr, d["rate_hz"], half_pi, None, None, d["lead"], n_out=self.n_lfo)
-            mod = torch.where((self.kind_id == 2).to(dev).unsqueeze(1), mod_ph, mod)
+            mod = torch.where(self._is_ph_dev.unsqueeze(1), mod_ph, mod)
         dry, wet = self.audio[:, 0, :], self.audio[:, 1, :]
         if self.has_dry:
             wet.copy_(dry)                           # effect rows are overwritten below
@@ -280,9 +291,12 @@ class SyntheticFxBatcher:
         slot = self._slot
         self._slot ^= 1
         self.src, self.audio = self._src[slot], self._audio[slot]
+        p = self.sample_params()
+        with torch.cuda.stream(self._side), torch.no_grad():
+            dev_params = self.to_device(p)      # host-blocking copies: before the wait below (see to_device)
         self._side.wait_stream(main)            # the idle set was last read two steps ago; also orders the RNG state
         with torch.cuda.stream(self._side), torch.no_grad():
-            batch = self.render(self.sample_params())
+            batch = self.render(p, dev_params)
             extra = self.ahead_fn(batch) if self.ahead_fn is not None else None
             ev = torch.cuda.Event()
             ev.record(self._side)
