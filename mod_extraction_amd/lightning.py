@@ -285,6 +285,10 @@ class TBPTTLFOEffectModeling(BaseLightingModule):
             log.info("No valid LFO signals found")
             return None
         if keep is not None and keep.numel() < dry.size(0):
+            # (pinned: a copy from pageable memory holds the HOST until the stream has reached it, i.e. until the whole
+            #  previous batch has run -- and the device then idles while the host catches up)
+            if dry.is_cuda:
+                keep = keep.pin_memory()
             keep = keep.to(dry.device, non_blocking=True)
             dry, wet, mod_sig_hat = dry[keep], wet[keep], mod_sig_hat[keep]
             if mod_sig is not None:
