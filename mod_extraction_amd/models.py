@@ -294,8 +294,10 @@ class _CNNStack(torch.autograd.Function):
         ds_part = torch.empty((B, 64), device=dev, dtype=torch.float32)
         slope_last = params[3 * (n_blocks - 1) + 2].contiguous()
         # max|G| of the last block's gradient for its f16x3 scale: taken while G is written (no sweep)
-        gmax_ws = (torch.zeros(1, device=dev, dtype=torch.int32)
-                   if _use_f16(saved[3 * (n_blocks - 1)].size(1), precision) else None)
+        # one zeroed workspace for every atomic-max cell of this backward pass (each used to be its own fill launch): cells
+        # 4 l .. 4 l + 3 belong to block l
+        zws = torch.zeros(4 * (n_blocks + 1), device=dev, dtype=torch.int32)
+        gmax_ws = zws[4 * n_blocks:4 * n_blocks + 1] if _use_f16(saved[3 * (n_blocks - 1)].size(1), precision) else None
         _hip.call("mx_head_bwd", _hip.ptr(p_last), _hip.ptr(slope_last), _hip.ptr(wout.contiguous()),
                   _hip.ptr(latent), _hip.ptr(out), _hip.ptr(d_out), _hip.ptr(d_latent), B, 64, Hl, n_frames, L,
                   _hip.ptr(G), _hip.ptr(dw_part), _hip.ptr(db_part), _hip.ptr(ds_part), _hip.ptr(gmax_ws), st)
@@ -417,7 +419,7 @@ class _CNNStack(torch.autograd.Function):
                         # that pass writes the block below's pooled operand itself, max|dxhat| / max|xhat| for its scale
                         ln_part = torch.empty((B, 64, H, 2, 2), device=dev, dtype=torch.float32)
                         fuse_g = GPOOL_FUSED and _pooled_only(l - 1, saved[3 * (l - 1)].size(1), dilations, precision, n_frames)
-                        gx_bits = torch.zeros(2, device=dev, dtype=torch.int32) if fuse_g else None
+                        gx_bits = zws[4 * l:4 * l + 2] if fuse_g else None
                         _hip.call("mx_conv_block_dgrad_sp_f16", _hip.ptr(gc_hi), _hip.ptr(gc_lo), _hip.ptr(gc_idx),
                                   _hip.ptr(ws_hi), _hip.ptr(ws_lo), _hip.ptr(scale), B, H, n_frames, int(dilations[l]),
                                   _hip.ptr(dxhat), _hip.ptr(x_hi), _hip.ptr(x_lo), _hip.ptr(ln_part), _hip.ptr(gx_bits), st)
@@ -462,7 +464,7 @@ class _CNNStack(torch.autograd.Function):
                     del part2, m12, dxhat
                 else:
                     want_gmax = _use_f16(saved[3 * (l - 1)].size(1), precision) or (l == 1 and 0 in ctx.splits)
-                    gmax_ws = torch.zeros(1, device=dev, dtype=torch.int32) if want_gmax else None
+                    gmax_ws = zws[4 * l + 2:4 * l + 3] if want_gmax else None
                     _hip.call("mx_ln_prelu_bwd", _hip.ptr(x_in), _hip.ptr(dxhat), _hip.ptr(stats), _hip.ptr(slope_prev),
                               B, 64, H, n_frames, _hip.ptr(ds_part), _hip.ptr(bsum), _hip.ptr(gmax_ws), _hip.ptr(ln_part), st)
                     G = dxhat
