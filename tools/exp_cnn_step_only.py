@@ -7,6 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 import bench
+bench.torch = torch          # (bench.py imports torch lazily in main)
 from mod_extraction_amd import trainer as tr
 
 dev = torch.device("cuda:0")
