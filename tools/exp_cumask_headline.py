@@ -8,6 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 import bench
+bench.torch = torch          # (bench.py imports torch lazily in main)
 from mod_extraction_amd import trainer as tr
 
 hip = ctypes.CDLL("libamdhip64.so")
