@@ -448,3 +448,29 @@ def test_parameter_gradients_written_in_place_equal_the_accumulated_ones(dev):
     assert float(g_plain.abs().max()) > 0 and torch.equal(g_direct, g_plain)
     g2 = grads(True, True)                                                 # first backward in place, second accumulated
     assert float((g2 - 2 * g_plain).abs().max()) <= 1e-6 * float(g_plain.abs().max())
+
+
+@pytest.mark.gpu
+def test_batches_rendered_one_step_ahead_equal_the_serial_ones(dev):
+    """SyntheticFxBatcher with overlap renders batch i + 1 on a side stream while batch i is consumed (its host-sampled
+    parameters are copied to the device BEFORE the side stream waits for the work in flight): the batches must be the ones
+    the serial batcher produces from the same seeds, bit for bit, also while the consumer keeps the main stream busy."""
+    from mod_extraction_amd import data_modules
+
+    def run(overlap):
+        torch.manual_seed(11); np.random.seed(11)
+        bt = data_modules.SyntheticFxBatcher(6, 22272, 44100, ("flanger", "chorus", "phaser"), dev, audio_seed=4, overlap=overlap)
+        out = []
+        busy = torch.randn(2048, 2048, device=dev)
+        for _ in range(3):
+            dry, wet, mod, fxp = bt.next_batch()
+            for _ in range(4):
+                busy = (busy @ busy).clamp_(-1, 1)              # main-stream work between the batches
+            out.append((dry.clone(), wet.clone(), mod.clone(), {k: v.clone() for k, v in fxp.items() if isinstance(v, torch.Tensor)}))
+        torch.cuda.synchronize()
+        return out
+
+    serial, ahead = run(False), run(True)
+    for (d0, w0, m0, p0), (d1, w1, m1, p1) in zip(serial, ahead):
+        assert torch.equal(d0, d1) and torch.equal(w0, w1) and torch.equal(m0, m1)
+        assert p0.keys() == p1.keys() and all(torch.equal(p0[k], p1[k]) for k in p0)
