@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void split_prep_fwd_kernel(const float *__rest
         const int i = tid + 256 * k, c = i >> 3, c4 = i & 7;
         const size_t off = (((size_t)b * 64 + c) * H + h0) * CV_PITCH + wt * 32 + c4 * 4;
 #pragma unroll
-        for (int r = 0; r < ROWS; ++r) v[r][k] = *reinterpret_cast<const floatx4 *>(x + off + (size_t)r * CV_PITCH);
+        for (int r = 0; r < ROWS; ++r) v[r][k] = __builtin_nontemporal_load(reinterpret_cast<const floatx4 *>(x + off + (size_t)r * CV_PITCH));
     }
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
@@ -113,8 +113,8 @@ __global__ __launch_bounds__(256) void split_prep_fwd_kernel(const float *__rest
             lo[j] = (_Float16)(t - (float)hh);
         }
         const size_t o = ((((size_t)b * H + h0 + r) * 4 + (cg >> 1)) * CV_PITCH + wt * 32 + pos) * 16 + (cg & 1) * 8;
-        *reinterpret_cast<half8 *>(out_hi + o) = hi;
-        *reinterpret_cast<half8 *>(out_lo + o) = lo;
+        __builtin_nontemporal_store(hi, reinterpret_cast<half8 *>(out_hi + o));
+        __builtin_nontemporal_store(lo, reinterpret_cast<half8 *>(out_lo + o));
     }
 }
 
@@ -235,8 +235,8 @@ __global__ __launch_bounds__(256) void split_prep_kvec_kernel(const float *__res
             lo[j] = (_Float16)(v - (float)hh);
         }
         const size_t o = (((size_t)b * H + h) * CV_PITCH + pos) * 16 + cg * 8;
-        *reinterpret_cast<half8 *>(out_hi + o) = hi;
-        *reinterpret_cast<half8 *>(out_lo + o) = lo;
+        __builtin_nontemporal_store(hi, reinterpret_cast<half8 *>(out_hi + o));
+        __builtin_nontemporal_store(lo, reinterpret_cast<half8 *>(out_lo + o));
     }
 }
 

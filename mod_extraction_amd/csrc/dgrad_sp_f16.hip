@@ -490,8 +490,8 @@ __global__ __launch_bounds__(256) void lnbwd_gpool_kernel(const float *__restric
     for (int k = 0; k < NIT; ++k) {                             // all loads first
         const int i = tid + 256 * k, ch = i / (GP_TW / 4), c4 = i % (GP_TW / 4), w0 = wt * GP_TW + c4 * 4;
         const size_t off = (((size_t)b * 64 + ch) * Hp + hp) * CV_PITCH + (w0 < CV_PITCH ? w0 : 0);
-        pv[k] = *reinterpret_cast<const floatx4 *>(p + off);
-        gv[k] = *reinterpret_cast<const floatx4 *>(dxhat + off);
+        pv[k] = __builtin_nontemporal_load(reinterpret_cast<const floatx4 *>(p + off));          // read exactly once
+        gv[k] = __builtin_nontemporal_load(reinterpret_cast<const floatx4 *>(dxhat + off));
         av[k] = *reinterpret_cast<const uchar4 *>(amax + off);
         const size_t pl = (size_t)b * 64 + ch;
         mean[k] = stats[pl * 2]; rstd[k] = stats[pl * 2 + 1]; sl[k] = slope[ch];
@@ -551,8 +551,8 @@ __global__ __launch_bounds__(256) void lnbwd_gpool_kernel(const float *__restric
             lo[j] = (_Float16)(v - (float)hv);
         }
         const size_t o = ((((size_t)b * Hp + hp) * 4 + (cg >> 1)) * CV_PITCH + w) * 16 + (cg & 1) * 8;
-        *reinterpret_cast<half8 *>(g_hi + o) = hi;
-        *reinterpret_cast<half8 *>(g_lo + o) = lo;
+        __builtin_nontemporal_store(hi, reinterpret_cast<half8 *>(g_hi + o));
+        __builtin_nontemporal_store(lo, reinterpret_cast<half8 *>(g_lo + o));
         if (cg < 4) {
             unsigned word = 0;
 #pragma unroll

@@ -192,8 +192,8 @@ __global__ __launch_bounds__(LNB_THREADS) void ln_prelu_bwd_kernel(const float *
             const bool ok = i < n4;
             const int ic = ok ? i : (int)threadIdx.x;
             col[u] = ok ? (ic % (CV_PITCH / 4)) * 4 : CV_PITCH;          // tail: every element masked
-            pv[u] = pp[ic];
-            gv[u] = gp[ic];
+            pv[u] = __builtin_nontemporal_load(pp + ic);        // both tensors are read exactly once
+            gv[u] = __builtin_nontemporal_load(gp + ic);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(LNB_THREADS) void ln_prelu_bwd_kernel(const float *
             ds += (double)tds;
             gs += (double)tgs;
             const int i = i0 + u * LNB_THREADS;
-            if (i < n4) gp[i] = o;
+            if (i < n4) __builtin_nontemporal_store(o, gp + i);
         }
     }
     block_sum2(ds, gs, sh);
