@@ -829,13 +829,16 @@ def _worker_cmd(args, config, steps, extra=()):
 def launch(args) -> int:
     script = os.path.join(ROOT, "bench.py")
     flags = (["--no-cpu-baseline"] if args.no_cpu_baseline else []) + (["--no-fp32-leg"] if args.no_fp32_leg else [])
-    if args.gpus > 1:
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-               "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), script] + \
-              _worker_cmd(args, args.config, args.steps, flags)
-    else:
-        cmd = [sys.executable, script, "--worker"] + _worker_cmd(args, args.config, args.steps, flags)
-    out, rc, err = _run_child(cmd, 3000)
+    for _ in range(4):                          # (a free port can be taken between finding it and torchrun's bind: try another one)
+        if args.gpus > 1:
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+                   "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), script] + \
+                  _worker_cmd(args, args.config, args.steps, flags)
+        else:
+            cmd = [sys.executable, script, "--worker"] + _worker_cmd(args, args.config, args.steps, flags)
+        out, rc, err = _run_child(cmd, 3000)
+        if out is not None or args.gpus == 1 or not ("EADDRINUSE" in err or "address already in use" in err.lower()):
+            break
     if out is None:
         sys.stderr.write(f"bench worker failed (rc {rc})\n")
         return rc or 1

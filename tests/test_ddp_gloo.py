@@ -17,6 +17,35 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
+def _run_two_ranks(target, extra_args=(), timeout=240):
+    """Two spawned ranks on a free local port; results {rank: dict} from the queue.  A rank that dies before reporting (the
+    port found free can be taken before the rendezvous store binds it) makes the launch repeat on another port."""
+    import queue
+    import time
+    ctx = mp.get_context("spawn")
+    for attempt in range(3):
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=target, args=(r, 2, port, *extra_args, q)) for r in range(2)]
+        for p in procs:
+            p.start()
+        results, t0 = {}, time.time()
+        while len(results) < 2 and time.time() - t0 < timeout:
+            try:
+                k, v = q.get(timeout=1.0)
+                results[k] = v
+            except queue.Empty:
+                if all(not p.is_alive() for p in procs) and q.empty():
+                    break
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.kill()
+        if len(results) == 2 and all(p.exitcode == 0 for p in procs):
+            return results
+    raise AssertionError(f"two-rank launch failed {attempt + 1} times: exit codes {[p.exitcode for p in procs]}, got {sorted(results)}")
+
+
 class FakeOpt:
     """FlatAdamW stand-in: plain SGD on a flat CPU buffer, counting steps."""
 
@@ -101,16 +130,7 @@ def _worker(rank, world, port, out):
 
 
 def test_two_rank_host_logic():
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    results = dict(q.get(timeout=240) for _ in range(2))
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    results = _run_two_ranks(_worker)
     r0, r1 = results[0], results[1]
     assert r0["grad"] == r1["grad"] == [1.5] * 10                     # (1 + 2) / 2
     assert r0["metrics"] == r1["metrics"] == {"train/l1": 2.5, "train/loss": 0.5}
@@ -157,17 +177,7 @@ def test_cli_gives_each_rank_its_own_data_stream_and_identical_replicas():
     """with one seed_everything value on all ranks every rank drew the same batch.  Through
     CustomLightningCLI the replicas must start identical while parameter draws and SpecAugment masks differ."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_cli_worker, args=(r, 2, port, "../configs/train_lfo_interwoven_all.yml",
-                                                   os.path.join(root, "scripts"), q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    results = dict(q.get(timeout=240) for _ in range(2))
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    results = _run_two_ranks(_cli_worker, ("../configs/train_lfo_interwoven_all.yml", os.path.join(root, "scripts")))
     r0, r1 = results[0], results[1]
     assert r0["param_sum"] == r1["param_sum"] and r0["param_abs"] == r1["param_abs"]
     assert r0["draw"] != r1["draw"]

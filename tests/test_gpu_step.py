@@ -230,9 +230,8 @@ def test_train_step_through_the_rccl_init_path_world_size_1(dev):
         return losses, opt.flat_param.clone(), metrics
 
     base = run(False)
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)
+    from tests.helpers.torchrun import init_world1_process_group
+    init_world1_process_group("nccl", device_id=dev)
     try:
         assert dist.get_backend() == "nccl"
         with_pg = run(True)
@@ -250,18 +249,11 @@ def test_bench_two_ranks_sharing_the_gpu_over_gloo(config):
     ranks on one device, so the collectives go through gloo (MODEX_DIST_BACKEND) and LOCAL_RANK is folded onto the
     existing device (MODEX_SHARE_GPU): the code path is the driver's multi-GPU launch, only the transport differs."""
     import json
-    import socket
-    import subprocess
-    import sys
+    from tests.helpers.torchrun import run_torchrun
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
     env = dict(os.environ, MODEX_SHARE_GPU="1", MODEX_DIST_BACKEND="gloo")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--config", str(config), "--steps", "2",
-           "--warmup", "1", "--batch", "8"]
-    res = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    res = run_torchrun(2, [os.path.join(root, "bench.py"), "--gpus", "2", "--config", str(config), "--steps", "2",
+                           "--warmup", "1", "--batch", "8"], env=env, cwd=root, timeout=600)
     assert res.returncode == 0, res.stderr[-2000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, res.stdout[-2000:]                 # rank 0 only
@@ -352,9 +344,8 @@ def test_tbptt_step_through_rccl_with_the_cu_partition_installed(dev):
         return opt.flat_param.clone(), len(calls), opt.step_count
 
     base = run(False)
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)
+    from tests.helpers.torchrun import init_world1_process_group
+    init_world1_process_group("nccl", device_id=dev)
     try:
         with_pg = run(True)
         dist.barrier()
@@ -395,13 +386,9 @@ def test_two_rank_step_equals_the_single_process_step_on_the_joined_batch(tmp_pa
     res = subprocess.run([sys.executable, worker, one, "4", mode], capture_output=True, text=True, timeout=600,
                          env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
     assert res.returncode == 0, res.stderr[-2000:]
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
+    from tests.helpers.torchrun import run_torchrun
     env = dict(os.environ, MODEX_SHARE_GPU="1", MODEX_DIST_BACKEND="gloo")
-    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-                          "127.0.0.1", "--master-port", str(port), worker, two, "4", mode], env=env, capture_output=True, text=True,
-                         timeout=600)
+    res = run_torchrun(2, [worker, two, "4", mode], env=env, timeout=600)
     assert res.returncode == 0, res.stderr[-2000:]
     a, b = torch.load(one), torch.load(two)
     assert a["world"] == 1 and b["world"] == 2
