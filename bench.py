@@ -98,11 +98,20 @@ def conv_flops(block: int, batch: int) -> float:
 
 
 def hbm_block(kernel: str, bytes_alg: float, ms: float, floor_ms=None, note=None, bound="hbm"):
-    """Roofline block of an HBM-nominal kernel: ALGORITHMIC bytes per launch / HIP-event duration."""
+    """Roofline block of an HBM-nominal kernel: ALGORITHMIC bytes per launch / HIP-event duration.
+    bound = "latency" (the sample-recurrent kernels K2 / K3 / K10): achieved / peak / frac stay the NOMINAL HBM figures
+    (SURVEY 8d asks for them), the governing bound is the dependency chain -- `frac_of_independent_floor` (a floor built from a
+    stand-alone microbenchmark, not from the kernel) and `frac_of_serial_floor` (the kernel's own probe twin) say how close
+    the launch is to it."""
     gbps = bytes_alg / (ms * 1e-3) / 1e9
     out = {"bound": bound, "kernel": kernel, "algorithmic_bytes": int(bytes_alg), "avg_launch_ms": round(ms, 4),
            "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(gbps / HBM_PEAK_GBPS, 5),
            "traffic": None}
+    if bound == "latency":
+        out["nominal_bound"] = "hbm"
+        out["bound_note"] = ("latency-bound: one workgroup per clip, the launch lasts as long as its chain of dependent steps; "
+                             "achieved / peak / frac are the nominal HBM figures, the governing fractions are "
+                             "frac_of_independent_floor / frac_of_serial_floor")
     if floor_ms is not None:
         out["serial_floor_ms"] = round(floor_ms, 4)
         out["frac_of_serial_floor"] = round(floor_ms / ms, 4)
@@ -139,7 +148,7 @@ def build_lfo_job(device, rank, batch, kinds, overlap=True):
     return module, opt, batcher
 
 
-def cpu_baseline_lfo(kinds, batch_cpu: int = 8, steps: int = 5):
+def cpu_baseline_lfo(kinds, batch_cpu: int = 8, steps: int = 5, reference_shaped: bool = True):
     """The CPU oracle's version of the same step on the host cores, bounded sample (~10 s).
     Thread count: torch's CPU conv stops scaling at ~32 threads for this batch (measured on the 256-core
     GPU host: 16 thr 14.5, 32 thr 16.2, 64 thr 9.4, 256 thr 0.5 audio-s/s), so min(32, cores) is used
@@ -169,7 +178,8 @@ def cpu_baseline_lfo(kinds, batch_cpu: int = 8, steps: int = 5):
                      f"{'/'.join(kinds)} recipe; torch fp32 CNN on {cores} threads (host has {os.cpu_count()} cores; more "
                      f"threads are slower), effects = single-threaded C restatement (faster than the reference's python "
                      f"per-sample loop, so this baseline is conservative; `reference_shaped` is the SURVEY 8d form)"}
-    out["reference_shaped"] = cpu_reference_shaped(kinds, model, opt, cores)
+    if reference_shaped:
+        out["reference_shaped"] = cpu_reference_shaped(kinds, model, opt, cores)
     return out
 
 
@@ -344,6 +354,29 @@ def lds_roundtrip_ns(device, steps=200000):
     return 1e6 * a.elapsed_time(b) / steps
 
 
+def _probe_ns(name, device, steps, *lead_args, per=1, out_floats=1):
+    """ns per step of a stand-alone latency microbenchmark entry point (second of two launches timed)."""
+    from mod_extraction_amd import _hip
+    out = torch.empty(out_floats, device=device)
+    _hip.call(name, *lead_args, steps, _hip.ptr(out), _hip.stream())
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    _hip.call(name, *lead_args, steps, _hip.ptr(out), _hip.stream())
+    b.record()
+    torch.cuda.synchronize()
+    return 1e6 * a.elapsed_time(b) / (steps * per)
+
+
+def lstm_step_ns(device, kind, steps=100000):
+    """One bare recurrent step (kind 0 forward, 1 backward) on one 512-lane workgroup: mx_lstm_step_probe, ns."""
+    return _probe_ns("mx_lstm_step_probe", device, steps, kind)
+
+
+def phaser_cascade_ns(device, steps=20000):
+    """One (sample, run) of the bare 6-stage all-pass cascade at 8 runs per lane, 512 lanes: mx_phaser_cascade_probe, ns."""
+    return _probe_ns("mx_phaser_cascade_probe", device, steps, per=8, out_floats=512)
+
+
 def fx_blocks(batcher, params, res):
     n_fx, n_ph = int(batcher.rows_fx.numel()), int(batcher.rows_ph.numel())
     N = batcher.N
@@ -351,7 +384,7 @@ def fx_blocks(batcher, params, res):
     if n_fx and "mx_flanger_fwd" in res[0]:
         out["flanger_kernel"] = hbm_block(
             f"flanger_kernel ({n_fx} flanger/chorus clips x {N} samples, fx.py:104-115)", n_fx * N * 8.0,
-            res[0]["mx_flanger_fwd"], res[1].get("mx_flanger_fwd"),
+            res[0]["mx_flanger_fwd"], res[1].get("mx_flanger_fwd"), bound="latency",
             note="8 B/sample: x in, y out; the 882-point LFO is resampled in-kernel. One workgroup (8 producer waves + 1 consumer "
                  "wave) per clip, delay line in LDS; the launch lasts as long as its slowest clip's read-after-write chain, so "
                  "the serial floor, not HBM, is the governing roofline")
@@ -374,11 +407,25 @@ def fx_blocks(batcher, params, res):
         bytes_ph = float(((lead + N) * (4 + 4 + 2)).sum()) + n_ph * N * 8.0
         out["phaser_kernel"] = hbm_block(
             f"phaser_scan_kernel ({n_ph} clips x ({N} + lead) samples, datasets.py:455-482)", bytes_ph,
-            res[0]["mx_phaser_fwd"], res[1].get("mx_phaser_fwd"),
+            res[0]["mx_phaser_fwd"], res[1].get("mx_phaser_fwd"), bound="latency",
             note="4 B/sample read twice over lead + N samples (both passes of the scan), 8 B/sample written (wet + cropped dry), "
                  "1 B/sample of cut-offs parked and re-read; one workgroup per clip, the clip cut into 512 chunks whose affine "
-                 "state maps are built in parallel and chained (csrc/phaser.hip) -- VALU-bound, no per-sample dependency chain "
-                 "longer than a chunk")
+                 "state maps are built in parallel and chained (csrc/phaser.hip) -- a launch lasts as long as ONE workgroup's "
+                 "vector work on its slowest clip (85 of 256 CUs busy), no per-sample dependency chain longer than a chunk")
+        try:                                                # the independent floor: bare cascade arithmetic x the scan's run count
+            pk = out["phaser_kernel"]
+            t_run = phaser_cascade_ns(batcher.device)
+            per_lane = -(-int(lead.max() + N) // 512)
+            pk["cascade_ns_per_sample_and_run"] = round(t_run, 2)
+            pk["independent_floor_ms"] = round(per_lane * 9 * t_run * 1e-6, 4)
+            pk["frac_of_independent_floor"] = round(pk["independent_floor_ms"] / pk["avg_launch_ms"], 4)
+            pk["independent_floor_note"] = ("samples per lane of the slowest clip (ceil((lead + N) / 512)) x 9 runs (8 of phase A: seven unit "
+                                            "states + the driven zero state; 1 of phase C) x the duration of one (sample, run) of the "
+                                            "bare 6-stage all-pass cascade + feedback measured by mx_phaser_cascade_probe (8 independent "
+                                            "runs per lane on one 512-lane workgroup: no loads, stores, fp64 sin / pow / tan, chunk maps "
+                                            "or chaining)")
+        except Exception as e:
+            out["phaser_kernel"]["independent_floor_error"] = repr(e)
     return out
 
 
@@ -446,7 +493,9 @@ def run_lfo_config(args, env, cfg_id):
         "metric": METRIC[cfg_id],
         "value": audio_s / dt, "unit": "audio-seconds/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32 (f16x3 products)" if f16 else "f32",
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "compute_dtype": "f32 tensors; conv MACs as f16x3 products (hi*hi + hi*lo + lo*hi on the fp16 matrix cores, fp32 accumulate)"
+                         if f16 else "f32 (exact fp32 MFMA)",
         "data": "synthetic",
         "config": {"workload": f"{cfg['name']}: 2D-CNN LFO extractor train step, bs={batch} x 2 s "
                                f"@44.1 kHz per GPU, {'/'.join(cfg['kinds'])} interleaved, fp32 parity (1e-5)",
@@ -489,7 +538,10 @@ def run_lfo_config(args, env, cfg_id):
         out["exact_fp32_path"] = {"ms_per_step": round(1e3 * t, 2), "value": round(batch * (N_SAMPLES / SR) / t, 1),
                                   "note": "same step with every convolution on v_mfma_f32_32x32x2_f32 (--conv-precision f32), 3 steps"}
     if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline_lfo(cfg["kinds"])
+        if args.cpu_baseline_short:         # the launcher's `other_configs` legs: a shorter sample, no reference-shaped leg
+            out["cpu_baseline"] = cpu_baseline_lfo(cfg["kinds"], batch_cpu=4, steps=2, reference_shaped=False)
+        else:
+            out["cpu_baseline"] = cpu_baseline_lfo(cfg["kinds"])
     return out
 
 
@@ -592,14 +644,32 @@ def run_config4(args, env):
             "barrier + the dependent FMA / activation chain (csrc/lstm.hip)")
     kernels = {
         "lstm_fwd_kernel": hbm_block(f"lstm_fwd_kernel ({B} clips x {S} steps, models.py:325-339)", fwd_bytes,
-                                     iso[0]["mx_lstm_fwd"], iso[1]["mx_lstm_fwd"],
+                                     iso[0]["mx_lstm_fwd"], iso[1]["mx_lstm_fwd"], bound="latency",
                                      note="12 B/sample I/O + 1536 B/sample BPTT stash written; " + note),
         "lstm_bwd_kernel": hbm_block(
             f"lstm_bwd_kernel ({B} clips x {S} steps, BPTT + L1 + weight gradients, lightning.py:355-384)", bwd_bytes,
-            iso[0]["mx_lstm_bwd_l1"], iso[1]["mx_lstm_bwd_l1"],
+            iso[0]["mx_lstm_bwd_l1"], iso[1]["mx_lstm_bwd_l1"], bound="latency",
             note="stash read once (1536 B/sample) + x, lfo, y, wet (16 B/sample) + one gradient row per clip; the weight "
                  "gradients accumulate on the matrix pipes inside the recurrence (fp32 MFMA, operands from LDS); " + note),
     }
+    # the independent floor: S x one bare dependent step measured by a stand-alone microbenchmark
+    for kind, key in ((0, "lstm_fwd_kernel"), (1, "lstm_bwd_kernel")):
+        try:
+            ns = lstm_step_ns(device, kind)
+            k_ = kernels[key]
+            k_["step_ns_bare"] = round(ns, 1)
+            k_["step_ns_real"] = round(1e6 * k_["avg_launch_ms"] / S, 1)
+            k_["independent_floor_ms"] = round(S * ns * 1e-6, 4)
+            k_["frac_of_independent_floor"] = round(k_["independent_floor_ms"] / k_["avg_launch_ms"], 4)
+            k_["independent_floor_note"] = (
+                f"{S} steps x the duration of ONE bare dependent step measured by mx_lstm_step_probe({kind}) on one 512-lane "
+                "workgroup: " + ("LDS broadcast of h -> 16 packed FMAs -> cross-lane adds -> v_exp / v_rcp gate -> exchange -> cell "
+                                 "update -> tanh -> LDS write -> s_barrier" if kind == 0 else
+                                 "gate gradients from LDS -> 16 packed FMAs -> all-reduce over 16 row groups -> dh, dc, dg (local "
+                                 "derivatives from seven LDS values) -> LDS write -> s_barrier") +
+                "; no global memory, input term, stash, output layer or weight gradients")
+        except Exception as e:
+            kernels[key]["independent_floor_error"] = repr(e)
     live = {k: mean(v) for k, v in timings.items()}
     per_batch = {k: round(sum(v) / args.steps, 3) for k, v in timings.items()}
     with torch.no_grad():
@@ -754,6 +824,8 @@ def parse_args(argv=None):
     ap.add_argument("--batch", type=int, default=None, help="clips per GPU (default: the BASELINE config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fp32-leg", action="store_true", help="skip the 3 extra steps on the exact-fp32 convolutions")
+    ap.add_argument("--cpu-baseline-short", action="store_true",
+                    help="config 2 / 3: a shorter bounded CPU sample (4 clips, 2 steps, no reference-shaped leg)")
     ap.add_argument("--conv-precision", choices=["f16x3", "f32"], default=None,
                     help="arithmetic of the 64->64 convolutions (default: the package default, f16x3)")
     ap.add_argument("--no-cu-partition", action="store_true",
@@ -789,12 +861,13 @@ def _free_port() -> int:
 
 
 def _run_child(cmd, timeout_s):
-    """Run one worker command; returns (json dict or None, return code, stderr tail).  stderr is relayed."""
+    """Run one worker command; returns (json dict or None, return code, stderr tail, port_in_use).  stderr is relayed;
+    `port_in_use` is looked for in the WHOLE stderr (torchrun's multi-rank tracebacks are longer than the tail)."""
     import subprocess
     try:
         res = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=timeout_s)
     except subprocess.TimeoutExpired as e:
-        return None, 124, f"timeout after {timeout_s} s: {' '.join(cmd)}\n{(e.stderr or '')[-2000:]}"
+        return None, 124, f"timeout after {timeout_s} s: {' '.join(cmd)}\n{(e.stderr or '')[-2000:]}", False
     if res.stderr:
         sys.stderr.write(res.stderr)
         sys.stderr.flush()
@@ -805,7 +878,8 @@ def _run_child(cmd, timeout_s):
             out = json.loads(lines[-1])
         except ValueError:
             out = None
-    return out, res.returncode, res.stderr[-2000:]
+    port_in_use = "EADDRINUSE" in res.stderr or "address already in use" in res.stderr.lower()
+    return out, res.returncode, res.stderr[-2000:], port_in_use
 
 
 def _worker_cmd(args, config, steps, extra=()):
@@ -836,8 +910,8 @@ def launch(args) -> int:
                   _worker_cmd(args, args.config, args.steps, flags)
         else:
             cmd = [sys.executable, script, "--worker"] + _worker_cmd(args, args.config, args.steps, flags)
-        out, rc, err = _run_child(cmd, 3000)
-        if out is not None or args.gpus == 1 or not ("EADDRINUSE" in err or "address already in use" in err.lower()):
+        out, rc, err, port_in_use = _run_child(cmd, 3000)
+        if out is not None or args.gpus == 1 or not port_in_use:     # (a rendezvous that fails on the port fails within seconds)
             break
     if out is None:
         sys.stderr.write(f"bench worker failed (rc {rc})\n")
@@ -852,8 +926,9 @@ def launch(args) -> int:
         others = {}
         for c, steps in ((2, 30), (4, 5), (5, 20)):
             t0 = time.perf_counter()
-            o, rc_c, err_c = _run_child([sys.executable, script, "--worker"] +
-                                        _worker_cmd(args, c, steps, ["--no-cpu-baseline", "--no-fp32-leg"]), 900)
+            # every config carries its own bounded cpu_baseline: short samples, ~5-10 s each
+            leg = ["--no-fp32-leg"] + (["--no-cpu-baseline"] if args.no_cpu_baseline else ["--cpu-baseline-short"])
+            o, rc_c, err_c, _ = _run_child([sys.executable, script, "--worker"] + _worker_cmd(args, c, steps, leg), 900)
             worst = worst or rc_c
             if o is None:
                 others[str(c)] = {"error": f"rc {rc_c}", "stderr_tail": err_c[-400:]}
@@ -861,7 +936,7 @@ def launch(args) -> int:
             keep = {k: o[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "roofline", "step_ms",
                                       "kernels", "fx_kernels", "fx_kernel_frac_of_serial_floor", "fx_kernel_frac_of_hbm",
                                       "fx_kernel_frac_of_independent_floor", "ms_per_batch_by_entry_point",
-                                      "avg_launch_ms_in_step", "final_loss", "loss_variants") if k in o}
+                                      "avg_launch_ms_in_step", "final_loss", "loss_variants", "cpu_baseline", "compute_dtype") if k in o}
             keep["config"] = o["config"]
             keep["process_wall_s"] = round(time.perf_counter() - t0, 1)
             keep["worker_rc"] = rc_c

@@ -7,7 +7,7 @@
  * reference's modules (see INTEGRATION.md for the ctypes stub).  Conventions:
  *
  *   - every pointer is a DEVICE pointer borrowed from the caller (torch tensor .data_ptr());
- *     nothing is allocated, freed or retained by the library; no global state
+ *     nothing is allocated, freed or retained by the library; no caller-observable global state
  *   - tensors are dense, row-major, float32 unless stated otherwise
  *   - `stream` is a hipStream_t (0 / NULL = default stream); calls are asynchronous and
  *     re-entrant per stream; the library never synchronises
@@ -31,7 +31,9 @@ extern "C" {
 
 /* ABI version, bumped on any signature change. */
 int mx_abi_version(void);
-/* The library keeps no mutable global state: every entry point is a function of its arguments and its stream. */
+/* The library keeps no caller-observable mutable state: every entry point is a function of its arguments and its stream.
+ * (Internally: per-device latches of the dynamic-LDS function attribute, and kernel-variant knobs read once from MODEX_*
+ * environment variables; neither changes a result.) */
 
 /* ---- K1: LFO synthesis -- mod_extraction/modulations.py:16-57 (make_mod_signal) -------------
  * One row per LFO.  freq, phase, exp: (B,) float32; shape: (B,) int32 in
@@ -55,7 +57,10 @@ int mx_interp_linear(const float *x, int64_t rows, int64_t n_in, int64_t n_out, 
  *   min_delay     = min_delay_width * max_min_delay_samples  (fx.py:98)
  *   feedback, depth, mix, one_minus_mix                      (fx.py:114-117)
  * max_delay (B,) int32: delay-line length M per clip (fx.py:42), max_delay_max = max over the
- * batch (<= 40000).  rows/n_rows: optional subset of clip indices to process (NULL = all B).
+ * batch.  The delay line lives in LDS: max_delay_max (+ n_mod when the LFO is resampled in-kernel) <= 34784 floats
+ * (FL_MAX_M = the CU's 160 KB minus the 24.7 KB record ring of eight 64-sample rows per chunk; it was 37872 with four
+ * rows per chunk) = 789 ms at 44.1 kHz -- the shipped configs need 11 ms (flanger) / 40 ms (chorus); longer lines
+ * return MX_ERR_UNSUPPORTED.   rows/n_rows: optional subset of clip indices to process (NULL = all B).
  * y: row b at y + b*y_stride, N samples, clipped to [-1,1].  Optional (NULL to skip): mod_up (B,N) resampled LFO,
  * dbg_prev (B,N) int64 and dbg_frac (B,N) = prev_idx_all / delay_read_fraction_all of
  * fx.py:101-102 for index-parity tests. */
@@ -342,6 +347,20 @@ int mx_lstm_bwd_l1_probe(const float *x, int64_t x_stride, const float *lfo, int
                    int64_t y_stride, const float *wet, int64_t wet_stride, const float *stash,
                    const float *w_hh, const float *fc_w, const float *h_init, const float *c_init,
                    float loss_scale, float *part, int64_t B, int64_t T, void *stream);
+
+/* Measurement aid (bench.py, `frac_of_independent_floor` of the phaser scan): `steps` samples of the bare 6-stage all-pass
+ * cascade + feedback (38 flops) for eight independent state vectors per lane -- the shape of the scan's phase A -- on ONE
+ * 512-lane workgroup: no loads, stores, cut-off evaluation, chunk maps or chaining.  time / (steps x 8) x ceil((lead + N) / 512)
+ * x 9 runs is a floor of mx_phaser_fwd that does not come from that kernel.  out: >= 512 floats.  No reference counterpart. */
+int mx_phaser_cascade_probe(int64_t steps, float *out, void *stream);
+
+/* Measurement aid (bench.py, `frac_of_independent_floor` of the LSTM kernels): `steps` dependent recurrent steps of the bare
+ * shape of models.py:333 (kind 0: LDS broadcast of h -> 16 packed FMAs -> cross-lane adds -> v_exp / v_rcp gate -> exchange ->
+ * cell update -> tanh -> LDS write -> s_barrier) or of its BPTT (kind 1: gate gradients from LDS -> 16 packed FMAs -> all-reduce
+ * over 16 row groups -> dh, dc, dg -> LDS write -> s_barrier) on ONE 512-lane workgroup: no global memory, no input term, no
+ * stash, no output layer, no weight gradients.  Time / steps x T is a floor of a T-step launch that does not come from the
+ * product kernels.  out: 1 float (keeps the chain live).  No reference counterpart. */
+int mx_lstm_step_probe(int32_t kind, int64_t steps, float *out, void *stream);
 
 /* ---- TCN extractors -- mod_extraction/tcn.py:106-302 (TCNBlock / TCN) under models.py:72-125,218-289
  * (SpectralTCN / SpectralDSTCN).  Activations: (B, C, 352) fp32 planes with T <= 352 valid columns.

@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # MODEX_HIP_LIB: load another build of the same library (kernel experiments); there is no non-HIP fallback
 SO_PATH = os.environ.get("MODEX_HIP_LIB") or os.path.join(_HERE, "_lib", "libmodex_hip.so")
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 _ERR = {-1: "MX_ERR_ARG (bad argument)", -2: "MX_ERR_UNSUPPORTED (size not supported)",
         -3: "MX_ERR_LAUNCH (HIP launch error)"}
@@ -27,6 +27,8 @@ SIGNATURES = {
     "mx_flanger_fwd": [_P, _I64, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _I32, _P, _I64, _I64, _I64,
                        _P, _I64, _P, _P, _P, _P],
     "mx_lds_roundtrip_probe": [_I64, _P, _P],
+    "mx_lstm_step_probe": [_I32, _I64, _P, _P],
+    "mx_phaser_cascade_probe": [_I64, _P, _P],
     "mx_phaser_fwd": [_P, _I64, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _F64, _I32, _P, _I64, _P, _P, _I64, _P],
     "mx_logmel_fwd": [_P, _I64, _I64, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _F32, _I32, _I32,
                       _I32, _I32, _P, _P],

@@ -19,6 +19,22 @@ static inline int mx_launch_status()
     return hipGetLastError() == hipSuccess ? MX_OK : MX_ERR_LAUNCH;
 }
 
+// Dynamic LDS above 64 KB needs hipFuncAttributeMaxDynamicSharedMemorySize, which is a PER-DEVICE property of the loaded
+// code object: one process may drive several GPUs, so the "already set" latch is kept per device (a plain static bool would
+// leave the second device without the attribute and its launches failing with MX_ERR_LAUNCH).  The latch only caches an
+// idempotent driver call; it carries no state a caller could observe.
+struct MxLdsLatch { bool set[64]; };
+static inline int mx_set_dyn_lds(MxLdsLatch &latch, const void *fn, size_t bytes)
+{
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const bool cached = dev >= 0 && dev < 64;
+    if (cached && latch.set[dev]) return MX_OK;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return MX_ERR_LAUNCH;
+    if (cached) latch.set[dev] = true;
+    return MX_OK;
+}
+
 // ---- wave-level reductions (64 lanes, DPP/permute based via __shfl_xor) ---------------------
 __device__ __forceinline__ int wave_min_i32(int v)
 {

@@ -1616,13 +1616,8 @@ static int launch_f16_dma16(const ConvF16Args &a, int B, hipStream_t st)
     constexpr int PWP = CV_PITCH + 12 * T;
     constexpr size_t lds = 2 * (2 * 7 * 2048) + (RING ? 4 * (size_t)((4 * PWP + 63) / 64) : 2 * (size_t)((8 * PWP + 63) / 64)) * 1024;
     static_assert(lds <= 160 * 1024, "LDS budget");
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute((const void *)conv_f16x3_dma16_kernel<T, RING>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
-            hipSuccess)
-            return MX_ERR_LAUNCH;
-        attr_done = true;
-    }
+    static MxLdsLatch latch = {};                             // per device (common.h)
+    if (mx_set_dyn_lds(latch, (const void *)conv_f16x3_dma16_kernel<T, RING>, lds) != MX_OK) return MX_ERR_LAUNCH;
     hipLaunchKernelGGL((conv_f16x3_dma16_kernel<T, RING>), dim3(a.H / 2, B), dim3(256), lds, st, a);
     return mx_launch_status();
 }
@@ -1633,13 +1628,8 @@ static int launch_f16_dma(const ConvF16Args &a, int B, hipStream_t st)
     constexpr int PWP = CV_PITCH + 12 * T;
     constexpr size_t lds = 2 * (2 * 7 * 2048) + 2 * (size_t)((8 * PWP + 63) / 64) * 1024;
     static_assert(lds <= 160 * 1024, "LDS budget");
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute((const void *)conv_f16x3_dma_kernel<T, OUTMODE, NCB, NKH>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return MX_ERR_LAUNCH;
-        attr_done = true;
-    }
+    static MxLdsLatch latch = {};                             // per device (common.h)
+    if (mx_set_dyn_lds(latch, (const void *)conv_f16x3_dma_kernel<T, OUTMODE, NCB, NKH>, lds) != MX_OK) return MX_ERR_LAUNCH;
     hipLaunchKernelGGL((conv_f16x3_dma_kernel<T, OUTMODE, NCB, NKH>), dim3(a.H / 2, B), dim3(256), lds, st, a);
     return mx_launch_status();
 }
@@ -1649,13 +1639,8 @@ static int launch_f16(const ConvF16Args &a, int B, hipStream_t st)
 {
     constexpr int PWP = CV_PITCH + 12 * T;
     const size_t lds = (size_t)(2 * CV_KW * 64 * 16 + 2 * 2 * PWP * 16) * sizeof(_Float16);
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute((const void *)conv_f16x3_kernel<T, OUTMODE>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds) != hipSuccess)
-            return MX_ERR_LAUNCH;
-        attr_done = true;
-    }
+    static MxLdsLatch latch = {};                             // per device (common.h)
+    if (mx_set_dyn_lds(latch, (const void *)conv_f16x3_kernel<T, OUTMODE>, lds) != MX_OK) return MX_ERR_LAUNCH;
     hipLaunchKernelGGL((conv_f16x3_kernel<T, OUTMODE>), dim3(a.H / 2, B), dim3(256), lds, st, a);
     return mx_launch_status();
 }
@@ -1804,13 +1789,10 @@ MX_EXPORT int mx_conv_block1_fwd_f16(const void *xk_hi, const void *xk_lo, const
     if (!persist) return launch_f16_dma<1, 0, 1, 1>(a, (int)B, (hipStream_t)stream);
     constexpr size_t lds = 2 * CV_KW * 2048 + 2 * (size_t)((8 * (CV_PITCH + 12) + 63) / 64) * 1024;
     static_assert(lds <= 160 * 1024, "LDS budget");
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute((const void *)conv1_f16x3_persist_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-            hipFuncSetAttribute((const void *)conv1_f16x3_persist_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return MX_ERR_LAUNCH;
-        attr_done = true;
-    }
+    static MxLdsLatch latch0 = {}, latch1 = {};                 // per device (common.h)
+    if (mx_set_dyn_lds(latch0, (const void *)conv1_f16x3_persist_kernel<0>, lds) != MX_OK ||
+        mx_set_dyn_lds(latch1, (const void *)conv1_f16x3_persist_kernel<1>, lds) != MX_OK)
+        return MX_ERR_LAUNCH;
     const int n_tiles = (int)(B * (H / 2));
     int grid = 1024;                                            // 4 workgroups per CU over the launch: contiguous ranges, a short tail
     if (grid > n_tiles) grid = n_tiles;

@@ -641,13 +641,8 @@ static int launch_dgrad_sp(const DgradSpArgs &a, int B, hipStream_t st)
     constexpr size_t scratch = 4 * 3 * 32 * 33 * 4;              // epilogue: transposition tiles + the LN partial reduction
     constexpr size_t lds = 2 * buf > scratch ? 2 * buf : scratch;
     static_assert(lds <= 160 * 1024, "LDS budget");
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute((const void *)dgrad_sp_f16x3_kernel<T, LN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
-            hipSuccess)
-            return MX_ERR_LAUNCH;
-        attr_done = true;
-    }
+    static MxLdsLatch latch = {};                             // per device (common.h)
+    if (mx_set_dyn_lds(latch, (const void *)dgrad_sp_f16x3_kernel<T, LN>, lds) != MX_OK) return MX_ERR_LAUNCH;
     hipLaunchKernelGGL((dgrad_sp_f16x3_kernel<T, LN>), dim3(a.H / 2, B), dim3(256), lds, st, a);
     return mx_launch_status();
 }

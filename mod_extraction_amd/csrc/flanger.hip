@@ -189,7 +189,10 @@ __global__ __launch_bounds__(FL_THREADS) void flanger_kernel(
                 int k;
 // (the two independent products of fx.py:113 as ONE packed multiplication on fixed register pairs -- v[84:85] = {next, prev},
 //  v[86:87] = {frac, 1 - frac}: one instruction less on the dependent path of every lock-step; each product is still its own
-//  IEEE multiplication, so the waveform stays bit-identical)
+//  IEEE multiplication, so the waveform stays bit-identical).  The pair registers are named because AMDGPU inline assembly has
+//  no operand modifier for one half of a 64-bit operand (ds_read_b32 must land IN a half of the pair v_pk_mul_f32 consumes); they
+//  are declared as clobbers, so the register allocator keeps every operand of this statement and every live value out of
+//  v84-v87 whatever FL_V or the register budget is -- the choice of numbers affects nothing but the allocation around the loop.)
 #define FL_LOCK_STEP                                                                                                   \
     "ds_read_b32 v85, %[ap]\n"        /* fx.py:111 */                                                                 \
     "ds_read_b32 v84, %[an]\n"        /* fx.py:112 */                                                                 \

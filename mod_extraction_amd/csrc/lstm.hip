@@ -573,3 +573,99 @@ MX_EXPORT int mx_lstm_bwd(const float *x, int64_t x_stride, const float *lfo, in
     return lstm_bwd_l1_launch(x, x_stride, lfo, lfo_stride, y, y_stride, nullptr, 0, stash, w_hh, fc_w, h_init, c_init, 0.0f,
                               dy, dy_stride, part, B, T, stream, 0);
 }
+
+// ---- independent latency floor of one recurrent step (bench.py) ---------------------------------------
+// The `*_probe` twins above re-run the PRODUCT kernels without global traffic: that floor inherits their schedule.  This
+// microbenchmark is built the way the flanger's `mx_lds_roundtrip_probe` is: nothing but the chain of operations ANY schedule of
+// the step has to go through on this decomposition (one 512-lane workgroup per clip, the 256 x 64 matrix-vector product split
+// 16 k per lane), on one workgroup, with no global memory, no input term, no stash, no output layer, no weight gradients, no
+// address bookkeeping beyond a row toggle:
+//   kind 0 (forward step, models.py:333):  broadcast read of h_{t-1} from LDS (4 x 16 B per lane) -> 16 packed FMAs (two
+//          chains of 8) -> 2 + 2 cross-lane adds -> one gate activation (v_exp_f32, v_rcp_f32) -> exchange of i, f, g, o inside
+//          the unit's 8 lanes -> c = f c + i g -> tanh(c) (v_exp_f32, v_rcp_f32) -> h = o tanh(c) -> LDS write -> s_barrier
+//   kind 1 (backward step, lightning.py:380): read of the 16 gate gradients of step t + 1 -> 16 packed FMAs -> 4 + 4 cross-lane
+//          adds (all-reduce over the 16 row groups) -> dh, dc, dg of step t (the local derivatives tanh(c), o (1 - tanh^2),
+//          a (1 - a) from seven LDS values read beside the gradients) -> LDS write -> s_barrier
+// `steps` such steps on ONE workgroup; time / steps x T is a floor of a T-step launch that does not come from the product kernels.
+__global__ __launch_bounds__(LS_THREADS) void lstm_step_probe_kernel(int steps, int kind, int stride, float *__restrict__ out)
+{
+    __shared__ __attribute__((aligned(16))) float row[2][256 + 16];      // h (64 used) or gate gradients (256) of the previous step
+    __shared__ float vals[8 * 64];                                        // stand-in for the saved activations of a step (backward)
+    __shared__ float sink[LS_THREADS];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    ls_f2 w[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) w[j] = (ls_f2){0.001f * (float)((tid + 3 * j) % 17) - 0.008f, 0.001f * (float)((tid + 5 * j) % 13) - 0.006f};
+    for (int i = tid; i < 2 * (256 + 16); i += LS_THREADS) (&row[0][0])[i] = 0.01f * (float)(i % 23) - 0.1f;
+    vals[tid] = 0.3f + 0.001f * (float)(tid & 63);
+    __syncthreads();
+    float acc_out = 0.0f;
+    if (kind == 0) {
+        const int kq = lane & 3, gp = (lane >> 2) & 1, u = wv * 8 + (lane >> 3);
+        const bool odd = kq & 1, writer = gp == 0;
+        const int q = 2 * gp + (kq & 1);
+        const float sc = q == 2 ? 2.0f : 1.0f, nsl2e = -sc * 1.4426950408889634f, oms = 1.0f - sc;
+        float c = 0.1f;
+        int cur = 0;
+        for (int t = 0; t < steps; ++t) {
+            const float *hr = &row[cur][16 * kq];
+            const float4 h0 = *(const float4 *)hr, h1 = *(const float4 *)(hr + 4), h2 = *(const float4 *)(hr + 8), h3 = *(const float4 *)(hr + 12);
+            ls_f2 acc = {0.01f, 0.02f};
+            LS_PK16(acc, w, h0, h1, h2, h3);
+            float pa = acc.x, pb = acc.y;
+            pa += ls_dpp<0xB1>(pa); pb += ls_dpp<0xB1>(pb);
+            pa += ls_dpp<0x4E>(pa); pb += ls_dpp<0x4E>(pb);
+            const float a = ls_act(odd ? pb : pa, nsl2e, sc, oms);
+            const float m = ls_dpp<0x141>(a);
+            const float gi = ls_dpp<0x00>(a), gf = ls_dpp<0x55>(a), gg = ls_dpp<0x55>(m), go = ls_dpp<0x00>(m);
+            c = fmaf(gf, c, gi * gg);
+            const float hv = go * ls_tanh(c);
+            cur = (cur + 1 + stride) & 1;                                 // `stride` is 0 at run time (the compiler cannot know)
+            *(writer ? &row[cur][u] : &sink[tid]) = hv;
+            ls_barrier();
+            acc_out = hv;
+        }
+    } else {
+        const int rg = lane & 15, kp = wv * 4 + (lane >> 4), e = rg & 7, q = e & 3, k = 2 * kp + (e >> 2);
+        const bool second = e >> 2, owner = rg < 8;
+        const float alpha = q == 2 ? 1.0f : 0.0f, beta = q == 2 ? 0.0f : 1.0f, fcw = 0.01f * (float)k;
+        float dc_next = 0.0f;
+        int cur = 0;
+        for (int t = 0; t < steps; ++t) {
+            const float *dr = &row[cur][rg * 4];
+            const float4 g0 = *(const float4 *)dr, g1 = *(const float4 *)(dr + 64), g2 = *(const float4 *)(dr + 128), g3 = *(const float4 *)(dr + 192);
+            // the saved values of step t (a, its partner, f, o, c, d loss / d pre-tanh output, h): seven LDS reads, as from a staged stash slab
+            const float *v = vals + ((t + stride) & 7) * 64 + (k & 63) - (k & 63) + (lane & 7);
+            const float a = v[0], pp = v[8], f = v[16], o = v[24], cc = v[32], dzy = v[40] * 1e-3f;
+            const float tc = ls_tanh(cc);
+            const float kc = o * fmaf(-tc, tc, 1.0f);
+            const float der = fmaf(a, beta - a, alpha);
+            const float kqv = der * (q == 3 ? tc : pp);
+            ls_f2 acc = {0.0f, 0.0f};
+            LS_PK16(acc, w, g0, g1, g2, g3);
+            float da = acc.x, db = acc.y;
+            da += ls_dpp<0xB1>(da); db += ls_dpp<0xB1>(db);
+            da += ls_dpp<0x4E>(da); db += ls_dpp<0x4E>(db);
+            da += ls_dpp<0x141>(da); db += ls_dpp<0x141>(db);
+            da += ls_dpp<0x140>(da); db += ls_dpp<0x140>(db);
+            const float dhn = second ? db : da;
+            const float dh = fmaf(dzy, fcw, dhn);
+            const float dc = fmaf(dh, kc, dc_next);
+            const float dg = (q == 3 ? dh : dc) * kqv;
+            dc_next = dc * f;
+            cur = (cur + 1 + stride) & 1;
+            *(owner ? &row[cur][ls_dg_slot(q * LS_H + k)] : &sink[tid]) = dg;
+            ls_barrier();
+            acc_out = dg;
+        }
+    }
+    if (tid == 0) out[0] = acc_out;
+}
+
+// kind 0: forward step, 1: backward step (see above); `steps` dependent steps on one 512-lane workgroup; out: 1 float
+MX_EXPORT int mx_lstm_step_probe(int32_t kind, int64_t steps, float *out, void *stream)
+{
+    if (!out || steps <= 0 || steps >= (1ll << 30) || kind < 0 || kind > 1) return MX_ERR_ARG;
+    hipLaunchKernelGGL(lstm_step_probe_kernel, dim3(1), dim3(LS_THREADS), 0, (hipStream_t)stream, (int)steps, (int)kind, 0, out);
+    return mx_launch_status();
+}

@@ -335,6 +335,22 @@ MX_EXPORT int mx_logmel_fwd(const float *x, int64_t planes, int64_t N, const flo
     const int tiles = (int)((out_pitch + MEL_FR - 1) / MEL_FR);
     const int coef_cap = 2 * ((int)n_fft / 2 + 1) + 2 * (int)n_mels;    // triangular filters: every bin lies in <= 2 bands
     const size_t lds = ((size_t)n_mels * (MEL_FR + 1) + coef_cap + n_mels + 1) * sizeof(float);
+    // static (FFT exchange buffers, twiddles) + dynamic (mel tile, packed filter coefficients) LDS must fit the CU's 160 KB:
+    // a large n_mels is MX_ERR_UNSUPPORTED here, not a failed launch; above 64 KB the dynamic part needs the function attribute
+    const void *fn = n_fft == MEL_NFFT ? (const void *)melspec_kernel
+                     : n_fft == 512    ? (const void *)melspec_wf_kernel<512>
+                                       : (const void *)melspec_wf_kernel<2048>;
+    static size_t static_lds[3] = {0, 0, 0};                      // a constant of the code object, cached
+    static MxLdsLatch latch[3] = {};
+    const int ki = n_fft == MEL_NFFT ? 0 : n_fft == 512 ? 1 : 2;
+    if (!static_lds[ki]) {
+        hipFuncAttributes fa;
+        if (hipFuncGetAttributes(&fa, fn) != hipSuccess) return MX_ERR_LAUNCH;
+        static_lds[ki] = fa.sharedSizeBytes ? fa.sharedSizeBytes : 1;
+    }
+    const size_t lds_cap = 160 * 1024;
+    if (static_lds[ki] + lds > lds_cap) return MX_ERR_UNSUPPORTED;
+    if (static_lds[ki] + lds > 64 * 1024 && mx_set_dyn_lds(latch[ki], fn, lds_cap - static_lds[ki]) != MX_OK) return MX_ERR_LAUNCH;
     if (n_fft != MEL_NFFT) {
         if (n_fft == 512)
             hipLaunchKernelGGL((melspec_wf_kernel<512>), dim3(tiles, (unsigned)planes), dim3(WF<512>::WAVES * 64), lds, (hipStream_t)stream,

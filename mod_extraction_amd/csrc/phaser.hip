@@ -389,3 +389,50 @@ MX_EXPORT int mx_phaser_fwd_probe(const float *x, int64_t x_stride, const float 
 {
     return phaser_fwd_launch(x, x_stride, rate, depth, centre, feedback, mix, lead, rows, n_rows, B, N, sr, exact_order, y, y_stride, dry_out, workspace, workspace_stride, stream, 1);
 }
+
+// ---- independent floor of the scan (bench.py) -----------------------------------------------------------
+// `mx_phaser_fwd_probe` re-runs the product kernel without global traffic: that floor inherits its schedule.  This
+// microbenchmark is nothing but the arithmetic NO schedule of the scan can avoid: the 6-stage all-pass cascade of one sample
+// (JUCE's FirstOrderTPTFilter step x 6 + feedback, 38 flops) for EIGHT independent state vectors per lane -- the shape of
+// phase A (seven unit states + the driven zero state) -- on one 512-lane workgroup, with a constant cut-off and input: no loads,
+// no stores, no fp64 sin / pow / tan, no chunk maps, no chaining.  time / (steps x 8) = the cost of one (sample, run) at the
+// kernel's occupancy; a clip needs ceil((lead + N) / 512) samples per lane x 9 runs (8 of phase A + phase C).
+__global__ __launch_bounds__(PS_P) void phaser_cascade_probe_kernel(int steps, float G, float fb, float *__restrict__ out)
+{
+    float s[8][6], last[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        last[r] = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) s[r][k] = (r == k) ? 1.0f : 0.001f * (float)(threadIdx.x & 7);
+    }
+    float in = 0.25f + 1e-3f * (float)(threadIdx.x & 15);
+    for (int t = 0; t < steps; ++t) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            float o = __fsub_rn(r == 7 ? in : 0.0f, last[r]);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                const float v = __fmul_rn(G, __fsub_rn(o, s[r][k]));
+                const float yk = __fadd_rn(v, s[r][k]);
+                s[r][k] = __fadd_rn(v, yk);
+                o = __fsub_rn(__fmul_rn(2.0f, yk), o);
+            }
+            last[r] = __fmul_rn(o, fb);
+        }
+        in = -in;
+    }
+    float acc = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) acc += last[r] + s[r][5];
+    if (acc == 123.456f) out[threadIdx.x] = acc;             // keeps the chains live; never true for these constants
+    if (threadIdx.x == 0) out[0] = acc;
+}
+
+// `steps` samples x 8 independent cascade runs per lane on one 512-lane workgroup (see above); out: >= 512 floats
+MX_EXPORT int mx_phaser_cascade_probe(int64_t steps, float *out, void *stream)
+{
+    if (!out || steps <= 0 || steps >= (1ll << 30)) return MX_ERR_ARG;
+    hipLaunchKernelGGL(phaser_cascade_probe_kernel, dim3(1), dim3(PS_P), 0, (hipStream_t)stream, (int)steps, 0.37f, 0.45f, out);
+    return mx_launch_status();
+}

@@ -310,13 +310,8 @@ static int launch_wgrad_f16(const WgradF16Args &a, hipStream_t st)
 {
     constexpr int WIN = WF_CH + 12 * T;
     const size_t lds = (size_t)(2 * WF_CH * 64 + 2 * WIN * 64) * sizeof(_Float16);
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute((const void *)wgrad_f16x3_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
-            hipSuccess)
-            return MX_ERR_LAUNCH;
-        attr_done = true;
-    }
+    static MxLdsLatch latch = {};                             // per device (common.h)
+    if (mx_set_dyn_lds(latch, (const void *)wgrad_f16x3_kernel<T>, lds) != MX_OK) return MX_ERR_LAUNCH;
     const int groups = (a.n_slabs + 7) / 8;
     hipLaunchKernelGGL((wgrad_f16x3_kernel<T>), dim3(groups * 8 * CV_KH), dim3(256), lds, st, a);
     return mx_launch_status();

@@ -527,13 +527,8 @@ static int launch_wgrad_sp(const WgradSpArgs &a, hipStream_t st)
 {
     constexpr int KC = T >= 16 ? 3 : 6, CHP = KC * 16, WINP = CHP + 12 * T;
     const size_t lds = 2 * (size_t)(CHP * 128) + ((64 * KC * 4 + 15) / 16) * 16 + 2 * (size_t)(2 * WINP * 128);
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute((const void *)wgrad_sp_f16x3_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
-            hipSuccess)
-            return MX_ERR_LAUNCH;
-        attr_done = true;
-    }
+    static MxLdsLatch latch = {};                             // per device (common.h)
+    if (mx_set_dyn_lds(latch, (const void *)wgrad_sp_f16x3_kernel<T>, lds) != MX_OK) return MX_ERR_LAUNCH;
     const int groups = (a.n_slabs + 7) / 8;
     hipLaunchKernelGGL((wgrad_sp_f16x3_kernel<T>), dim3(groups * 8 * CV_KH), dim3(256), lds, st, a);
     return mx_launch_status();

@@ -155,10 +155,12 @@ def _reduce_rows(part: T, rows: int, cols: int, out: Optional[T] = None) -> T:
 
 def _direct_grad_views(params) -> Optional[List[T]]:
     """The parameters' ``.grad`` tensors when the backward pass may write its results straight into them: all of them are
-    contiguous views of ONE flat gradient buffer (optim.FlatAdamW) that was zeroed since the last backward
-    (``_modex_fresh`` on the buffer, set by ``FlatAdamW.zero_grad`` and consumed here).  autograd then gets ``None`` for
-    those inputs and skips its 20 ``grad += g`` launches per step; any other situation -- no flat buffer, a second backward
-    into the same buffer (sub-batches), plain ``torch.optim`` -- keeps the ordinary accumulate path."""
+    contiguous views of ONE flat gradient buffer (optim.FlatAdamW) and the caller has armed the in-place path for THIS
+    backward (``with optimizer.direct_backward(): loss.backward()`` -- ``_modex_fresh`` on the buffer, set on entry, consumed
+    here, cleared on exit; ``Trainer.train_step`` does it for the first backward after ``zero_grad()``).  autograd then gets
+    ``None`` for those inputs and skips its 20 ``grad += g`` launches per step.  Any other situation -- no flat buffer, a
+    backward outside such a scope (weight penalties, a second sub-batch, ``torch.autograd.grad``), plain ``torch.optim`` --
+    keeps the ordinary accumulate path, so nothing already in ``.grad`` is ever overwritten silently."""
     views = []
     base = None
     for p in params:

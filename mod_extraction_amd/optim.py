@@ -6,7 +6,8 @@ All trainable parameters of the module are re-homed as views into one contiguous
 ``.grad`` as views into a second one, so that a DDP step is ONE RCCL all-reduce over the flat
 gradient followed by ONE kernel launch (the reference's Lightning/DDP path buckets per tensor).
 """
-from typing import Dict, Iterable, List, Tuple
+import contextlib
+from typing import Dict, Iterable, Iterator, List, Tuple
 
 import torch
 from torch import Tensor as T, nn
@@ -43,13 +44,27 @@ class FlatAdamW:
 
     def zero_grad(self, set_to_none: bool = False) -> None:
         self.flat_grad.zero_()
-        self.flat_grad._modex_fresh = True      # a backward pass may write its parameter gradients in place once (models._direct_grad_views)
+        self.flat_grad._modex_fresh = False     # in-place gradient writes are armed only by direct_backward() below
         off = 0
         for p in self.params:          # re-attach views if something replaced .grad
             k = p.numel()
             if p.grad is None or p.grad.data_ptr() != self.flat_grad[off:off + k].data_ptr():
                 p.grad = self.flat_grad[off:off + k].view(p.shape)
             off += k
+
+    @contextlib.contextmanager
+    def direct_backward(self) -> Iterator[None]:
+        """Scope of ONE ``loss.backward()`` that may WRITE its parameter gradients into the flat buffer instead of
+        accumulating (``models._direct_grad_views``).  The caller promises that the buffer holds nothing it wants to keep
+        -- i.e. this is the first backward after ``zero_grad()`` -- and that neither ``torch.autograd.grad`` nor parameter
+        hooks are used for that call (autograd is handed ``None`` for those inputs).  The flag is consumed by the first
+        CNN backward inside the scope and is always cleared on exit, so a backward outside the scope (a weight penalty, a
+        second sub-batch, a manual add into ``flat_grad``) takes the ordinary accumulate path."""
+        self.flat_grad._modex_fresh = True
+        try:
+            yield
+        finally:
+            self.flat_grad._modex_fresh = False
 
     def step(self, grad_scale: float = 1.0) -> None:
         self.step_count += 1

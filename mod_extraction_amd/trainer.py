@@ -124,7 +124,8 @@ class Trainer:
         optimizer.zero_grad()
         loss = module.training_step(batch, 0)
         if loss is not None:
-            loss.backward()
+            with optimizer.direct_backward():       # first backward after zero_grad(): gradients may be written in place
+                loss.backward()
         elif self.env["world_size"] == 1:
             return None                 # Lightning skips the optimizer step when training_step returns None
         scale = allreduce_flat_grad(optimizer.flat_grad, self.env["world_size"])   # DDP: stay in lock-step

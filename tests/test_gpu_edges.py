@@ -172,6 +172,8 @@ def test_tbptt_training_with_other_warmup_and_step_lengths(dev, W, S, n):
     (dict(n_fft=2048, hop_len=512, n_mels=128), 88200),
     (dict(n_fft=2048, hop_len=256, n_mels=256), 30001),
     (dict(n_fft=512, hop_len=100, n_mels=64, sr=16000), 16000),
+    # 59 KB static + 49 KB dynamic LDS: above 64 KB, needs the per-device dynamic-LDS attribute
+    (dict(n_fft=2048, hop_len=512, n_mels=512, out_channels=[64] * 7, temp_dilations=[1, 1, 2, 4, 8, 16, 1]), 88200),
 ])
 def test_logmel_other_hops_rates_and_band_counts(dev, over, n_samples):
     """mel front end away from the shipped (hop 256, 256 bands, 44.1 kHz): frame count, filter bank and framing follow
@@ -200,6 +202,23 @@ def test_logmel_other_hops_rates_and_band_counts(dev, over, n_samples):
     err = (got - want).abs()
     assert float(err[live].max()) <= 2e-5 + 1e-5 * float(want[live].abs().max()), float(err[live].max())
     assert float(err[~live].max()) < 0.05 if (~live).any() else True
+
+
+def test_logmel_band_count_beyond_the_lds_budget_is_unsupported_not_a_failed_launch(dev):
+    """mx_logmel_fwd sizes its LDS from n_mels: a band count whose mel tile + filter coefficients do not fit the CU's
+    160 KB beside the FFT buffers must come back as MX_ERR_UNSUPPORTED before any launch (it used to fail AT launch)."""
+    from mod_extraction_amd import _hip
+    n_fft, n_mels, N, hop = 2048, 2048, 30000, 512
+    n_frames = N // hop + 1
+    z = lambda *s, dt=torch.float32: torch.zeros(*s, device=dev, dtype=dt)
+    x, win, tw = z(2, N), z(n_fft), z(n_fft, 2)
+    fb, lo, hi = z(n_fft // 2 + 1, n_mels), z(n_mels, dt=torch.int32), z(n_mels, dt=torch.int32)
+    out = z(2, n_mels, n_frames)
+    args = lambda m: (_hip.ptr(x), 2, N, _hip.ptr(win), _hip.ptr(tw), _hip.ptr(fb), _hip.ptr(lo), _hip.ptr(hi), n_fft, hop, m,
+                      n_frames, n_frames, 1e-7, 0, 0, 0, 0, _hip.ptr(out), _hip.stream())
+    assert _hip.load().mx_logmel_fwd(*args(n_mels)) == -2                 # MX_ERR_UNSUPPORTED
+    assert _hip.load().mx_logmel_fwd(*args(1024)) == 0                    # 59 + 90 KB: fits, with the attribute
+    torch.cuda.synchronize()
 
 
 @pytest.mark.parametrize("kw", [dict(lr=3e-3, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.1),

@@ -121,6 +121,70 @@ def test_batch_synthesis_and_train_step(dev):
     assert opt.step_count == 1
 
 
+def test_lfo_extraction_twenty_step_trajectory_vs_oracle(dev):
+    """one-step parity cannot see an accumulation problem (fused LayerNorm statistics, the f16x3 scale
+    bound, AdamW moments), so the HEADLINE path runs 20 free-running AdamW steps of LFOExtraction (lightning.py:96-158,
+    187-192) on the HIP kernels and on the CPU oracle: same initial weights, the SAME rendered batches (the device's
+    batches are fed to the oracle), SpecAugment on with a shared host seed per step, nobody's max-pool / PReLU decisions
+    shared -- two independent trajectories.
+    Gates: per-step loss within 1e-4 relative; final parameters within 1e-3 of the distance the trajectory moved them
+    (L2, per tensor and overall) and the bulk (99.9 % of all elements) within 1e-3 of their tensor's max magnitude.  The
+    max-norm over ALL elements is printed, not gated at that level: Adam's update is lr * m / (sqrt(v) + eps) ~ lr *
+    sign(g) while the moments are young, so the few elements whose gradient is below the 1e-5 norm-wise noise of fp32
+    (on either side) take steps of either sign -- they are bounded by 2 * lr per step, which IS asserted."""
+    from mod_extraction_amd import data_modules, lightning, models, optim, trainer
+    n, sr, B, steps, lr = 22272, 44100, 4, 20, 1e-4
+    cfg = dict(in_ch=2, n_samples=n, sr=sr, n_fft=1024, hop_len=256, n_mels=64, kernel_size=(5, 13),
+               out_channels=[64] * 6, temp_dilations=[1, 1, 2, 4, 8, 16], pool_size=(2, 1), latent_dim=1,
+               freq_mask_amount=0.25, time_mask_amount=0.25, use_ln=True)
+    loss_dict = {"l1": 1.0, "fdl1": 5.0, "sdl1": 10.0, "mse": 0.0}
+    torch.manual_seed(11); np.random.seed(11)
+    ref = om.Spectral2DCNN(**cfg).train()
+    mine = models.Spectral2DCNN(**cfg)
+    mine.load_state_dict(ref.state_dict())
+    init = {k: v.detach().clone() for k, v in ref.named_parameters()}
+    module = lightning.LFOExtraction(mine, sr=sr, model_smooth_n_frames=0, loss_dict=loss_dict).to(dev).train()
+    opt = optim.FlatAdamW(module.parameters(), lr=lr, betas=(0.8, 0.99))
+    ref_opt = torch.optim.AdamW(ref.parameters(), lr=lr, betas=(0.8, 0.99))
+    batcher = data_modules.SyntheticFxBatcher(B, n, sr, ("flanger", "chorus", "phaser"), dev, audio_seed=7)
+    runner = trainer.Trainer(log_fn=None)
+    worst_loss = 0.0
+    losses = []
+    for i in range(steps):
+        dry, wet, mod, _ = batcher.render(batcher.sample_params())
+        torch.manual_seed(1000 + i)                          # SpecAugment masks come from the host generator on both sides
+        loss_r, _ = ol.lfo_train_step(ref, ref_opt, dry.cpu(), wet.cpu(), mod.cpu(), loss_dict)
+        torch.manual_seed(1000 + i)
+        loss = float(runner.train_step(module, opt, (dry, wet, mod, None)))
+        rel = abs(loss - loss_r) / max(abs(loss_r), 1e-12)
+        worst_loss = max(worst_loss, rel)
+        losses.append((loss, loss_r))
+        assert rel < 1e-4, (i, loss, loss_r)
+    assert opt.step_count == steps
+    moved2 = diff2 = 0.0
+    worst_l2 = worst_max = worst_abs = 0.0
+    n_bad = n_all = 0
+    for (name, p), (_, q) in zip(mine.named_parameters(), ref.named_parameters()):
+        p, q = p.detach().cpu().double(), q.detach().double()
+        d, mv = (p - q), (q - init[name].double())
+        moved2 += float((mv * mv).sum()); diff2 += float((d * d).sum())
+        worst_l2 = max(worst_l2, float(d.norm() / mv.norm().clamp_min(1e-30)))
+        mag = float(q.abs().max())
+        worst_max = max(worst_max, float(d.abs().max()) / mag)
+        worst_abs = max(worst_abs, float(d.abs().max()))
+        n_bad += int((d.abs() > 1e-3 * mag).sum()); n_all += d.numel()
+    overall = (diff2 / moved2) ** 0.5
+    print(f"20-step trajectory: worst per-step loss rel err {worst_loss:.2e}; ||p_hip - p_oracle|| / ||p_oracle - p_init|| "
+          f"overall {overall:.2e}, worst tensor {worst_l2:.2e}; max |diff| / max |param| {worst_max:.2e} (abs {worst_abs:.2e} = "
+          f"{worst_abs / lr:.2f} lr); elements beyond 1e-3 of their tensor's max: {n_bad} of {n_all}; "
+          f"loss {losses[0][0]:.5f} -> {losses[-1][0]:.5f}")
+    assert worst_loss < 1e-4
+    assert overall < 1e-3
+    assert worst_l2 < 1e-3
+    assert n_bad / n_all < 1e-3
+    assert worst_abs / (2 * lr * steps) < 1.0
+
+
 def test_eval_lfo_variants_vs_reference_golden(dev, golden_dir):
     """(f) rank 2: quasi-periodic / combined / concave-convex LFOs (modulations.py:104-210).  The PRODUCT (host control
     flow and RNG draws in the reference's order; synthesis, corners, resampling in the device kernels) under the same
@@ -405,13 +469,14 @@ def test_two_rank_step_equals_the_single_process_step_on_the_joined_batch(tmp_pa
 
 
 def test_parameter_gradients_written_in_place_equal_the_accumulated_ones(dev):
-    """FlatAdamW.zero_grad marks the flat gradient buffer fresh; the first CNN backward after it writes every parameter
-    gradient straight into its `.grad` view and hands autograd `None` (20 `grad += g` launches less per step).  The flat
-    gradient must be bit-identical to the ordinary accumulate path, and a SECOND backward into the same buffer (sub-batches)
-    must still accumulate."""
+    """`with FlatAdamW.direct_backward():` arms the in-place path for ONE backward: the first CNN backward inside the scope
+    writes every parameter gradient straight into its `.grad` view and hands autograd `None` (20 `grad += g` launches less
+    per step).  The flat gradient must be bit-identical to the ordinary accumulate path; a SECOND backward (sub-batches)
+    must still accumulate; and OUTSIDE the scope nothing is ever overwritten (a weight penalty's backward
+    before the main one, `torch.autograd.grad`)."""
     from mod_extraction_amd import data_modules, lightning, models, optim
 
-    def grads(direct, twice):
+    def setup():
         torch.manual_seed(5); np.random.seed(5)
         cfg = dict(in_ch=2, n_samples=22272, sr=44100, n_fft=1024, hop_len=256, n_mels=64, kernel_size=(5, 13),
                    out_channels=[64] * 6, temp_dilations=[1, 1, 2, 4, 8, 16], pool_size=(2, 1), latent_dim=1,
@@ -420,21 +485,48 @@ def test_parameter_gradients_written_in_place_equal_the_accumulated_ones(dev):
                                          loss_dict={"l1": 1.0, "fdl1": 5.0, "sdl1": 10.0, "mse": 0.0}).to(dev).train()
         opt = optim.FlatAdamW(module.parameters(), lr=1e-4, betas=(0.8, 0.99))
         bt = data_modules.SyntheticFxBatcher(4, 22272, 44100, ("flanger", "chorus"), dev, audio_seed=3)
-        batch = bt.next_batch()
-        models.DIRECT_GRADS = direct
-        try:
-            opt.zero_grad()
-            module.training_step(batch, 0).backward()
-            if twice:
+        return module, opt, bt.next_batch()
+
+    def grads(direct, twice):
+        module, opt, batch = setup()
+        opt.zero_grad()
+        if direct:
+            with opt.direct_backward():
                 module.training_step(batch, 0).backward()
-        finally:
-            models.DIRECT_GRADS = True
+                assert opt.flat_grad._modex_fresh is False            # consumed by the CNN backward
+        else:
+            module.training_step(batch, 0).backward()
+        if twice:
+            module.training_step(batch, 0).backward()
+        assert not getattr(opt.flat_grad, "_modex_fresh", False)
         return opt.flat_grad.clone()
 
     g_direct, g_plain = grads(True, False), grads(False, False)
     assert float(g_plain.abs().max()) > 0 and torch.equal(g_direct, g_plain)
     g2 = grads(True, True)                                                 # first backward in place, second accumulated
     assert float((g2 - 2 * g_plain).abs().max()) <= 1e-6 * float(g_plain.abs().max())
+    # outside a direct_backward() scope zero_grad() arms nothing: what is already in .grad is kept
+    module, opt, batch = setup()
+    opt.zero_grad()
+    penalty = sum((p * p).sum() for p in module.parameters())
+    penalty.backward()                                                     # e.g. a weight penalty before the main loss
+    g_pen = opt.flat_grad.clone()
+    assert float(g_pen.abs().max()) > 0
+    module.training_step(batch, 0).backward()
+    assert float((opt.flat_grad - (g_pen + g_plain)).abs().max()) <= 1e-6 * float((g_pen + g_plain).abs().max())
+    # ... and torch.autograd.grad returns real tensors there, without touching .grad
+    opt.zero_grad()
+    got = torch.autograd.grad(module.training_step(batch, 0), list(module.parameters()))
+    assert all(g is not None for g in got) and float(opt.flat_grad.abs().max()) == 0.0
+    flat = torch.cat([g.reshape(-1) for g in got])
+    assert torch.equal(flat, g_plain)
+    # an exception inside the scope leaves the flag cleared
+    try:
+        with opt.direct_backward():
+            raise RuntimeError("boom")
+    except RuntimeError:
+        pass
+    assert opt.flat_grad._modex_fresh is False
 
 
 @pytest.mark.gpu
