@@ -14,7 +14,10 @@
 //        output row, tap, ci tile) in fragment order and loaded straight from global memory (L2-resident, 32 bytes per
 //        lane) -- they would not fit the LDS beside the patch for both output rows.
 // K loop = 4 channel blocks x 3 pooling pairs = 12 stages of 13 taps (the dense kernel: 20 stages), 33 sparse MFMAs per
-// tap and wave.  Workgroup = (clip, output row pair), waves = (output row, position half) with the accumulator split of
+// tap and wave.  Round 5: a STAGE of the staging pipeline covers DS_NCB = 2 channel blocks (26 taps) for dilations <= 8 -- the
+// commit to LDS, the workgroup barrier and the first tap's exposed reads (2.2 k of a 13-tap stage's 22.9 k cycles, s_memtime
+// stamps of round 4) are paid 6 times per workgroup instead of 12; the two 31 KB images of a stage sit side by side in each of
+// the two buffers (124-143 KB of LDS; dilation 16 would need 174 KB and keeps one block per stage).  Workgroup = (clip, output row pair), waves = (output row, position half) with the accumulator split of
 // conv_f16.hip; the patch (31 KB per stage) is register-staged into double-buffered LDS.  The epilogue transposes the
 // [position][ci] tiles through wave-private LDS and writes dxhat (B, 64, H, 352) rows coalesced.
 #include "conv_common.h"
@@ -56,16 +59,28 @@ __device__ __forceinline__ half16 ds_w_frag(const _Float16 *p)
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
 }
 
+#ifndef DS_NCB
+#define DS_NCB 2                        // channel blocks per staging stage for dilations <= 8 (1: the round-4 pipeline; same-box A/B knob)
+#endif
+template <int T> struct DsGeom {
+    static constexpr int NCB = T <= 8 ? DS_NCB : 1;
+    static constexpr int PWP = CV_PITCH + 12 * T;
+    static constexpr size_t IMG = ((2 * (size_t)PWP * DS_ROWB + PWP * 4 + 15) / 16) * 16;   // one channel block: hi, lo, index words
+    static constexpr size_t BUF = NCB * IMG;
+};
+
 template <int T, bool LN>
 __global__ __launch_bounds__(256, 1) void dgrad_sp_f16x3_kernel(DgradSpArgs a)
 {
+    constexpr int NCB = DsGeom<T>::NCB;                     // channel blocks per stage
     constexpr int PWP = CV_PITCH + 12 * T;                  // patch rows (position w = row - 6T)
     constexpr int PA_SPLIT = PWP * DS_ROWB;                 // bytes per split
-    constexpr int IDX_BYTES = PWP * 4;
-    constexpr int BUF_BYTES = ((2 * PA_SPLIT + IDX_BYTES + 15) / 16) * 16;
+    constexpr int IMG_BYTES = (int)DsGeom<T>::IMG;          // one channel block's image
+    constexpr int BUF_BYTES = (int)DsGeom<T>::BUF;
     constexpr int QP = (PWP + 127) / 128;                   // patch iterations: thread = (position (tid >> 1) + 128 q, 16-byte half)
     constexpr int QI = (PWP + 255) / 256;
-    constexpr int N_STAGE = 12;
+    constexpr int N_STAGE = 12 / NCB;                       // stage st = cbg * 3 + m: channel blocks cbg * NCB .. + NCB - 1, pooled row hp + m - 1
+    constexpr int N_TAPS = CV_KW * NCB;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     // (wave index pinned to a scalar register: row / c are then wave-uniform for the compiler and the weight-fragment addresses
@@ -86,57 +101,68 @@ __global__ __launch_bounds__(256, 1) void dgrad_sp_f16x3_kernel(DgradSpArgs a)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
 
-    // ---- patch staging (registers -> LDS), stage st = cb * 3 + m: pooled row hp + m - 1, channel block cb
-    floatx4 pv[2 * QP];
-    unsigned pidx[QI];
+    // ---- patch staging (registers -> LDS), stage st = cbg * 3 + m: pooled row hp + m - 1, channel blocks cbg * NCB + s
+    floatx4 pv[NCB][2 * QP];
+    unsigned pidx[NCB][QI];
     const int spos = tid >> 1, spart = tid & 1;
     auto stage_row = [&](int st) { return hp + (st % 3) - 1; };
     auto issue = [&](int st) {
-        const int cb = st / 3, hq = stage_row(st);
+        const int hq = stage_row(st);
         const int hq_eff = hq < 0 ? 0 : (hq >= Hp ? Hp - 1 : hq);       // out-of-image pairs are skipped by the caller
-        const size_t rbase = (((size_t)b * Hp + hq_eff) * 4 + cb) * CV_PITCH;
 #pragma unroll
-        for (int k = 0; k < 2 * QP; ++k) {
-            const int split = k / QP, q = k - split * QP;
-            const int pos = spos + 128 * q, w = pos - 6 * T;
-            const int w_eff = (w >= 0 && w < CV_PITCH) ? w : CV_PITCH - 1;      // column 351 is zero (Wv <= 351)
-            pv[k] = *reinterpret_cast<const floatx4 *>((split ? a.g_lo : a.g_hi) + (rbase + w_eff) * 16 + spart * 8);
-        }
+        for (int s = 0; s < NCB; ++s) {
+            const int cb = (st / 3) * NCB + s;
+            const size_t rbase = (((size_t)b * Hp + hq_eff) * 4 + cb) * CV_PITCH;
 #pragma unroll
-        for (int q = 0; q < QI; ++q) {
-            const int pos = tid + 256 * q, w = pos - 6 * T;
-            const int w_eff = (w >= 0 && w < CV_PITCH) ? w : CV_PITCH - 1;
-            pidx[q] = a.g_idx[rbase + w_eff];
-        }
-    };
-    auto commit = [&](unsigned char *buf) {
-        typedef float floatx2 __attribute__((ext_vector_type(2)));
+            for (int k = 0; k < 2 * QP; ++k) {
+                const int split = k / QP, q = k - split * QP;
+                const int pos = spos + 128 * q, w = pos - 6 * T;
+                const int w_eff = (w >= 0 && w < CV_PITCH) ? w : CV_PITCH - 1;      // column 351 is zero (Wv <= 351)
+                pv[s][k] = *reinterpret_cast<const floatx4 *>((split ? a.g_lo : a.g_hi) + (rbase + w_eff) * 16 + spart * 8);
+            }
 #pragma unroll
-        for (int k = 0; k < 2 * QP; ++k) {
-            const int split = k / QP, q = k - split * QP;
-            const int pos = spos + 128 * q;
-            if (pos < PWP) {
-                unsigned char *dst = buf + split * PA_SPLIT + pos * DS_ROWB + spart * 16;
-                reinterpret_cast<floatx2 *>(dst)[0] = floatx2{pv[k][0], pv[k][1]};
-                reinterpret_cast<floatx2 *>(dst)[1] = floatx2{pv[k][2], pv[k][3]};
+            for (int q = 0; q < QI; ++q) {
+                const int pos = tid + 256 * q, w = pos - 6 * T;
+                const int w_eff = (w >= 0 && w < CV_PITCH) ? w : CV_PITCH - 1;
+                pidx[s][q] = a.g_idx[rbase + w_eff];
             }
         }
+    };
+    auto commit = [&](unsigned char *buf0) {
+        typedef float floatx2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-        for (int q = 0; q < QI; ++q) {
-            const int pos = tid + 256 * q;
-            if (pos < PWP) reinterpret_cast<unsigned *>(buf + 2 * PA_SPLIT)[pos] = pidx[q];
+        for (int s = 0; s < NCB; ++s) {
+            unsigned char *buf = buf0 + s * IMG_BYTES;
+#pragma unroll
+            for (int k = 0; k < 2 * QP; ++k) {
+                const int split = k / QP, q = k - split * QP;
+                const int pos = spos + 128 * q;
+                if (pos < PWP) {
+                    unsigned char *dst = buf + split * PA_SPLIT + pos * DS_ROWB + spart * 16;
+                    reinterpret_cast<floatx2 *>(dst)[0] = floatx2{pv[s][k][0], pv[s][k][1]};
+                    reinterpret_cast<floatx2 *>(dst)[1] = floatx2{pv[s][k][2], pv[s][k][3]};
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < QI; ++q) {
+                const int pos = tid + 256 * q;
+                if (pos < PWP) reinterpret_cast<unsigned *>(buf + 2 * PA_SPLIT)[pos] = pidx[s][q];
+            }
         }
     };
     auto stage_live = [&](int st) { const int hq = stage_row(st); return hq >= 0 && hq < Hp; };
 
-    // weights of (stage, this wave's output row): fragment f = 0: ci tile c, f = 1: ci tile c ^ 1
-    auto w_ptr = [&](const _Float16 *base, int st, int kwf, int f) {
+    // weights of (stage, tap kk of its NCB x 13, this wave's output row): fragment f = 0: ci tile c, f = 1: ci tile c ^ 1
+    // (packed per (channel block, pair): index ws = cb * 3 + m)
+    auto w_ptr = [&](const _Float16 *base, int st, int kk, int f) {
         const int tile = f ? (c ^ 1) : c;
+        const int ws = ((st / 3) * NCB + kk / CV_KW) * 3 + st % 3;
+        int kwf = kk % CV_KW;
 #ifdef DS_ABL_WFIX        // ablation (wrong results): every tap reads tap 0's fragments -> the weight stream stays in the CU's L1
         kwf = 0;
 #endif
         // (wave-uniform part) + (32-bit lane offset): the loads take the scalar-base form, no vector address arithmetic
-        const _Float16 *ub = base + (((size_t)(st * 2 + row) * CV_KW + kwf) * 2 + tile) * (64 * 16);
+        const _Float16 *ub = base + (((size_t)(ws * 2 + row) * CV_KW + kwf) * 2 + tile) * (64 * 16);
         return ub + (unsigned)(lane * 16);
     };
 
@@ -158,8 +184,7 @@ __global__ __launch_bounds__(256, 1) void dgrad_sp_f16x3_kernel(DgradSpArgs a)
         while (nst < N_STAGE && !stage_live(nst)) ++nst;
         if (nst < N_STAGE) issue(nst);                  // in flight during this stage's MFMAs
         __syncthreads();
-        // ---- 13 taps: A fragments (6 position tiles x hi/lo + index words) one tap ahead, weight fragments one tap ahead
-        const unsigned char *pa_h = buf, *pa_l = buf + PA_SPLIT, *pidx_img = buf + 2 * PA_SPLIT;
+        // ---- NCB x 13 taps: A fragments (6 position tiles x hi/lo + index words) one tap ahead, weight fragments one tap ahead
         // position tile t < 5: tile c*6 + t; t = 5: the middle tile 5
         const int a_lane = (l32 + c * 6 * 32) * DS_ROWB + hh * 8;
         const int m_lane = (l32 + 5 * 32) * DS_ROWB + hh * 8;
@@ -167,7 +192,10 @@ __global__ __launch_bounds__(256, 1) void dgrad_sp_f16x3_kernel(DgradSpArgs a)
         half8 AH[2][6], AL[2][6];
         int IX[2][6];
         half16 WH[2][2], WL[2][2];
-        auto rd_tap = [&](int f, int kwf, int t0, int t1) {
+        auto rd_tap = [&](int f, int kk, int t0, int t1) {          // tap kk of the stage: image kk / 13, kernel column kk % 13
+            const unsigned char *img = buf + (kk / CV_KW) * IMG_BYTES;
+            const unsigned char *pa_h = img, *pa_l = img + PA_SPLIT, *pidx_img = img + 2 * PA_SPLIT;
+            const int kwf = kk % CV_KW;
 #pragma unroll
             for (int t = t0; t < t1; ++t) {
                 const int off = (t < 5 ? a_lane + t * 32 * DS_ROWB : m_lane) + kwf * T * DS_ROWB;
@@ -177,20 +205,20 @@ __global__ __launch_bounds__(256, 1) void dgrad_sp_f16x3_kernel(DgradSpArgs a)
                 IX[f][t] = (int)*reinterpret_cast<const unsigned short *>(pidx_img + ioff);
             }
         };
-        auto ld_w = [&](int f, int kwf) {
+        auto ld_w = [&](int f, int kk) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                WH[f][j] = ds_w_frag(w_ptr(a.w_hi, st, kwf, j));
-                WL[f][j] = ds_w_frag(w_ptr(a.w_lo, st, kwf, j));
+                WH[f][j] = ds_w_frag(w_ptr(a.w_hi, st, kk, j));
+                WL[f][j] = ds_w_frag(w_ptr(a.w_lo, st, kk, j));
             }
         };
         rd_tap(0, 0, 0, 6);
 #pragma unroll
         for (int j = 0; j < 2; ++j) { WH[0][j] = WNH[j]; WL[0][j] = WNL[j]; }
 #pragma unroll
-        for (int kwf = 0; kwf < CV_KW; ++kwf) {
+        for (int kwf = 0; kwf < N_TAPS; ++kwf) {                     // (kwf counts the stage's taps: 13 per channel block)
             const int f = kwf & 1;
-            const bool more_taps = kwf + 1 < CV_KW;
+            const bool more_taps = kwf + 1 < N_TAPS;
             __builtin_amdgcn_sched_barrier(0);
             // accumulator u = 2t + j (t < 5): position tile c*6 + t, weight fragment j; u = 10: middle tile, fragment 0
             // Segment 1 (11 MFMAs): the next tap's 8 weight loads are fenced into it -- left to itself the scheduler
@@ -636,8 +664,7 @@ __global__ __launch_bounds__(256) void plane_partials_sum_kernel(const float *__
 template <int T, bool LN>
 static int launch_dgrad_sp(const DgradSpArgs &a, int B, hipStream_t st)
 {
-    constexpr int PWP = CV_PITCH + 12 * T;
-    constexpr size_t buf = ((2 * (size_t)PWP * DS_ROWB + PWP * 4 + 15) / 16) * 16;
+    constexpr size_t buf = DsGeom<T>::BUF;                        // NCB channel-block images per buffer
     constexpr size_t scratch = 4 * 3 * 32 * 33 * 4;              // epilogue: transposition tiles + the LN partial reduction
     constexpr size_t lds = 2 * buf > scratch ? 2 * buf : scratch;
     static_assert(lds <= 160 * 1024, "LDS budget");

@@ -200,7 +200,17 @@ def test_logmel_other_hops_rates_and_band_counts(dev, over, n_samples):
     floor = np.log(1e-7)
     live = want > floor + 1.0
     err = (got - want).abs()
-    assert float(err[live].max()) <= 2e-5 + 1e-5 * float(want[live].abs().max()), float(err[live].max())
+    # narrow filters (512 bands over 1025 bins: single-bin bands) pass one bin's power through unaveraged, and a bin that
+    # holds 1e-5 of the frame's power is only known to ~1e-2 in fp32 on EITHER side: there an fp64 evaluation of the oracle
+    # arbitrates (as for the MR-STFT gradients) -- the kernel may be as far from it as 3x the fp32 oracle is, or inside the gate
+    import copy
+    want64 = copy.deepcopy(ref).double().log_mel(x.double(), masks)
+    e_mine = (got.double() - want64)[live].abs().max()
+    e_orc32 = (want.double() - want64)[live].abs().max()
+    gate = 2e-5 + 1e-5 * float(want[live].abs().max())
+    assert float(e_mine) <= max(gate, 3.0 * float(e_orc32)), (float(e_mine), float(e_orc32))
+    if cfg["n_mels"] <= 256:
+        assert float(err[live].max()) <= gate, float(err[live].max())
     assert float(err[~live].max()) < 0.05 if (~live).any() else True
 
 
