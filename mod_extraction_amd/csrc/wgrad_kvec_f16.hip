@@ -23,8 +23,16 @@ typedef short short4v __attribute__((__vector_size__(4 * sizeof(short))));
 
 #define WK_KS_MAX 6                     // k-steps (of 32 positions) per chunk: a row = chunks of 6 + 5
 #define WK_CH (WK_KS_MAX * 32)          // 192 positions
-#define WK_AP (WK_CH + 8)               // A image pitch in halfs (400 B rows: 16-byte aligned, bank-spreading)
+#define WK_AP (WK_CH + 16)              // A image pitch in halfs: 416 B rows.  ds_read_b128 serves 16 lanes at a time in the groups
+                                        // {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ... (MI355X_MICROARCH.md, LDS table), i.e. eight
+                                        // lanes of one k-group and eight of the next: with 400 B rows (round 4) seven of a group's
+                                        // eight lane pairs met on a bank (2 x the cycles, SQ_LDS_BANK_CONFLICT = 43 % of the kernel's
+                                        // LDS cycles, profiles/r05); 416 B puts the 16 lanes of every group on 16 different 16-byte columns
 #define WK_BR (WK_CH + 12)              // B image rows: positions w0 - 6 .. w0 + 191 + 6
+
+#define WK_A_BYTES (2 * 64 * WK_AP * 2)
+#define WK_B_ROWS ((WK_BR + 7) / 8 * 8)
+#define WK_LDS_BYTES (WK_A_BYTES + 2 * WK_B_ROWS * 32)
 
 struct WgradKvecArgs {
     const float *G;                     // (B, 64, H/2, 352) gradient w.r.t. the pooled output
@@ -40,12 +48,21 @@ __device__ __forceinline__ floatx4 mfma_16x16x32(half8 a, half8 b, floatx4 c)
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
 
-// B fragment: 8 consecutive rows (positions) r0 + 8 kg .. + 7 of this lane's column (k-channel) of a [row][16] image
+// Bank conflicts (round 5).  A transposing read serves lanes 0-31 together, i.e. k-groups kg = 0 and 1.  With the natural K
+// order (lane group kg = positions 8 kg .. 8 kg + 7 of the k-step) the two groups read rows r0 .. r0 + 3 and r0 + 8 .. r0 + 11 of
+// the 32-byte-row B image: 256 bytes apart, the SAME banks -- every B fragment read of round 4 took twice its cycles.  K is a
+// reduction index, so its order inside a k-step is free as long as both operands agree: lane group kg holds
+//     positions 4 kg .. 4 kg + 3   and   16 + 4 kg .. 16 + 4 kg + 3     of the k-step
+// The B reads of lanes 0-31 are then rows r0 .. r0 + 7 (one contiguous 256 bytes) and r0 + 16 .. r0 + 23, conflict-free for every
+// tap offset, from the plain image; the A image stores each k-step's 32 positions in that order (slot 8 kg + e), which the
+// staging pass does for free (its 4-position items move as whole 8-byte units), so an A fragment is still ONE ds_read_b128.
+__device__ __forceinline__ int wk_a_slot(int c8) { return c8 < 4 ? 8 * c8 : 8 * (c8 - 4) + 4; }   // half index inside the k-step of 4-position item c8
+// B fragment: rows r0 + 4 kg .. + 3 and r0 + 16 + 4 kg .. + 3 of this lane's column (k-channel) of a [row][16] image
 __device__ __forceinline__ half8 tr_frag16(const unsigned char *img, int lane_off, int r0)
 {
     const unsigned char *ptr = img + lane_off + r0 * 32;
     const short4v v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4v __attribute__((address_space(3))) *)ptr);
-    const short4v v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4v __attribute__((address_space(3))) *)(ptr + 4 * 32));
+    const short4v v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4v __attribute__((address_space(3))) *)(ptr + 16 * 32));
     typedef short short8v __attribute__((__vector_size__(8 * sizeof(short))));
     const short8v both = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
     return __builtin_bit_cast(half8, both);
@@ -53,8 +70,9 @@ __device__ __forceinline__ half8 tr_frag16(const unsigned char *img, int lane_of
 
 __global__ __launch_bounds__(256, 2) void wgrad_kvec_f16_kernel(WgradKvecArgs a)
 {
-    __shared__ __attribute__((aligned(16))) _Float16 dzA[2 * 64 * WK_AP];      // [split][co][position]   51,200 B
-    __shared__ __attribute__((aligned(16))) _Float16 xB[2 * WK_BR * 16];       // [split][position][16]   13,056 B
+    extern __shared__ __attribute__((aligned(256))) unsigned char wk_smem[];     // dynamic: 66,560 B (two workgroups per CU)
+    _Float16 *const dzA = reinterpret_cast<_Float16 *>(wk_smem);                // [split][co][position]   53,248 B
+    _Float16 *const xB = reinterpret_cast<_Float16 *>(wk_smem + WK_A_BYTES);    // [split][position][16]   13,312 B
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: wave-uniform address parts stay off the vector unit
     const int tap0 = wave * 3 + (wave >> 1);                                    // first tap of the wave's group (tap 6 is shared)
     const int m16 = lane & 15, kg = lane >> 4;
@@ -68,8 +86,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kvec_f16_kernel(WgradKvecArgs a)
 
     // fragment addressing (bytes)
     const int a_lane = (m16 * WK_AP + 8 * kg) * 2;                              // + j*16*WK_AP*2 (co tile) + ks*64 (+ split)
-    const int b_lane = (8 * kg + (m16 >> 2)) * 32 + (m16 & 3) * 8;              // + (ks*32 + kw)*32 (+ split)
-    constexpr int A_SPLIT = 64 * WK_AP * 2, B_SPLIT = WK_BR * 32;
+    const int b_lane = (4 * kg + (m16 >> 2)) * 32 + (m16 & 3) * 8;              // + (ks*32 + kw)*32 (+ split); second half 16 rows on
+    constexpr int A_SPLIT = 64 * WK_AP * 2, B_SPLIT = WK_B_ROWS * 32;
     const unsigned char *Ab = reinterpret_cast<const unsigned char *>(dzA);
     const unsigned char *Bb = reinterpret_cast<const unsigned char *>(xB);
 
@@ -94,8 +112,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kvec_f16_kernel(WgradKvecArgs a)
             ama[q] = 0x02020202u;                                   // matches neither row of the pooling pair
             if (c4 * 4 < npos) {
                 const size_t off = (((size_t)b * 64 + co) * Hp + (h >> 1)) * CV_PITCH + w0 + c4 * 4;
-                ga[q] = *reinterpret_cast<const floatx4 *>(a.G + off);
-                ama[q] = *reinterpret_cast<const unsigned *>(a.amax + off);
+                ga[q] = __builtin_nontemporal_load(reinterpret_cast<const floatx4 *>(a.G + off));     // read once: 2.9 GB per step
+                ama[q] = __builtin_nontemporal_load(reinterpret_cast<const unsigned *>(a.amax + off));
             }
         }
     };
@@ -129,15 +147,16 @@ __global__ __launch_bounds__(256, 2) void wgrad_kvec_f16_kernel(WgradKvecArgs a)
                 hi[e] = hh;
                 lo[e] = (_Float16)(v - (float)hh);
             }
-            *reinterpret_cast<half4 *>(dzA + co * WK_AP + c4 * 4) = hi;
-            *reinterpret_cast<half4 *>(dzA + 64 * WK_AP + co * WK_AP + c4 * 4) = lo;
+            const int slot = (c4 >> 3) * 32 + wk_a_slot(c4 & 7);               // the k-step's K order (see wk_a_slot)
+            *reinterpret_cast<half4 *>(dzA + co * WK_AP + slot) = hi;
+            *reinterpret_cast<half4 *>(dzA + 64 * WK_AP + co * WK_AP + slot) = lo;
         }
 #pragma unroll
         for (int q = 0; q < NB; ++q) {
             const int i = tid + q * 256;
             if (i < 2 * WK_BR * 2) {
                 const int split = i / (WK_BR * 2), k = i - split * (WK_BR * 2);
-                *reinterpret_cast<floatx4 *>(xB + (size_t)split * (WK_BR * 16) + (k >> 1) * 16 + (k & 1) * 8) = vb[q];
+                *reinterpret_cast<floatx4 *>(xB + (size_t)split * (WK_B_ROWS * 16) + (k >> 1) * 16 + (k & 1) * 8) = vb[q];
             }
         }
     };
@@ -262,7 +281,9 @@ MX_EXPORT int mx_conv_block1_wgrad_f16(const float *G, const uint8_t *amax, cons
     hipLaunchKernelGGL(wk_pow2_scale_kernel, dim3(1), dim3(1), 0, st, amax_bits, scale);
     WgradKvecArgs a{G, amax, scale, (const _Float16 *)xk_hi, (const _Float16 *)xk_lo, part, (int)B, (int)H, (int)Wv,
                     (int)rows_per_slab, (int)n_slabs};
-    hipLaunchKernelGGL(wgrad_kvec_f16_kernel, dim3((unsigned)n_slabs), dim3(256), 0, st, a);
+    static MxLdsLatch latch = {};                             // per device (common.h)
+    if (mx_set_dyn_lds(latch, (const void *)wgrad_kvec_f16_kernel, WK_LDS_BYTES) != MX_OK) return MX_ERR_LAUNCH;
+    hipLaunchKernelGGL(wgrad_kvec_f16_kernel, dim3((unsigned)n_slabs), dim3(256), WK_LDS_BYTES, st, a);
     const int total = CV_KW * 64 * 16;
     hipLaunchKernelGGL(wgrad_kvec_reduce_kernel, dim3(total / 16), dim3(256), 0, st, part, (int)n_slabs, scale, dW);
     return mx_launch_status();
