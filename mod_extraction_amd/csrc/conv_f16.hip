@@ -1247,6 +1247,259 @@ __global__ __launch_bounds__(256, 1) void conv1_f16x3_persist_kernel(ConvF16Args
 #endif
 }
 
+// ---- first block, persistent, TILE-OUTER (round 5; MODEX_BLOCK1_PERSIST=3, the default) --------------------------------------
+// The kernel above keeps all 176 accumulator registers of a row pair alive through its 13 taps and then runs a 14 k-cycle
+// epilogue that nothing overlaps: one wave per SIMD, taps and epilogue simply add (15.0 k + 14.4 k cycles per row pair).  The
+// first block is special: K = 13 taps x 16 "channels" only, so the WEIGHTS of a wave's 32 output channels fit in registers
+// (13 taps x {hi, lo} x 4 = 104) and the loops can be turned inside out:
+//   for each 32-column tile:  both rows of the pooling pair x 13 taps x 3 split products = 78 matrix instructions on TWO
+//   accumulators (32 registers), patch fragments straight from the LDS image (4 ds_read_b128 per tap, one tap ahead),
+// and the tile is DONE: its max-pool, transposition through the wave's private LDS image, bias, LayerNorm partial sums and
+// 16-byte stores (the pair-wave epilogue above, cut into pieces) run in the shadow of the matrix instructions of tile t + 1
+// (two accumulator sets, ping-pong), with no workgroup barrier inside a row pair.
+// Waves = (channel tile jt, column half c); 352 columns = 11 tiles: c = 0 takes tiles 0..5, c = 1 tiles 5..10 -- tile 5 is
+// computed by both (bit-identical values, stored twice; its partial sums are counted once): 6 x 78 = 468 instead of 429 matrix
+// instructions per wave and row pair, in exchange for no cross-wave exchange of the middle tile.
+// (A first version with swapped operands -- a lane = one channel, 16-byte stores straight from the accumulators, no LDS at all
+//  -- was store-bound: 64 scattered 16-byte pieces per store instruction, 2.1 ms for the stores alone.)
+//   LDS = P[2] (46 KB each: the row pair's patch, LDS-DMA double buffered as above) | 4 transposition images (17 KB) | sums (8 KB) | DMA descriptors (12 KB)
+#ifndef C1T_ABL
+#define C1T_ABL 0       // ablation knobs of the tile-outer kernel (wrong results; tools/exp_block1.py): 1 no epilogue, 2 no matrix instructions, 4 no global stores
+#endif
+template <bool STATS>     // STATS: leave the next block's LayerNorm partial sums (stats_part / slope_out given); a template so that a tile's epilogue is branch-free
+__global__ __launch_bounds__(256, 1) void conv1_f16x3_tile_kernel(ConvF16Args a, int n_tiles, int tiles_per_wg)
+{
+    constexpr int T = 1;
+    constexpr int PWP = CV_PITCH + 12 * T;
+    constexpr int PLANE = PWP * 16;
+    constexpr int P_SLOTS = 8 * PWP;
+    constexpr int P_PIECES = (P_SLOTS + 63) / 64;
+    constexpr int P_BYTES = P_PIECES * 1024;
+    constexpr int PPW = (P_PIECES + 3) / 4;                      // 12
+    constexpr int ROWB = CV_PITCH * 32;
+    constexpr int NT = 6;                                        // column tiles per wave
+    static_assert(PPW == 12, "DMA schedule");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char *const P0 = smem;
+    unsigned char *const scr = smem + 2 * P_BYTES;                           // 4 waves x 4352 B: [32 co][32 w] image + 64 flag words
+    float *const xch = reinterpret_cast<float *>(scr + 4 * 4352);            // [2][wave * 4 + q][64 lanes]
+    int *const desc_l = reinterpret_cast<int *>(scr + 4 * 4352 + 8192);      // [piece k][thread]: the DMA descriptors (12 registers otherwise)
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int jt = wave >> 1, c = wave & 1, half = lane >> 5, l32 = lane & 31;
+    int wg = blockIdx.x;
+    if ((gridDim.x & 7) == 0) wg = (wg & 7) * (gridDim.x >> 3) + (wg >> 3);
+    const int t_begin = wg * tiles_per_wg, t_end = min(t_begin + tiles_per_wg, n_tiles);
+    if (t_begin >= t_end) return;
+    const int Hp = a.H >> 1, H = a.H;
+    auto make_desc = [&](int k) {
+        const int i = (wave + 4 * k) * 64 + lane;
+        const int plane = i / PWP, pos = i - plane * PWP, w = pos - 6 * T;
+        const int split = plane >> 2, r = (plane >> 1) & 1, part = plane & 1;
+        return (i < P_SLOTS && w >= 0 && w < CV_PITCH) ? ((split << 30) | (r << 29) | (r * ROWB + w * 32 + part * 16)) : -1;
+    };
+    const unsigned long long zero_src = (unsigned long long)k_zero_slot, xh = (unsigned long long)a.x_hi, xl = (unsigned long long)a.x_lo;
+    // patch piece k (descriptor d) of row pair `tile` -> patch buffer pb; a wave without a piece k repeats its piece k - 1 (harmless)
+    auto issue_piece = [&](int tile, int pb, int k, int d) {
+        const int pp = wave + 4 * k < P_PIECES ? wave + 4 * k : wave + 4 * (k - 1);
+        const int tb = tile / Hp, th0 = (tile - tb * Hp) * 2;
+        const long long st_off = ((long long)tb * H + th0) * (CV_PITCH * 32);
+        const unsigned long long src = ((d & (1 << 30)) ? xl : xh) + st_off + (unsigned)(d & 0xFFFFF);
+        glds16(d >= 0 ? src : zero_src, lds0 + pb * P_BYTES + pp * 1024);
+    };
+#pragma unroll
+    for (int k = 0; k < PPW; ++k) {
+        const int d = make_desc(wave + 4 * k < P_PIECES ? k : k - 1);
+        desc_l[k * 256 + tid] = d;
+        if (wave + 4 * k < P_PIECES) issue_piece(t_begin, 0, k, d);
+    }
+
+    // the wave's weights: A operand, lane (row = channel jt*32 + l32, k half) -> 8 halfs of [kw][khalf][co][8]
+    half8 WH[CV_KW], WL[CV_KW];
+#pragma unroll
+    for (int kw = 0; kw < CV_KW; ++kw) {
+        const size_t o = ((size_t)(kw * 2 + half) * 64 + jt * 32 + l32) * 8;
+        WH[kw] = *reinterpret_cast<const half8 *>(a.w_hi + o);
+        WL[kw] = *reinterpret_cast<const half8 *>(a.w_lo + o);
+    }
+    // the loads have landed BEFORE the loop as far as the compiler is concerned too: otherwise its wait-count pass guards the first
+    // tile's matrix instructions of EVERY row pair with vmcnt(24) .. vmcnt(0) -- which in the steady state waits for the previous
+    // row pair's stores to retire (first version of this kernel: 2.7 ms)
+#pragma unroll
+    for (int kw = 0; kw < CV_KW; ++kw) asm volatile("" : "+v"(WH[kw]), "+v"(WL[kw]));
+    // transposed role of the lane in the epilogue (conv1_pairwave_epilogue): 4 channel rows q*8 + co_l, 4 columns w4 .. w4 + 3
+    const PairwaveConsts kc = pairwave_consts(a, jt, lane);
+    const int co_l = lane >> 3, w4 = (lane & 7) * 4, rbit0 = co_l & 3, fhalf = (co_l >> 2) & 1;
+    float *const img = reinterpret_cast<float *>(scr + wave * 4352);
+    unsigned *const flg = reinterpret_cast<unsigned *>(scr + wave * 4352 + 4096);
+    unsigned voff[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) voff[q] = (unsigned)((q * 8 + co_l) * Hp * CV_PITCH + w4);
+    const float inv = 1.0f / F16_WSCALE;
+    const int tile0 = c ? 5 : 0;                                  // first column tile of this wave
+    const float tile5_w = c ? 0.0f : 1.0f;                        // column tile 5 is computed by both column-half waves: its sums count once
+    DMA_WAIT();
+    __syncthreads();
+
+#pragma unroll 1
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        const int pb = (tile - t_begin) & 1;
+        const unsigned char *const Pc = P0 + pb * P_BYTES;
+        const int tn = tile + 1 < t_end ? tile + 1 : tile;
+        const int b = tile / Hp, hp = tile - b * Hp;
+        const size_t sbase = (((size_t)b * CV_CO + jt * 32) * Hp + hp) * CV_PITCH;      // wave-uniform
+        float *const out_b = a.out + sbase;
+        unsigned char *const amax_b = a.out_amax + sbase;
+        // patch fragment (B operand): lane (column = position l32, k half) of plane (split, row r, k half) at column tile*32 + l32 + kw
+        const unsigned char *const fr = Pc + half * PLANE + (tile0 * 32 + l32) * 16;
+        float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+        floatx16 acc[2][2];                                       // [set][row]
+        half8 F[2][4];                                            // [buffer][row * 2 + split]
+        auto rd = [&](int buf, int t, int kw) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                F[buf][q] = *reinterpret_cast<const half8 *>(fr + ((q & 1) * 4 + (q >> 1) * 2) * PLANE + t * 512 + kw * 16);
+        };
+        // ---- the epilogue of a finished tile, in pieces.  A: max over the pair + flags -> the wave's image ([co][w], in the
+        // accumulator layout: lane = column, register = channel row); B: read back transposed (lane = 4 channel rows x 4 columns);
+        // C(q): bias, LayerNorm partial sums, 16-byte store of channel row q*8 + co_l
+        uint4 flw;
+        floatx4 tvq[4], mq;
+        unsigned flags = 0;
+        auto epi_a = [&](int set, int r0) {                       // four channel rows per call (taps 0..3)
+            if (r0 == 0) flags = 0;
+#pragma unroll
+            for (int r = r0; r < r0 + 4; ++r) {
+                const bool take_bot = acc[set][1][r] > acc[set][0][r];         // ties keep the first row (torch)
+                img[mfma_row(r, lane) * 32 + l32] = take_bot ? acc[set][1][r] : acc[set][0][r];
+                flags |= (take_bot ? 1u : 0u) << r;
+            }
+            if (r0 == 12) flg[lane] = flags;
+        };
+        auto epi_b = [&]() {                                      // (the wave's own LDS operations execute in order: no barrier)
+            flw = *reinterpret_cast<const uint4 *>(flg + fhalf * 32 + w4);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) tvq[q] = *reinterpret_cast<const floatx4 *>(img + (q * 8 + co_l) * 32 + w4);
+        };
+        auto epi_c1 = [&](int t, int q) {                         // bias, pad mask, argmax bytes, the two stores
+            const int wt = tile0 + t, w = wt * 32 + w4;
+            const unsigned fl[4] = {flw.x, flw.y, flw.z, flw.w};
+            const floatx4 invv = {inv, inv, inv, inv}, bv4 = {kc.bias[q], kc.bias[q], kc.bias[q], kc.bias[q]};
+            floatx4 m = __builtin_elementwise_fma(tvq[q], invv, bv4);
+            unsigned am = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) am |= ((fl[e] >> (q * 4 + rbit0)) & 1u) << (8 * e);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) m[e] = w + e < a.Wv ? m[e] : 0.0f;
+            mq = m;
+            if ((C1T_ABL & 4) && m[0] + m[1] + m[2] + m[3] != 12345.0f && am != 77u) return;       // ablation: no global stores
+            *reinterpret_cast<floatx4 *>(out_b + (voff[q] + (unsigned)(wt * 32))) = m;
+            *reinterpret_cast<unsigned *>(amax_b + (voff[q] + (unsigned)(wt * 32))) = am;
+        };
+        auto epi_c2 = [&](int t, int q) {                         // LayerNorm partial sums of PReLU(out) - PReLU(bias)
+            if (!STATS) return;
+            const int w = (tile0 + t) * 32 + w4;
+            const floatx4 m = mq;
+            const floatx4 sm = m * floatx4{kc.slope[q], kc.slope[q], kc.slope[q], kc.slope[q]};
+            floatx4 d;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) d[e] = (m[e] > 0.0f ? m[e] : sm[e]) + kc.nshift[q];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) d[e] = w + e < a.Wv ? d[e] : 0.0f;                // pad columns add nothing
+            if (t == 0) d = d * floatx4{tile5_w, tile5_w, tile5_w, tile5_w};             // (t == 0 of the c = 1 wave is column tile 5 again)
+            s1[q] += (d[0] + d[1]) + (d[2] + d[3]);
+            const floatx4 dd = d * d;
+            s2[q] += (dd[0] + dd[1]) + (dd[2] + dd[3]);
+        };
+        rd(0, 0, 0);
+        int dnext = -1;
+#pragma unroll
+        for (int t = 0; t <= NT; ++t) {
+            const int set = t & 1;
+            if (t < NT) {
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) acc[set][r][i] = 0.0f;
+            }
+#pragma unroll
+            for (int kw = 0; kw < CV_KW; ++kw) {
+                const int f = (t * CV_KW + kw) & 1;
+                __builtin_amdgcn_sched_barrier(0);
+                if (t < NT && (C1T_ABL & 2)) {
+                    acc[set][0][kw] += (float)F[f][0][0] + (float)F[f][1][1] + (float)WL[kw][0];      // keep the reads alive
+                    acc[set][1][kw] += (float)F[f][2][0] + (float)F[f][3][1] + (float)WH[kw][0];
+                    if (kw + 1 < CV_KW) rd(f ^ 1, t, kw + 1);
+                    else if (t + 1 < NT) rd(f ^ 1, t + 1, 0);
+                }
+                if (t < NT && !(C1T_ABL & 2)) {
+                    // split products in the order of the other kernels: w_lo x p_hi, w_hi x p_lo, w_hi x p_hi
+                    acc[set][0] = mfma16(WL[kw], F[f][0], acc[set][0]);
+                    acc[set][1] = mfma16(WL[kw], F[f][2], acc[set][1]);
+                    acc[set][0] = mfma16(WH[kw], F[f][1], acc[set][0]);
+                    acc[set][1] = mfma16(WH[kw], F[f][3], acc[set][1]);
+                    acc[set][0] = mfma16(WH[kw], F[f][0], acc[set][0]);
+                    acc[set][1] = mfma16(WH[kw], F[f][2], acc[set][1]);
+                    if (kw + 1 < CV_KW) rd(f ^ 1, t, kw + 1);
+                    else if (t + 1 < NT) rd(f ^ 1, t + 1, 0);
+                }
+                // the previous tile's epilogue in the matrix instructions' shadow: A over taps 0..1, B at tap 3, C(q) at taps 5, 7, 9, 11
+                if (t > 0 && !(C1T_ABL & 1)) {
+                    if (kw < 4) epi_a(set ^ 1, 4 * kw);
+                    if (kw == 4) epi_b();
+                    if (kw >= 5 && (kw & 1)) epi_c1(t - 1, (kw - 5) >> 1);         // taps 5, 7, 9, 11
+                    if (kw >= 6 && !(kw & 1)) epi_c2(t - 1, (kw - 6) >> 1);        // taps 6, 8, 10, 12
+                }
+                // two DMA pieces of the next row pair's patch per tile (descriptor read from LDS a tap earlier)
+                if (t < NT && (kw == 3 || kw == 8)) dnext = desc_l[(2 * t + (kw == 8 ? 1 : 0)) * 256 + tid];
+                if (t < NT && (kw == 4 || kw == 9) && !(C1_ABL & 8)) issue_piece(tn, pb ^ 1, 2 * t + (kw == 9 ? 1 : 0), dnext);
+                if (t < NT) {
+#pragma unroll
+                    for (int q_ = 0; q_ < 6; ++q_) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // MFMA
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // DS read
+                        __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);      // VALU
+                        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);      // DS write
+                        __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);      // VMEM write
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // the next patch has landed: its last piece was issued at (tile 5, tap 9); behind it in program order sit the 2 + 8 stores of
+        // the last epilogue pieces, which need not have retired (vmcnt retires in order: <= 10 outstanding = every DMA piece is in)
+        asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        if (STATS) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                xch[(wave * 4 + q) * 64 + lane] = s1[q];
+                xch[1024 + (wave * 4 + q) * 64 + lane] = s2[q];
+            }
+        }
+        __syncthreads();                                          // patch buffer pb is free; the other one is visible; sums exchanged
+        if (STATS) {
+            // [wave][q][lane] partial sums -> thread co < 64 adds the 2 waves x 8 column lanes of its channel in a fixed order
+            const int co = threadIdx.x;
+            if (co < CV_CO) {
+                const int cjt = co >> 5, q = (co >> 3) & 3, col = co & 7;
+                float t1 = 0.0f, t2 = 0.0f;
+#pragma unroll
+                for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        t1 += xch[((cjt * 2 + cc) * 4 + q) * 64 + col * 8 + e];
+                        t2 += xch[1024 + ((cjt * 2 + cc) * 4 + q) * 64 + col * 8 + e];
+                    }
+                float *sp = a.stats_part + (((size_t)b * Hp + hp) * CV_CO + co) * 2;
+                sp[0] = t1;
+                sp[1] = t2;
+            }
+            __syncthreads();                                      // (the exchange slots are rewritten by the next row pair)
+        }
+    }
+}
+
 // ---- LDS-DMA version on v_mfma_f32_16x16x32_f16 (forward, T <= 4) -------------------------------------------------
 // Same workgroup tile, wave tile (64 channels x 5.5 column tiles = 176 accumulator registers), operand images, LDS-DMA
 // staging and epilogue as conv_f16x3_dma_kernel; only the matrix instruction differs.  Why: these kernels are power
@@ -1785,8 +2038,25 @@ MX_EXPORT int mx_conv_block1_fwd_f16(const void *xk_hi, const void *xk_lo, const
                   nullptr, out, out_amax, (int)H, (int)Wv, slope_out, stats_part};
     // MODEX_BLOCK1_PERSIST=0 selects the one-row-pair-per-workgroup kernel (same-box A/B)
     // (1: the persistent kernel with the row-exchanging epilogue; default 2: its pair-wave layout)
-    static const int persist = getenv("MODEX_BLOCK1_PERSIST") ? atoi(getenv("MODEX_BLOCK1_PERSIST")) : 2;
+    // 3 (default, round 5): the tile-outer kernel (weights in registers, the epilogue of a column tile under the next one's MFMAs)
+    static const int persist = getenv("MODEX_BLOCK1_PERSIST") ? atoi(getenv("MODEX_BLOCK1_PERSIST")) : 3;
     if (!persist) return launch_f16_dma<1, 0, 1, 1>(a, (int)B, (hipStream_t)stream);
+    if (persist == 3) {
+        constexpr size_t lds3 = 2 * (size_t)((8 * (CV_PITCH + 12) + 63) / 64) * 1024 + 4 * 4352 + 8192 + 12 * 256 * sizeof(int);
+        static MxLdsLatch latch3 = {};
+        static MxLdsLatch latch3n = {};
+        if (mx_set_dyn_lds(latch3, (const void *)conv1_f16x3_tile_kernel<true>, lds3) != MX_OK ||
+            mx_set_dyn_lds(latch3n, (const void *)conv1_f16x3_tile_kernel<false>, lds3) != MX_OK)
+            return MX_ERR_LAUNCH;
+        const int n_tiles3 = (int)(B * (H / 2));
+        int grid3 = 1024;
+        if (grid3 > n_tiles3) grid3 = n_tiles3;
+        const int per3 = (n_tiles3 + grid3 - 1) / grid3;
+        grid3 = (n_tiles3 + per3 - 1) / per3;
+        if (stats_part) hipLaunchKernelGGL(conv1_f16x3_tile_kernel<true>, dim3((unsigned)grid3), dim3(256), lds3, (hipStream_t)stream, a, n_tiles3, per3);
+        else hipLaunchKernelGGL(conv1_f16x3_tile_kernel<false>, dim3((unsigned)grid3), dim3(256), lds3, (hipStream_t)stream, a, n_tiles3, per3);
+        return mx_launch_status();
+    }
     constexpr size_t lds = 2 * CV_KW * 2048 + 2 * (size_t)((8 * (CV_PITCH + 12) + 63) / 64) * 1024;
     static_assert(lds <= 160 * 1024, "LDS budget");
     static MxLdsLatch latch0 = {}, latch1 = {};                 // per device (common.h)

@@ -52,7 +52,7 @@ def run(B=256, H=256):
         lib = ctypes.CDLL(so)
         name = os.path.basename(so)[6:-3]
         # the library reads the variable once (static): a variant whose name ends in "p1" runs the row-exchanging layout
-        os.environ["MODEX_BLOCK1_PERSIST"] = "1" if name.endswith("p1") else "2"
+        os.environ["MODEX_BLOCK1_PERSIST"] = "1" if name.endswith("p1") else "3" if name.endswith("p3") else "2"
 
         def call():
             return lib.mx_conv_block1_fwd_f16(vp(x_hi.data_ptr()), vp(x_lo.data_ptr()), vp(w_hi[0].data_ptr()),
