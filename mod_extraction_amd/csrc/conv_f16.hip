@@ -1263,6 +1263,13 @@ __global__ __launch_bounds__(256, 1) void conv1_f16x3_persist_kernel(ConvF16Args
 // (A first version with swapped operands -- a lane = one channel, 16-byte stores straight from the accumulators, no LDS at all
 //  -- was store-bound: 64 scattered 16-byte pieces per store instruction, 2.1 ms for the stores alone.)
 //   LDS = P[2] (46 KB each: the row pair's patch, LDS-DMA double buffered as above) | 4 transposition images (17 KB) | sums (8 KB) | DMA descriptors (12 KB)
+// Measured (one box, 256 clips x 256 mel bins): 2.23 -> 2.06 ms inside the train step, 1.97 -> 1.92 ms alone.  Ablations (alone):
+// without the matrix instructions 1.18 ms, without the global stores 1.68 ms: ~2 500 vector / LDS / store instructions ride on 468
+// matrix instructions per row pair, and a lone wave issues one of them per ~7 cycles -- the wave is VECTOR-ISSUE bound (17.6 k
+// cycles of issue against 15 k of matrix pipe), the two now overlap only where the interleave is even (the scheduler still
+// leaves ~30 of the 468 gaps with 17-37 instructions).  Tried and dropped: the tile stream continued ACROSS row pairs (the last
+// tile's epilogue under the next pair's first tile, sums exchanged one pair late): parity-green, 2.27 ms in the step -- the
+// accumulators carried around the loop cost 100 more AGPR copies than the exposed epilogue saved.
 #ifndef C1T_ABL
 #define C1T_ABL 0       // ablation knobs of the tile-outer kernel (wrong results; tools/exp_block1.py): 1 no epilogue, 2 no matrix instructions, 4 no global stores
 #endif
