@@ -49,6 +49,12 @@ int mx_lfo_synth(const float *freq, const float *phase, const int32_t *shape, co
 int mx_interp_linear(const float *x, int64_t rows, int64_t n_in, int64_t n_out, float *y,
                      void *stream);
 
+/* Transpose of mx_interp_linear restricted to a window of the output axis: dy (rows, j_len) = d loss / d y[:, j0 : j0 + j_len]
+ * (zero elsewhere) -> dx (rows, n_in).  Used by an UNFROZEN LFO model inside the TBPTT step (mod_extraction/lightning.py:
+ * 361-366: each step back-propagates through its own chunk of the resampled LFO).  Deterministic gather, no atomics. */
+int mx_interp_linear_bwd(const float *dy, int64_t dy_stride, int64_t rows, int64_t n_in, int64_t n_out, int64_t j0,
+                         int64_t j_len, float *dx, void *stream);
+
 /* ---- K2: flanger / chorus -- mod_extraction/fx.py:72-119 (MonoFlangerChorusModule.apply_effect)
  * x: mono clips, row b at x + b*x_stride (N samples each; x_stride = N for a dense (B,N) tensor);
  * mod (B,n_mod), n_mod == N or shorter (resampled in-kernel).
@@ -347,6 +353,16 @@ int mx_lstm_bwd_l1_probe(const float *x, int64_t x_stride, const float *lfo, int
                    int64_t y_stride, const float *wet, int64_t wet_stride, const float *stash,
                    const float *w_hh, const float *fc_w, const float *h_init, const float *c_init,
                    float loss_scale, float *part, int64_t B, int64_t T, void *stream);
+
+/* mx_lstm_bwd_l1 / mx_lstm_bwd that ALSO leaves the gate gradients dgate (B, T, 256) (row order of weight_ih_l0): wet != NULL
+ * selects the fused nn.L1Loss (loss_scale), else dy = d loss / d y.  mx_lstm_dlfo: dlfo[b][t] = sum_r weight_ih[r][0] dgate[b][t][r]
+ * = d loss / d lfo of every sample -- mod_extraction/lightning.py:258,344-366 with freeze_lfo_model: false (the LFO model is
+ * re-run inside every TBPTT step and trained through the effect model). */
+int mx_lstm_bwd_dgate(const float *x, int64_t x_stride, const float *lfo, int64_t lfo_stride, const float *y,
+                      int64_t y_stride, const float *wet, int64_t wet_stride, const float *dy, int64_t dy_stride,
+                      const float *stash, const float *w_hh, const float *fc_w, const float *h_init, const float *c_init,
+                      float loss_scale, float *part, float *dgate, int64_t B, int64_t T, void *stream);
+int mx_lstm_dlfo(const float *dgate, const float *w_ih, int64_t B, int64_t T, float *dlfo, int64_t dlfo_stride, void *stream);
 
 /* Measurement aid (bench.py, `frac_of_independent_floor` of the phaser scan): `steps` samples of the bare 6-stage all-pass
  * cascade + feedback (38 flops) for eight independent state vectors per lane -- the shape of the scan's phase A -- on ONE

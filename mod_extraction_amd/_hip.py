@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # MODEX_HIP_LIB: load another build of the same library (kernel experiments); there is no non-HIP fallback
 SO_PATH = os.environ.get("MODEX_HIP_LIB") or os.path.join(_HERE, "_lib", "libmodex_hip.so")
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 _ERR = {-1: "MX_ERR_ARG (bad argument)", -2: "MX_ERR_UNSUPPORTED (size not supported)",
         -3: "MX_ERR_LAUNCH (HIP launch error)"}
@@ -24,10 +24,13 @@ SIGNATURES = {
     "mx_abi_version": [],
     "mx_lfo_synth": [_P, _P, _P, _P, _P, _I64, _I64, _I64, _F32, _P, _P],
     "mx_interp_linear": [_P, _I64, _I64, _I64, _P, _P],
+    "mx_interp_linear_bwd": [_P, _I64, _I64, _I64, _I64, _I64, _I64, _P, _P],
     "mx_flanger_fwd": [_P, _I64, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _I32, _P, _I64, _I64, _I64,
                        _P, _I64, _P, _P, _P, _P],
     "mx_lds_roundtrip_probe": [_I64, _P, _P],
     "mx_lstm_step_probe": [_I32, _I64, _P, _P],
+    "mx_lstm_bwd_dgate": [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _P, _P, _P, _P, _F32, _P, _P, _I64, _I64, _P],
+    "mx_lstm_dlfo": [_P, _P, _I64, _I64, _P, _I64, _P],
     "mx_phaser_cascade_probe": [_I64, _P, _P],
     "mx_phaser_fwd": [_P, _I64, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _F64, _I32, _P, _I64, _P, _P, _I64, _P],
     "mx_logmel_fwd": [_P, _I64, _I64, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _F32, _I32, _I32,

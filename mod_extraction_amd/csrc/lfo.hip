@@ -132,3 +132,52 @@ MX_EXPORT int mx_interp_linear(const float *x, int64_t rows, int64_t n_in, int64
                        (int)n_out, interp_scale_host(n_in, n_out), y);
     return mx_launch_status();
 }
+
+// Transpose of mx_interp_linear for a WINDOW of the output axis: dy (rows, j_len) = d loss / d y[:, j0 : j0 + j_len] (zero outside the
+// window: a TBPTT step only back-propagates through its own chunk of the resampled LFO, lightning.py:361-366) ->
+//   dx[r][i] = sum over j in the window of  [i0(j) == i] lam0(j) dy[j] + [i1(j) == i] lam1(j) dy[j]
+// with the taps of util.py:15 / aten UpSample.h exactly as the forward evaluates them (interp_tap).  One thread per (row, i): it
+// walks the j that can touch point i (scale * j within (i - 1, i + 1), widened by one on either side against rounding) in
+// ascending order -- a gather: deterministic, no atomics.
+__global__ __launch_bounds__(256) void interp_rows_bwd_kernel(const float *__restrict__ dy, long long dy_stride, int n_in, int n_out,
+                                                              float scale, int j0, int j_len, float *__restrict__ dx)
+{
+    const int r = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_in) return;
+    const float *row = dy + (size_t)r * dy_stride;
+    float acc = 0.0f;
+    if (n_in == n_out) {
+        if (i >= j0 && i < j0 + j_len) acc = row[i - j0];
+    } else {
+        int lo, hi;
+        if (scale > 0.0f) {
+            lo = (int)floorf((float)(i - 1) / scale) - 1;
+            hi = (int)ceilf((float)(i + 1) / scale) + 1;
+        } else {                                        // n_out == 1: every output reads point 0
+            lo = 0;
+            hi = n_out - 1;
+        }
+        lo = lo < j0 ? j0 : lo;
+        hi = hi > j0 + j_len - 1 ? j0 + j_len - 1 : hi;
+        for (int j = lo; j <= hi; ++j) {
+            const InterpTap t = interp_tap(scale, j, n_in);
+            const float g = row[j - j0];
+            if (t.i0 == i) acc = fmaf(t.lam0, g, acc);
+            if (t.i1 == i) acc = fmaf(t.lam1, g, acc);       // (i0 == i1 at the last point: lam1 is 0 there)
+        }
+    }
+    dx[(size_t)r * n_in + i] = acc;
+}
+
+MX_EXPORT int mx_interp_linear_bwd(const float *dy, int64_t dy_stride, int64_t rows, int64_t n_in, int64_t n_out, int64_t j0,
+                                   int64_t j_len, float *dx, void *stream)
+{
+    if (!dy || !dx || rows <= 0 || n_in <= 0 || n_out <= 0 || j0 < 0 || j_len <= 0 || j0 + j_len > n_out || dy_stride < j_len)
+        return MX_ERR_ARG;
+    if (rows > 65535 || n_in >= (1ll << 30) || n_out >= (1ll << 30)) return MX_ERR_UNSUPPORTED;
+    const dim3 grid((unsigned)((n_in + 255) / 256), (unsigned)rows);
+    hipLaunchKernelGGL(interp_rows_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, dy, (long long)dy_stride, (int)n_in,
+                       (int)n_out, interp_scale_host(n_in, n_out), (int)j0, (int)j_len, dx);
+    return mx_launch_status();
+}

@@ -305,6 +305,7 @@ __device__ __forceinline__ int ls_dg_slot(int r)   // LDS slot of gate row r: [1
     return ((r & 15) >> 2) * 64 + (r >> 4) * 4 + (r & 3);
 }
 
+template <bool DGOUT>    // DGOUT: also write the gate gradients (B, T, 256) -- the input of mx_lstm_dlfo (an UNFROZEN LFO model, lightning.py:258,361)
 __global__ __launch_bounds__(LS_THREADS) void lstm_bwd_kernel(const float *__restrict__ x, long long xs,
                                                               const float *__restrict__ lfo, long long ls,
                                                               const float *__restrict__ y, long long ys,
@@ -315,7 +316,7 @@ __global__ __launch_bounds__(LS_THREADS) void lstm_bwd_kernel(const float *__res
                                                               const float *__restrict__ h_init,
                                                               const float *__restrict__ c_init, float loss_scale,
                                                               const float *__restrict__ dy, long long dys,
-                                                              float *__restrict__ part, int T, int probe)
+                                                              float *__restrict__ part, float *__restrict__ dgate, int T, int probe)
 {
     // d loss / d y of every step: `dy` rows when given (any loss, mx_lstm_bwd), else the fused nn.L1Loss
     // loss_scale * sign(y - wet) (mx_lstm_bwd_l1: one launch and one (B, T) tensor less per optimizer step)
@@ -474,6 +475,7 @@ __global__ __launch_bounds__(LS_THREADS) void lstm_bwd_kernel(const float *__res
             const float dg = (q == 3 ? dh : dc) * kq;
             dc_next = dc * f;
             *(owner ? dgl + b_wr * 256 + dg_wr : dummy + tid) = dg;
+            if (DGOUT && owner) dgate[((size_t)b * T + (t0 + s)) * 256 + q * LS_H + k] = dg;       // row order of weight_ih_l0: gate * 64 + unit
             {
                 const int t_ = b_prev;                                 // rotate: the buffer of dg(t+2) is free after this step
                 b_prev = b_cur;
@@ -524,22 +526,25 @@ __global__ __launch_bounds__(LS_THREADS) void lstm_bwd_kernel(const float *__res
 static int lstm_bwd_l1_launch(const float *x, int64_t x_stride, const float *lfo, int64_t lfo_stride, const float *y,
                              int64_t y_stride, const float *wet, int64_t wet_stride, const float *stash,
                              const float *w_hh, const float *fc_w, const float *h_init, const float *c_init,
-                             float loss_scale, const float *dy, int64_t dy_stride, float *part, int64_t B, int64_t T, void *stream, int probe)
+                             float loss_scale, const float *dy, int64_t dy_stride, float *part, int64_t B, int64_t T, void *stream, int probe,
+                             float *dgate = nullptr)
 {
     if (!x || !lfo || !y || (!wet && !dy) || !stash || !w_hh || !fc_w || !h_init || !c_init || !part || B <= 0 || T <= 0)
         return MX_ERR_ARG;
     if (T >= (1ll << 30)) return MX_ERR_UNSUPPORTED;
     const size_t lds = (size_t)(2 * LS_SLAB_FLOATS + 768 + LS_THREADS) * sizeof(float);
-    static bool attr_set[64] = {};
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-        (void)hipFuncSetAttribute((const void *)lstm_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (dev >= 0 && dev < 64) attr_set[dev] = true;
+    static MxLdsLatch latch = {}, latch_dg = {};              // per device (common.h)
+    if (dgate) {
+        if (mx_set_dyn_lds(latch_dg, (const void *)lstm_bwd_kernel<true>, lds) != MX_OK) return MX_ERR_LAUNCH;
+        hipLaunchKernelGGL(lstm_bwd_kernel<true>, dim3((unsigned)B), dim3(LS_THREADS), lds, (hipStream_t)stream, x,
+                           (long long)x_stride, lfo, (long long)lfo_stride, y, (long long)y_stride, wet, (long long)wet_stride,
+                           stash, w_hh, fc_w, h_init, c_init, loss_scale, dy, (long long)dy_stride, part, dgate, (int)T, probe);
+        return mx_launch_status();
     }
-    hipLaunchKernelGGL(lstm_bwd_kernel, dim3((unsigned)B), dim3(LS_THREADS), lds, (hipStream_t)stream, x,
+    if (mx_set_dyn_lds(latch, (const void *)lstm_bwd_kernel<false>, lds) != MX_OK) return MX_ERR_LAUNCH;
+    hipLaunchKernelGGL(lstm_bwd_kernel<false>, dim3((unsigned)B), dim3(LS_THREADS), lds, (hipStream_t)stream, x,
                        (long long)x_stride, lfo, (long long)lfo_stride, y, (long long)y_stride, wet, (long long)wet_stride,
-                       stash, w_hh, fc_w, h_init, c_init, loss_scale, dy, (long long)dy_stride, part, (int)T, probe);
+                       stash, w_hh, fc_w, h_init, c_init, loss_scale, dy, (long long)dy_stride, part, nullptr, (int)T, probe);
     return mx_launch_status();
 }
 
@@ -572,6 +577,47 @@ MX_EXPORT int mx_lstm_bwd(const float *x, int64_t x_stride, const float *lfo, in
     if (!dy || dy_stride < T) return MX_ERR_ARG;
     return lstm_bwd_l1_launch(x, x_stride, lfo, lfo_stride, y, y_stride, nullptr, 0, stash, w_hh, fc_w, h_init, c_init, 0.0f,
                               dy, dy_stride, part, B, T, stream, 0);
+}
+
+// The same BPTT that ALSO leaves the gate gradients: dgate (B, T, 256), row order of weight_ih_l0 (gate * 64 + unit).  With them
+// mx_lstm_dlfo forms d loss / d lfo of every sample -- what an UNFROZEN LFO model needs (lightning.py:258,361: the extractor is
+// re-run inside every TBPTT step and receives the effect model's gradient through the LFO it produced).  wet != NULL: nn.L1Loss
+// fused (loss_scale as mx_lstm_bwd_l1); else dy (B rows, stride dy_stride) = d loss / d y.
+MX_EXPORT int mx_lstm_bwd_dgate(const float *x, int64_t x_stride, const float *lfo, int64_t lfo_stride, const float *y,
+                                int64_t y_stride, const float *wet, int64_t wet_stride, const float *dy, int64_t dy_stride,
+                                const float *stash, const float *w_hh, const float *fc_w, const float *h_init,
+                                const float *c_init, float loss_scale, float *part, float *dgate, int64_t B, int64_t T,
+                                void *stream)
+{
+    if (!dgate || (!wet && !dy) || (wet && dy) || (dy && dy_stride < T)) return MX_ERR_ARG;
+    return lstm_bwd_l1_launch(x, x_stride, lfo, lfo_stride, y, y_stride, wet, wet_stride, stash, w_hh, fc_w, h_init, c_init,
+                              loss_scale, dy, dy_stride, part, B, T, stream, 0, dgate);
+}
+
+// dlfo[b][t] = sum_r weight_ih[r][0] * dgate[b][t][r]   (the LSTM's input is (lfo, audio): models.py:328; column 0 = the LFO)
+__global__ __launch_bounds__(256) void lstm_dlfo_kernel(const float *__restrict__ dgate, const float *__restrict__ w_ih,
+                                                        long long n_bt, int T, float *__restrict__ dlfo, long long dlfo_stride)
+{
+    const int lane = threadIdx.x & 63;
+    const long long bt = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (bt >= n_bt) return;
+    const float4 g = *reinterpret_cast<const float4 *>(dgate + bt * 256 + 4 * lane);
+    const int r = 4 * lane;
+    float v = (g.x * w_ih[2 * r] + g.y * w_ih[2 * r + 2]) + (g.z * w_ih[2 * r + 4] + g.w * w_ih[2 * r + 6]);
+    v = wave_sum_f32(v);
+    if (lane == 0) dlfo[(bt / T) * dlfo_stride + (bt % T)] = v;
+}
+
+// dgate (B, T, 256) from mx_lstm_bwd_dgate, w_ih (256, 2) -> dlfo: row b at dlfo + b * dlfo_stride, T values
+MX_EXPORT int mx_lstm_dlfo(const float *dgate, const float *w_ih, int64_t B, int64_t T, float *dlfo, int64_t dlfo_stride,
+                           void *stream)
+{
+    if (!dgate || !w_ih || !dlfo || B <= 0 || T <= 0 || dlfo_stride < T) return MX_ERR_ARG;
+    if (B * T >= (1ll << 32)) return MX_ERR_UNSUPPORTED;
+    const long long n = B * T;
+    hipLaunchKernelGGL(lstm_dlfo_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, dgate, w_ih, n, (int)T,
+                       dlfo, (long long)dlfo_stride);
+    return mx_launch_status();
 }
 
 // ---- independent latency floor of one recurrent step (bench.py) ---------------------------------------

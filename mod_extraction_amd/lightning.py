@@ -18,7 +18,7 @@ from torch import Tensor as T, nn
 from . import losses as L
 from .models import HiddenStateModel, RandomLFO
 from .modulations import find_valid_mod_sig_indices, smoothen, stretch_corners, valid_mod_sig_mask
-from .util import linear_interpolate_last_dim
+from .util import linear_interpolate_last_dim, linear_interpolate_last_dim_bwd
 
 log = logging.getLogger(__name__)
 log.setLevel(level=os.environ.get("LOGLEVEL", "INFO"))
@@ -189,9 +189,14 @@ class TBPTTLFOEffectModeling(BaseLightingModule):
         assert warmup_n_samples > 0
         if param_model is not None:
             raise NotImplementedError("param_model is not used by any shipped config")
-        if lfo_model is not None and not freeze_lfo_model:
-            raise NotImplementedError("the LSTM kernels do not propagate gradients into the LFO model; every "
-                                      "shipped config trains with freeze_lfo_model: true")
+        if lfo_model is not None and not freeze_lfo_model and not isinstance(lfo_model, RandomLFO):
+            # lightning.py:258,344-366: the extractor is re-run inside every TBPTT step and trained through the effect model.
+            # Built for what that path needs when the LFO is NOT stretched: CNN -> moving average -> resampling -> LSTM all
+            # have backward kernels.  stretch_corners (modulations.py:260-307) has a gradient in the reference too (its
+            # segment-wise rescaling is written with differentiable torch ops), which has no kernel here.
+            if should_stretch:
+                raise NotImplementedError("an unfrozen LFO model with should_stretch: true needs the gradient of "
+                                          "stretch_corners, which has no HIP kernel (every shipped config freezes the LFO model)")
         from .effect_losses import GRAD_NAMES
         for name, w in self.loss_dict.items():
             if w > 0 and name not in GRAD_NAMES:
@@ -215,10 +220,11 @@ class TBPTTLFOEffectModeling(BaseLightingModule):
                 log.info("Loading LFO model weights")
                 assert os.path.isfile(lfo_model_weights_path)
                 lfo_model.load_state_dict(torch.load(lfo_model_weights_path, map_location="cpu"))
-            log.info("Freezing LFO model")
-            lfo_model.eval()
-            for p in lfo_model.parameters():
-                p.requires_grad = False
+            if freeze_lfo_model:
+                log.info("Freezing LFO model")
+                lfo_model.eval()
+                for p in lfo_model.parameters():
+                    p.requires_grad = False
         else:
             log.info("Using ground truth mod_sig")
         self.lfo_model = lfo_model
@@ -227,7 +233,7 @@ class TBPTTLFOEffectModeling(BaseLightingModule):
 
     def train(self, mode: bool = True):
         super().train(mode)
-        if self.lfo_model is not None:
+        if self.lfo_model is not None and self.freeze_lfo_model:
             self.lfo_model.eval()               # frozen extractor stays in eval mode (lightning.py:243-244)
         return self
 
@@ -347,6 +353,20 @@ class TBPTTLFOEffectModeling(BaseLightingModule):
         em, W, S = self.effect_model, self.warmup_n_samples, self.step_n_samples
         n = dry.size(-1)
         B = dry.size(0)
+        # lightning.py:344-349: an UNFROZEN extractor is re-run inside every training step (on the full-length, unfiltered
+        # input -- the reference does not re-apply its validity filter there, so it only works when no clip was dropped)
+        relearn = (is_training and self.lfo_model is not None and not self.freeze_lfo_model
+                   and not isinstance(self.lfo_model, RandomLFO))
+        if relearn:
+            if B != batch[0].size(0):
+                raise ValueError("freeze_lfo_model: false re-extracts the LFO of EVERY clip inside the step (lightning.py:344-349): "
+                                 "it cannot be combined with clips dropped by discard_invalid_lfos")
+            lfo_in = stack_dry_wet(batch[0], batch[1]) if self.use_dry else batch[1]
+            g_off = (em.lstm.weight_ih_l0.grad.data_ptr() - optimizer.flat_grad.data_ptr()) // 4
+            from .models import LSTM_NPARAM
+            assert em.fc.bias.grad.data_ptr() == optimizer.flat_grad.data_ptr() + 4 * (g_off + LSTM_NPARAM - 1), \
+                "the effect model's parameters must be contiguous in the flat gradient (state-dict order)"
+            lstm_grad = optimizer.flat_grad[g_off:g_off + LSTM_NPARAM]
         em.clear_hidden()
         with torch.no_grad():
             chunks = [em.run_chunk(dry[:, :, :W], lfo_sr[:, :, :W])[0]]          # warm-up, no loss
@@ -360,7 +380,32 @@ class TBPTTLFOEffectModeling(BaseLightingModule):
                 if end > n:
                     break
                 x, lat, tgt = dry[:, :, start:end], lfo_sr[:, :, start:end], wet[:, :, start:end]
-                if is_training:
+                if relearn:
+                    # lightning.py:344-384 with the extractor in the graph: CNN -> moving average -> resampling -> this chunk
+                    # of the LFO -> LSTM -> loss; backward in the opposite order, every stage on its own kernel
+                    optimizer.zero_grad()
+                    with torch.enable_grad():
+                        hat, _ = self.lfo_model(lfo_in)
+                    hs = smoothen(hat.detach().squeeze(1), self.model_smooth_n_frames)
+                    n_f = hs.size(-1)
+                    lfo_sr = linear_interpolate_last_dim(hs, n, align_corners=True).unsqueeze(1)
+                    lat = lfo_sr[:, :, start:end]
+                    y, h0, c0 = em.run_chunk(x, lat, stash)
+                    if self._fused_l1:
+                        dlat = em.bptt_chunk_dlfo(x, lat, y, stash, h0, c0, lstm_grad, wet=tgt, loss_scale=w_l1 / (B * S))
+                    else:
+                        dy = effect_loss_grad(y, tgt, self.loss_dict, mrstft=self._loss_module("mrstft") if "mrstft" in self.loss_dict else None)
+                        dlat = em.bptt_chunk_dlfo(x, lat, y, stash, h0, c0, lstm_grad, dy=dy)
+                    d_hs = linear_interpolate_last_dim_bwd(dlat[:, 0, :], n_f, n, start)
+                    k = self.model_smooth_n_frames
+                    if k > 1:        # transpose of the moving average = the same average over the zero-padded gradient
+                        d_hs = smoothen(torch.nn.functional.pad(d_hs, (k - 1, k - 1)), k)
+                    hat.backward(d_hs.view_as(hat))
+                    optimizer.step(grad_scale=allreduce_flat_grad(optimizer.flat_grad, world_size))
+                    em.detach_hidden()
+                    mod_sig_hat = hs
+                    done += 1
+                elif is_training:
                     y, h0, c0 = em.run_chunk(x, lat, stash)
                     # no zero_grad(): the BPTT launch OVERWRITES the whole flat gradient (one fill kernel less per step)
                     if self._fused_l1:

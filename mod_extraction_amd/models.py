@@ -837,6 +837,33 @@ class LSTMEffectModel(HiddenStateModel):
                   _hip.ptr(h0.contiguous()), _hip.ptr(c0.contiguous()), _hip.ptr(part), B, Tn, _hip.stream())
         _hip.call("mx_reduce_rows", _hip.ptr(part), B, LSTM_NPARAM, 0, _hip.ptr(grad_out), _hip.stream())
 
+    def bptt_chunk_dlfo(self, x: T, latent: T, y: T, stash: T, h0: T, c0: T, grad_out: T, wet: Optional[T] = None,
+                        loss_scale: float = 0.0, dy: Optional[T] = None) -> T:
+        """``bptt_l1_chunk`` (``wet`` + ``loss_scale``) or ``bptt_chunk`` (``dy``) that also returns d loss / d latent (B,1,T):
+        the gradient an UNFROZEN LFO model receives through the LFO it produced (lightning.py:258,361).  The kernel leaves the
+        gate gradients (B,T,256); ``mx_lstm_dlfo`` contracts them with the LFO column of ``weight_ih_l0``."""
+        B, _, Tn = x.shape
+        assert grad_out.numel() == LSTM_NPARAM and grad_out.is_contiguous()
+        assert (wet is None) != (dy is None)
+        part = torch.empty((B, LSTM_NPARAM), device=x.device, dtype=torch.float32)
+        dgate = torch.empty((B, Tn, 256), device=x.device, dtype=torch.float32)
+        dlat = torch.empty((B, 1, Tn), device=x.device, dtype=torch.float32)
+        xp, xs = _rows(x)
+        lp, ls = _rows(latent)
+        yp, ys = _rows(y)
+        wp, ws = _rows(wet) if wet is not None else (None, 0)
+        if dy is not None:
+            dy = dy.view(B, Tn)
+            assert dy.stride(1) == 1
+        _hip.call("mx_lstm_bwd_dgate", xp, xs, lp, ls, yp, ys, wp, ws, None if dy is None else dy.data_ptr(),
+                  0 if dy is None else dy.stride(0), _hip.ptr(stash), _hip.ptr(self.lstm.weight_hh_l0.detach().contiguous()),
+                  _hip.ptr(self.fc.weight.detach().contiguous()), _hip.ptr(h0.contiguous()), _hip.ptr(c0.contiguous()),
+                  float(loss_scale), _hip.ptr(part), _hip.ptr(dgate), B, Tn, _hip.stream())
+        _hip.call("mx_reduce_rows", _hip.ptr(part), B, LSTM_NPARAM, 0, _hip.ptr(grad_out), _hip.stream())
+        _hip.call("mx_lstm_dlfo", _hip.ptr(dgate), _hip.ptr(self.lstm.weight_ih_l0.detach().contiguous()), B, Tn,
+                  _hip.ptr(dlat), Tn, _hip.stream())
+        return dlat
+
     def forward(self, x: T, latent: T) -> T:
         """Inference / validation forward (no autograd graph; training goes through the fused TBPTT
         step of ``lightning.TBPTTLFOEffectModeling``)."""

@@ -155,7 +155,9 @@ class Trainer:
         manual = getattr(module, "automatic_optimization", True) is False
         if self.num_sanity_val_steps:
             self.validate(module, datamodule, self.num_sanity_val_steps)
-        prefetch = manual and hasattr(module, "prepare_ahead") and hasattr(datamodule, "set_ahead_fn")
+        # (an extractor that is being trained must see the weights of the step that uses it: no look-ahead then)
+        prefetch = (manual and hasattr(module, "prepare_ahead") and hasattr(datamodule, "set_ahead_fn")
+                    and getattr(module, "freeze_lfo_model", True))
         main = None
         if prefetch:
             datamodule.set_ahead_fn(module.prepare_ahead)        # frozen-extractor forward one batch ahead (side stream)

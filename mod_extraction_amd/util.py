@@ -25,6 +25,18 @@ def linear_interpolate_last_dim(x: T, n: int, align_corners: bool = True) -> T:
     return y
 
 
+def linear_interpolate_last_dim_bwd(dy: T, n_in: int, n_out: int, j0: int = 0) -> T:
+    """Transpose of ``linear_interpolate_last_dim`` for a window of the output axis: ``dy`` (..., j_len) is the gradient
+    w.r.t. ``y[..., j0 : j0 + j_len]`` (zero elsewhere); returns the gradient w.r.t. the (..., n_in) input."""
+    assert 1 <= dy.ndim <= 3 and dy.stride(-1) == 1
+    lead = dy.shape[:-1]
+    d2 = dy.reshape(-1, dy.size(-1)).contiguous().float()
+    dx = torch.empty((d2.size(0), n_in), device=dy.device, dtype=torch.float32)
+    _hip.call("mx_interp_linear_bwd", _hip.ptr(d2), d2.stride(0), d2.size(0), n_in, n_out, j0, d2.size(1), _hip.ptr(dx),
+              _hip.stream())
+    return dx.view(lead + (n_in,))
+
+
 def randint(low: int, high: int, n: int = 1) -> Union[int, T]:
     x = torch.randint(low=low, high=high, size=(n,))
     return x.item() if n == 1 else x
