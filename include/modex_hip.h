@@ -308,6 +308,11 @@ int mx_find_corners(const float *x, int64_t rows, int64_t n, float *top, float *
 /* stretch_corners after smoothing (modulations.py:260-307): out (rows, n). */
 int mx_stretch_corners(const float *x, int64_t rows, int64_t n, int64_t max_n_corners, float *out,
                        void *stream);
+/* Gradient of mx_stretch_corners w.r.t. its input (mod_extraction/modulations.py:260-291 is written with differentiable torch
+ * ops; lightning.py:294-296 with an unfrozen LFO model back-propagates through it): x = that call's input, dout = gradient
+ * w.r.t. its output -> dx.  Corner positions / targets are discrete and carry no gradient. */
+int mx_stretch_corners_bwd(const float *x, const float *dout, int64_t rows, int64_t n, int64_t max_n_corners, float *dx,
+                           void *stream);
 /* check_mod_sig (modulations.py:311-343) per row: valid (rows,) int32 0/1;
  * min_gap = int(min_fraction_between_corners * n). */
 int mx_check_mod_sig(const float *x, int64_t rows, int64_t n, int32_t min_top, int32_t max_top,

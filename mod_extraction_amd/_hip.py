@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # MODEX_HIP_LIB: load another build of the same library (kernel experiments); there is no non-HIP fallback
 SO_PATH = os.environ.get("MODEX_HIP_LIB") or os.path.join(_HERE, "_lib", "libmodex_hip.so")
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 _ERR = {-1: "MX_ERR_ARG (bad argument)", -2: "MX_ERR_UNSUPPORTED (size not supported)",
         -3: "MX_ERR_LAUNCH (HIP launch error)"}
@@ -66,6 +66,7 @@ SIGNATURES = {
     "mx_smoothen": [_P, _I64, _I64, _I64, _P, _P],
     "mx_find_corners": [_P, _I64, _I64, _P, _P, _P],
     "mx_stretch_corners": [_P, _I64, _I64, _I64, _P, _P],
+    "mx_stretch_corners_bwd": [_P, _P, _I64, _I64, _I64, _P, _P],
     "mx_check_mod_sig": [_P, _I64, _I64, _I32, _I32, _I32, _I32, _I32, _P, _P],
     "mx_lstm_fwd": [_P, _I64, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _I64, _I64, _P],
     "mx_lstm_bwd_l1": [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _P, _P, _P, _P, _F32, _P, _I64, _I64, _P],

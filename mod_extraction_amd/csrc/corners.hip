@@ -122,6 +122,78 @@ MX_EXPORT int mx_stretch_corners(const float *x, int64_t rows, int64_t n, int64_
     return mx_launch_status();
 }
 
+// Gradient of stretch_corners w.r.t. its (smoothed) input -- the reference's _stretch_corners is written with differentiable
+// torch ops (modulations.py:260-291), and an UNFROZEN LFO model inside the TBPTT step back-propagates through it
+// (lightning.py:258,294-296,344-349).  The corner positions and targets are discrete (no gradient); a stretched segment
+// S = (p, i] with anchors p = previous anchor, i = this anchor is, in exact arithmetic (the segment minimum cancels),
+//     out_j = (m_j - m_i) g + target,      g = |A - target| / |m_p - m_i|,
+// A = the previous target (the tensor m_0 for the first segment), target = 1 / 0 at a corner, the tensor m_(n-1) at the end.
+// With the upstream gradient G:  s1 = sum_S G_j,  s2 = sum_S G_j (m_j - m_i):
+//     dm_j += G_j g (j in S);   dm_i -= g s1;   dg = s2:  dm_p -= s2 g sign(m_p - m_i) / |m_p - m_i|,  dm_i += the same;
+//     first segment: dm_0 += s2 sign(A - target) / |m_p - m_i|;   last segment: dm_i += s1 - s2 sign(A - target) / |m_p - m_i|.
+// Unstretched segments (previous target == target), sample 0 and rows with too many corners pass the gradient through.
+__global__ void stretch_corners_bwd_kernel(const float *__restrict__ x, const float *__restrict__ dout, int R, int n,
+                                           int max_n_corners, float *__restrict__ dx)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const float *m = x + (size_t)r * n, *G = dout + (size_t)r * n;
+    float *d = dx + (size_t)r * n;
+    float n_corners = 0.0f;
+    for (int i = 1; i <= n - 2; ++i) {
+        float t, b;
+        corner_values(m, i, t, b);
+        n_corners = __fadd_rn(n_corners, __fadd_rn(t, b));
+    }
+    for (int i = 0; i < n; ++i) d[i] = G[i];
+    if (n_corners > (float)max_n_corners) return;
+    int prev_i = 0;
+    float prev_target = m[0];
+    for (int i = 1; i <= n - 1; ++i) {
+        float target;
+        const bool last = i == n - 1;
+        if (last) {
+            target = m[n - 1];
+        } else {
+            float t, b;
+            corner_values(m, i, t, b);
+            if (t == 1.0f) target = 1.0f;
+            else if (b == 1.0f) target = 0.0f;
+            else continue;
+        }
+        if (prev_target != target) {
+            const float D = m[prev_i] - m[i], have = fabsf(D);
+            const float E = prev_target - target, want = fabsf(E);
+            const float gain = want / have;
+            float s1 = 0.0f, s2 = 0.0f;
+            for (int j = prev_i + 1; j <= i; ++j) {
+                s1 += G[j];
+                s2 = fmaf(G[j], m[j] - m[i], s2);
+                d[j] = G[j] * gain;                         // (overwrites the pass-through value set above)
+            }
+            const float sD = D > 0.0f ? 1.0f : (D < 0.0f ? -1.0f : 0.0f), sE = E > 0.0f ? 1.0f : (E < 0.0f ? -1.0f : 0.0f);
+            const float dH = -s2 * gain / have;             // d loss / d |m_p - m_i|
+            const float dW = s2 / have;                     // d loss / d |A - target|
+            d[i] -= gain * s1 + dH * sD;
+            d[prev_i] += dH * sD;
+            if (prev_i == 0) d[0] += dW * sE;               // A = m_0 only for the first segment (later ones: the constant 1 / 0)
+            if (last) d[i] += s1 - dW * sE;                 // target = m_(n-1)
+        }
+        prev_i = i;
+        prev_target = target;
+    }
+}
+
+// x: the (rows, n) input of mx_stretch_corners, dout: gradient w.r.t. its output -> dx (rows, n)
+MX_EXPORT int mx_stretch_corners_bwd(const float *x, const float *dout, int64_t rows, int64_t n, int64_t max_n_corners,
+                                     float *dx, void *stream)
+{
+    if (!x || !dout || !dx || rows <= 0 || n < 3) return MX_ERR_ARG;
+    hipLaunchKernelGGL(stretch_corners_bwd_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, (hipStream_t)stream, x, dout,
+                       (int)rows, (int)n, (int)max_n_corners, dx);
+    return mx_launch_status();
+}
+
 // modulations.py:311-356 (check_mod_sig / find_valid_mod_sig_indices): valid[r] = 1 iff the row has
 // min_top..max_top top corners, min_bot..max_bot bottom corners and consecutive like corners are at
 // least min_gap frames apart (min_gap = int(min_fraction_between_corners * n), computed by the host).

@@ -17,7 +17,8 @@ from torch import Tensor as T, nn
 
 from . import losses as L
 from .models import HiddenStateModel, RandomLFO
-from .modulations import find_valid_mod_sig_indices, smoothen, stretch_corners, valid_mod_sig_mask
+from .modulations import (find_valid_mod_sig_indices, smoothen, smoothen_bwd, stretch_corners, stretch_corners_bwd,
+                          valid_mod_sig_mask)
 from .util import linear_interpolate_last_dim, linear_interpolate_last_dim_bwd
 
 log = logging.getLogger(__name__)
@@ -189,14 +190,9 @@ class TBPTTLFOEffectModeling(BaseLightingModule):
         assert warmup_n_samples > 0
         if param_model is not None:
             raise NotImplementedError("param_model is not used by any shipped config")
-        if lfo_model is not None and not freeze_lfo_model and not isinstance(lfo_model, RandomLFO):
-            # lightning.py:258,344-366: the extractor is re-run inside every TBPTT step and trained through the effect model.
-            # Built for what that path needs when the LFO is NOT stretched: CNN -> moving average -> resampling -> LSTM all
-            # have backward kernels.  stretch_corners (modulations.py:260-307) has a gradient in the reference too (its
-            # segment-wise rescaling is written with differentiable torch ops), which has no kernel here.
-            if should_stretch:
-                raise NotImplementedError("an unfrozen LFO model with should_stretch: true needs the gradient of "
-                                          "stretch_corners, which has no HIP kernel (every shipped config freezes the LFO model)")
+        # freeze_lfo_model: false (lightning.py:258,344-366): the extractor is re-run inside every TBPTT step and trained through the
+        # effect model -- CNN -> moving average -> stretch_corners -> resampling -> LSTM, every stage with a backward kernel
+        # (common_step below, `relearn`).
         from .effect_losses import GRAD_NAMES
         for name, w in self.loss_dict.items():
             if w > 0 and name not in GRAD_NAMES:
@@ -387,8 +383,10 @@ class TBPTTLFOEffectModeling(BaseLightingModule):
                     with torch.enable_grad():
                         hat, _ = self.lfo_model(lfo_in)
                     hs = smoothen(hat.detach().squeeze(1), self.model_smooth_n_frames)
-                    n_f = hs.size(-1)
-                    lfo_sr = linear_interpolate_last_dim(hs, n, align_corners=True).unsqueeze(1)
+                    hst = stretch_corners(hs, max_n_corners=self.max_n_corners, smooth_n_frames=self.stretch_smooth_n_frames) \
+                        if self.should_stretch else hs
+                    n_f = hst.size(-1)
+                    lfo_sr = linear_interpolate_last_dim(hst, n, align_corners=True).unsqueeze(1)
                     lat = lfo_sr[:, :, start:end]
                     y, h0, c0 = em.run_chunk(x, lat, stash)
                     if self._fused_l1:
@@ -397,13 +395,13 @@ class TBPTTLFOEffectModeling(BaseLightingModule):
                         dy = effect_loss_grad(y, tgt, self.loss_dict, mrstft=self._loss_module("mrstft") if "mrstft" in self.loss_dict else None)
                         dlat = em.bptt_chunk_dlfo(x, lat, y, stash, h0, c0, lstm_grad, dy=dy)
                     d_hs = linear_interpolate_last_dim_bwd(dlat[:, 0, :], n_f, n, start)
-                    k = self.model_smooth_n_frames
-                    if k > 1:        # transpose of the moving average = the same average over the zero-padded gradient
-                        d_hs = smoothen(torch.nn.functional.pad(d_hs, (k - 1, k - 1)), k)
+                    if self.should_stretch:
+                        d_hs = stretch_corners_bwd(hs, d_hs, max_n_corners=self.max_n_corners, smooth_n_frames=self.stretch_smooth_n_frames)
+                    d_hs = smoothen_bwd(d_hs, self.model_smooth_n_frames)     # transpose of the moving average
                     hat.backward(d_hs.view_as(hat))
                     optimizer.step(grad_scale=allreduce_flat_grad(optimizer.flat_grad, world_size))
                     em.detach_hidden()
-                    mod_sig_hat = hs
+                    mod_sig_hat = hst
                     done += 1
                 elif is_training:
                     y, h0, c0 = em.run_chunk(x, lat, stash)

@@ -82,6 +82,26 @@ def stretch_corners(mod_sig: T, max_n_corners: int = 10, smooth_n_frames: int = 
     return out
 
 
+def smoothen_bwd(dy: T, smooth_n_frames: int) -> T:
+    """Transpose of ``smoothen``: the same moving average over the zero-padded gradient."""
+    if smooth_n_frames <= 1:
+        return dy
+    k = smooth_n_frames
+    return smoothen(torch.nn.functional.pad(dy, (k - 1, k - 1)), k)
+
+
+def stretch_corners_bwd(mod_sig: T, d_out: T, max_n_corners: int = 10, smooth_n_frames: int = 32) -> T:
+    """Gradient of ``stretch_corners(mod_sig, ...)`` w.r.t. ``mod_sig`` given the gradient w.r.t. its result (the reference's
+    _stretch_corners is differentiable torch code, modulations.py:260-291; corner positions carry no gradient)."""
+    m = _rows2d(smoothen(mod_sig, smooth_n_frames))
+    g = _rows2d(d_out)
+    assert g.shape == m.shape
+    dm = torch.empty_like(m)
+    _hip.call("mx_stretch_corners_bwd", _hip.ptr(m), _hip.ptr(g), m.size(0), m.size(1), int(max_n_corners), _hip.ptr(dm),
+              _hip.stream())
+    return smoothen_bwd(dm, smooth_n_frames)
+
+
 def valid_mod_sig_mask(mod_sig: T, min_top_corners: int = 1, max_top_corners: int = 6,
                        min_bottom_corners: int = 1, max_bottom_corners: int = 6,
                        min_fraction_between_corners: float = 0.10) -> T:

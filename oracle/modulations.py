@@ -188,6 +188,42 @@ def stretch_corners(mod_sig: torch.Tensor, max_n_corners: int = 10, smooth_n_fra
     return torch.from_numpy(np.stack(rows, axis=0))
 
 
+def stretch_corners_torch(mod_sig: torch.Tensor, max_n_corners: int = 10, smooth_n_frames: int = 32) -> torch.Tensor:
+    """modulations.py:260-307 as differentiable torch code: the reference's operations in its order, but OUT of place.
+    The reference's own formulation (``segment -= segment.min(); segment *= scale; segment += ...`` on a view of a clone)
+    cannot be back-propagated: torch raises "one of the variables needed for gradient computation has been modified by an
+    inplace operation" (``min`` saves the segment it is then subtracted from) -- checked here with torch 2.10 -- so the
+    reference itself cannot train an unfrozen LFO model with should_stretch (lightning.py:258,294-296) as soon as one row is
+    stretched.  This restatement defines the gradient of the SAME function for the tests of mx_stretch_corners_bwd; its
+    values equal ``stretch_corners`` above."""
+    assert mod_sig.ndim == 2
+    if smooth_n_frames > 1:                                         # modulations.py:359-363
+        mod_sig = mod_sig.unfold(dimension=-1, size=smooth_n_frames, step=1).mean(dim=-1)
+    top_all, bot_all = find_corners(mod_sig.detach())
+    rows = []
+    for m, t, b in zip(mod_sig, top_all, bot_all):
+        if t.sum() + b.sum() > max_n_corners:                       # modulations.py:301-303
+            rows.append(m)
+            continue
+        idx = [(int(i), 1.0) for i in (t == 1).nonzero(as_tuple=True)[0]] + [(int(i), 0.0) for i in (b == 1).nonzero(as_tuple=True)[0]]
+        idx += [(m.size(0) - 1, m[-1])]
+        idx.sort(key=lambda v: v[0])
+        prev_i, prev_anchor = 0, m[0]
+        pieces = [m[:1]]
+        for cur_i, target in idx:                                   # modulations.py:273-289
+            segment = m[prev_i + 1:cur_i + 1]
+            cur_val, orig_prev = m[cur_i], m[prev_i]
+            if prev_anchor != target:
+                scale = abs(prev_anchor - target) / abs(orig_prev - cur_val)
+                segment = segment - segment.min()
+                segment = segment * scale
+                segment = segment + (target - segment[-1])
+            pieces.append(segment)
+            prev_i, prev_anchor = cur_i, target
+        rows.append(torch.cat(pieces))
+    return torch.stack(rows, dim=0)
+
+
 def check_mod_sig_np(m: np.ndarray, top: np.ndarray, bot: np.ndarray,
                      min_top: int = 1, max_top: int = 6, min_bot: int = 1, max_bot: int = 6,
                      min_fraction_between_corners: float = 0.10) -> bool:

@@ -146,10 +146,83 @@ def test_unfrozen_lfo_tbptt_step_vs_oracle(dev):
     assert opt.step_count == 2
 
 
-def test_unfrozen_lfo_needs_every_clip_and_no_stretch(dev):
-    from mod_extraction_amd import lightning, models as am
-    cfg = dict(in_ch=2, n_samples=22272, sr=44100, n_fft=1024, hop_len=256, n_mels=64, kernel_size=(5, 13), out_channels=[64] * 6,
+@pytest.mark.parametrize("smooth", [0, 5])
+@pytest.mark.parametrize("max_n_corners", [16, 2])
+def test_stretch_corners_gradient_vs_autograd(dev, smooth, max_n_corners):
+    """mx_stretch_corners_bwd against torch autograd through the reference's operation sequence restated out of place (oracle
+    stretch_corners_torch, modulations.py:260-307, with a tensor-valued first anchor and last target; the reference's in-place
+    original raises under autograd, see there): LFO-like rows with 1-7 corners, rows above max_n_corners (identity), a monotone
+    row (one segment from sample 0 to the last sample).  Values of the restatement are checked against the bit-exact kernel first."""
+    from mod_extraction_amd import modulations as amod
+    from oracle import modulations as omod
+    torch.manual_seed(8)
+    n = 90
+    t = torch.arange(n) / n
+    rows = [0.5 + 0.4 * torch.sin(2 * np.pi * (f * t + ph)) * (0.6 + 0.4 * t) for f, ph in
+            [(1.0, 0.1), (2.3, 0.4), (0.6, 0.8), (3.4, 0.0), (1.7, 0.55), (0.2, 0.3)]]
+    rows.append(0.1 + 0.8 * t ** 2)                                  # monotone: no corner
+    x = torch.stack(rows).clamp(0, 1).float()                       # (smooth rows: noise would add a corner at every other sample)
+    xr = x.clone().requires_grad_(True)
+    y_r = omod.stretch_corners_torch(xr, max_n_corners, smooth)
+    y_m = amod.stretch_corners(x.to(dev), max_n_corners, smooth)
+    assert float((y_m.cpu() - y_r.detach()).abs().max()) < 1e-6
+    g = torch.randn(y_r.shape)
+    y_r.backward(g)
+    dx = amod.stretch_corners_bwd(x.to(dev), g.to(dev), max_n_corners, smooth)
+    e = _rel(dx.cpu(), xr.grad)
+    print(f"[measured] stretch_corners gradient (smooth {smooth}, max corners {max_n_corners}): rel err {e:.2e}")
+    assert e < 1e-4, e                                              # (autograd's route subtracts the segment minimum twice: its cancellation noise)
+    n_stretched = int(((y_r.detach() - (x if smooth <= 1 else x.unfold(-1, smooth, 1).mean(-1))).abs().amax(-1) > 1e-3).sum())
+    assert n_stretched >= (5 if max_n_corners == 16 else 2)
+
+
+def test_unfrozen_lfo_with_stretch_trains_both_models(dev):
+    """The class defaults (should_stretch = True) with an unfrozen extractor: one step runs, every parameter of both models
+    receives a finite gradient, and the extractor's gradient equals -- through the chain resampling^T -> stretch^T ->
+    moving-average^T evaluated by torch autograd on the CPU from the SAME d loss / d lfo -- what the CNN was handed."""
+    from mod_extraction_amd import lightning, models as am, optim
+    n, B, W, S, k = 22272, 3, 1024, 12000, 8
+    cfg = dict(in_ch=2, n_samples=n, sr=44100, n_fft=1024, hop_len=256, n_mels=64, kernel_size=(5, 13), out_channels=[64] * 6,
                temp_dilations=[1, 1, 2, 4, 8, 16], pool_size=(2, 1), latent_dim=1, use_ln=True)
-    with pytest.raises(NotImplementedError):
-        lightning.TBPTTLFOEffectModeling(1024, 1024, am.LSTMEffectModel(), lfo_model=am.Spectral2DCNN(**cfg), freeze_lfo_model=False,
-                                         should_stretch=True)
+    torch.manual_seed(41)
+    cnn, em = am.Spectral2DCNN(**cfg), am.LSTMEffectModel()
+    mod = lightning.TBPTTLFOEffectModeling(W, S, em, lfo_model=cnn, freeze_lfo_model=False, discard_invalid_lfos=False,
+                                           model_smooth_n_frames=k).to(dev).train()
+    assert mod.should_stretch
+    opt = optim.FlatAdamW([p for p in mod.parameters() if p.requires_grad], lr=1e-4, betas=(0.8, 0.99))
+    before = opt.flat_param.clone()
+    g = torch.Generator().manual_seed(3)
+    dry = torch.rand(B, 1, n, generator=g) * 1.6 - 0.8
+    wet = (0.7 * dry + 0.25 * torch.roll(dry, 3, -1)).clamp(-1, 1)
+    loss = mod.training_step((dry.to(dev), wet.to(dev), None, None), 0, optimizer=opt)
+    assert loss is not None and torch.isfinite(loss)
+    assert torch.isfinite(opt.flat_grad).all()
+    n_lstm = am.LSTM_NPARAM
+    assert float(opt.flat_grad[:n_lstm].abs().max()) > 0 and float(opt.flat_grad[n_lstm:].abs().max()) > 0
+    assert float((opt.flat_param - before)[n_lstm:].abs().max()) > 0          # the extractor moved
+
+
+def test_unfrozen_lfo_needs_every_clip(dev):
+    """The reference re-extracts the LFO of every clip inside the step without re-applying its validity filter
+    (lightning.py:344-349): with clips dropped its shapes no longer match; here that is a ValueError."""
+    from mod_extraction_amd import lightning, models as am, optim
+    n = 22272
+    cfg = dict(in_ch=2, n_samples=n, sr=44100, n_fft=1024, hop_len=256, n_mels=64, kernel_size=(5, 13), out_channels=[64] * 6,
+               temp_dilations=[1, 1, 2, 4, 8, 16], pool_size=(2, 1), latent_dim=1, use_ln=True)
+
+    class HalfValid(torch.nn.Module):                                # an extractor whose first row is a clean triangle, the rest flat
+        def __init__(self, net):
+            super().__init__()
+            self.net, self.n_frames = net, net.n_frames
+        def forward(self, x):
+            hat, lat = self.net(x)
+            tri = (1 - (torch.arange(hat.size(-1), device=hat.device) / 20 % 2 - 1).abs()).view(1, 1, -1)
+            keep = torch.zeros(hat.size(0), 1, 1, device=hat.device); keep[0] = 1
+            return keep * tri + (1 - keep) * 0.5 + 0.0 * hat, lat
+    torch.manual_seed(2)
+    mod = lightning.TBPTTLFOEffectModeling(1024, 12000, am.LSTMEffectModel(), lfo_model=HalfValid(am.Spectral2DCNN(**cfg)),
+                                           freeze_lfo_model=False, discard_invalid_lfos=True).to(dev).train()
+    opt = optim.FlatAdamW([p for p in mod.parameters() if p.requires_grad], lr=1e-4)
+    dry = torch.rand(3, 1, n, device=dev) - 0.5
+    with pytest.raises(ValueError):
+        mod.training_step((dry, dry.clone(), None, None), 0, optimizer=opt)
