@@ -40,5 +40,10 @@ rm -rf $O/pmc5_fetch $O/pmc5_write
 # the sample-recurrent kernels of config 4 (LSTM forward / backward): issue and LDS counters
 rocprofv3 --kernel-trace --pmc SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_lstm -- python3 tools/bench_lstm.py > $O/pmc_lstm.log 2>&1
 python tools/pmc_summary.py $O/pmc_lstm lstm > $O/pmc_lstm_sq.txt
-rm -rf $O/pmc_sq $O/pmc_fetch $O/pmc_write $O/pmc_lstm $O/*.log $O/*.err
+# LDS-side and VALU-side counters of the headline step's kernels (the limiter table of profiles/rNN/README.md)
+run_pmc lds SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES
+python tools/pmc_summary.py $O/pmc_lds > $O/pmc_b64_lds.txt
+run_pmc valu SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VMEM SQ_WAIT_ANY SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES
+python tools/pmc_summary.py $O/pmc_valu > $O/pmc_b64_valu.txt
+rm -rf $O/pmc_sq $O/pmc_fetch $O/pmc_write $O/pmc_lstm $O/pmc_lds $O/pmc_valu $O/*.log $O/*.err
 ls -la $O
