@@ -230,6 +230,8 @@ def conv_key(name, a):
         return f"64x{a[6]}"
     if name in ("mx_conv_block1_fwd_f16", "mx_conv_block1_wgrad_f16"):
         return f"2x{a[6]}"
+    if name == "mx_conv_block1_wgrad_pair_f16":
+        return f"2x{a[6]}"            # (Gp, amax, scale, xk_hi, xk_lo, B, H, ...)
     if name in ("mx_conv_block_wgrad_sp_f16", "mx_conv_block_dgrad_sp_f16"):
         return f"64x{a[7]}"          # (.., scale, B, H, Wv, ..)
     if name == "mx_conv_prep_gpool_cl_f16":
@@ -243,7 +245,8 @@ def conv_key(name, a):
 
 CONV_NAMES = {"mx_conv_block_fwd", "mx_conv_block_dgrad", "mx_conv_block_wgrad", "mx_conv_block_fwd_f16",
               "mx_conv_block_dgrad_f16", "mx_conv_block_wgrad_f16", "mx_conv_block1_fwd_f16", "mx_conv_block1_wgrad_f16",
-              "mx_conv_block_wgrad_sp_f16", "mx_conv_block_dgrad_sp_f16", "mx_conv_prep_gpool_cl_f16"}
+              "mx_conv_block_wgrad_sp_f16", "mx_conv_block_dgrad_sp_f16", "mx_conv_prep_gpool_cl_f16",
+              "mx_conv_block1_wgrad_pair_f16"}
 
 
 def timed_loop(step, steps, world, device, timer_names, key_fn=None):

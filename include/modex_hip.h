@@ -199,6 +199,10 @@ int mx_conv_block1_fwd_f16(const void *xk_hi, const void *xk_lo, const void *w_h
 int mx_conv_block1_wgrad_f16(const float *G, const uint8_t *amax, const uint32_t *amax_bits, const void *xk_hi,
                              const void *xk_lo, int64_t B, int64_t H, int64_t Wv, int64_t rows_per_slab, float *scale,
                              float *part, float *dW, void *stream);
+/* The same with the gradient handed over as f16x3 PAIRS: Gp (B,64,H/2,352) uint32 = (hi | lo << 16) of G * scale[0] per element
+ * (fp16 bit patterns), as mx_ln_prelu_bwd_pair leaves them; scale {S, 1/S} from mx_ln_bwd_finish.  Same reference lines. */
+int mx_conv_block1_wgrad_pair_f16(const void *Gp, const uint8_t *amax, const float *scale, const void *xk_hi, const void *xk_lo,
+                                  int64_t B, int64_t H, int64_t Wv, int64_t rows_per_slab, float *part, float *dW, void *stream);
 
 /* weight gradient from the same prepared operands (dz pair of mx_conv_prep_dgrad_f16, x pair of
  * mx_conv_prep_fwd_f16); part = workspace of ceil(B*H/rows_per_slab)*65*64*64 floats; dW (64,64,5,13). */
@@ -275,6 +279,11 @@ int mx_ln_prelu_bwd_gpool_f16(const float *p, const float *dxhat, const uint8_t 
 int mx_ln_prelu_bwd(const float *p, float *dxhat_inout, const float *stats, const float *slope, int64_t B,
                     int64_t C, int64_t H, int64_t Wv, float *dslope_part, float *gsum_part, uint32_t *gmax_bits,
                     const float *ln_part, void *stream);
+/* mx_ln_prelu_bwd that leaves G as f16x3 pairs in place: element -> (hi | lo << 16) of G * scale[0] (the operand of
+ * mx_conv_block1_wgrad_pair_f16); scale = {S, 1/S} from mx_ln_bwd_finish, ln_part required.  Same reference lines. */
+int mx_ln_prelu_bwd_pair(const float *p, float *dxhat_inout, const float *stats, const float *slope, int64_t B, int64_t C,
+                         int64_t H, int64_t Wv, float *dslope_part, float *gsum_part, const float *ln_part, const float *scale,
+                         void *stream);
 
 /* out[c] (+)= sum_r part[r*C + c]  (fp64 accumulate; deterministic) */
 int mx_reduce_rows(const float *part, int64_t R, int64_t C, int32_t accumulate, float *out, void *stream);

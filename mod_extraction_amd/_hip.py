@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # MODEX_HIP_LIB: load another build of the same library (kernel experiments); there is no non-HIP fallback
 SO_PATH = os.environ.get("MODEX_HIP_LIB") or os.path.join(_HERE, "_lib", "libmodex_hip.so")
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 _ERR = {-1: "MX_ERR_ARG (bad argument)", -2: "MX_ERR_UNSUPPORTED (size not supported)",
         -3: "MX_ERR_LAUNCH (HIP launch error)"}
@@ -53,11 +53,13 @@ SIGNATURES = {
     "mx_conv_prep_gpool_cl_f16": [_P, _P, _P, _I64, _I64, _I64, _P, _P, _P, _P, _P],
     "mx_conv_block_dgrad_sp_f16": [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I32, _P, _P, _P, _P, _P, _P],
     "mx_conv_block1_wgrad_f16": [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _P, _P, _P, _P],
+    "mx_conv_block1_wgrad_pair_f16": [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _P, _P, _P],
     "mx_conv_block_wgrad_f16": [_P, _P, _P, _P, _P, _I64, _I64, _I32, _I64, _P, _P, _P],
     "mx_conv_block_wgrad": [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I32, _I64, _P, _P, _P],
     "mx_ln_bwd_finish": [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _P, _P, _P, _P],
     "mx_ln_prelu_bwd_gpool_f16": [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _P, _P, _P, _P, _P, _P, _P, _P],
     "mx_ln_prelu_bwd": [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _P, _P, _P, _P, _P],
+    "mx_ln_prelu_bwd_pair": [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _P, _P, _P, _P, _P],
     "mx_reduce_rows": [_P, _I64, _I64, _I32, _P, _P],
     "mx_plane_sum": [_P, _I64, _I64, _I64, _P, _P],
     "mx_head_fwd": [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _P, _P, _P],

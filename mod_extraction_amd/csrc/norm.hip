@@ -149,7 +149,8 @@ __global__ __launch_bounds__(LNB_THREADS) void ln_prelu_bwd_kernel(const float *
                                                            const float *__restrict__ stats,
                                                            const float *__restrict__ slope, int C, int H, int Wv,
                                                            float *__restrict__ dslope_part, float *__restrict__ gsum_part,
-                                                           unsigned *__restrict__ gmax_bits, const float *__restrict__ ln_part)
+                                                           unsigned *__restrict__ gmax_bits, const float *__restrict__ ln_part,
+                                                           const float *__restrict__ pair_scale)
 {
     __shared__ double sh[32];
     const int plane = blockIdx.x;
@@ -228,6 +229,19 @@ __global__ __launch_bounds__(LNB_THREADS) void ln_prelu_bwd_kernel(const float *
             ds += (double)tds;
             gs += (double)tgs;
             const int i = i0 + u * LNB_THREADS;
+            if (pair_scale) {
+                // the first block's weight gradient takes G as f16x3 pairs: written here, in place, as (hi | lo << 16) of G * S per
+                // element -- the same 4 bytes -- so that its staging pass only routes and unpacks (mx_ln_prelu_bwd_pair)
+                const float S = pair_scale[0];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = o[e] * S;
+                    const _Float16 hh = (_Float16)v;
+                    const _Float16 ll = (_Float16)(v - (float)hh);
+                    o[e] = __uint_as_float((unsigned)__builtin_bit_cast(unsigned short, hh) |
+                                           ((unsigned)__builtin_bit_cast(unsigned short, ll) << 16));
+                }
+            }
             if (i < n4) __builtin_nontemporal_store(o, gp + i);
         }
     }
@@ -250,7 +264,22 @@ MX_EXPORT int mx_ln_prelu_bwd(const float *p, float *dxhat_inout, const float *s
         Wv > CV_PITCH)
         return MX_ERR_ARG;
     hipLaunchKernelGGL(ln_prelu_bwd_kernel, dim3((unsigned)(B * C)), dim3(LNB_THREADS), 0, (hipStream_t)stream, p,
-                       dxhat_inout, stats, slope, (int)C, (int)H, (int)Wv, dslope_part, gsum_part, gmax_bits, ln_part);
+                       dxhat_inout, stats, slope, (int)C, (int)H, (int)Wv, dslope_part, gsum_part, gmax_bits, ln_part, nullptr);
+    return mx_launch_status();
+}
+
+// The same pass leaving G as f16x3 PAIRS in place: element -> (hi | lo << 16) of G * scale[0] (fp16 bit patterns in one 32-bit
+// word; pad columns 0).  scale: {S, 1/S} from mx_ln_bwd_finish (a bound on max |G| that exists before the pass; ln_part is
+// therefore required).  Consumer: mx_conv_block1_wgrad_pair_f16.
+MX_EXPORT int mx_ln_prelu_bwd_pair(const float *p, float *dxhat_inout, const float *stats, const float *slope,
+                                   int64_t B, int64_t C, int64_t H, int64_t Wv, float *dslope_part, float *gsum_part,
+                                   const float *ln_part, const float *scale, void *stream)
+{
+    if (!p || !dxhat_inout || !stats || !slope || !dslope_part || !ln_part || !scale || B <= 0 || C <= 0 || H <= 0 || Wv <= 0 ||
+        Wv > CV_PITCH)
+        return MX_ERR_ARG;
+    hipLaunchKernelGGL(ln_prelu_bwd_kernel, dim3((unsigned)(B * C)), dim3(LNB_THREADS), 0, (hipStream_t)stream, p,
+                       dxhat_inout, stats, slope, (int)C, (int)H, (int)Wv, dslope_part, gsum_part, nullptr, ln_part, scale);
     return mx_launch_status();
 }
 

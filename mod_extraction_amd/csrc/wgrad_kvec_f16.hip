@@ -41,6 +41,7 @@ struct WgradKvecArgs {
     const _Float16 *xk_hi, *xk_lo;      // (B, H, 352, 16)
     float *part;                        // (n_slabs, 13, 64, 16)
     int B, H, Wv, rows_per_slab, n_slabs;
+    int packed;                         // G holds (hi | lo << 16) fp16 pairs of G * S (mx_ln_prelu_bwd_pair) instead of fp32 values
 };
 
 __device__ __forceinline__ floatx4 mfma_16x16x32(half8 a, half8 b, floatx4 c)
@@ -139,6 +140,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_kvec_f16_kernel(WgradKvecArgs a)
             const int i = tid + q * 256, co = i / (WK_CH / 4), c4 = i - co * (WK_CH / 4);
             const int wq = w0 + c4 * 4;
             half4 hi, lo;
+            if (a.packed) {
+                // the pairs exist already (scaled, split, pad columns zero): route by the row parity and unpack -- 4 instead of 10
+                // vector instructions per element on a SIMD whose issue port the other workgroup's matrix instructions share
+                unsigned v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = ((ama[q] >> (8 * e)) & 0xffu) == want ? __float_as_uint(ga[q][e]) : 0u;
+                const unsigned h01 = __builtin_amdgcn_perm(v[1], v[0], 0x05040100u), h23 = __builtin_amdgcn_perm(v[3], v[2], 0x05040100u);
+                const unsigned l01 = __builtin_amdgcn_perm(v[1], v[0], 0x07060302u), l23 = __builtin_amdgcn_perm(v[3], v[2], 0x07060302u);
+                typedef unsigned uintx2 __attribute__((ext_vector_type(2)));
+                hi = __builtin_bit_cast(half4, uintx2{h01, h23});
+                lo = __builtin_bit_cast(half4, uintx2{l01, l23});
+            } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const bool keep = ((ama[q] >> (8 * e)) & 0xffu) == want && wq + e < a.Wv;
@@ -146,6 +159,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kvec_f16_kernel(WgradKvecArgs a)
                 const _Float16 hh = (_Float16)v;
                 hi[e] = hh;
                 lo[e] = (_Float16)(v - (float)hh);
+            }
             }
             const int slot = (c4 >> 3) * 32 + wk_a_slot(c4 & 7);               // the k-step's K order (see wk_a_slot)
             *reinterpret_cast<half4 *>(dzA + co * WK_AP + slot) = hi;
@@ -280,7 +294,29 @@ MX_EXPORT int mx_conv_block1_wgrad_f16(const float *G, const uint8_t *amax, cons
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(wk_pow2_scale_kernel, dim3(1), dim3(1), 0, st, amax_bits, scale);
     WgradKvecArgs a{G, amax, scale, (const _Float16 *)xk_hi, (const _Float16 *)xk_lo, part, (int)B, (int)H, (int)Wv,
-                    (int)rows_per_slab, (int)n_slabs};
+                    (int)rows_per_slab, (int)n_slabs, 0};
+    static MxLdsLatch latch = {};                             // per device (common.h)
+    if (mx_set_dyn_lds(latch, (const void *)wgrad_kvec_f16_kernel, WK_LDS_BYTES) != MX_OK) return MX_ERR_LAUNCH;
+    hipLaunchKernelGGL(wgrad_kvec_f16_kernel, dim3((unsigned)n_slabs), dim3(256), WK_LDS_BYTES, st, a);
+    const int total = CV_KW * 64 * 16;
+    hipLaunchKernelGGL(wgrad_kvec_reduce_kernel, dim3(total / 16), dim3(256), 0, st, part, (int)n_slabs, scale, dW);
+    return mx_launch_status();
+}
+
+// The same weight gradient from G given as f16x3 PAIRS: Gp (B,64,H/2,352) uint32 = (hi | lo << 16) of G * scale[0] per element, written
+// by mx_ln_prelu_bwd_pair with scale = {S, 1/S} of mx_ln_bwd_finish (no amax_bits / scale kernel here).  Other arguments as above.
+MX_EXPORT int mx_conv_block1_wgrad_pair_f16(const void *Gp, const uint8_t *amax, const float *scale, const void *xk_hi,
+                                            const void *xk_lo, int64_t B, int64_t H, int64_t Wv, int64_t rows_per_slab,
+                                            float *part, float *dW, void *stream)
+{
+    if (!Gp || !amax || !scale || !xk_hi || !xk_lo || !part || !dW || B <= 0 || rows_per_slab <= 0) return MX_ERR_ARG;
+    if (H < 2 || (H & 1) || Wv <= 0 || Wv > CV_PITCH) return MX_ERR_UNSUPPORTED;
+    rows_per_slab += rows_per_slab & 1;
+    const int64_t n_slabs = (B * H + rows_per_slab - 1) / rows_per_slab;
+    if (n_slabs > 1000000) return MX_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    WgradKvecArgs a{(const float *)Gp, amax, scale, (const _Float16 *)xk_hi, (const _Float16 *)xk_lo, part, (int)B, (int)H, (int)Wv,
+                    (int)rows_per_slab, (int)n_slabs, 1};
     static MxLdsLatch latch = {};                             // per device (common.h)
     if (mx_set_dyn_lds(latch, (const void *)wgrad_kvec_f16_kernel, WK_LDS_BYTES) != MX_OK) return MX_ERR_LAUNCH;
     hipLaunchKernelGGL(wgrad_kvec_f16_kernel, dim3((unsigned)n_slabs), dim3(256), WK_LDS_BYTES, st, a);

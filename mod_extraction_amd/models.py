@@ -140,6 +140,9 @@ STATS_FUSED = os.environ.get("MODEX_STATS", "fused") != "sweep"   # next block's
 # on the sparse instruction): dL/dp never exists in fp32.  "split" keeps the two passes (A/B knob).
 GPOOL_FUSED = os.environ.get("MODEX_GPOOL", "fused") != "split"
 LN_FUSED = os.environ.get("MODEX_LN", "fused") != "sweep"      # LayerNorm-backward statistics from the data-gradient epilogue
+# the gradient of the first block handed to its weight gradient as f16x3 pairs (written in place by the LayerNorm backward, scale
+# from the bound on max|G|) instead of fp32 values that the weight gradient scales / splits while staging ("0": round-4 route)
+BLOCK1_PAIR = os.environ.get("MODEX_BLOCK1_PAIR", "1") != "0"
 
 
 def _use_f16(cin: int, precision: str) -> bool:
@@ -299,6 +302,7 @@ class _CNNStack(torch.autograd.Function):
         # one zeroed workspace for every atomic-max cell of this backward pass (each used to be its own fill launch): cells
         # 4 l .. 4 l + 3 belong to block l
         zws = torch.zeros(4 * (n_blocks + 1), device=dev, dtype=torch.int32)
+        pair_scale, pair1 = None, False   # the first block's gradient as f16x3 pairs (BLOCK1_PAIR)
         gmax_ws = zws[4 * n_blocks:4 * n_blocks + 1] if _use_f16(saved[3 * (n_blocks - 1)].size(1), precision) else None
         _hip.call("mx_head_bwd", _hip.ptr(p_last), _hip.ptr(slope_last), _hip.ptr(wout.contiguous()),
                   _hip.ptr(latent), _hip.ptr(out), _hip.ptr(d_out), _hip.ptr(d_latent), B, 64, Hl, n_frames, L,
@@ -315,7 +319,7 @@ class _CNNStack(torch.autograd.Function):
             slope_prev = params[3 * (l - 1) + 2].contiguous() if l > 0 else None
             # bias gradient: sum of G over (b, h, w)
             if DEBUG_TAP is not None:
-                if G is not None:                  # (with the fused LayerNorm backward dL/dp of blocks 2-4 never exists in fp32)
+                if G is not None and pair_scale is None:   # (with the fused LayerNorm backward dL/dp of blocks 2-4 never exists in fp32)
                     DEBUG_TAP[f"G{l}"] = G.clone()
                 DEBUG_TAP[f"amax{l}"] = amax.clone()
                 DEBUG_TAP[f"p{l}"] = (p_last if l == n_blocks - 1 else saved[3 * (l + 1)]).clone()
@@ -387,6 +391,16 @@ class _CNNStack(torch.autograd.Function):
                 del part
                 if not (sparse_d and LN_FUSED):
                     del x_hi, x_lo
+            elif l == 0 and 0 in ctx.splits and pair_scale is not None:
+                # first block on the fp16 pipes, gradient already in f16x3 pairs (mx_ln_prelu_bwd_pair): routed while staging
+                xk_hi, xk_lo = ctx.splits.pop(0)
+                rps = max(1, -(-rows // 2048))
+                n_slabs = -(-rows // rps)
+                part = torch.empty(n_slabs * 13 * 64 * 16, device=dev, dtype=torch.float32)
+                _hip.call("mx_conv_block1_wgrad_pair_f16", _hip.ptr(G), _hip.ptr(amax), _hip.ptr(pair_scale), _hip.ptr(xk_hi),
+                          _hip.ptr(xk_lo), B, H, n_frames, rps, _hip.ptr(part), _hip.ptr(dW), st)
+                pair_scale = None
+                del part, xk_hi, xk_lo
             elif l == 0 and 0 in ctx.splits and gmax_ws is not None:
                 # first block on the fp16 pipes: the kept k-vector operand, gradient routed / scaled / split on the fly
                 xk_hi, xk_lo = ctx.splits.pop(0)
@@ -409,7 +423,7 @@ class _CNNStack(torch.autograd.Function):
             grads[3 * l] = dW
             if l > 0:
                 dxhat = torch.empty((B, 64, H, PITCH), device=dev, dtype=torch.float32)
-                ln_part, fuse_g = None, False
+                ln_part, fuse_g, pair1 = None, False, False
                 if f16 and sparse_d:
                     # sparse matrix instruction, transposed tiles: pooled channels-last gradient x fragment-packed weights
                     ws_hi = torch.empty(4 * 3 * 2 * 13 * 2 * 64 * 16, device=dev, dtype=torch.float16)
@@ -421,7 +435,8 @@ class _CNNStack(torch.autograd.Function):
                         # that pass writes the block below's pooled operand itself, max|dxhat| / max|xhat| for its scale
                         ln_part = torch.empty((B, 64, H, 2, 2), device=dev, dtype=torch.float32)
                         fuse_g = GPOOL_FUSED and _pooled_only(l - 1, saved[3 * (l - 1)].size(1), dilations, precision, n_frames)
-                        gx_bits = zws[4 * l:4 * l + 2] if fuse_g else None
+                        pair1 = BLOCK1_PAIR and l == 1 and 0 in ctx.splits and not fuse_g
+                        gx_bits = zws[4 * l:4 * l + 2] if (fuse_g or pair1) else None
                         _hip.call("mx_conv_block_dgrad_sp_f16", _hip.ptr(gc_hi), _hip.ptr(gc_lo), _hip.ptr(gc_idx),
                                   _hip.ptr(ws_hi), _hip.ptr(ws_lo), _hip.ptr(scale), B, H, n_frames, int(dilations[l]),
                                   _hip.ptr(dxhat), _hip.ptr(x_hi), _hip.ptr(x_lo), _hip.ptr(ln_part), _hip.ptr(gx_bits), st)
@@ -464,6 +479,17 @@ class _CNNStack(torch.autograd.Function):
                     pooled = (gn_hi, gn_lo, gn_idx, gn_pidx, scale_n)
                     gmax_ws, G = None, None
                     del part2, m12, dxhat
+                elif pair1:
+                    # the first block's gradient as f16x3 pairs, in place: scale from the bound on max|G| (known before the pass)
+                    m12 = torch.empty((B, 64, 2), device=dev, dtype=torch.float32)
+                    bound_ws = torch.empty(1, device=dev, dtype=torch.int32)
+                    pair_scale = torch.empty(2, device=dev, dtype=torch.float32)
+                    _hip.call("mx_ln_bwd_finish", _hip.ptr(ln_part), _hip.ptr(stats), _hip.ptr(slope_prev), _hip.ptr(gx_bits),
+                              B, 64, H, n_frames, _hip.ptr(m12), _hip.ptr(bound_ws), _hip.ptr(pair_scale), st)
+                    _hip.call("mx_ln_prelu_bwd_pair", _hip.ptr(x_in), _hip.ptr(dxhat), _hip.ptr(stats), _hip.ptr(slope_prev),
+                              B, 64, H, n_frames, _hip.ptr(ds_part), _hip.ptr(bsum), _hip.ptr(ln_part), _hip.ptr(pair_scale), st)
+                    G, gmax_ws = dxhat, None
+                    del m12
                 else:
                     want_gmax = _use_f16(saved[3 * (l - 1)].size(1), precision) or (l == 1 and 0 in ctx.splits)
                     gmax_ws = zws[4 * l + 2:4 * l + 3] if want_gmax else None
