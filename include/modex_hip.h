@@ -45,6 +45,13 @@ int mx_lfo_synth(const float *freq, const float *phase, const int32_t *shape, co
                  const int32_t *start, int64_t B, int64_t n_src, int64_t n_out, float sr,
                  float *out, void *stream);
 
+/* Synthetic dry audio of the benchmark / test batches (no reference counterpart: the reference trains on recorded
+ * guitar): uniform noise in [lo, hi), Philox-4x32-10 keyed by (seed; sample, clip, counter).  Row of clip b at out + b * stride;
+ * rows: optional list of n_rows clip indices (NULL = 0 .. n_rows - 1); length of a row = (lens ? lens[clip] : 0) + len_add,
+ * at most max_len. */
+int mx_uniform_rows(float *out, int64_t stride, const int32_t *rows, int64_t n_rows, const int32_t *lens, int64_t len_add,
+                    int64_t max_len, uint64_t seed, uint32_t counter, float lo, float hi, void *stream);
+
 /* ---- util.py:15-29 (linear_interpolate_last_dim, align_corners=True): (rows,n_in)->(rows,n_out) */
 int mx_interp_linear(const float *x, int64_t rows, int64_t n_in, int64_t n_out, float *y,
                      void *stream);

@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # MODEX_HIP_LIB: load another build of the same library (kernel experiments); there is no non-HIP fallback
 SO_PATH = os.environ.get("MODEX_HIP_LIB") or os.path.join(_HERE, "_lib", "libmodex_hip.so")
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 _ERR = {-1: "MX_ERR_ARG (bad argument)", -2: "MX_ERR_UNSUPPORTED (size not supported)",
         -3: "MX_ERR_LAUNCH (HIP launch error)"}
@@ -23,6 +23,7 @@ _P, _I64, _I32, _F32, _F64 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ct
 SIGNATURES = {
     "mx_abi_version": [],
     "mx_lfo_synth": [_P, _P, _P, _P, _P, _I64, _I64, _I64, _F32, _P, _P],
+    "mx_uniform_rows": [_P, _I64, _P, _I64, _P, _I64, _I64, ctypes.c_uint64, ctypes.c_uint32, _F32, _F32, _P],
     "mx_interp_linear": [_P, _I64, _I64, _I64, _P, _P],
     "mx_interp_linear_bwd": [_P, _I64, _I64, _I64, _I64, _I64, _I64, _P, _P],
     "mx_flanger_fwd": [_P, _I64, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _I32, _P, _I64, _I64, _I64,

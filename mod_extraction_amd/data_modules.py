@@ -23,7 +23,7 @@ import numpy as np
 import torch
 from torch import Tensor as T
 
-from . import fx, util
+from . import _hip, fx, util
 from .modulations import SHAPE_IDS, make_mod_signals
 
 LFO_SHAPES = ["cos", "rect_cos", "inv_rect_cos", "tri", "saw", "rsaw"]
@@ -121,7 +121,9 @@ class SyntheticFxBatcher:
                      for _ in range(n_sets)]
         self._audio = [torch.empty((batch_size, 2, n_samples), device=device, dtype=torch.float32)
                        for _ in range(n_sets)]
-        self.src, self.audio = self._src[0], self._audio[0]
+        self._src_cur, self.audio = self._src[0], self._audio[0]
+        self.rows_nonph = torch.nonzero(self.kind_id != 2).view(-1).to(torch.int32).to(device)
+        self._noise_seed, self._noise_counter = int(audio_seed), 0
         # recorded audio is gathered on the host into a pinned staging buffer and copied over in one piece
         self._host = None
         self._host_ev = None                  # recorded after each async copy out of the pinned staging buffer
@@ -251,14 +253,24 @@ class SyntheticFxBatcher:
             if self._host_ev is not None:
                 self._host_ev.synchronize()       # the previous async H2D copy must have read the staging buffer
             self.chunk_source.fill(self._host, (extra + N).clamp(max=self._host.size(1)))
-            self.src.copy_(self._host, non_blocking=True)
+            self._src_cur.copy_(self._host, non_blocking=True)
             if dev.type == "cuda":
                 self._host_ev = torch.cuda.Event()
                 self._host_ev.record(torch.cuda.current_stream(dev))
+            self.audio[:, 0, :].copy_(self._src_cur[:, :N])
         else:
-            # synthetic dry audio: uniform noise at `peak`
-            self.src.uniform_(-self.peak, self.peak, generator=self.gen)
-        self.audio[:, 0, :].copy_(self.src[:, :N])
+            # synthetic dry audio: uniform noise at `peak`, written ONCE where it is read (csrc/noise.hip):
+            # clips without a phaser straight into the batch's dry channel, phaser clips into the staging row the phaser takes its
+            # lead-in from (N + lead samples of it; the phaser writes the cropped dry clip itself)
+            self._noise_counter += 1
+            st = _hip.stream()
+            if self.rows_nonph.numel():
+                _hip.call("mx_uniform_rows", _hip.ptr(self.audio), 2 * N, _hip.ptr(self.rows_nonph), int(self.rows_nonph.numel()),
+                          None, N, N, self._noise_seed, self._noise_counter, -self.peak, self.peak, st)
+            if self.has_ph:
+                _hip.call("mx_uniform_rows", _hip.ptr(self._src_cur), self._src_cur.stride(0), _hip.ptr(self.rows_ph),
+                          int(self.rows_ph.numel()), _hip.ptr(d["lead"].to(torch.int32).contiguous()), N, N + self.max_lead,
+                          self._noise_seed, self._noise_counter, -self.peak, self.peak, st)
         # LFO labels at n_samples // 100 points
         mod = make_mod_signals(self.n_lfo, self.lfo_sr, d["rate_hz"], d["phase"], shape_id, d["exp"])
         if self.has_ph:
@@ -275,10 +287,19 @@ class SyntheticFxBatcher:
                       "one_minus_mix": (1.0 - d["mix"]).contiguous()}
             fx.flanger_forward(dry, mod, consts, self.max_delay, self.max_delay_max, rows=self.rows_fx, out=wet)
         if self.has_ph:
-            fx.phaser_forward(self.src, d, d["lead"], self.sr, N, rows=self.rows_ph, out=wet, dry_out=dry)
+            fx.phaser_forward(self._src_cur, d, d["lead"], self.sr, N, rows=self.rows_ph, out=wet, dry_out=dry)
         fx_params = dict(d)
         fx_params["shape"] = p["shape"]
         return self.audio[:, 0:1, :], self.audio[:, 1:2, :], mod, fx_params
+
+    @property
+    def src(self) -> T:
+        """(B, N + longest lead) source audio of the batch rendered last (tests / smoke hand it to the oracle): rows without a
+        phaser are read back from the dry channel they were generated into."""
+        if self.chunk_source is None and self.rows_nonph.numel():
+            idx = self.rows_nonph.long()
+            self._src_cur[idx, :self.N] = self.audio[idx, 0, :]
+        return self._src_cur
 
     def use_side_stream(self, stream) -> None:
         """render ahead on ``stream`` (e.g. one confined to its own CUs, streams.cu_partition) instead of the private one"""
@@ -290,7 +311,7 @@ class SyntheticFxBatcher:
         main = torch.cuda.current_stream(self.device)
         slot = self._slot
         self._slot ^= 1
-        self.src, self.audio = self._src[slot], self._audio[slot]
+        self._src_cur, self.audio = self._src[slot], self._audio[slot]
         p = self.sample_params()
         with torch.cuda.stream(self._side), torch.no_grad():
             dev_params = self.to_device(p)      # host-blocking copies: before the wait below (see to_device)

@@ -71,7 +71,8 @@ def test_entry_points_reject_bad_arguments_before_touching_the_device(so_path):
     launches): NULL pointers and non-positive sizes are refused here on a box without a GPU."""
     from mod_extraction_amd import _hip
     lib = _hip.load()
-    zeros = {ctypes.c_void_p: None, ctypes.c_int64: 0, ctypes.c_int32: 0, ctypes.c_float: 0.0, ctypes.c_double: 0.0}
+    zeros = {ctypes.c_void_p: None, ctypes.c_int64: 0, ctypes.c_int32: 0, ctypes.c_float: 0.0, ctypes.c_double: 0.0,
+             ctypes.c_uint64: 0, ctypes.c_uint32: 0}
     skip = {"mx_abi_version"}
     checked = 0
     for name, argtypes in _hip.SIGNATURES.items():
