@@ -1542,11 +1542,20 @@ __global__ __launch_bounds__(256, 1) void conv1_f16x3_tile_kernel(ConvF16Args a,
 //   slots; the odd stage still issues its patch pieces only behind the barrier that follows the straddling pair.  The
 //   fragment bases become per-couple values (a dozen vector adds per 3 432 matrix instructions).
 //   Measured (one box, inside the train step): block 2 / 3 / 4 forward 12.24 -> 11.77 / 5.92 -> 5.72 / 2.96 -> 2.88 ms.
+#ifndef DMA16_PWP_PAD
+#define DMA16_PWP_PAD 1   // 0: the round-4 plane pitch (same-box A/B)
+#endif
 template <int T, bool RING>
 __global__ __launch_bounds__(256, 1) void conv_f16x3_dma16_kernel(ConvF16Args a)
 {
     constexpr int NCB = 4, NKH = CV_KH;
-    constexpr int PWP = CV_PITCH + 12 * T;
+    // Plane pitch of the patch images, in positions.  A B fragment of this kernel is read by lane groups (tap parity, k half): the
+    // hardware serves a ds_read_b128 sixteen lanes at a time -- eight lanes of k half 0 and eight of k half 1 -- and with 352 + 12 T
+    // positions per plane (5 824 / 6 016 bytes at T = 1 / 2: 192 / 128 mod 256) the two halves of a group met on the same banks:
+    // every patch-fragment read took twice its cycles (SQ_LDS_BANK_CONFLICT = 43 % of the kernel's LDS cycles at T = 1, 2 and 0.2 %
+    // at T = 4, whose 6 400-byte planes are a multiple of 256: profiles/r05/pmc_b64_lds.txt).  Rounded up to a multiple of 16
+    // positions every plane starts on bank 0 -- the extra positions are halo (zeros) and fit the same number of DMA pieces.
+    constexpr int PWP = DMA16_PWP_PAD ? (CV_PITCH + 12 * T + 15) / 16 * 16 : CV_PITCH + 12 * T;
     constexpr int WSL = CV_KW * 64 * 16;
     constexpr int PLANE = PWP * 16;
     constexpr int P_SLOTS = 8 * PWP;
@@ -1873,7 +1882,7 @@ __global__ __launch_bounds__(256, 1) void conv_f16x3_dma16_kernel(ConvF16Args a)
 template <int T, bool RING>
 static int launch_f16_dma16(const ConvF16Args &a, int B, hipStream_t st)
 {
-    constexpr int PWP = CV_PITCH + 12 * T;
+    constexpr int PWP = DMA16_PWP_PAD ? (CV_PITCH + 12 * T + 15) / 16 * 16 : CV_PITCH + 12 * T;
     constexpr size_t lds = 2 * (2 * 7 * 2048) + (RING ? 4 * (size_t)((4 * PWP + 63) / 64) : 2 * (size_t)((8 * PWP + 63) / 64)) * 1024;
     static_assert(lds <= 160 * 1024, "LDS budget");
     static MxLdsLatch latch = {};                             // per device (common.h)
