@@ -17,7 +17,6 @@
 // eight waves of a CU, is what this kernel waits for.)  Partial results per slab, deterministic fp64 slab reduction (as the other wgrad kernels).
 #include "conv_common.h"
 #include <stdlib.h>
-#include <type_traits>
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
@@ -35,7 +34,6 @@ typedef short short4v __attribute__((__vector_size__(4 * sizeof(short))));
 #define WK_A_BYTES (2 * 64 * WK_AP * 2)
 #define WK_B_ROWS ((WK_BR + 7) / 8 * 8)
 #define WK_LDS_BYTES (WK_A_BYTES + 2 * WK_B_ROWS * 32)
-#define WK_PIPE_IMG_BYTES (WK_A_BYTES + 3 * WK_B_ROWS * 32)   // pipelined kernel: a third B "split" takes the surplus stores
 
 struct WgradKvecArgs {
     const float *G;                     // (B, 64, H/2, 352) gradient w.r.t. the pooled output
@@ -242,196 +240,16 @@ __global__ __launch_bounds__(256, 2) void wgrad_kvec_f16_kernel(WgradKvecArgs a)
     }
 }
 
-// ---- the same weight gradient, software-pipelined (round 5; packed-pair gradient only; MODEX_WGRAD_KVEC=1 keeps the kernel above)
-// The kernel above runs two workgroups per CU so that one stages while the other multiplies; in practice the two stage and
-// multiply at the same time more often than not (matrix duty 52-58 %).  Here ONE workgroup per CU (one wave per SIMD, the whole
-// register file) does both at once by construction: the LDS images are double buffered, a unit's 5-6 k-steps of matrix
-// instructions carry, in their shadow, (i) the fragment reads of the next k-step (two fragment sets), (ii) a fifth of the NEXT
-// unit's staging pass per k-step (route by the row parity, unpack the f16x3 pairs, 8-byte stores into the other image) and
-// (iii) the global loads of the unit after that (two staging register sets: loads are issued a whole unit ahead of their
-// use).  One workgroup barrier per unit.  Unit = (row, chunk of 192 / 160 positions), in the order (row pair, chunk, row parity).
-__global__ __launch_bounds__(256, 1) void wgrad_kvec_pipe_kernel(WgradKvecArgs a)
-{
-    extern __shared__ __attribute__((aligned(256))) unsigned char wk_smem[];     // 2 x (A image 53,248 B | B image 19,968 B)
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tap0 = wave * 3 + (wave >> 1);
-    const int m16 = lane & 15, kg = lane >> 4;
-    const int slab = blockIdx.x;
-    const int Hp = a.H >> 1;
-    floatx4 acc[CV_KW];
-#pragma unroll
-    for (int i = 0; i < CV_KW; ++i) acc[i] = floatx4{0.f, 0.f, 0.f, 0.f};
-    const int a_lane = (m16 * WK_AP + 8 * kg) * 2;
-    const int b_lane = (4 * kg + (m16 >> 2)) * 32 + (m16 & 3) * 8;
-    constexpr int A_SPLIT = 64 * WK_AP * 2, B_SPLIT = WK_B_ROWS * 32, IMG = WK_PIPE_IMG_BYTES;
-
-    const int row_begin = slab * a.rows_per_slab;
-    int row_end = row_begin + a.rows_per_slab;
-    if (row_end > a.B * a.H) row_end = a.B * a.H;
-    const int n_units = (row_end - row_begin) * 2;             // rows come in pooling pairs: a multiple of 4
-    if (n_units <= 0) return;
-    // unit u -> (row, first position, k-steps)
-    auto unit_row = [&](int u) { return row_begin + 2 * (u >> 2) + (u & 1); };
-    auto unit_w0 = [&](int u) { return ((u >> 1) & 1) * WK_CH; };
-
-    floatx4 ga[2][12], vb[2][4];
-    unsigned ama[2][12];
-    // Loads of unit u, branch-free (an exec-masked load or store is a scheduling barrier for the matrix instructions around it):
-    // every lane loads from a clamped, valid address; what lies outside the unit is zeroed by a select -- the argmax word of an
-    // A item (0x02020202 matches neither row parity), the four dwords of a B item.  part 0: the 12 A items, part 1: the 4 B items.
-    // The per-thread part of every address is unit-invariant and kept in registers; a unit adds one scalar base.
-    int a_co_off[12], a_c4[12], b_pos[4], b_off16[4];
-#pragma unroll
-    for (int q = 0; q < 12; ++q) {
-        const int i = tid + q * 256, co = i / (WK_CH / 4), c4 = i - co * (WK_CH / 4);
-        a_co_off[q] = co * Hp * CV_PITCH;
-        a_c4[q] = c4 * 4;
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int i = tid + q * 256;
-        const int split = i / (WK_BR * 2), k = i - split * (WK_BR * 2);
-        b_pos[q] = i < 2 * WK_BR * 2 ? (k >> 1) : 100000;      // (items beyond the two splits never match a position)
-        b_off16[q] = (k & 1) * 8 + ((split & 1) ? 1 << 30 : 0); // bit 30: the lo operand
-    }
-    auto issue = [&](auto set_tag, int u, int part_sel) {
-        constexpr int SET = decltype(set_tag)::value;
-        const int rid = unit_row(u), w0 = unit_w0(u);
-        const int b = rid / a.H, h = rid - b * a.H;
-        const int npos = (CV_PITCH - w0 >= WK_CH) ? WK_CH : (CV_PITCH - w0);
-        if (part_sel == 0) {
-            const float *gb = a.G + ((size_t)b * 64 * Hp + (h >> 1)) * CV_PITCH + w0;              // wave-uniform
-            const unsigned char *ab = a.amax + ((size_t)b * 64 * Hp + (h >> 1)) * CV_PITCH + w0;
-#pragma unroll
-            for (int q = 0; q < 12; ++q) {
-                const bool in = a_c4[q] < npos;
-                const int off = a_co_off[q] + (in ? a_c4[q] : 0);
-                ga[SET][q] = *reinterpret_cast<const floatx4 *>(gb + off);         // (read by both rows of the pair: the second time from L2)
-                ama[SET][q] = *reinterpret_cast<const unsigned *>(ab + off);       // (raw: zeroed at commit time -- a select here would wait for the load)
-            }
-        } else {
-            const size_t rb = ((size_t)b * a.H + h) * CV_PITCH;                                      // wave-uniform
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int w = w0 - 6 + b_pos[q];
-                const bool in = b_pos[q] < npos + 12 && w >= 0 && w < CV_PITCH;
-                const _Float16 *src = ((b_off16[q] >> 30) ? a.xk_lo : a.xk_hi) + (rb + (in ? w : 0)) * 16 + (b_off16[q] & 8);
-                vb[SET][q] = *reinterpret_cast<const floatx4 *>(src);
-            }
-        }
-    };
-    // slice s (0..4) of the staging pass of the unit held in register set SET -> image buffer SET.  The B image has a third, unused
-    // "split": the 4 x 256 B items of a unit are 1 024 sixteen-byte stores for 816 slots, the rest land there (no exec mask)
-    auto commit_slice = [&](auto set_tag, int u, int s) {
-        constexpr int SET = decltype(set_tag)::value;
-        _Float16 *dzA = reinterpret_cast<_Float16 *>(wk_smem + SET * IMG);
-        _Float16 *xB = reinterpret_cast<_Float16 *>(wk_smem + SET * IMG + WK_A_BYTES);
-        const unsigned want = (unsigned)(unit_row(u) & 1);     // (H is even: row parity = parity of the row index)
-        const int w0c = unit_w0(u), nposc = (CV_PITCH - w0c >= WK_CH) ? WK_CH : (CV_PITCH - w0c);
-        const int q0 = s < 2 ? 3 * s : 2 * s + 2, q1 = s < 2 ? q0 + 3 : q0 + 2;       // items {0-2}, {3-5}, {6,7}, {8,9}, {10,11}
-#pragma unroll
-        for (int q = 0; q < 12; ++q) {
-            if (q < q0 || q >= q1) continue;
-            const int i = tid + q * 256, co = i / (WK_CH / 4), c4 = i - co * (WK_CH / 4);
-            unsigned v[4];
-            const unsigned amq = a_c4[q] < nposc ? ama[SET][q] : 0x02020202u;       // outside the unit: matches neither row
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = ((amq >> (8 * e)) & 0xffu) == want ? __float_as_uint(ga[SET][q][e]) : 0u;
-            const unsigned h01 = __builtin_amdgcn_perm(v[1], v[0], 0x05040100u), h23 = __builtin_amdgcn_perm(v[3], v[2], 0x05040100u);
-            const unsigned l01 = __builtin_amdgcn_perm(v[1], v[0], 0x07060302u), l23 = __builtin_amdgcn_perm(v[3], v[2], 0x07060302u);
-            typedef unsigned uintx2 __attribute__((ext_vector_type(2)));
-            const int slot = (c4 >> 3) * 32 + wk_a_slot(c4 & 7);
-            *reinterpret_cast<uintx2 *>(dzA + co * WK_AP + slot) = uintx2{h01, h23};
-            *reinterpret_cast<uintx2 *>(dzA + 64 * WK_AP + co * WK_AP + slot) = uintx2{l01, l23};
-        }
-        if (s < 4) {
-            const int i = tid + s * 256;
-            const int split = i / (WK_BR * 2), k = i - split * (WK_BR * 2);         // split 2 = the dump region
-            const int wv = w0c - 6 + b_pos[s];
-            const bool in = b_pos[s] < nposc + 12 && wv >= 0 && wv < CV_PITCH;
-            floatx4 bv = vb[SET][s];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) bv[e] = in ? bv[e] : 0.0f;
-            *reinterpret_cast<floatx4 *>(xB + (size_t)split * (WK_B_ROWS * 16) + (k >> 1) * 16 + (k & 1) * 8) = bv;
-        }
-    };
-    half8 ah[2][5], al[2][5], bh[2][4], bl[2][4];
-    auto rd_frags = [&](auto set_tag, int f, int ks) {
-        constexpr int SET = decltype(set_tag)::value;
-        const unsigned char *Ab = wk_smem + SET * IMG, *Bb = Ab + WK_A_BYTES;
-#pragma unroll
-        for (int j = 0; j < 5; ++j) {
-            const int jt = j < 4 ? j : wave;
-            ah[f][j] = *reinterpret_cast<const half8 *>(Ab + a_lane + jt * (16 * WK_AP * 2) + ks * 64);
-            al[f][j] = *reinterpret_cast<const half8 *>(Ab + A_SPLIT + a_lane + jt * (16 * WK_AP * 2) + ks * 64);
-        }
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int kw = t < 3 ? tap0 + t : 6;
-            bh[f][t] = tr_frag16(Bb, b_lane, ks * 32 + kw);
-            bl[f][t] = tr_frag16(Bb + B_SPLIT, b_lane, ks * 32 + kw);
-        }
-    };
-    // one unit: matrix instructions on image buffer SET, the next unit's staging into buffer SET ^ 1, the loads of the unit after it.
-    // Everything is unconditional and the k-step count a template constant (units come in groups of four: two of 6 k-steps, two
-    // of 5), so that a unit is ONE basic block the scheduler can interleave; past the slab's end the look-ahead repeats the last
-    // unit (a few wasted loads and stores per slab).
-    const int u_last = n_units - 1;
-    auto body = [&](auto set_tag, auto nks_tag, int u) {
-        constexpr int SET = decltype(set_tag)::value, NKS = decltype(nks_tag)::value;
-        using Other = std::integral_constant<int, SET ^ 1>;
-        const int u1 = u + 1 < n_units ? u + 1 : u_last, u2 = u + 2 < n_units ? u + 2 : u_last;
-        rd_frags(set_tag, 0, 0);
-#pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) {
-            const int f = ks & 1;
-            __builtin_amdgcn_sched_barrier(0);
-            if (ks + 1 < NKS) rd_frags(set_tag, f ^ 1, ks + 1);
-            if (ks < 5) commit_slice(Other{}, u1, ks);
-            if (ks < 2) issue(set_tag, u2, ks);                // into the register set this unit's own staging has left (consumed a unit ago)
-#pragma unroll
-            for (int x = 0; x < 13; ++x) acc[x] = mfma_16x16x32(al[f][x < 12 ? (x & 3) : 4], bh[f][x < 12 ? (x >> 2) : 3], acc[x]);
-#pragma unroll
-            for (int x = 0; x < 13; ++x) acc[x] = mfma_16x16x32(ah[f][x < 12 ? (x & 3) : 4], bl[f][x < 12 ? (x >> 2) : 3], acc[x]);
-#pragma unroll
-            for (int x = 0; x < 13; ++x) acc[x] = mfma_16x16x32(ah[f][x < 12 ? (x & 3) : 4], bh[f][x < 12 ? (x >> 2) : 3], acc[x]);
-#pragma unroll
-            for (int g_ = 0; g_ < 13; ++g_) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);      // MFMA
-                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);      // DS read
-                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);      // VALU
-                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);      // DS write
-                __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);      // VMEM read
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        __syncthreads();                                       // the next unit's images are complete; this unit's are free
-    };
-
-    using S0 = std::integral_constant<int, 0>;
-    using S1 = std::integral_constant<int, 1>;
-    using K6 = std::integral_constant<int, WK_KS_MAX>;
-    using K5 = std::integral_constant<int, (CV_PITCH - WK_CH) / 32>;
-    issue(S0{}, 0, 0); issue(S0{}, 0, 1);
-    issue(S1{}, 1, 0); issue(S1{}, 1, 1);
-#pragma unroll
-    for (int s_ = 0; s_ < 5; ++s_) commit_slice(S0{}, 0, s_);
-    __syncthreads();
-#pragma unroll 1
-    for (int u = 0; u < n_units; u += 4) {                     // (row pair: chunk 0 of both rows, then chunk 1 of both rows)
-        body(S0{}, K6{}, u);
-        body(S1{}, K6{}, u + 1);
-        body(S0{}, K5{}, u + 2);
-        body(S1{}, K5{}, u + 3);
-    }
-#pragma unroll
-    for (int u = 0; u < CV_KW; ++u) {
-        const int kw = u < 12 ? tap0 + (u >> 2) : 6, j = u < 12 ? (u & 3) : wave;
-        float *dst = a.part + (((size_t)slab * CV_KW + kw) * 64 + j * 16) * 16;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) dst[(4 * kg + r) * 16 + m16] = acc[u][r];
-    }
-}
+// ---- experiment record (round 5): the same weight gradient software-pipelined, ONE workgroup per CU ------------------------
+// Idea: instead of two workgroups per CU that stage and multiply at uncorrelated times (matrix duty 52-58 %), one workgroup
+// with double-buffered LDS images and two staging register sets, each unit's 5-6 k-steps of matrix instructions carrying the
+// next unit's staging pass and the loads of the unit after that in their shadow; one barrier per unit.  Measured on the same
+// box, headline batch: 3.27 ms with the out-of-range selects at load-issue time (every select waits for its load), 2.02 ms
+// with the selects moved to commit time and branch-free staging -- against 1.57 ms for the kernel above.  A lone wave per
+// SIMD issues about one vector instruction per 7 cycles, so the ~600 VALU/LDS instructions of a unit's staging pass do not
+// fit under its 214 matrix instructions (39 per k-step); the two-workgroup kernel hides the same work behind a second wave
+// per SIMD.  The matrix-instruction floor of this layer is 0.73 ms at 2.4 GHz (214 x 16 cycles x 512 units per CU): the
+// kernel above runs at 0.47 of it -- what is left is staging issue slots, not matrix throughput.  The pipelined kernel is in the history (commit b93fdee) and was removed from the build.
 
 // dW[co][ci][kh][kw] = (1/S) * sum over slabs of part[slab][kw][co][kh*2 + ci]   (fp64 accumulate, fixed order)
 // 256 threads = 16 slab lanes x 16 consecutive outputs: only 13 312 sums exist, so each is split over 16 lanes
@@ -511,18 +329,9 @@ MX_EXPORT int mx_conv_block1_wgrad_pair_f16(const void *Gp, const uint8_t *amax,
     hipStream_t st = (hipStream_t)stream;
     WgradKvecArgs a{(const float *)Gp, amax, scale, (const _Float16 *)xk_hi, (const _Float16 *)xk_lo, part, (int)B, (int)H, (int)Wv,
                     (int)rows_per_slab, (int)n_slabs, 1};
-    // default 1: the two-workgroups-per-CU kernel; MODEX_WGRAD_KVEC=2: the software-pipelined experiment (measured slower:
-    // 2.02 ms against 1.57 ms on the same box -- a lone wave per SIMD issues its staging VALU work too slowly)
-    static const int variant = getenv("MODEX_WGRAD_KVEC") ? atoi(getenv("MODEX_WGRAD_KVEC")) : 1;
-    if (variant == 2) {
-        static MxLdsLatch latch2 = {};
-        if (mx_set_dyn_lds(latch2, (const void *)wgrad_kvec_pipe_kernel, 2 * WK_PIPE_IMG_BYTES) != MX_OK) return MX_ERR_LAUNCH;
-        hipLaunchKernelGGL(wgrad_kvec_pipe_kernel, dim3((unsigned)n_slabs), dim3(256), 2 * WK_PIPE_IMG_BYTES, st, a);
-    } else {
-        static MxLdsLatch latch = {};                             // per device (common.h)
-        if (mx_set_dyn_lds(latch, (const void *)wgrad_kvec_f16_kernel, WK_LDS_BYTES) != MX_OK) return MX_ERR_LAUNCH;
-        hipLaunchKernelGGL(wgrad_kvec_f16_kernel, dim3((unsigned)n_slabs), dim3(256), WK_LDS_BYTES, st, a);
-    }
+    static MxLdsLatch latch = {};                             // per device (common.h)
+    if (mx_set_dyn_lds(latch, (const void *)wgrad_kvec_f16_kernel, WK_LDS_BYTES) != MX_OK) return MX_ERR_LAUNCH;
+    hipLaunchKernelGGL(wgrad_kvec_f16_kernel, dim3((unsigned)n_slabs), dim3(256), WK_LDS_BYTES, st, a);
     const int total = CV_KW * 64 * 16;
     hipLaunchKernelGGL(wgrad_kvec_reduce_kernel, dim3(total / 16), dim3(256), 0, st, part, (int)n_slabs, scale, dW);
     return mx_launch_status();
