@@ -424,6 +424,39 @@ int mx_tcn_act_bwd(const float *dy, const float *zb, const float *slope, int64_t
 int mx_tcn_ln_bwd(const float *x, const float *dxhat, const float *stats, const float *add, int64_t B, int64_t C,
                   int64_t T, float *dx, void *stream);
 
+/* ---- Spectral2DCNN outside the 5x13 / 64-channel / pool (2,1) family -- mod_extraction/models.py:127-215 with any kernel
+ * size, channel list, dilations, MaxPool2d((p,1)), use_ln, in_ch, frame count and latent_dim (the class's own defaults
+ * are such a configuration).  Dense NCHW fp32 tensors, exact fp32 arithmetic; the three convolution products are
+ * mx_sgemm_f32 on the matrices these gathers build.
+ * mx_im2col2d: col[(ci kh + i) kw + j][(b H + h) W + w] = x[b][ci][h + i dh - pt][w + j dw - pl] (0 outside the image) for
+ *   the nb clips at x; "same" padding (models.py:187): pt = dh (kh - 1) / 2, pl = dw (kw - 1) / 2 (aten: the remainder goes
+ *   after).  mx_col2im2d: the transposed gather, dx[b][ci][y][x] = sum over taps of dcol[...] (gradient w.r.t. x).
+ * mx_rowln_fwd / _bwd: nn.LayerNorm([bins, frames], elementwise_affine=False) (models.py:186) of `rows` contiguous rows of n
+ *   elements: y = (x - mean) rstd, stats (rows, 2) = {mean, rstd}; dx = rstd (dy - mean(dy) - y mean(dy y)).
+ * mx_pool_prelu_fwd / _bwd: Conv2d bias + MaxPool2d((p,1)) + PReLU(C) (models.py:187-189) of the products z (planes, H, W),
+ *   planes = B C: v (planes, H/p, W) = window maximum of z + bias[c] (first maximum wins; rows beyond (H/p) p are dropped), out = v > 0 ? v : slope[c] v,
+ *   amax = row offset of the maximum; backward: dz (planes, H, W) routed (zero elsewhere), part (planes, 2) = {sum of dz
+ *   (bias gradient), sum of g v where v <= 0 (slope gradient)} -> mx_reduce_rows over the clips.
+ * mx_binmean_head_fwd / _bwd: latent (B, C, W) = mean over bins of x (B, C, H, W), out (B, L, W) = sigmoid(Conv1d(C, L, 1))
+ *   (models.py:209-215); backward from d_out (B, L, W) and / or d_latent (B, C, W) (either may be NULL): ds (B, L, W) = the
+ *   gradient at the Conv1d output (its weight / bias gradients are an mx_sgemm_f32 / mx_row_sums of it), dx (B, C, H, W).
+ * mx_row_sums: out[r] = sum of the n contiguous elements of row r (fp64 accumulate). */
+int mx_im2col2d(const float *x, int64_t nb, int64_t Cin, int64_t H, int64_t W, int64_t kh, int64_t kw, int64_t dh, int64_t dw,
+                int64_t pt, int64_t pl, float *col, void *stream);
+int mx_col2im2d(const float *dcol, int64_t nb, int64_t Cin, int64_t H, int64_t W, int64_t kh, int64_t kw, int64_t dh, int64_t dw,
+                int64_t pt, int64_t pl, float *dx, void *stream);
+int mx_rowln_fwd(const float *x, int64_t rows, int64_t n, float eps, float *y, float *stats, void *stream);
+int mx_rowln_bwd(const float *dy, const float *y, const float *stats, int64_t rows, int64_t n, float *dx, void *stream);
+int mx_row_sums(const float *x, int64_t rows, int64_t n, float *out, void *stream);
+int mx_pool_prelu_fwd(const float *z, const float *bias, int64_t planes, int64_t C, int64_t H, int64_t W, int64_t p,
+                      const float *slope, float *v, float *out, uint8_t *amax, void *stream);
+int mx_pool_prelu_bwd(const float *g, const float *v, const uint8_t *amax, int64_t planes, int64_t C, int64_t H, int64_t W,
+                      int64_t p, const float *slope, float *dz, float *part, void *stream);
+int mx_binmean_head_fwd(const float *x, int64_t B, int64_t C, int64_t H, int64_t W, const float *wout, const float *bout,
+                        int64_t L, float *latent, float *out, void *stream);
+int mx_binmean_head_bwd(const float *d_out, const float *d_latent, const float *out, const float *wout, int64_t B, int64_t C,
+                        int64_t H, int64_t W, int64_t L, float *ds, float *dx, void *stream);
+
 /* ---- effect-model losses -- mod_extraction/losses.py:14-67 (ESR, DC) and nn.L1Loss:
  * part (B,4) = per-clip sums of |y - y_hat|, (y - y_hat)^2, y^2, (y - y_hat). */
 int mx_effect_loss_sums(const float *y_hat, int64_t y_hat_stride, const float *y, int64_t y_stride, int64_t B,

@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # MODEX_HIP_LIB: load another build of the same library (kernel experiments); there is no non-HIP fallback
 SO_PATH = os.environ.get("MODEX_HIP_LIB") or os.path.join(_HERE, "_lib", "libmodex_hip.so")
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 _ERR = {-1: "MX_ERR_ARG (bad argument)", -2: "MX_ERR_UNSUPPORTED (size not supported)",
         -3: "MX_ERR_LAUNCH (HIP launch error)"}
@@ -80,6 +80,15 @@ SIGNATURES = {
     "mx_tcn_act_fwd": [_P, _P, _P, _P, _I64, _I64, _I64, _P, _P],
     "mx_tcn_act_bwd": [_P, _P, _P, _I64, _I64, _I64, _P, _P, _P],
     "mx_tcn_ln_bwd": [_P, _P, _P, _P, _I64, _I64, _I64, _P, _P],
+    "mx_im2col2d": [_P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _P, _P],
+    "mx_col2im2d": [_P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _P, _P],
+    "mx_rowln_fwd": [_P, _I64, _I64, _F32, _P, _P, _P],
+    "mx_rowln_bwd": [_P, _P, _P, _I64, _I64, _P, _P],
+    "mx_row_sums": [_P, _I64, _I64, _P, _P],
+    "mx_pool_prelu_fwd": [_P, _P, _I64, _I64, _I64, _I64, _I64, _P, _P, _P, _P, _P],
+    "mx_pool_prelu_bwd": [_P, _P, _P, _I64, _I64, _I64, _I64, _I64, _P, _P, _P, _P],
+    "mx_binmean_head_fwd": [_P, _I64, _I64, _I64, _I64, _P, _P, _I64, _P, _P, _P],
+    "mx_binmean_head_bwd": [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _P, _P, _P],
     "mx_effect_loss_sums": [_P, _I64, _P, _I64, _I64, _I64, _P, _P],
     "mx_effect_loss_grad": [_P, _I64, _P, _I64, _I64, _I64, _F32, _F32, _F32, _F32, _F32, _I32, _P, _I64, _P],
     "mx_mrstft_loss": [_P, _I64, _P, _I64, _I64, _I64, _I32, _P, _P, _P, _P, _F32, _F32, _F32, _P, _P, _P, _P, _P,

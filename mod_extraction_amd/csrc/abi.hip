@@ -4,4 +4,4 @@
 // from the environment (MODEX_MFMA_SHAPE, MODEX_PATCH_RING, MODEX_BLOCK1_PERSIST, MODEX_LSTM_KQ: kernel variants that compute the
 // same results; DESIGN.md names each).
 #include "common.h"
-MX_EXPORT int mx_abi_version(void) { return 15; }
+MX_EXPORT int mx_abi_version(void) { return 16; }

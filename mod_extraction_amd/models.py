@@ -88,16 +88,16 @@ class MelSpectrogramHIP(nn.Module):
             self._bands = (lo.to(fb.device), hi.to(fb.device), fb._version)
         return self._bands[0], self._bands[1]
 
-    def log_mel(self, x: T, n_frames: int, eps: float, masks: Sequence[int] = (0, 0, 0, 0)) -> T:
-        """x (B, C, N) -> (B, C, n_mels, PITCH) = log(clip(mel, eps)) with SpecAugment ranges."""
+    def log_mel(self, x: T, n_frames: int, eps: float, masks: Sequence[int] = (0, 0, 0, 0), pitch: int = PITCH) -> T:
+        """x (B, C, N) -> (B, C, n_mels, pitch) = log(clip(mel, eps)) with SpecAugment ranges."""
         B, C, N = x.shape
         xc = x.contiguous().float()
-        out = torch.empty((B, C, self.n_mels, PITCH), device=x.device, dtype=torch.float32)
+        out = torch.empty((B, C, self.n_mels, pitch), device=x.device, dtype=torch.float32)
         lo, hi = self.bands()
         f0, f1, t0, t1 = (int(v) for v in masks)
         _hip.call("mx_logmel_fwd", _hip.ptr(xc), B * C, N, _hip.ptr(self.spectrogram.window), _hip.ptr(self.twiddle),
                   _hip.ptr(self.mel_scale.fb), _hip.ptr(lo), _hip.ptr(hi), self.n_fft, self.hop_length, self.n_mels,
-                  n_frames, PITCH, float(eps), f0, f1, t0, t1, _hip.ptr(out), _hip.stream())
+                  n_frames, pitch, float(eps), f0, f1, t0, t1, _hip.ptr(out), _hip.stream())
         return out
 
 
@@ -537,15 +537,19 @@ class Spectral2DCNN(nn.Module):
             list(temp_dilations)
         self.in_ch = in_ch
         self.n_frames = n_samples // hop_len + 1
-        # what the gfx950 kernels are built for (the only configuration the reference ships):
-        unsupported = (self.kernel_size != (5, 13) or self.pool_size != (2, 1) or not use_ln
-                       or any(c != 64 for c in out_channels) or any(d != 1 for d in bin_dilations)
-                       or any(d not in (1, 2, 4, 8, 16) for d in temp_dilations) or in_ch not in (1, 2)
-                       or self.n_frames > PITCH or n_mels % (2 ** len(out_channels)) != 0 or latent_dim > 4)
-        if unsupported:
-            raise NotImplementedError("Spectral2DCNN HIP kernels support the shipped spectral_2dcnn.yml family: "
-                                      "5x13 kernels, 64 channels, pool (2,1), LayerNorm, temp dilations in "
-                                      "{1,2,4,8,16}, in_ch <= 2, <= 352 frames")
+        # what the f16x3 / fp32 block kernels are built for (the only configuration the reference ships); everything else -- the
+        # class's own defaults included -- runs the general kernels of csrc/cnn_generic.hip (cnn_generic.GenericCNNStack)
+        self.generic = (self.kernel_size != (5, 13) or self.pool_size != (2, 1) or not use_ln
+                        or any(c != 64 for c in out_channels) or any(d != 1 for d in bin_dilations)
+                        or any(d not in (1, 2, 4, 8, 16) for d in temp_dilations) or in_ch not in (1, 2)
+                        or self.n_frames > PITCH or n_mels % (2 ** len(out_channels)) != 0 or latent_dim > 4)
+        if self.generic:
+            n_bins = n_mels
+            for _ in out_channels:
+                n_bins //= self.pool_size[0]
+            if n_bins < 1 or min(self.kernel_size) < 1 or min(self.bin_dilations + self.temp_dilations) < 1 or self.pool_size[0] > 255:
+                raise ValueError(f"Spectral2DCNN: {n_mels} mel bins do not survive {len(out_channels)} poolings by "
+                                 f"{self.pool_size[0]} (or a kernel size / dilation below 1)")
         self.conv_precision = CONV_PRECISION        # "f16x3" (default) or "f32", see the module header
         self.spectrogram = MelSpectrogramHIP(int(sr), n_fft, hop_len, n_mels)
         self.freq_mask_param = int(freq_mask_amount * n_mels)
@@ -553,7 +557,8 @@ class Spectral2DCNN(nn.Module):
         layers: List[nn.Module] = []
         n_bins, c_in = n_mels, in_ch
         for out_ch, b_dil, t_dil in zip(out_channels, bin_dilations, temp_dilations):
-            layers.append(nn.LayerNorm([n_bins, self.n_frames], elementwise_affine=False))
+            if use_ln:
+                layers.append(nn.LayerNorm([n_bins, self.n_frames], elementwise_affine=False))
             layers.append(nn.Conv2d(c_in, out_ch, self.kernel_size, stride=(1, 1), dilation=(b_dil, t_dil),
                                     padding="same"))
             layers.append(nn.MaxPool2d(kernel_size=self.pool_size))
@@ -564,10 +569,11 @@ class Spectral2DCNN(nn.Module):
 
     def _stack_params(self) -> List[T]:
         ps: List[T] = []
+        per, first = (4, 1) if self.use_ln else (3, 0)          # module indices as in the reference's nn.Sequential (models.py:184-191)
         for i in range(len(self.out_channels)):
-            conv, prelu = self.cnn[4 * i + 1], self.cnn[4 * i + 3]
+            conv, prelu = self.cnn[per * i + first], self.cnn[per * i + first + 2]
             w = conv.weight
-            if i == 0 and self.in_ch == 1:      # pad the single input channel to the 2-channel kernel
+            if i == 0 and self.in_ch == 1 and not self.generic:      # pad the single input channel to the 2-channel kernel
                 w = torch.cat([w, torch.zeros_like(w)], dim=1)
             ps += [w, conv.bias, prelu.weight]
         # (the Conv1d's (latent_dim, 64, 1) weight itself, not a 2-D view of it: a view is not a leaf, and its gradient could
@@ -589,6 +595,9 @@ class Spectral2DCNN(nn.Module):
         n_frames = x.size(-1) // self.hop_len + 1
         assert n_frames == self.n_frames, "clip length does not match the LayerNorm shape"
         masks = self.draw_masks() if masks is None else masks
+        if self.generic:                        # dense (B, in_ch, n_mels, n_frames)
+            with torch.no_grad():
+                return self.spectrogram.log_mel(x, self.n_frames, self.eps, masks, pitch=self.n_frames)
         if self.in_ch == 1:
             x = torch.cat([x, torch.zeros_like(x)], dim=1)
         with torch.no_grad():
@@ -596,6 +605,11 @@ class Spectral2DCNN(nn.Module):
 
     def forward(self, x: T, masks: Optional[Sequence[int]] = None) -> (T, T):
         logmel = self.log_mel(x, masks)
+        if self.generic:
+            from .cnn_generic import GenericCNNStack
+            cfg = (self.kernel_size, int(self.pool_size[0]), bool(self.use_ln),
+                   tuple(zip(self.out_channels, self.bin_dilations, self.temp_dilations)))
+            return GenericCNNStack.apply(logmel, cfg, *self._stack_params())
         out, latent = _CNNStack.apply(logmel, self.n_frames, tuple(self.temp_dilations), self.conv_precision,
                                       *self._stack_params())
         return out, latent

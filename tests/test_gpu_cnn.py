@@ -163,16 +163,21 @@ def test_lfo_loss_kernel(dev):
 ], ids=["4blocks-permuted", "3blocks-dilated-first", "5blocks-pow2"])
 def test_cnn_other_members_of_the_supported_family(dev, over, precision):
     """Block counts, dilation orders, mel-bin counts and latent widths other than the shipped spectral_2dcnn.yml, inside
-    what Spectral2DCNN accepts (everything else raises NotImplementedError, test below)."""
+    what the f16x3 / fp32 block kernels cover (everything else takes the general kernels, test below)."""
     ref, mine = make_pair(dev, n_samples=22272, **over)
     mine.conv_precision = precision
     ref.eval(); mine.eval()
     run_pair(dev, ref, mine, audio(3, 22272), (2, 7, 10, 31))
 
 
-def test_cnn_outside_the_family_raises(dev):
+def test_cnn_outside_the_family_takes_the_general_kernels(dev):
+    """Configurations the f16x3 block kernels are not built for no longer raise: they run csrc/cnn_generic.hip
+    (tests/test_gpu_generic_cnn.py holds their parity tests); the shipped family stays on the fast kernels."""
     from mod_extraction_amd import models as amodels
-    for bad in (dict(kernel_size=(3, 3)), dict(pool_size=(3, 1)), dict(out_channels=[32] * 6), dict(use_ln=False),
-                dict(temp_dilations=[1, 1, 2, 4, 8, 32]), dict(n_mels=100), dict(n_samples=200000)):
-        with pytest.raises((NotImplementedError, AssertionError)):
-            amodels.Spectral2DCNN(**{**CFG, "n_samples": 88200, **bad})
+    assert not amodels.Spectral2DCNN(**{**CFG, "n_samples": 88200}).generic
+    for other in (dict(kernel_size=(3, 3)), dict(pool_size=(3, 1), out_channels=[64] * 5, temp_dilations=[1, 2, 4, 8, 16]),
+                  dict(out_channels=[32] * 6), dict(use_ln=False), dict(temp_dilations=[1, 1, 2, 4, 8, 32]), dict(n_mels=100),
+                  dict(n_samples=200000)):
+        assert amodels.Spectral2DCNN(**{**CFG, "n_samples": 88200, **other}).generic
+    with pytest.raises(ValueError):             # 256 bins do not survive six poolings by 3
+        amodels.Spectral2DCNN(**{**CFG, "n_samples": 88200, "pool_size": (3, 1)})
