@@ -457,6 +457,23 @@ int mx_binmean_head_fwd(const float *x, int64_t B, int64_t C, int64_t H, int64_t
 int mx_binmean_head_bwd(const float *d_out, const float *d_latent, const float *out, const float *wout, int64_t B, int64_t C,
                         int64_t H, int64_t W, int64_t L, float *ds, float *dx, void *stream);
 
+/* ---- LSTMEffectModel of any size -- mod_extraction/models.py:311-339 with in_ch / out_ch / n_hidden / latent_dim other than
+ * the shipped 1 / 1 / 64 / 1 (a param_model, lightning.py:344-347, widens latent_dim).  Only the recurrences are kernels of
+ * their own; the input projection, the output layer and every gradient product are mx_sgemm_f32 calls over all steps.
+ * mx_lstmg_fwd: zin (B, T, 4 Hn) = W_ih u_t (gate order i, f, g, o); per step gates = act(zin + bias_ih + bias_hh + W_hh h),
+ *   c = f c + i g, h = o tanh(c); stash (B, T, 6, Hn) = (i, f, g, o, c, h) of every step; (h1, c1) = the final state.
+ * mx_lstmg_bwd: dhfc (B, T, Hn) = d loss / d h_t through the output layer; dgate (B, T, 4 Hn) = d loss / d gate
+ *   pre-activations (BPTT inside the chunk; the incoming state is a constant, lightning.py:353,383).
+ * mx_lstmg_out_fwd: y (B, Co, T) = tanh(fc (B, T, out_ch) + bias + x (B, in_ch, T)), Co = max(out_ch, in_ch), torch's
+ *   broadcast (models.py:337-338).  mx_lstmg_out_bwd: dpre (B, T, out_ch) = dy (1 - y^2) summed over the broadcast channels. */
+int mx_lstmg_fwd(const float *zin, const float *bias_ih, const float *bias_hh, const float *w_hh, const float *h0, const float *c0,
+                 int64_t B, int64_t T, int64_t Hn, float *stash, float *h1, float *c1, void *stream);
+int mx_lstmg_bwd(const float *stash, const float *dhfc, const float *w_hh, const float *c0, int64_t B, int64_t T, int64_t Hn,
+                 float *dgate, void *stream);
+int mx_lstmg_out_fwd(const float *fc, const float *bias, const float *x, int64_t B, int64_t T, int64_t out_ch, int64_t in_ch,
+                     float *y, void *stream);
+int mx_lstmg_out_bwd(const float *dy, const float *y, int64_t B, int64_t T, int64_t out_ch, int64_t Co, float *dpre, void *stream);
+
 /* ---- effect-model losses -- mod_extraction/losses.py:14-67 (ESR, DC) and nn.L1Loss:
  * part (B,4) = per-clip sums of |y - y_hat|, (y - y_hat)^2, y^2, (y - y_hat). */
 int mx_effect_loss_sums(const float *y_hat, int64_t y_hat_stride, const float *y, int64_t y_stride, int64_t B,

@@ -161,6 +161,12 @@ class LFOExtraction(BaseLightingModule):
             return step(batch, is_training=False)
 
 
+def _channel_rows(t: T) -> T:
+    """(B, C, T) -> (B C, 1, T): the effect-model losses reduce over clips AND channels alike (losses.py:33-38,61-66: a mean over
+    (batch, channel) of per-row ratios; nn.L1Loss: a mean over everything)."""
+    return t if t.size(1) == 1 else t.contiguous().view(-1, 1, t.size(-1))
+
+
 class TBPTTLFOEffectModeling(BaseLightingModule):
     """lightning.py:202-431: frozen LFO-net -> smooth / stretch / crop -> discard invalid LFOs -> LSTM
     effect model trained with truncated BPTT (1024-sample warm-up, then one optimizer step per
@@ -188,8 +194,9 @@ class TBPTTLFOEffectModeling(BaseLightingModule):
                  loss_dict: Optional[Dict[str, float]] = None) -> None:
         super().__init__(loss_dict)
         assert warmup_n_samples > 0
-        if param_model is not None:
-            raise NotImplementedError("param_model is not used by any shipped config")
+        # param_model (lightning.py:344-347,371-375): any nn.Module wet (B, C, n) -> (B, P); its output is repeated over time and
+        # concatenated to the LFO as extra latent channels (the effect model then has latent_dim = 1 + P, i.e. the general LSTM
+        # of lstm_generic.py, an autograd node -- the step below runs such models through `_general_train_chunk`).
         # freeze_lfo_model: false (lightning.py:258,344-366): the extractor is re-run inside every TBPTT step and trained through the
         # effect model -- CNN -> moving average -> stretch_corners -> resampling -> LSTM, every stage with a backward kernel
         # (common_step below, `relearn`).
@@ -353,11 +360,15 @@ class TBPTTLFOEffectModeling(BaseLightingModule):
         # input -- the reference does not re-apply its validity filter there, so it only works when no clip was dropped)
         relearn = (is_training and self.lfo_model is not None and not self.freeze_lfo_model
                    and not isinstance(self.lfo_model, RandomLFO))
+        # effect models outside the fused LSTM-64 kernels, and every step with a param_model, go through autograd
+        general = bool(getattr(em, "generic", False)) or self.param_model is not None
+        lfo_in = None
         if relearn:
             if B != batch[0].size(0):
                 raise ValueError("freeze_lfo_model: false re-extracts the LFO of EVERY clip inside the step (lightning.py:344-349): "
                                  "it cannot be combined with clips dropped by discard_invalid_lfos")
             lfo_in = stack_dry_wet(batch[0], batch[1]) if self.use_dry else batch[1]
+        if relearn and not general:
             g_off = (em.lstm.weight_ih_l0.grad.data_ptr() - optimizer.flat_grad.data_ptr()) // 4
             from .models import LSTM_NPARAM
             assert em.fc.bias.grad.data_ptr() == optimizer.flat_grad.data_ptr() + 4 * (g_off + LSTM_NPARAM - 1), \
@@ -365,9 +376,16 @@ class TBPTTLFOEffectModeling(BaseLightingModule):
             lstm_grad = optimizer.flat_grad[g_off:g_off + LSTM_NPARAM]
         em.clear_hidden()
         with torch.no_grad():
-            chunks = [em.run_chunk(dry[:, :, :W], lfo_sr[:, :, :W])[0]]          # warm-up, no loss
+            param_latent = None
+            if general:
+                if self.param_model is not None:
+                    param_latent = self.param_model(wet).unsqueeze(-1)            # lightning.py:344-347
+                chunks = [em(dry[:, :, :W], self._with_params(lfo_sr[:, :, :W], param_latent))]
+            else:
+                chunks = [em.run_chunk(dry[:, :, :W], lfo_sr[:, :, :W])[0]]          # warm-up, no loss
             if is_training:
                 em.detach_hidden()
+            if is_training and not general:
                 stash = torch.empty((B, S, 384), device=dry.device, dtype=torch.float32)
                 w_l1 = float(self.loss_dict.get("l1", 0.0))
             done = 0
@@ -376,7 +394,13 @@ class TBPTTLFOEffectModeling(BaseLightingModule):
                 if end > n:
                     break
                 x, lat, tgt = dry[:, :, start:end], lfo_sr[:, :, start:end], wet[:, :, start:end]
-                if relearn:
+                if general and is_training:
+                    y, lfo_sr, mod_sig_hat = self._general_train_chunk(x, tgt, wet, lfo_sr, mod_sig_hat, start, end, lfo_in if relearn
+                                                                       else None, optimizer, world_size)
+                    done += 1
+                elif general:
+                    y = em(x, self._with_params(lat, param_latent))
+                elif relearn:
                     # lightning.py:344-384 with the extractor in the graph: CNN -> moving average -> resampling -> this chunk
                     # of the LFO -> LSTM -> loss; backward in the opposite order, every stage on its own kernel
                     optimizer.zero_grad()
@@ -424,10 +448,11 @@ class TBPTTLFOEffectModeling(BaseLightingModule):
             wet_hat = torch.cat(chunks, dim=-1)
             m = wet_hat.size(-1)
             dry_c, wet_c, wet_hat = dry[:, :, W:m], wet[:, :, W:m].contiguous(), wet_hat[:, :, W:m].contiguous()
-            terms = effect_loss_terms(wet_hat, wet_c)
+            wet_c = wet_c.expand_as(wet_hat).contiguous() if wet_c.shape != wet_hat.shape else wet_c
+            terms = effect_loss_terms(_channel_rows(wet_hat), _channel_rows(wet_c))
             for name in self.loss_dict:
                 if name not in terms:
-                    terms[name] = self._loss_module(name)(wet_hat, wet_c)
+                    terms[name] = self._loss_module(name)(_channel_rows(wet_hat), _channel_rows(wet_c))
             loss = None
             for name, w in self.loss_dict.items():
                 self.log(f"{prefix}/{name}", terms[name])
@@ -438,6 +463,50 @@ class TBPTTLFOEffectModeling(BaseLightingModule):
         if mod_sig is not None:
             data_dict["mod_sig"] = mod_sig
         return loss, data_dict, batch[3]
+
+    @staticmethod
+    def _with_params(lfo: T, param_latent: Optional[T]) -> T:
+        """lightning.py:345-347,374-375: the param_model's vector repeated over the chunk, after the LFO channel."""
+        if param_latent is None:
+            return lfo
+        return torch.cat([lfo, param_latent.repeat(1, 1, lfo.size(-1))], dim=1)
+
+    def _general_train_chunk(self, x, tgt, wet, lfo_sr, mod_sig_hat, start, end, lfo_in, optimizer, world_size):
+        """One TBPTT training step (lightning.py:358-384) with the effect model as an autograd node: any LSTM size, a
+        param_model in the graph (re-evaluated on every step like the reference does), and -- ``lfo_in`` given -- the unfrozen
+        extractor re-run and trained through the LFO it produces (the backward chain of the fused path: resampling window ->
+        stretch_corners -> moving average -> CNN)."""
+        from .effect_losses import effect_loss_grad
+        from .trainer import allreduce_flat_grad
+        em, n = self.effect_model, wet.size(-1)
+        optimizer.zero_grad()
+        with torch.enable_grad():
+            hat = None
+            if lfo_in is not None:
+                hat, _ = self.lfo_model(lfo_in)
+                hs = smoothen(hat.detach().squeeze(1), self.model_smooth_n_frames)
+                hst = stretch_corners(hs, max_n_corners=self.max_n_corners, smooth_n_frames=self.stretch_smooth_n_frames) \
+                    if self.should_stretch else hs
+                lfo_sr = linear_interpolate_last_dim(hst, n, align_corners=True).unsqueeze(1)
+                mod_sig_hat = hst
+            lat_lfo = lfo_sr[:, :, start:end]
+            if hat is not None:
+                lat_lfo = lat_lfo.detach().clone().requires_grad_(True)
+            p = self.param_model(wet).unsqueeze(-1) if self.param_model is not None else None       # lightning.py:371-373
+            y = em(x, self._with_params(lat_lfo, p))
+        tgt = tgt.expand_as(y) if tgt.shape != y.shape else tgt
+        dy = effect_loss_grad(_channel_rows(y.detach()), _channel_rows(tgt), self.loss_dict,
+                              mrstft=self._loss_module("mrstft") if "mrstft" in self.loss_dict else None)
+        y.backward(dy.view_as(y))
+        if hat is not None:
+            d_hs = linear_interpolate_last_dim_bwd(lat_lfo.grad[:, 0, :].contiguous(), hst.size(-1), n, start)
+            if self.should_stretch:
+                d_hs = stretch_corners_bwd(hs, d_hs, max_n_corners=self.max_n_corners, smooth_n_frames=self.stretch_smooth_n_frames)
+            d_hs = smoothen_bwd(d_hs, self.model_smooth_n_frames)
+            hat.backward(d_hs.view_as(hat))
+        optimizer.step(grad_scale=allreduce_flat_grad(optimizer.flat_grad, world_size))
+        em.detach_hidden()
+        return y.detach(), lfo_sr, mod_sig_hat
 
     def _loss_module(self, name: str):
         """One module per loss name for the lifetime of the step object (the MR-STFT module owns window / twiddle tables on

@@ -804,8 +804,11 @@ class LSTMEffectModel(HiddenStateModel):
 
     def __init__(self, in_ch: int = 1, out_ch: int = 1, n_hidden: int = 64, latent_dim: int = 1) -> None:
         super().__init__()
-        if (in_ch, out_ch, n_hidden, latent_dim) != (1, 1, 64, 1):
-            raise NotImplementedError("the LSTM kernels are built for the shipped LSTM-64 (in 1 + latent 1, out 1)")
+        # the fused kernels of csrc/lstm.hip are the shipped LSTM-64 with one audio and one LFO channel; any other size runs
+        # the general recurrence of csrc/lstm_generic.hip as an autograd node (lstm_generic.GenericLSTM)
+        self.generic = (in_ch, out_ch, n_hidden, latent_dim) != (1, 1, 64, 1)
+        if self.generic and not (out_ch == in_ch or out_ch == 1 or in_ch == 1):
+            raise ValueError("LSTMEffectModel: fc output (out_ch) and x (in_ch) do not broadcast (models.py:338)")
         self.in_ch, self.out_ch, self.n_hidden, self.latent_dim = in_ch, out_ch, n_hidden, latent_dim
         self.lstm = nn.LSTM(in_ch + latent_dim, n_hidden, batch_first=True)     # parameter holder
         self.fc = nn.Linear(n_hidden, out_ch)                                    # parameter holder
@@ -817,9 +820,9 @@ class LSTMEffectModel(HiddenStateModel):
     def _state(self, B: int, device) -> Tuple[T, T]:
         if self.is_hidden_init:
             h, c = self.hidden
-            return h.reshape(B, 64), c.reshape(B, 64)
-        return (torch.zeros((B, 64), device=device, dtype=torch.float32),
-                torch.zeros((B, 64), device=device, dtype=torch.float32))
+            return h.reshape(B, self.n_hidden), c.reshape(B, self.n_hidden)
+        return (torch.zeros((B, self.n_hidden), device=device, dtype=torch.float32),
+                torch.zeros((B, self.n_hidden), device=device, dtype=torch.float32))
 
     def detach_hidden(self) -> None:
         """models.py:303-305 clones the detached state; the state tensors here never carry a graph and the kernels never
@@ -906,7 +909,16 @@ class LSTMEffectModel(HiddenStateModel):
 
     def forward(self, x: T, latent: T) -> T:
         """Inference / validation forward (no autograd graph; training goes through the fused TBPTT
-        step of ``lightning.TBPTTLFOEffectModeling``)."""
+        step of ``lightning.TBPTTLFOEffectModeling``).  A model of another size (``self.generic``) is an ordinary autograd node:
+        gradients reach its parameters and ``latent``; the carried state is a constant (detached, as lightning.py:353,383 do)."""
+        if self.generic:
+            from .lstm_generic import GenericLSTM
+            assert x.ndim == 3 and latent.shape == (x.size(0), self.latent_dim, x.size(-1)) and x.size(1) == self.in_ch
+            B = x.size(0)
+            h0, c0 = self._state(B, x.device)
+            y, h1, c1 = GenericLSTM.apply(x, latent, h0, c0, *self._params())
+            self.update_hidden((h1.view(1, B, self.n_hidden), c1.view(1, B, self.n_hidden)))
+            return y
         with torch.no_grad():
             y, _, _ = self.run_chunk(x.contiguous().float(), latent.contiguous().float())
         return y
