@@ -474,6 +474,27 @@ int mx_lstmg_out_fwd(const float *fc, const float *bias, const float *x, int64_t
                      float *y, void *stream);
 int mx_lstmg_out_bwd(const float *dy, const float *y, int64_t B, int64_t T, int64_t out_ch, int64_t Co, float *dpre, void *stream);
 
+/* ---- TCN variants outside SpectralTCN / SpectralDSTCN -- mod_extraction/tcn.py:14-103,130-195: explicit padding with the causal /
+ * centre crop of the residual branch, the cached streaming convolution, FiLM with or without its BatchNorm1d.  Dense
+ * (B, C, T) fp32 tensors of any length; convolutions = mx_im2col2d (one bin row) + mx_sgemm_f32, LayerNorm = mx_rowln_*.
+ * mx_chan_stats: stats (C, 2) = {mean, biased variance} of every channel over (clips, frames) (BatchNorm1d training mode).
+ * mx_chan_norm_fwd: xhat = (z - norm[c][0]) norm[c][1], norm (C, 2) = {mean, rstd}; _bwd: dz = rstd (g - mean(g) - xhat
+ *   mean(g xhat)) with the means over (clips, frames) when train != 0 (batch statistics), else dz = rstd g.
+ * mx_film_fwd: a = xhat gb[b][c] + gb[b][C + c], gb (B, 2 C) = the adaptor's output (tcn.py:95-102); _bwd: dxhat = da gain,
+ *   dgb = {sum over frames of da xhat, of da}.
+ * mx_prelu_res_fwd: y = PReLU(a; slope[c]) (slope NULL: identity) + res (NULL: none) (tcn.py:185-191); _bwd: da = dy PReLU'(a),
+ *   part (B C,) = sum over frames of dy a where a <= 0 (slope gradient after mx_reduce_rows over the clips). */
+int mx_chan_stats(const float *z, int64_t B, int64_t C, int64_t T, float *stats, void *stream);
+int mx_chan_norm_fwd(const float *z, const float *norm, int64_t B, int64_t C, int64_t T, float *xhat, void *stream);
+int mx_chan_norm_bwd(const float *g, const float *xhat, const float *norm, int64_t B, int64_t C, int64_t T, int32_t train, float *dz,
+                     void *stream);
+int mx_film_fwd(const float *xhat, const float *gb, int64_t B, int64_t C, int64_t T, float *a, void *stream);
+int mx_film_bwd(const float *da, const float *xhat, const float *gb, int64_t B, int64_t C, int64_t T, float *dxhat, float *dgb,
+                void *stream);
+int mx_prelu_res_fwd(const float *a, const float *slope, const float *res, int64_t B, int64_t C, int64_t T, float *y, void *stream);
+int mx_prelu_res_bwd(const float *dy, const float *a, const float *slope, int64_t B, int64_t C, int64_t T, float *da, float *part,
+                     void *stream);
+
 /* ---- effect-model losses -- mod_extraction/losses.py:14-67 (ESR, DC) and nn.L1Loss:
  * part (B,4) = per-clip sums of |y - y_hat|, (y - y_hat)^2, y^2, (y - y_hat). */
 int mx_effect_loss_sums(const float *y_hat, int64_t y_hat_stride, const float *y, int64_t y_stride, int64_t B,

@@ -93,6 +93,13 @@ SIGNATURES = {
     "mx_lstmg_bwd": [_P, _P, _P, _P, _I64, _I64, _I64, _P, _P],
     "mx_lstmg_out_fwd": [_P, _P, _P, _I64, _I64, _I64, _I64, _P, _P],
     "mx_lstmg_out_bwd": [_P, _P, _I64, _I64, _I64, _I64, _P, _P],
+    "mx_chan_stats": [_P, _I64, _I64, _I64, _P, _P],
+    "mx_chan_norm_fwd": [_P, _P, _I64, _I64, _I64, _P, _P],
+    "mx_chan_norm_bwd": [_P, _P, _P, _I64, _I64, _I64, _I32, _P, _P],
+    "mx_film_fwd": [_P, _P, _I64, _I64, _I64, _P, _P],
+    "mx_film_bwd": [_P, _P, _P, _I64, _I64, _I64, _P, _P, _P],
+    "mx_prelu_res_fwd": [_P, _P, _P, _I64, _I64, _I64, _P, _P],
+    "mx_prelu_res_bwd": [_P, _P, _P, _I64, _I64, _I64, _P, _P, _P],
     "mx_effect_loss_sums": [_P, _I64, _P, _I64, _I64, _I64, _P, _P],
     "mx_effect_loss_grad": [_P, _I64, _P, _I64, _I64, _I64, _F32, _F32, _F32, _F32, _F32, _I32, _P, _I64, _P],
     "mx_mrstft_loss": [_P, _I64, _P, _I64, _I64, _I64, _I32, _P, _P, _P, _P, _F32, _F32, _F32, _P, _P, _P, _P, _P,

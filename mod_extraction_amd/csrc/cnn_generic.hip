@@ -93,16 +93,6 @@ MX_EXPORT int mx_col2im2d(const float *dcol, int64_t nb, int64_t Cin, int64_t H,
     return mx_launch_status();
 }
 
-// ---- block-wide fp64 sums (256 threads) ---------------------------------------------------------------------------------
-__device__ __forceinline__ double block_sum_f64(double v, double *red)
-{
-    v = wave_sum_f64(v);
-    __syncthreads();                                            // red may still be read from the previous call
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    return red[0] + red[1] + red[2] + red[3];
-}
-
 // ---- LayerNorm over one contiguous row (nn.LayerNorm([bins, frames], elementwise_affine=False), models.py:186) ----------
 // biased variance, eps inside the square root; fp64 sums (two passes: mean, then centred squares)
 __global__ __launch_bounds__(256) void rowln_fwd_kernel(const float *__restrict__ x, int64_t n, float eps, float *__restrict__ y,
@@ -113,13 +103,13 @@ __global__ __launch_bounds__(256) void rowln_fwd_kernel(const float *__restrict_
     float *yr = y + (size_t)blockIdx.x * n;
     double s = 0.0;
     for (int64_t i = threadIdx.x; i < n; i += 256) s += (double)xr[i];
-    const double mean = block_sum_f64(s, red) / (double)n;
+    const double mean = block256_sum_f64(s, red) / (double)n;
     double q = 0.0;
     for (int64_t i = threadIdx.x; i < n; i += 256) {
         const double d = (double)xr[i] - mean;
         q += d * d;
     }
-    const double var = block_sum_f64(q, red) / (double)n;
+    const double var = block256_sum_f64(q, red) / (double)n;
     const float mu = (float)mean, rstd = (float)(1.0 / sqrt(var + (double)eps));
     for (int64_t i = threadIdx.x; i < n; i += 256) yr[i] = (xr[i] - mu) * rstd;
     if (threadIdx.x == 0) {
@@ -142,8 +132,8 @@ __global__ __launch_bounds__(256) void rowln_bwd_kernel(const float *__restrict_
         s1 += g;
         s2 += g * (double)yr[i];
     }
-    const float m1 = (float)(block_sum_f64(s1, red) / (double)n);
-    const float m2 = (float)(block_sum_f64(s2, red) / (double)n);
+    const float m1 = (float)(block256_sum_f64(s1, red) / (double)n);
+    const float m2 = (float)(block256_sum_f64(s2, red) / (double)n);
     const float rstd = stats[2 * row + 1];
     for (int64_t i = threadIdx.x; i < n; i += 256) dr[i] = rstd * (gr[i] - m1 - yr[i] * m2);
 }
@@ -170,7 +160,7 @@ __global__ __launch_bounds__(256) void row_sums_kernel(const float *__restrict__
     const float *xr = x + (size_t)blockIdx.x * n;
     double s = 0.0;
     for (int64_t i = threadIdx.x; i < n; i += 256) s += (double)xr[i];
-    s = block_sum_f64(s, red);
+    s = block256_sum_f64(s, red);
     if (threadIdx.x == 0) out[blockIdx.x] = (float)s;
 }
 
@@ -239,8 +229,8 @@ __global__ __launch_bounds__(256) void pool_prelu_bwd_kernel(const float *__rest
         for (int r = 0; r < p; ++r) dp[((size_t)hp * p + r) * W + w] = r == am ? d : 0.0f;
     }
     for (int e = Hp * p * W + threadIdx.x; e < H * W; e += 256) dp[e] = 0.0f;          // rows the floor-mode pooling dropped
-    sb = block_sum_f64(sb, red);
-    ss = block_sum_f64(ss, red);
+    sb = block256_sum_f64(sb, red);
+    ss = block256_sum_f64(ss, red);
     if (threadIdx.x == 0) {
         part[2 * plane] = (float)sb;
         part[2 * plane + 1] = (float)ss;

@@ -61,6 +61,16 @@ __device__ __forceinline__ float wave_max_f32(float v)
     return v;
 }
 
+// sum over a 256-thread workgroup (fixed order: lanes by butterfly, then the four waves); red: 4 doubles of LDS
+__device__ __forceinline__ double block256_sum_f64(double v, double *red)
+{
+    v = wave_sum_f64(v);
+    __syncthreads();                                            // red may still be read from the previous call
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
 // torch.remainder(a, b) for fp32: fmod (exact) + sign fix (aten BinaryOpsKernel.cpp).
 __device__ __forceinline__ float torch_remainderf(float a, float b)
 {

@@ -52,10 +52,17 @@ def test_product_state_dict_keys_and_unsupported_variants():
                                              "blocks.0.res.weight", "blocks.1.act.weight", "blocks.1.conv.weight",
                                              "blocks.1.conv.bias", "blocks.1.res.weight"]
     assert net.calc_receptive_field() == 3 + 2 * 2
-    with pytest.raises(NotImplementedError):
-        tcn.TCN([8], [1], 5, 3)                                    # the reference's default is causal (streaming)
-    with pytest.raises(NotImplementedError):
-        tcn.TCN([8], [1], 5, 3, None, None, cond_dim=3, is_causal=False)
+    assert all(b.fast for b in net.blocks)                          # the SpectralTCN family keeps the plane kernels
+    causal = tcn.TCN([8], [1], 5, 3)                               # the reference's default is causal: the general kernels
+    assert not causal.blocks[0].fast and causal.blocks[0].crop_fn is tcn.causal_crop
+    film = tcn.TCN([8], [1], 5, 3, None, None, cond_dim=3, use_film_bn=True, is_causal=False)
+    assert [k for k in film.state_dict() if "film" in k] == [
+        "blocks.0.film.bn.running_mean", "blocks.0.film.bn.running_var", "blocks.0.film.bn.num_batches_tracked",
+        "blocks.0.film.adaptor.weight", "blocks.0.film.adaptor.bias"]
+    cached = tcn.TCN([8], [2], 5, 3, is_cached=True)
+    assert "blocks.0.conv.pad.pad_buf" in cached.state_dict() and cached.state_dict()["blocks.0.conv.pad.pad_buf"].shape == (1, 5, 4)
+    with pytest.raises(NotImplementedError):                       # an output longer than its input
+        tcn.TCN([8], [1], 5, 3, None, 5, is_causal=False)
     m = models.SpectralTCN(n_samples=22272, out_channels=[16, 16], dilations=[1, 2])
     keys = list(m.state_dict().keys())
     assert keys[0] == "spectrogram.window" and "tcn.blocks.1.res.weight" in keys and keys[-2:] == ["output.weight", "output.bias"]
