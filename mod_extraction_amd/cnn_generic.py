@@ -144,3 +144,75 @@ class GenericCNNStack(torch.autograd.Function):
                 else:
                     g = dxh
         return (g if need_x else None, None, *grads)
+
+
+class BinMeanHead(torch.autograd.Function):
+    """x (B, C, H, W) -> (sigmoid(Conv1d(C, L, 1)(mean over H)) (B, L, W), the mean (B, C, W)): models.py:209-215 on its own --
+    also the SpectralTCN head (H = 1: models.py:121-124) and, with H = W = 1, a Linear + sigmoid on (B, C) vectors."""
+
+    @staticmethod
+    def forward(ctx, x: T, wout: T, bout: T):
+        x = x.contiguous().float()
+        B, C, H, W = x.shape
+        w, b = wout.detach().contiguous().float(), bout.detach().contiguous().float()
+        L = w.size(0)
+        latent, y = _empty((B, C, W), x.device), _empty((B, L, W), x.device)
+        _hip.call("mx_binmean_head_fwd", _hip.ptr(x), B, C, H, W, _hip.ptr(w), _hip.ptr(b), L, _hip.ptr(latent), _hip.ptr(y), _hip.stream())
+        ctx.dims = (B, C, H, W, L)
+        ctx.save_for_backward(latent, y, w)
+        ctx.w_shape = wout.shape
+        return y, latent
+
+    @staticmethod
+    def backward(ctx, d_out, d_latent):
+        latent, y, w = ctx.saved_tensors
+        B, C, H, W, L = ctx.dims
+        dev, st = y.device, _hip.stream()
+        ds, dx = _empty((B, L, W), dev), _empty((B, C, H, W), dev)
+        _hip.call("mx_binmean_head_bwd", _hip.ptr(d_out.contiguous().float()) if d_out is not None else None,
+                  _hip.ptr(d_latent.contiguous().float()) if d_latent is not None else None, _hip.ptr(y), _hip.ptr(w), B, C, H, W, L,
+                  _hip.ptr(ds), _hip.ptr(dx), st)
+        dwo = _empty((L, C), dev)
+        _sgemm(_hip.ptr(ds), W, 1, L * W, _hip.ptr(latent), 1, W, C * W, _hip.ptr(dwo), C, 1, 0, L, C, W, B, per_group=B)
+        rs, dbo = _empty((B * L,), dev), _empty((L,), dev)
+        _hip.call("mx_row_sums", _hip.ptr(ds), B * L, W, _hip.ptr(rs), st)
+        _hip.call("mx_reduce_rows", _hip.ptr(rs), B, L, 0, _hip.ptr(dbo), st)
+        return dx, dwo.view(ctx.w_shape), dbo
+
+
+class LinearPReLU(torch.autograd.Function):
+    """(B, Cin) -> PReLU(Linear(Cin, Cout)) (B, Cout): the hidden layer of the SpectralDSTCN head (models.py:284-287)."""
+
+    @staticmethod
+    def forward(ctx, x: T, w: T, b: T, slope: T):
+        x = x.contiguous().float()
+        wc, bc, sc = (t.detach().contiguous().float() for t in (w, b, slope))
+        B, cin, cout, st = x.size(0), x.size(1), wc.size(0), _hip.stream()
+        a = bc.view(1, cout).expand(B, cout).contiguous()                        # the products accumulate onto the bias
+        _sgemm(_hip.ptr(x), cin, 1, 0, _hip.ptr(wc), 1, cin, 0, _hip.ptr(a), cout, 1, 0, B, cout, cin, 1, accumulate=1)
+        y = _empty((B, cout), x.device)
+        _hip.call("mx_prelu_res_fwd", _hip.ptr(a), _hip.ptr(sc), None, B, cout, 1, _hip.ptr(y), st)
+        ctx.save_for_backward(x, a, wc, sc)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy: T):
+        x, a, w, slope = ctx.saved_tensors
+        B, cin, cout, dev, st = x.size(0), x.size(1), w.size(0), x.device, _hip.stream()
+        da, part = _empty((B, cout), dev), _empty((B * cout,), dev)
+        _hip.call("mx_prelu_res_bwd", _hip.ptr(dy.contiguous().float()), _hip.ptr(a), _hip.ptr(slope), B, cout, 1, _hip.ptr(da), _hip.ptr(part), st)
+        d_slope, d_b = _empty((cout,), dev), _empty((cout,), dev)
+        _hip.call("mx_reduce_rows", _hip.ptr(part), B, cout, 0, _hip.ptr(d_slope), st)
+        _hip.call("mx_reduce_rows", _hip.ptr(da), B, cout, 0, _hip.ptr(d_b), st)
+        d_w, d_x = _empty((cout, cin), dev), _empty((B, cin), dev)
+        _sgemm(_hip.ptr(da), 1, cout, 0, _hip.ptr(x), cin, 1, 0, _hip.ptr(d_w), cin, 1, 0, cout, cin, B, 1)
+        _sgemm(_hip.ptr(da), cout, 1, 0, _hip.ptr(w), cin, 1, 0, _hip.ptr(d_x), cin, 1, 0, B, cin, cout, 1)
+        return d_x, d_w, d_b, d_slope
+
+
+def time_mean(x: T) -> T:
+    """(B, C, T) dense -> (B, C): the mean over frames through the bin-mean kernel (frames in the bins' place, one column)."""
+    B, C, Tn = x.shape
+    zero_w = torch.zeros((1, C), device=x.device, dtype=torch.float32)
+    _, latent = BinMeanHead.apply(x.contiguous().view(B, C, Tn, 1), zero_w, zero_w[0, :1])
+    return latent.view(B, C)

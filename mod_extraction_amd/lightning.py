@@ -17,7 +17,7 @@ from torch import Tensor as T, nn
 
 from . import losses as L
 from .models import HiddenStateModel, RandomLFO
-from .modulations import (find_valid_mod_sig_indices, smoothen, smoothen_bwd, stretch_corners, stretch_corners_bwd,
+from .modulations import (find_valid_mod_sig_indices, smoothen, smoothen_bwd, smoothen_with_grad, stretch_corners, stretch_corners_bwd,
                           valid_mod_sig_mask)
 from .util import linear_interpolate_last_dim, linear_interpolate_last_dim_bwd
 
@@ -119,9 +119,8 @@ class LFOExtraction(BaseLightingModule):
             mod_sig = linear_interpolate_last_dim(mod_sig, mod_sig_hat.size(-1), align_corners=True)
         assert mod_sig.shape == mod_sig_hat.shape
         if self.model_smooth_n_frames > 1:
-            if mod_sig_hat.requires_grad:
-                # training with smoothing is not used by any shipped config; keep autograd correct
-                mod_sig_hat = mod_sig_hat.unfold(-1, self.model_smooth_n_frames, 1).mean(-1)
+            if mod_sig_hat.requires_grad:       # training with smoothing (no shipped config): the kernel and its transpose as one autograd node
+                mod_sig_hat = smoothen_with_grad(mod_sig_hat, self.model_smooth_n_frames)
             else:
                 mod_sig_hat = smoothen(mod_sig_hat, self.model_smooth_n_frames)
             mod_sig = self.center_crop_mod_sig(mod_sig, mod_sig_hat.size(-1))

@@ -683,7 +683,7 @@ class SpectrogramHIP(nn.Module):
 class SpectralTCN(nn.Module):
     """models.py:72-125: log power spectrogram (513 bins) -> 5-block dilated TCN over time (LayerNorm, 13 taps, PReLU,
     1x1 residual) -> Conv1d(96 -> latent_dim, 1) -> sigmoid; (B, 1, N) -> (B, latent_dim, frames).  The front end and the
-    TCN stack run in HIP kernels (``tcn.py``); the 1x1 head is a library matmul."""
+    TCN stack run in HIP kernels (``tcn.py``); the 1x1 head + sigmoid is ``mx_binmean_head_*`` at one bin."""
 
     def __init__(self, n_samples: int = 88200, n_fft: int = 1024, hop_len: int = 256, kernel_size: int = 13,
                  out_channels: Optional[List[int]] = None, dilations: Optional[List[int]] = None, latent_dim: int = 1,
@@ -715,9 +715,10 @@ class SpectralTCN(nn.Module):
         return y[:, :, :t_out]
 
     def forward(self, x: T) -> T:
-        f = self.features(x)
-        w = self.output.weight.view(self.latent_dim, -1)
-        return torch.sigmoid(torch.matmul(w, f) + self.output.bias.view(1, -1, 1))
+        from .cnn_generic import BinMeanHead
+        f = self.features(x)                                        # (B, C, T'): Conv1d(C, L, 1) + sigmoid = the bin-mean head at one bin
+        y, _ = BinMeanHead.apply(f.unsqueeze(2), self.output.weight, self.output.bias)
+        return y
 
 
 class SpectralDSTCN(nn.Module):
@@ -759,8 +760,11 @@ class SpectralDSTCN(nn.Module):
         with torch.no_grad():
             spec = self.spectrogram.log_power(x, n_frames, self.eps)
         y, t_out = self.tcn.forward_planes(spec, n_frames)
-        f = y[:, :, :t_out].mean(dim=-1)
-        return torch.sigmoid(self.output(self.fc_act(self.fc(f))))
+        from .cnn_generic import BinMeanHead, LinearPReLU, time_mean
+        f = time_mean(y[:, :, :t_out])                              # models.py:283: mean over the remaining frames
+        hid = LinearPReLU.apply(f, self.fc.weight, self.fc.bias, self.fc_act.weight)
+        out, _ = BinMeanHead.apply(hid.view(hid.size(0), -1, 1, 1), self.output.weight, self.output.bias)   # Linear + sigmoid
+        return out.view(out.size(0), -1)
 
 
 class HiddenStateModel(nn.Module):

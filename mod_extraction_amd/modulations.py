@@ -82,6 +82,22 @@ def stretch_corners(mod_sig: T, max_n_corners: int = 10, smooth_n_frames: int = 
     return out
 
 
+class _SmoothenFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x: T, k: int):
+        ctx.k = k
+        return smoothen(x.detach(), k)
+
+    @staticmethod
+    def backward(ctx, dy: T):
+        return smoothen_bwd(dy.contiguous(), ctx.k), None
+
+
+def smoothen_with_grad(x: T, smooth_n_frames: int) -> T:
+    """``smoothen`` as an autograd node (forward ``mx_smoothen``, backward its transpose): lightning.py:117-119 while training."""
+    return x if smooth_n_frames <= 1 else _SmoothenFn.apply(x, smooth_n_frames)
+
+
 def smoothen_bwd(dy: T, smooth_n_frames: int) -> T:
     """Transpose of ``smoothen``: the same moving average over the zero-padded gradient."""
     if smooth_n_frames <= 1:

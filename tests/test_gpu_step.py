@@ -574,3 +574,44 @@ def test_batches_rendered_one_step_ahead_equal_the_serial_ones(dev):
     for (d0, w0, m0, p0), (d1, w1, m1, p1) in zip(serial, ahead):
         assert torch.equal(d0, d1) and torch.equal(w0, w1) and torch.equal(m0, m1)
         assert p0.keys() == p1.keys() and all(torch.equal(p0[k], p1[k]) for k in p0)
+
+
+def test_lfo_extraction_trains_through_the_moving_average(dev):
+    """LFOExtraction with model_smooth_n_frames > 1 while TRAINING (lightning.py:117-120: unfold(k).mean on the prediction, centre crop
+    of the target): the moving average runs as mx_smoothen with its transpose as backward; loss and every gradient against the same
+    step written with torch's unfold on the oracle's model (1e-5 / 2e-5 norm-wise, pooling decisions shared as in test_gpu_cnn)."""
+    import torch.nn.functional as F
+    from mod_extraction_amd import lightning, models as am
+    from oracle import losses as olosses, models as om
+    n, k = 22272, 4
+    cfg = dict(in_ch=1, n_samples=n, n_mels=64, kernel_size=(5, 13), out_channels=[64] * 6, temp_dilations=[1, 1, 2, 4, 8, 16],
+               pool_size=(2, 1), latent_dim=1, use_ln=True)
+    torch.manual_seed(8)
+    ref = om.Spectral2DCNN(**cfg).eval()
+    mine = am.Spectral2DCNN(**cfg); mine.load_state_dict(ref.state_dict())
+    weights = {"l1": 1.0, "fdl1": 5.0, "sdl1": 10.0}
+    module = lightning.LFOExtraction(mine, sr=44100, use_dry=False, model_smooth_n_frames=k, loss_dict=weights).to(dev)
+    module.train(); mine.eval()                                    # (eval: no SpecAugment draw; gradients still flow)
+    g = torch.Generator().manual_seed(2)
+    wet = torch.rand(3, 1, n, generator=g) * 2 - 1
+    t = torch.linspace(0, 1, 882)
+    mod_sig = 0.5 + 0.5 * torch.cos(2 * torch.pi * (1.0 + torch.arange(3).view(3, 1)) * t)
+    am.DEBUG_TAP = {}
+    try:
+        loss = module.training_step((None, wet.to(dev), mod_sig.to(dev), None), 0)
+        loss.backward()
+        tap = am.DEBUG_TAP
+    finally:
+        am.DEBUG_TAP = None
+    hat, _, _ = om.forward_routed(ref, wet, (0, 0, 0, 0), tap, mine.n_frames)
+    hat = hat.squeeze(1).unfold(-1, k, 1).mean(-1)
+    tgt = F.interpolate(mod_sig.unsqueeze(1), size=mine.n_frames, mode="linear", align_corners=True).squeeze(1)
+    pad = tgt.size(-1) - hat.size(-1)
+    tgt = tgt[..., pad // 2:pad // 2 + hat.size(-1)]
+    want = sum(w * olosses.get_loss_func_by_name(name)(hat, tgt) for name, w in weights.items())
+    want.backward()
+    assert abs(float(loss) - float(want)) < 1e-5 * max(1.0, abs(float(want)))
+    gr = dict(ref.named_parameters())
+    for name, p in mine.named_parameters():
+        e = float((p.grad.cpu() - gr[name].grad).abs().max() / gr[name].grad.abs().max().clamp_min(1e-30))
+        assert e < 2e-5, (name, e)
