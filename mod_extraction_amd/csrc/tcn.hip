@@ -46,17 +46,37 @@ __global__ __launch_bounds__(256) void sgemm_f32_kernel(SgemmArgs g)
     const int b_beg = blockIdx.z * g.batches_per_group, b_end = min(g.n_batch, b_beg + g.batches_per_group);
     // staging roles: thread -> (k row, 4 consecutive m / n) of the 16 x 64 tiles
     const int sk = tid >> 4, sm = (tid & 15) * 4;
+    // per-thread element offsets of its four A / four B items at k = sk (out-of-range rows / columns: item 0 of the operand,
+    // masked below); a k-tile later they are 16 a_cs / 16 b_rs further -- one 64-bit add per item instead of two multiplies
+    long long oa[4], ob[4];
+    bool ma[4], mb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int m = m0 + sm + j, n = n0 + sm + j;
+        ma[j] = m < g.M;
+        mb[j] = n < g.N;
+        oa[j] = ma[j] ? (long long)m * g.a_rs + (long long)sk * g.a_cs : 0;
+        ob[j] = mb[j] ? (long long)sk * g.b_rs + (long long)n * g.b_cs : 0;
+    }
+    const long long da = (long long)TG_TK * g.a_cs, db = (long long)TG_TK * g.b_rs;
     for (int bi = b_beg; bi < b_end; ++bi) {
         const float *A = g.a + (long long)bi * g.a_bs, *Bm = g.b + (long long)bi * g.b_bs;
-        for (int k0 = 0; k0 < g.K; k0 += TG_TK) {
-            const int k = k0 + sk;
-            float av[4], bv[4];
+        long long pa[4], pb[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { pa[j] = oa[j]; pb[j] = ob[j]; }
+        float av[4], bv[4];
+        auto fetch = [&](int k0) {                             // the tile at k0 -> registers (its loads stay in flight)
+            const bool kin = k0 + sk < g.K;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int m = m0 + sm + j, n = n0 + sm + j;
-                av[j] = (k < g.K && m < g.M) ? A[(long long)m * g.a_rs + (long long)k * g.a_cs] : 0.0f;
-                bv[j] = (k < g.K && n < g.N) ? Bm[(long long)k * g.b_rs + (long long)n * g.b_cs] : 0.0f;
+                av[j] = (kin && ma[j]) ? A[pa[j]] : 0.0f;
+                bv[j] = (kin && mb[j]) ? Bm[pb[j]] : 0.0f;
+                pa[j] += ma[j] ? da : 0;
+                pb[j] += mb[j] ? db : 0;
             }
+        };
+        fetch(0);
+        for (int k0 = 0; k0 < g.K; k0 += TG_TK) {
             __syncthreads();                                   // the previous tile has been consumed
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -64,6 +84,7 @@ __global__ __launch_bounds__(256) void sgemm_f32_kernel(SgemmArgs g)
                 Bs[sk][sm + j] = bv[j];
             }
             __syncthreads();
+            if (k0 + TG_TK < g.K) fetch(k0 + TG_TK);           // the next tile's global loads run under this tile's matrix instructions
 #pragma unroll
             for (int kk = 0; kk < TG_TK; kk += 2)
                 acc = mfma32(As[kk + kpar][wm + c32], Bs[kk + kpar][wn + c32], acc);
