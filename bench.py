@@ -249,9 +249,16 @@ CONV_NAMES = {"mx_conv_block_fwd", "mx_conv_block_dgrad", "mx_conv_block_wgrad",
               "mx_conv_block1_wgrad_pair_f16"}
 
 
+STREAMING_NAMES = {"mx_conv_prep_gpool_cl_f16"}       # timed next to the convs, but HBM streaming passes
+
+
 def timed_loop(step, steps, world, device, timer_names, key_fn=None):
-    """EXACTLY `steps` steps bracketed by barrier + synchronize on both sides; max over ranks; per-step HIP events."""
-    from mod_extraction_amd import _hip
+    """EXACTLY `steps` steps bracketed by barrier + synchronize on both sides; max over ranks; per-step HIP events.
+    N > 1: every gradient all-reduce is bracketed by its own HIP event pair (trainer.CollectiveTimer) and every rank's
+    step statistics are gathered AFTER the timed region (`step_ms_per_rank`, `allreduce_ms`): the two numbers that explain
+    a scaling-efficiency loss -- time inside the collective (which includes waiting for the slowest rank) and the spread
+    of the ranks' own step times."""
+    from mod_extraction_amd import _hip, trainer as tr
 
     def fence():
         if world > 1:
@@ -261,7 +268,7 @@ def timed_loop(step, steps, world, device, timer_names, key_fn=None):
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     fence()
     t0 = time.perf_counter()
-    with _hip.KernelTimer(timer_names, key_fn) as kt:
+    with _hip.KernelTimer(timer_names, key_fn) as kt, tr.CollectiveTimer() as ct:
         marks[0].record()
         out = None
         for i in range(steps):
@@ -275,7 +282,33 @@ def timed_loop(step, steps, world, device, timer_names, key_fn=None):
     per_step = [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]
     stats = {"min": round(min(per_step), 3), "median": round(statistics.median(per_step), 3), "max": round(max(per_step), 3),
              "slowest_step": per_step.index(max(per_step))}
+    if world > 1:
+        ar = ct.results_ms()
+        mine = {"rank": torch.distributed.get_rank(), "step_ms": stats, "wall_ms_per_step": round(1e3 * dt / steps, 3),
+                "allreduce_ms": None if not ar else {"mean": round(mean(ar), 4), "max": round(max(ar), 4),
+                                                      "per_step": round(sum(ar) / steps, 4), "calls_per_step": len(ar) / steps}}
+        ranks = [None] * world
+        torch.distributed.all_gather_object(ranks, mine)
+        stats = dict(stats, per_rank=ranks)
     return float(dt_t), kt.results(), stats, out
+
+
+def scale_fields(step_ms, grad_bytes):
+    """N > 1: the scale-readiness numbers of the line, from timed_loop's gathered per-rank statistics."""
+    ranks = step_ms.pop("per_rank", None)
+    if not ranks:
+        return {}
+    ar = [r["allreduce_ms"] for r in ranks if r["allreduce_ms"]]
+    out = {"step_ms_per_rank": [[r["step_ms"]["min"], r["step_ms"]["median"], r["step_ms"]["max"]] for r in ranks],
+           "step_ms_per_rank_fields": "min, median, max of each rank's own steps (HIP events), rank order",
+           "rank_median_spread_ms": round(max(r["step_ms"]["median"] for r in ranks) - min(r["step_ms"]["median"] for r in ranks), 3)}
+    if ar:
+        out["allreduce_ms"] = {"mean": round(mean([a["mean"] for a in ar]), 4), "max": round(max(a["max"] for a in ar), 4),
+                               "per_step": round(max(a["per_step"] for a in ar), 4), "calls_per_step": ar[0]["calls_per_step"],
+                               "bytes": int(grad_bytes),
+                               "note": "HIP events around the flat-gradient sum all-reduce on its stream (includes the wait for the "
+                                       "slowest rank); mean / max over calls, per_step = slowest rank's total per step"}
+    return out
 
 
 def fx_floor_pass(batcher, params, n=3):
@@ -465,8 +498,9 @@ def run_lfo_config(args, env, cfg_id):
         cin, h = (int(v) for v in shape.split("x"))
         blk = BLOCK_H.index(h)
         avg = mean(ms)
-        kernels[f"{name[3:]}[block{blk + 1}]"] = {"avg_ms": round(avg, 3),
-                                                 "tflops": round(conv_flops(blk, batch) / (avg * 1e-3) / 1e12, 2)}
+        kernels[f"{name[3:]}[block{blk + 1}]"] = {"avg_ms": round(avg, 3)}
+        if name not in STREAMING_NAMES:           # (an operand-prep pass has no conv flops to its name)
+            kernels[f"{name[3:]}[block{blk + 1}]"]["tflops"] = round(conv_flops(blk, batch) / (avg * 1e-3) / 1e12, 2)
     f16 = "conv_block_fwd_f16[block2]" in kernels
     if f16:                      # roofline kernel = the heaviest conv launch of the step: block-2 forward
         dom = kernels["conv_block_fwd_f16[block2]"]
@@ -513,6 +547,7 @@ def run_lfo_config(args, env, cfg_id):
         "conv_ms_per_step": round(mfma_ms, 2),
         "final_loss": None if loss is None else float(loss.detach()),
     }
+    out.update(scale_fields(step_ms, opt.flat_grad.numel() * 4))
     # the effect kernels: live durations (side stream, concurrent with the train step) and an isolated pass with the
     # measured serial floor
     with torch.no_grad():
@@ -705,6 +740,11 @@ def run_config4(args, env):
         "step_ms": step_ms,
         "final_loss": None if loss is None else float(loss.detach()),
     }
+    # reference semantics: `value` counts every clip of the batch (all are rendered and pass the frozen extractor); the
+    # LSTM trains on the rows that survive the LFO validity filter -- both rates are quoted
+    out["value_clips_rendered"] = out["value"]
+    out["value_clips_trained"] = world * mean(kept) * cfg["seconds"] * args.steps / dt
+    out.update(scale_fields(step_ms, opt.flat_grad.numel() * 4))
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_tbptt()
     return out
@@ -788,6 +828,7 @@ def run_config5(args, env):
         "roofline": mr, "kernels": kernels, "step_ms": step_ms,
         "final_loss": None if loss is None else float(loss.detach()),
     }
+    out.update(scale_fields(step_ms, 0))
     if "flanger_kernel" in kernels:
         out["fx_kernel_frac_of_serial_floor"] = kernels["flanger_kernel"].get("frac_of_serial_floor")
         out["fx_kernel_frac_of_independent_floor"] = kernels["flanger_kernel"].get("frac_of_independent_floor")
@@ -818,6 +859,113 @@ def cpu_baseline_stress(N, batch_cpu: int = 8):
                       f"loop per sample --, torch fp32 MR-STFT forward + backward on {cores} threads)"}
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# output: ONE short JSON line on stdout (the driver parses it; < 6 KB, see tests/test_gpu_step.py), everything else
+# in bench_detail.json next to this file and as one `BENCH_DETAIL {...}` line on stderr
+LINE_CAP = 6000
+
+
+def _short(text, n=200):
+    if not isinstance(text, str) or len(text) <= n:
+        return text
+    return text[:n - 3].rstrip() + "..."
+
+
+def _compact_roofline(r):
+    if not r:
+        return r
+    keep = ("bound", "nominal_bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "flops_per_launch",
+            "algorithmic_bytes", "achieved_executed", "frac_executed", "x_fp32_mfma_peak", "serial_floor_ms", "frac_of_serial_floor",
+            "independent_floor_ms", "frac_of_independent_floor", "nominal_hbm", "executed_flops_per_launch", "traffic_over_algorithmic")
+    out = {k: r[k] for k in keep if k in r}
+    out["kernel"] = _short(r.get("kernel"), 140)
+    if r.get("traffic") is not None:
+        out["traffic_unit"] = "bytes/launch; committed rocprofv3 PMC pass at bs 64 scaled to this batch, not measured in this run"
+    if r.get("note"):
+        out["note"] = _short(r["note"], 200)
+    return out
+
+
+def _compact_cpu(c):
+    if not c:
+        return c
+    out = {k: c[k] for k in ("value", "unit", "cores", "kind") if k in c}
+    out["value"] = round(out["value"], 3)
+    out["sample"] = _short(c.get("sample"), 200)
+    if "reference_shaped" in c:
+        rs = c["reference_shaped"]
+        out["reference_shaped"] = {"value": round(rs["value"], 3), "batch": rs.get("batch"),
+                                   "note": "B = 16, flanger / chorus as the reference's per-sample python loop (timed stretch, extrapolated)"}
+    return out
+
+
+def compact(full):
+    """The short headline object of a full measurement dict (the LAST stdout line)."""
+    out = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                "vs_baseline", "dtype", "data") if k in full}
+    out["compute_dtype"] = _short(full.get("compute_dtype", full.get("dtype")), 120)
+    cfg = full.get("config", {})
+    out["config"] = {k: cfg[k] for k in ("baseline_config", "global_batch", "n_samples", "parallelism", "optimizer_steps_per_batch",
+                                         "clips_trained_per_batch") if k in cfg}
+    out["config"]["workload"] = _short(cfg.get("workload"), 260)
+    if "conv_precision" in cfg:
+        out["config"]["conv_precision"] = cfg["conv_precision"].split(":")[0].split(" ")[0]
+    out["roofline"] = _compact_roofline(full.get("roofline"))
+    if "cpu_baseline" in full:
+        out["cpu_baseline"] = _compact_cpu(full["cpu_baseline"])
+    for k in ("step_ms", "conv_ms_per_step", "fx_kernel_frac_of_serial_floor", "fx_kernel_frac_of_independent_floor",
+              "fx_kernel_frac_of_hbm", "value_clips_rendered", "value_clips_trained", "final_loss", "world_size", "dist_backend",
+              "rccl_version", "allreduce_ms", "step_ms_per_rank", "rank_median_spread_ms", "worker_rc", "worker_stderr_tail"):
+        if k in full:
+            out[k] = full[k]
+    if "exact_fp32_path" in full:
+        out["exact_fp32_path"] = {k: full["exact_fp32_path"][k] for k in ("ms_per_step", "value")}
+    for grp in ("kernels", "fx_kernels"):             # floors of the sample-recurrent kernels, numbers only
+        for name, k in (full.get(grp) or {}).items():
+            if isinstance(k, dict) and "frac_of_independent_floor" in k:
+                out.setdefault("recurrent_kernels", {})[name] = {
+                    "avg_launch_ms": k.get("avg_launch_ms"), "frac_of_independent_floor": k.get("frac_of_independent_floor"),
+                    "frac_of_serial_floor": k.get("frac_of_serial_floor"), "frac_of_hbm": k.get("frac")}
+    if "other_configs" in full:
+        oc = {}
+        for c, o in full["other_configs"].items():
+            if "error" in o:
+                oc[c] = {"error": o["error"]}
+                continue
+            r = o.get("roofline") or {}
+            oc[c] = {"value": round(o["value"], 1), "ms_per_step": round(o["ms_per_step"], 3),
+                     "roofline": {k: r.get(k) for k in ("bound", "frac", "frac_of_independent_floor", "frac_of_serial_floor") if k in r},
+                     "fx_kernel_frac_of_independent_floor": o.get("fx_kernel_frac_of_independent_floor"),
+                     "cpu_baseline": {"value": round(o["cpu_baseline"]["value"], 3)} if o.get("cpu_baseline") else None}
+            if "value_clips_trained" in o:
+                oc[c]["value_clips_trained"] = round(o["value_clips_trained"], 1)
+        out["other_configs"] = oc
+    out["detail"] = "bench_detail.json next to bench.py (also one `BENCH_DETAIL {...}` line on stderr): per-kernel tables, notes, floors"
+    line = json.dumps(out)
+    if len(line) > LINE_CAP:                          # never let the line outgrow the driver's parser again
+        for k in ("step_ms_per_rank", "recurrent_kernels", "exact_fp32_path", "other_configs"):
+            if len(line) <= LINE_CAP:
+                break
+            out.pop(k, None)
+            out["dropped_for_length"] = out.get("dropped_for_length", []) + [k]
+            line = json.dumps(out)
+    return line
+
+
+def emit(full, detail_path, to_stderr=True):
+    """Write the full detail to `detail_path` (and stderr), print the compact line as the LAST thing on stdout."""
+    try:
+        with open(detail_path, "w") as f:
+            json.dump(full, f, indent=1)
+    except OSError as e:
+        sys.stderr.write(f"bench: could not write {detail_path}: {e}\n")
+    if to_stderr:
+        sys.stderr.write("BENCH_DETAIL " + json.dumps(full) + "\n")
+        sys.stderr.flush()
+    sys.stdout.flush()
+    print(compact(full), flush=True)
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -843,6 +991,8 @@ def parse_args(argv=None):
                     help="config 4: no LFO validity filter, random-init extractor output used as is (the round-1/2 form)")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="N = 1, config 3: do not append the configs 2 / 4 / 5 measurements (`other_configs`)")
+    ap.add_argument("--detail-out", default=None,
+                    help="where the full measurement dict is written (default: bench_detail.json next to bench.py)")
     ap.add_argument("--worker", action="store_true",
                     help="run the measurement in THIS process (set by the launcher; use it under rocprofv3)")
     args = ap.parse_args(argv)
@@ -863,26 +1013,31 @@ def _free_port() -> int:
         return s.getsockname()[1]
 
 
-def _run_child(cmd, timeout_s):
-    """Run one worker command; returns (json dict or None, return code, stderr tail, port_in_use).  stderr is relayed;
-    `port_in_use` is looked for in the WHOLE stderr (torchrun's multi-rank tracebacks are longer than the tail)."""
+def _run_child(cmd, timeout_s, detail_path):
+    """Run one worker command; returns (full measurement dict or None, return code, stderr tail, port_in_use).  The worker
+    writes its full dict to `detail_path` (its stdout carries only the compact line); its stderr is relayed without the
+    BENCH_DETAIL line (the launcher prints ONE merged detail line itself).  `port_in_use` is looked for in the WHOLE
+    stderr (torchrun's multi-rank tracebacks are longer than the tail)."""
     import subprocess
+    if os.path.exists(detail_path):
+        os.remove(detail_path)
     try:
-        res = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=timeout_s)
+        res = subprocess.run(cmd + ["--detail-out", detail_path], cwd=ROOT, capture_output=True, text=True, timeout=timeout_s)
     except subprocess.TimeoutExpired as e:
         return None, 124, f"timeout after {timeout_s} s: {' '.join(cmd)}\n{(e.stderr or '')[-2000:]}", False
-    if res.stderr:
-        sys.stderr.write(res.stderr)
+    err = "\n".join(ln for ln in res.stderr.splitlines() if "BENCH_DETAIL " not in ln)
+    if err:
+        sys.stderr.write(err + "\n")
         sys.stderr.flush()
-    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
     out = None
-    if lines:
-        try:
-            out = json.loads(lines[-1])
-        except ValueError:
-            out = None
+    try:
+        with open(detail_path) as f:
+            out = json.load(f)
+        os.remove(detail_path)
+    except (OSError, ValueError):
+        out = None
     port_in_use = "EADDRINUSE" in res.stderr or "address already in use" in res.stderr.lower()
-    return out, res.returncode, res.stderr[-2000:], port_in_use
+    return out, res.returncode, err[-2000:], port_in_use
 
 
 def _worker_cmd(args, config, steps, extra=()):
@@ -905,6 +1060,8 @@ def _worker_cmd(args, config, steps, extra=()):
 
 def launch(args) -> int:
     script = os.path.join(ROOT, "bench.py")
+    import tempfile
+    tmp_detail = os.path.join(tempfile.gettempdir(), f"bench_detail_{os.getpid()}.json")
     flags = (["--no-cpu-baseline"] if args.no_cpu_baseline else []) + (["--no-fp32-leg"] if args.no_fp32_leg else [])
     for _ in range(4):                          # (a free port can be taken between finding it and torchrun's bind: try another one)
         if args.gpus > 1:
@@ -913,7 +1070,7 @@ def launch(args) -> int:
                   _worker_cmd(args, args.config, args.steps, flags)
         else:
             cmd = [sys.executable, script, "--worker"] + _worker_cmd(args, args.config, args.steps, flags)
-        out, rc, err, port_in_use = _run_child(cmd, 3000)
+        out, rc, err, port_in_use = _run_child(cmd, 3000, tmp_detail)
         if out is not None or args.gpus == 1 or not port_in_use:     # (a rendezvous that fails on the port fails within seconds)
             break
     if out is None:
@@ -931,15 +1088,13 @@ def launch(args) -> int:
             t0 = time.perf_counter()
             # every config carries its own bounded cpu_baseline: short samples, ~5-10 s each
             leg = ["--no-fp32-leg"] + (["--no-cpu-baseline"] if args.no_cpu_baseline else ["--cpu-baseline-short"])
-            o, rc_c, err_c, _ = _run_child([sys.executable, script, "--worker"] + _worker_cmd(args, c, steps, leg), 900)
+            o, rc_c, err_c, _ = _run_child([sys.executable, script, "--worker"] + _worker_cmd(args, c, steps, leg), 900, tmp_detail)
             worst = worst or rc_c
             if o is None:
                 others[str(c)] = {"error": f"rc {rc_c}", "stderr_tail": err_c[-400:]}
                 continue
-            keep = {k: o[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "roofline", "step_ms",
-                                      "kernels", "fx_kernels", "fx_kernel_frac_of_serial_floor", "fx_kernel_frac_of_hbm",
-                                      "fx_kernel_frac_of_independent_floor", "ms_per_batch_by_entry_point",
-                                      "avg_launch_ms_in_step", "final_loss", "loss_variants", "cpu_baseline", "compute_dtype") if k in o}
+            keep = {k: v for k, v in o.items() if k not in ("n_gpus", "higher_is_better", "scaling", "vs_baseline", "data", "config",
+                                                            "world_size", "dist_backend", "rccl_version")}
             keep["config"] = o["config"]
             keep["process_wall_s"] = round(time.perf_counter() - t0, 1)
             keep["worker_rc"] = rc_c
@@ -947,7 +1102,7 @@ def launch(args) -> int:
                 keep["worker_stderr_tail"] = err_c[-400:]
             others[str(c)] = keep
         out["other_configs"] = others
-    print(json.dumps(out), flush=True)
+    emit(out, args.detail_out or os.path.join(ROOT, "bench_detail.json"))
     return worst
 
 
@@ -979,7 +1134,7 @@ def main():
             out["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
         except Exception:
             out["rccl_version"] = None
-        print(json.dumps(out), flush=True)
+        emit(out, args.detail_out or os.path.join(ROOT, "bench_detail.json"))
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

@@ -44,11 +44,41 @@ def init_distributed(backend: Optional[str] = None) -> Dict[str, int]:
     return env
 
 
+class CollectiveTimer:
+    """Optional device timing of the gradient all-reduce (bench.py's N > 1 line: `allreduce_ms`).  Inside
+    ``with CollectiveTimer() as ct:`` every ``allreduce_flat_grad`` call is bracketed by a HIP event pair on the
+    stream the collective is enqueued on; ``ct.results_ms()`` synchronises and returns the durations."""
+
+    active: Optional["CollectiveTimer"] = None
+
+    def __init__(self) -> None:
+        self.pairs: List[Any] = []
+
+    def __enter__(self) -> "CollectiveTimer":
+        CollectiveTimer.active = self
+        return self
+
+    def __exit__(self, *exc) -> None:
+        CollectiveTimer.active = None
+
+    def results_ms(self) -> List[float]:
+        torch.cuda.synchronize()
+        return [a.elapsed_time(b) for a, b in self.pairs]
+
+
 def allreduce_flat_grad(flat_grad: torch.Tensor, world_size: int) -> float:
     """Sum all-reduce of the flat gradient; returns the scale the optimizer must apply (1/world).
     Every rank must call this every step -- a rank with no valid clip contributes zeros."""
     if world_size > 1:
-        dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
+        ct = CollectiveTimer.active
+        if ct is not None and flat_grad.is_cuda:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
+            b.record()
+            ct.pairs.append((a, b))
+        else:
+            dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
         return 1.0 / world_size
     return 1.0
 

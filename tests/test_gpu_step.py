@@ -347,19 +347,44 @@ def test_bench_two_ranks_sharing_the_gpu_over_gloo(config):
     assert out["config"]["global_batch"] == 16 and out["config"]["parallelism"] == "dp2"
     assert out["value"] > 0 and "cpu_baseline" not in out      # the CPU baseline is an N = 1 leg
     assert out["roofline"]["frac"] is None or out["roofline"]["frac"] > 0
+    assert len(lines[0]) < 6000
+    _check_scale_fields(out, 2, 1 if config == 3 else None)
 
 
-def _run_bench(argv, env=None, timeout=900):
+def _check_scale_fields(out, world, calls_per_step=None):
+    """The N > 1 line explains its own efficiency: time inside the gradient all-reduce and every rank's step spread."""
+    assert out["world_size"] == world and "rccl_version" in out
+    ar = out["allreduce_ms"]
+    assert ar["mean"] > 0 and ar["max"] >= ar["mean"] and ar["per_step"] > 0 and ar["bytes"] > 0
+    if calls_per_step is not None:
+        assert ar["calls_per_step"] == calls_per_step
+    spread = out["step_ms_per_rank"]
+    assert len(spread) == world and all(lo <= med <= hi for lo, med, hi in spread)
+    assert out["rank_median_spread_ms"] >= 0
+
+
+def _run_bench(argv, env=None, timeout=900, want_detail=False):
+    """Run bench.py as the driver does; returns the parsed LAST stdout line (and the full detail dict).  The line must be
+    the only JSON line, the last thing on stdout, and short (the driver stopped parsing the 25 KB line of round 5)."""
     import json
     import subprocess
     import sys
+    import tempfile
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    res = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + argv, env=dict(os.environ, **(env or {})), cwd=root,
-                         capture_output=True, text=True, timeout=timeout)
+    detail_path = os.path.join(tempfile.mkdtemp(), "detail.json")
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + argv + ["--detail-out", detail_path],
+                         env=dict(os.environ, **(env or {})), cwd=root, capture_output=True, text=True, timeout=timeout)
     assert res.returncode == 0, res.stderr[-2000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, res.stdout[-2000:]
-    return json.loads(lines[0])
+    assert res.stdout.rstrip("\n").splitlines()[-1] == lines[0]        # nothing follows the line on stdout
+    assert len(lines[0]) < 6000, len(lines[0])
+    out = json.loads(lines[0])
+    if want_detail:
+        assert "BENCH_DETAIL " in res.stderr
+        with open(detail_path) as f:
+            return out, json.load(f)
+    return out
 
 
 def test_bench_launches_its_own_ranks():
@@ -383,6 +408,7 @@ def test_bench_eight_ranks_sharing_the_gpu_over_gloo():
     assert out["n_gpus"] == 8 and out["world_size"] == 8 and out["dist_backend"] == "gloo"
     assert out["config"]["global_batch"] == 16 and out["config"]["parallelism"] == "dp8"
     assert out["value"] > 0 and out["worker_rc"] == 0 and "cpu_baseline" not in out
+    _check_scale_fields(out, 8, calls_per_step=1)
 
 
 def test_tbptt_step_through_rccl_with_the_cu_partition_installed(dev):
@@ -440,18 +466,32 @@ def test_tbptt_step_through_rccl_with_the_cu_partition_installed(dev):
     assert torch.equal(base[0], with_pg[0])
 
 
-def test_bench_single_gpu_line_carries_every_config():
-    """N = 1: the headline line carries `roofline`, and configs 2 / 4 / 5 measured in their own processes at their
-    BASELINE sizes under `other_configs` (CPU legs skipped here to keep the test short)."""
-    out = _run_bench(["--gpus", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-fp32-leg"], timeout=1500)
-    assert out["n_gpus"] == 1 and out["config"]["baseline_config"] == 3 and out["roofline"]["frac"] > 0
+def test_bench_driver_command_prints_one_short_parseable_line():
+    """The driver's exact command (`python3 bench.py --gpus 1 --steps 20 --warmup 5`): the LAST stdout line is one
+    self-contained JSON object under 6 KB with `roofline` and `cpu_baseline`, the other BASELINE configurations as short
+    summaries, nothing after it on stdout; the full per-kernel detail goes to bench_detail.json / stderr."""
+    out, detail = _run_bench(["--gpus", "1", "--steps", "20", "--warmup", "5"], timeout=1500, want_detail=True)
+    assert out["n_gpus"] == 1 and out["steps"] == 20 and out["warmup"] == 5 and out["dtype"] == "f32"
+    assert out["config"]["baseline_config"] == 3 and out["config"]["global_batch"] == 256
+    r = out["roofline"]
+    assert r["bound"] == "mfma" and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert r["avg_launch_ms"] > 0 and r["traffic"] > 0 and len(r["note"]) <= 200
+    c = out["cpu_baseline"]
+    assert c["value"] > 0 and c["cores"] >= 1 and c["kind"] == "port" and len(c["sample"]) <= 200
+    assert abs(out["value"] - 256 * 2.0 / (out["ms_per_step"] * 1e-3)) < 1e-6 * out["value"]
+    assert out["fx_kernel_frac_of_independent_floor"] > 0
     oc = out["other_configs"]
     assert sorted(oc) == ["2", "4", "5"]
-    for c, o in oc.items():
+    for k, o in oc.items():
         assert "error" not in o, o
-        assert o["value"] > 0 and o["ms_per_step"] > 0 and o["roofline"]["frac"] > 0, (c, o)
-        assert o["config"]["baseline_config"] == int(c)
-    assert 0 < oc["4"]["config"]["clips_trained_per_batch"]["mean"] <= 128        # the YAML's LFO validity filter is on
+        assert o["value"] > 0 and o["ms_per_step"] > 0 and o["roofline"]["frac"] > 0 and o["cpu_baseline"]["value"] > 0, (k, o)
+    assert oc["4"]["value_clips_trained"] < oc["4"]["value"]
+    # the detail file carries what the line dropped
+    assert detail["value"] == out["value"] and "kernels" in detail and "fx_kernels" in detail
+    for k, o in detail["other_configs"].items():
+        assert o["config"]["baseline_config"] == int(k) and "kernels" in o
+    assert 0 < detail["other_configs"]["4"]["config"]["clips_trained_per_batch"]["mean"] <= 128   # the YAML's LFO validity filter is on
+    assert all("tflops" not in v for k, v in detail["kernels"].items() if k.startswith("conv_prep"))
 
 
 @pytest.mark.parametrize("mode", ["lfo", "tbptt"])
