@@ -10,7 +10,7 @@ O=gpurun_out/$R
 rm -rf $O; mkdir -p $O
 ONLY=${2:-all}
 stats() { c=$1; steps=$2
-  rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c$c -- python3 bench.py --worker --config $c --steps $steps --warmup 1 --no-cpu-baseline --no-fp32-leg > $O/bench_c${c}_under_rocprof.json 2> $O/stats_c$c.err \
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c$c -- python3 bench.py --worker --config $c --steps $steps --warmup 1 --no-cpu-baseline --no-fp32-leg --detail-out $O/bench_c${c}_under_rocprof_detail.json > $O/bench_c${c}_under_rocprof.json 2> $O/stats_c$c.err \
     || echo "config $c: rocprofv3 exited with $? (after writing its CSVs; seen at process teardown with CU-masked streams)" >> $O/notes.txt
   cp $(find $O/stats_c$c -name "*kernel_stats.csv" | head -1) $O/bench_c${c}_kernel_stats.csv
   rm -rf $O/stats_c$c
