@@ -34,6 +34,7 @@
 // Algorithmic HBM traffic: 12 B/sample I/O + 1536 B/sample stash (written, read once).
 #include "conv_common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 #define LS_H 64
 #define LS_STASH 384        // floats per time step: gates 256 (i, f, g, o) + c 64 + h 64
@@ -45,6 +46,8 @@
 #define LS_PP 72            // plane pitch inside a slab row (64 + 8: the four gate planes land on different banks)
 #define LS_ROWP (6 * LS_PP) // slab row pitch (floats)
 #define LS_SLAB_FLOATS ((LS_SLAB + 2) * LS_ROWP + LS_SLAB + 72)   // rows -1 .. 32, dzy, (lfo, x) of 36 steps
+#define LS_DGL_FLOATS 1024                                        // backward: ring of four gate-gradient vectors
+#define LS_BWD_LDS_FLOATS (2 * LS_SLAB_FLOATS + LS_DGL_FLOATS + LS_THREADS + 768)
 
 typedef float ls_f2 __attribute__((ext_vector_type(2)));
 // acc(2) += W[j](2) * v[j] for j = 0..15: 16 packed FMAs in ONE asm block (the compiler pads an s_nop after every
@@ -305,8 +308,15 @@ __device__ __forceinline__ int ls_dg_slot(int r)   // LDS slot of gate row r: [1
     return ((r & 15) >> 2) * 64 + (r >> 4) * 4 + (r & 3);
 }
 
-template <bool DGOUT>    // DGOUT: also write the gate gradients (B, T, 256) -- the input of mx_lstm_dlfo (an UNFROZEN LFO model, lightning.py:258,361)
-__global__ __launch_bounds__(LS_THREADS) void lstm_bwd_kernel(const float *__restrict__ x, long long xs,
+// HELP (round 6): the weight-gradient products leave the recurrence waves.  The workgroup grows by LS_HELP_WAVES = 4 waves (one
+// per SIMD) that do nothing but the exact-fp32 matrix instructions of dW_hh (+ the dW_ih / bias sums that ride on the same A
+// values): helper wave j owns gate rows 64 j .. 64 j + 63 (four 32 x 32 tiles).  They read what the fused version read -- the gate
+// gradients of steps t + 1, t + 2 in the rotating LDS buffers and the h rows of the stash slab -- at the same point of the step and
+// join the same ONE barrier per step, so nothing about the hand-over changes; the eight recurrence waves no longer stall in-order
+// behind two 64-cycle matrix instructions and their five operand reads at the top of every second step.
+#define LS_HELP_WAVES 4
+template <bool DGOUT, bool HELP>    // DGOUT: also write the gate gradients (B, T, 256) -- the input of mx_lstm_dlfo (an UNFROZEN LFO model, lightning.py:258,361)
+__global__ __launch_bounds__(LS_THREADS + (HELP ? 64 * LS_HELP_WAVES : 0)) void lstm_bwd_kernel(const float *__restrict__ x, long long xs,
                                                               const float *__restrict__ lfo, long long ls,
                                                               const float *__restrict__ y, long long ys,
                                                               const float *__restrict__ wet, long long ws,
@@ -325,9 +335,82 @@ __global__ __launch_bounds__(LS_THREADS) void lstm_bwd_kernel(const float *__res
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int slab_floats = LS_SLAB_FLOATS;
     float *slab0 = smem, *slab1 = smem + slab_floats;
-    float *dgl = smem + 2 * slab_floats;                       // 3 x 256 gate gradients: dg(t+1), dg(t+2), and the one being written
-    float *dummy = dgl + 768;                                  // sink of the lanes that hold no gate gradient
+    float *dgl = smem + 2 * slab_floats;                       // 4 x 256 gate gradients: dg(t) lives in buffer t & 3 (dg(t+1), dg(t+2) are read while dg(t) is written)
+    float *dummy = dgl + LS_DGL_FLOATS;                        // sink of the lanes that hold no gate gradient (+ the buffer offset: LS_THREADS + 768 floats)
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (HELP && wv >= LS_THREADS / 64) {
+        // ---- helper wave: dW_hh = sum_t dg_t (x) h_{t-1}, dW_ih, biases for gate rows 64 hw .. 64 hw + 63
+        const int hw = wv - LS_THREADS / 64, c32h = lane & 31, tparh = lane >> 5;
+        const int a_slot0 = ls_dg_slot(64 * hw + c32h), a_slot1 = ls_dg_slot(64 * hw + 32 + c32h);
+        floatx16 w00, w01, w10, w11;                           // [row tile][column tile]
+#pragma unroll
+        for (int r = 0; r < 16; ++r) w00[r] = w01[r] = w10[r] = w11[r] = 0.0f;
+        float di00 = 0.0f, di01 = 0.0f, di10 = 0.0f, di11 = 0.0f, dbs0 = 0.0f, dbs1 = 0.0f;
+        const float *lbh = lfo + (size_t)b * ls, *xbh = x + (size_t)b * xs;
+        const int n_slabs_h = (T + LS_SLAB - 1) / LS_SLAB;
+        __syncthreads();                                       // the recurrence waves' first slab is in LDS, dgl is zeroed
+        for (int S = n_slabs_h - 1; S >= 0; --S) {
+            const int t0 = S * LS_SLAB, cnt = min(LS_SLAB, T - t0);
+            const float *sl = (S & 1 ? slab1 : slab0) + LS_ROWP;
+            const float *xll = (S & 1 ? slab1 : slab0) + (LS_SLAB + 2) * LS_ROWP + LS_SLAB;
+            for (int s_ = cnt - 1; s_ >= 0; --s_) {
+                if ((T - 1 - (t0 + s_)) & 1) {
+                    const float *dgb = dgl + ((s_ + 1 + tparh) & 3) * 256;         // dg(t + 1) / dg(t + 2): buffer t & 3, t0 is a multiple of 4
+                    const float av0 = dgb[a_slot0], av1 = dgb[a_slot1];
+                    const float *hrow = sl + (s_ + tparh) * LS_ROWP + 5 * LS_PP;
+                    const float bv0 = hrow[c32h], bv1 = hrow[32 + c32h];
+                    const float li = xll[s_ + 1 + tparh], xi = xll[36 + s_ + 1 + tparh];
+                    w00 = mfma32(av0, bv0, w00);
+                    w10 = mfma32(av1, bv0, w10);
+                    w01 = mfma32(av0, bv1, w01);
+                    w11 = mfma32(av1, bv1, w11);
+                    di00 = fmaf(av0, li, di00); di01 = fmaf(av0, xi, di01);
+                    di10 = fmaf(av1, li, di10); di11 = fmaf(av1, xi, di11);
+                    dbs0 += av0; dbs1 += av1;
+                }
+                ls_barrier();
+            }
+        }
+        {   // the steps the pairing left over: dg(0) (x) h_init always, dg(1) (x) h_0 when T is odd
+            const float *dgb = dgl + tparh * 256;              // dg(0) in buffer 0, dg(1) in buffer 1
+            const bool live = tparh == 0 || (T & 1);
+            const float av0 = live ? dgb[a_slot0] : 0.0f, av1 = live ? dgb[a_slot1] : 0.0f;
+            const float *hrow = tparh == 0 ? h_init + (size_t)b * LS_H : slab0 + LS_ROWP + 5 * LS_PP;
+            const float bv0 = hrow[c32h], bv1 = hrow[32 + c32h];
+            const float li = tparh < T ? (probe ? 0.5f : lbh[tparh]) : 0.0f, xi = tparh < T ? (probe ? 0.25f : xbh[tparh]) : 0.0f;
+            w00 = mfma32(av0, bv0, w00);
+            w10 = mfma32(av1, bv0, w10);
+            w01 = mfma32(av0, bv1, w01);
+            w11 = mfma32(av1, bv1, w11);
+            di00 = fmaf(av0, li, di00); di01 = fmaf(av0, xi, di01);
+            di10 = fmaf(av1, li, di10); di11 = fmaf(av1, xi, di11);
+            dbs0 += av0; dbs1 += av1;
+        }
+        float *pbh = part + (size_t)b * LS_NPARAM;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = 64 * hw + mfma_row(r, lane);
+            pbh[512 + row * LS_H + c32h] = w00[r];
+            pbh[512 + row * LS_H + 32 + c32h] = w01[r];
+            pbh[512 + (row + 32) * LS_H + c32h] = w10[r];
+            pbh[512 + (row + 32) * LS_H + 32 + c32h] = w11[r];
+        }
+        const float s00 = di00 + __shfl_xor(di00, 32, 64), s01 = di01 + __shfl_xor(di01, 32, 64);
+        const float s10 = di10 + __shfl_xor(di10, 32, 64), s11 = di11 + __shfl_xor(di11, 32, 64);
+        const float sb0 = dbs0 + __shfl_xor(dbs0, 32, 64), sb1 = dbs1 + __shfl_xor(dbs1, 32, 64);
+        if (tparh == 0) {
+            const int row = 64 * hw + c32h;
+            pbh[row * 2] = s00;
+            pbh[row * 2 + 1] = s01;
+            pbh[(row + 32) * 2] = s10;
+            pbh[(row + 32) * 2 + 1] = s11;
+            pbh[512 + 16384 + row] = sb0;
+            pbh[512 + 16384 + 256 + row] = sb0;
+            pbh[512 + 16384 + row + 32] = sb1;
+            pbh[512 + 16384 + 256 + row + 32] = sb1;
+        }
+        return;
+    }
     const int rg = lane & 15, kp = wv * 4 + (lane >> 4);       // 16 gate rows 16 rg .. 16 rg + 15, hidden units 2 kp, 2 kp + 1
     const int e = rg & 7, q = e & 3, k = 2 * kp + (e >> 2);    // the (unit, gate) this lane differentiates (rg >= 8: duplicate)
     const bool second = e >> 2;
@@ -360,135 +443,163 @@ __global__ __launch_bounds__(LS_THREADS) void lstm_bwd_kernel(const float *__res
 
     const int n_slabs = (T + LS_SLAB - 1) / LS_SLAB;
     float4 pre[6];
-    float pre_c = 0.0f, pre_dzy = 0.0f, pre_h32 = 0.0f, pre_xl = 0.0f;
+    float pre_c = 0.0f, pre_y = 0.0f, pre_w = 0.0f, pre_xl = 0.0f;
+    bool pre_live = false;
     // slab S -> registers (global, coalesced: 32 x 384 contiguous floats), registers -> LDS (plane-padded)
-    auto slab_load = [&](int S) {
-        const int t0 = S * LS_SLAB, cnt = min(LS_SLAB, T - t0);
+    // FULL (every slab but the clip's last, which is loaded once before the loop): no bounds predicates.  The addresses are a
+    // wave-uniform slab base + a 32-bit lane offset (the scalar-base form of the loads): hoisted 64-bit per-lane addresses of the
+    // six loads were spilled to scratch memory by the 168-register variant and reloaded in a chain of dependent round trips.
+    auto slab_load = [&](int S, auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        const int t0 = S * LS_SLAB, cnt = FULL ? LS_SLAB : min(LS_SLAB, T - t0);
         if (probe) {                                   // serial-floor measurement: no global traffic, constant values
 #pragma unroll
             for (int i = 0; i < 6; ++i) pre[i] = make_float4(0.5f, 0.5f, 0.5f, 0.5f);
             pre_c = 0.5f;
-            pre_dzy = 1e-3f;
-            pre_h32 = 0.5f;
+            pre_live = true;
+            pre_y = 0.0f;
+            pre_w = 0.0f;
             pre_xl = 0.25f;
             return;
         }
+        const char *gbase = reinterpret_cast<const char *>(sb + (size_t)t0 * LS_STASH);     // wave-uniform
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
-            const int e = (i * LS_THREADS + tid) * 4;                  // element of the 32 x 384 slab
-            pre[i] = e < cnt * LS_STASH ? *(const float4 *)(sb + (size_t)t0 * LS_STASH + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const unsigned e = (unsigned)(i * LS_THREADS + tid) * 4u;                      // element of the 32 x 384 slab
+            if (FULL || e < (unsigned)(cnt * LS_STASH)) pre[i] = *reinterpret_cast<const float4 *>(gbase + e * 4u);
+            else pre[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         if (tid < LS_H) pre_c = t0 > 0 ? sb[(size_t)(t0 - 1) * LS_STASH + 256 + tid] : c_init[(size_t)b * LS_H + tid];
-        if (tid >= 64 && tid < 64 + LS_SLAB) {
-            const int t = t0 + tid - 64;
-            if (t < T) {
-                const float yv = yb[t];
-                float g;
-                if (dy) g = dy[(size_t)b * dys + t];
-                else {
-                    const float e = yv - wb[t];
-                    g = loss_scale * (e > 0.0f ? 1.0f : (e < 0.0f ? -1.0f : 0.0f));
-                }
-                pre_dzy = g * (1.0f - yv * yv);
-            } else
-                pre_dzy = 0.0f;
+        if (tid >= 64 && tid < 64 + LS_SLAB) {                         // raw y and wet (or dy): d loss / d (pre-tanh output) is formed in
+            const int t = t0 + tid - 64;                               // slab_store, 16 steps later -- computing it here put a wait for ALL
+            pre_live = FULL || t < T;                                  // outstanding loads (the six slab vectors included) on this step's path
+            if (pre_live) {
+                pre_y = yb[t];
+                pre_w = dy ? dy[(size_t)b * dys + t] : wb[t];
+            }
         }
-        if (tid >= 96 && tid < 96 + LS_H) pre_h32 = t0 + LS_SLAB < T ? sb[(size_t)(t0 + LS_SLAB) * LS_STASH + 320 + tid - 96] : 0.0f;
         if (tid >= 160 && tid < 160 + 72) {                            // lfo of steps t0 .. t0 + 35, then x of the same steps
             const int i = tid - 160, t = t0 + (i < 36 ? i : i - 36);
             pre_xl = t < T ? (i < 36 ? lb[t] : xb[t]) : 0.0f;
         }
     };
-    auto slab_store = [&](float *dst) {
+    auto slab_store = [&](float *dst, const float *above) {
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             const int e = (i * LS_THREADS + tid) * 4, srow = e / LS_STASH, j = e % LS_STASH;
             *(float4 *)(dst + (srow + 1) * LS_ROWP + (j >> 6) * LS_PP + (j & 63)) = pre[i];
         }
         if (tid < LS_H) dst[4 * LS_PP + tid] = pre_c;                  // row -1, c plane
-        if (tid >= 64 && tid < 64 + LS_SLAB) dst[(LS_SLAB + 2) * LS_ROWP + tid - 64] = pre_dzy;
-        if (tid >= 96 && tid < 96 + LS_H) dst[(LS_SLAB + 1) * LS_ROWP + 5 * LS_PP + tid - 96] = pre_h32;   // row 32, h plane
+        if (tid >= 64 && tid < 64 + LS_SLAB) {
+            float dzy_ = 0.0f;
+            if (probe) dzy_ = 1e-3f;
+            else if (pre_live) {
+                float g = pre_w;                                       // dy given: d loss / d y itself
+                if (!dy) {
+                    const float e = pre_y - pre_w;
+                    g = loss_scale * (e > 0.0f ? 1.0f : (e < 0.0f ? -1.0f : 0.0f));
+                }
+                dzy_ = g * (1.0f - pre_y * pre_y);
+            }
+            dst[(LS_SLAB + 2) * LS_ROWP + tid - 64] = dzy_;
+        }
+        // row 32, h plane = h of the step after the slab = row 0 of the slab above, which is the OTHER buffer's (in LDS: no load)
+        if (tid >= 96 && tid < 96 + LS_H) dst[(LS_SLAB + 1) * LS_ROWP + 5 * LS_PP + tid - 96] = above ? above[LS_ROWP + 5 * LS_PP + tid - 96] : 0.0f;
         if (tid >= 160 && tid < 160 + 72) dst[(LS_SLAB + 2) * LS_ROWP + LS_SLAB + tid - 160] = pre_xl;
     };
 
-    for (int i = tid; i < 768; i += LS_THREADS) dgl[i] = 0.0f;        // dh from "step T" is zero
-    slab_load(n_slabs - 1);
-    slab_store((n_slabs - 1) & 1 ? slab1 : slab0);
+    for (int i = tid; i < LS_DGL_FLOATS; i += LS_THREADS) dgl[i] = 0.0f;        // dh from "step T" is zero
+    slab_load(n_slabs - 1, std::false_type{});
+    slab_store((n_slabs - 1) & 1 ? slab1 : slab0, nullptr);
     __syncthreads();
 
     float dc_next = 0.0f;
-    int b_cur = 0, b_prev = 1, b_wr = 2;                               // dgl buffers: dg(t+1), dg(t+2), written by this step
+    float n_a, n_p, n_f, n_o, n_c, n_z, n_h;                          // raw stash values of the next step processed (prefetched one step ahead)
+    float *const wr_base = owner ? dgl + dg_wr : dummy + tid;
+    const float *const dr_base = dgl + dg_rd;
+    // One step.  Called with a compile-time `s` from the unrolled loop over a full slab (round 6): every LDS address of the step
+    // is then a per-slab lane register + an immediate -- the ring position of the gate-gradient buffers (t & 3; t0 is a multiple
+    // of 32), the slab row, the slab-store point -- and nothing of the step's bookkeeping is vector arithmetic any more.
+    auto step = [&](const int s, const int cnt, const int S, const int t0, const float *sl, const float *dzl, const float *xll,
+                    const float *pa, const float *pp_, const float *pf, const float *po, const float *pc, const float *ph) {
+        const int bc = (s + 1) & 3, bw = s & 3;
+        // (0) [fused variant only] every second step: gate gradients of steps t+1, t+2 (x) the states entering them -> dW_hh, dW_ih, db
+        if (!HELP && ((T - 1 - (t0 + s)) & 1)) {
+            const float av = dgl[((s + 1 + tpar) & 3) * 256 + a_slot];
+            const float *hrow = sl + (s + tpar) * LS_ROWP + 5 * LS_PP;      // h_t (tpar 0) / h_{t+1} (tpar 1); row 32 exists
+            const float bv0 = hrow[c32], bv1 = hrow[32 + c32];
+            const float li = xll[s + 1 + tpar], xi = xll[36 + s + 1 + tpar];
+            wacc0 = mfma32(av, bv0, wacc0);
+            wacc1 = mfma32(av, bv1, wacc1);
+            dwi0 = fmaf(av, li, dwi0);
+            dwi1 = fmaf(av, xi, dwi1);
+            dbs += av;
+        }
+        // (1) the 16 gate gradients of step t+1 this lane multiplies
+        const float *dr = dr_base + bc * 256;
+        const float4 g0 = *(const float4 *)dr, g1 = *(const float4 *)(dr + 64), g2 = *(const float4 *)(dr + 128),
+                     g3 = *(const float4 *)(dr + 192);
+        __builtin_amdgcn_sched_barrier(0);                         // (first thing behind the barrier: these four reads head the step's dependent chain)
+        // (2) while they arrive: the local derivatives of step t from the values prefetched last step
+        const float a = n_a, pp = n_p, f = n_f, o = n_o, dzy = n_z;
+        dfw = fmaf(dzy, n_h, dfw);                                 // d fc.weight[k] = sum_t dzy_t h_t[k]
+        dfb += dzy;
+        const float tc = ls_tanh(n_c);
+        const float kc = o * fmaf(-tc, tc, 1.0f);                  // d h / d c = o (1 - tanh^2 c)
+        const float der = fmaf(a, beta - a, alpha);
+        const float kq = der * (q == 3 ? tc : pp);                 // i: g i(1-i); f: c_prev f(1-f); g: i (1-g^2); o: tanh(c) o(1-o)
+        // (3) prefetch the raw values of step t-1 (row -1 of the slab is never used as a step)
+        {   // unconditional (s = 0 re-reads row 0): the compiler can then count these reads behind the four above
+            const int sp = s > 0 ? s - 1 : 0;
+            n_a = pa[sp * LS_ROWP]; n_p = pp_[sp * LS_ROWP]; n_f = pf[sp * LS_ROWP]; n_o = po[sp * LS_ROWP]; n_c = pc[sp * LS_ROWP];
+            n_z = dzl[sp];
+            n_h = ph[sp * LS_ROWP];
+        }
+        __builtin_amdgcn_sched_barrier(0);                         // (the prefetch reads stay in FRONT of the FMA chain: sunk to the end of
+                                                                   //  the step they sit between the dg write and the barrier, on the critical path)
+        // (4) dh_prev[k] = sum_r W[r][k] dg[r] for the unit pair: 16 rows per lane, all-reduce over the 16 row groups
+        ls_f2 acc = {0.0f, 0.0f};
+        LS_PK16(acc, wp, g0, g1, g2, g3);
+        float da = acc.x, db = acc.y;
+        da += ls_dpp<0xB1>(da); db += ls_dpp<0xB1>(db);            // quad_perm [1,0,3,2]
+        da += ls_dpp<0x4E>(da); db += ls_dpp<0x4E>(db);            // quad_perm [2,3,0,1]
+        da += ls_dpp<0x141>(da); db += ls_dpp<0x141>(db);          // row_half_mirror
+        da += ls_dpp<0x140>(da); db += ls_dpp<0x140>(db);          // row_mirror
+        const float dhn = second ? db : da;
+        // (5) element-wise backward of step t
+        const float dh = fmaf(dzy, fcw, dhn);
+        const float dc = fmaf(dh, kc, dc_next);
+        const float dg = (q == 3 ? dh : dc) * kq;
+        dc_next = dc * f;
+        wr_base[bw * 256] = dg;
+        if (DGOUT && owner) dgate[((size_t)b * T + (t0 + s)) * 256 + q * LS_H + k] = dg;       // row order of weight_ih_l0: gate * 64 + unit
+        if (S > 0 && s == cnt / 2) slab_store((S - 1) & 1 ? slab1 : slab0, S & 1 ? slab1 : slab0);   // the other buffer is idle
+        ls_barrier();
+        __builtin_amdgcn_sched_barrier(0);                         // (nothing of the next step is hoisted in front of the barrier)
+    };
     for (int S = n_slabs - 1; S >= 0; --S) {
         const int t0 = S * LS_SLAB, cnt = min(LS_SLAB, T - t0);
         const float *sl = (S & 1 ? slab1 : slab0) + LS_ROWP;           // row 0 of the slab
         const float *dzl = (S & 1 ? slab1 : slab0) + (LS_SLAB + 2) * LS_ROWP;
         const float *xll = dzl + LS_SLAB;                              // lfo[t0 + i] at i, x[t0 + i] at 36 + i
-        if (S > 0) slab_load(S - 1);
-        // raw stash values of the first step processed (the loop below prefetches one step ahead)
-        const float *r0 = sl + (cnt - 1) * LS_ROWP;
-        float n_a = r0[off_a], n_p = r0[off_p], n_f = r0[off_f], n_o = r0[off_o], n_c = r0[off_c], n_z = dzl[cnt - 1];
-        float n_h = r0[off_h];
-        for (int s = cnt - 1; s >= 0; --s) {
-            // (0) every second step: gate gradients of steps t+1, t+2 (x) the states entering them -> dW_hh, dW_ih, db
-            if ((T - 1 - (t0 + s)) & 1) {
-                const float av = dgl[(tpar ? b_prev : b_cur) * 256 + a_slot];
-                const float *hrow = sl + (s + tpar) * LS_ROWP + 5 * LS_PP;      // h_t (tpar 0) / h_{t+1} (tpar 1); row 32 exists
-                const float bv0 = hrow[c32], bv1 = hrow[32 + c32];
-                const float li = xll[s + 1 + tpar], xi = xll[36 + s + 1 + tpar];
-                wacc0 = mfma32(av, bv0, wacc0);
-                wacc1 = mfma32(av, bv1, wacc1);
-                dwi0 = fmaf(av, li, dwi0);
-                dwi1 = fmaf(av, xi, dwi1);
-                dbs += av;
-            }
-            // (1) the 16 gate gradients of step t+1 this lane multiplies
-            const float *dr = dgl + b_cur * 256 + dg_rd;
-            const float4 g0 = *(const float4 *)dr, g1 = *(const float4 *)(dr + 64), g2 = *(const float4 *)(dr + 128),
-                         g3 = *(const float4 *)(dr + 192);
-            // (2) while they arrive: the local derivatives of step t from the values prefetched last step
-            const float a = n_a, pp = n_p, f = n_f, o = n_o, dzy = n_z;
-            dfw = fmaf(dzy, n_h, dfw);                                 // d fc.weight[k] = sum_t dzy_t h_t[k]
-            dfb += dzy;
-            const float tc = ls_tanh(n_c);
-            const float kc = o * fmaf(-tc, tc, 1.0f);                  // d h / d c = o (1 - tanh^2 c)
-            const float der = fmaf(a, beta - a, alpha);
-            const float kq = der * (q == 3 ? tc : pp);                 // i: g i(1-i); f: c_prev f(1-f); g: i (1-g^2); o: tanh(c) o(1-o)
-            // (3) prefetch the raw values of step t-1 (row -1 of the slab is never used as a step)
-            {   // unconditional (s = 0 re-reads row 0): the compiler can then count these reads behind the four above
-                const int sp = s > 0 ? s - 1 : 0;
-                const float *rn = sl + sp * LS_ROWP;
-                n_a = rn[off_a]; n_p = rn[off_p]; n_f = rn[off_f]; n_o = rn[off_o]; n_c = rn[off_c]; n_z = dzl[sp];
-                n_h = rn[off_h];
-            }
-            // (4) dh_prev[k] = sum_r W[r][k] dg[r] for the unit pair: 16 rows per lane, all-reduce over the 16 row groups
-            ls_f2 acc = {0.0f, 0.0f};
-            LS_PK16(acc, wp, g0, g1, g2, g3);
-            float da = acc.x, db = acc.y;
-            da += ls_dpp<0xB1>(da); db += ls_dpp<0xB1>(db);            // quad_perm [1,0,3,2]
-            da += ls_dpp<0x4E>(da); db += ls_dpp<0x4E>(db);            // quad_perm [2,3,0,1]
-            da += ls_dpp<0x141>(da); db += ls_dpp<0x141>(db);          // row_half_mirror
-            da += ls_dpp<0x140>(da); db += ls_dpp<0x140>(db);          // row_mirror
-            const float dhn = second ? db : da;
-            // (5) element-wise backward of step t
-            const float dh = fmaf(dzy, fcw, dhn);
-            const float dc = fmaf(dh, kc, dc_next);
-            const float dg = (q == 3 ? dh : dc) * kq;
-            dc_next = dc * f;
-            *(owner ? dgl + b_wr * 256 + dg_wr : dummy + tid) = dg;
-            if (DGOUT && owner) dgate[((size_t)b * T + (t0 + s)) * 256 + q * LS_H + k] = dg;       // row order of weight_ih_l0: gate * 64 + unit
-            {
-                const int t_ = b_prev;                                 // rotate: the buffer of dg(t+2) is free after this step
-                b_prev = b_cur;
-                b_cur = b_wr;
-                b_wr = t_;
-            }
-            if (S > 0 && s == cnt / 2) slab_store((S - 1) & 1 ? slab1 : slab0);   // the other buffer is idle
-            ls_barrier();
+        const float *pa = sl + off_a, *pp_ = sl + off_p, *pf = sl + off_f, *po = sl + off_o, *pc = sl + off_c, *ph = sl + off_h;
+        if (S > 0) slab_load(S - 1, std::true_type{});
+        // raw stash values of the first step processed (the steps prefetch one step ahead)
+        {
+            const int r0 = (cnt - 1) * LS_ROWP;
+            n_a = pa[r0]; n_p = pp_[r0]; n_f = pf[r0]; n_o = po[r0]; n_c = pc[r0]; n_z = dzl[cnt - 1];
+            n_h = ph[r0];
+        }
+        if (cnt == LS_SLAB) {
+#pragma unroll
+            for (int s = LS_SLAB - 1; s >= 0; --s) step(s, LS_SLAB, S, t0, sl, dzl, xll, pa, pp_, pf, po, pc, ph);
+        } else {
+            for (int s = cnt - 1; s >= 0; --s) step(s, cnt, S, t0, sl, dzl, xll, pa, pp_, pf, po, pc, ph);
         }
     }
     // the steps the pairing above left over: dg(0) (x) h_init always, dg(1) (x) h_0 when T is odd
-    {
-        const float av = tpar == 0 ? dgl[b_cur * 256 + a_slot] : ((T & 1) ? dgl[b_prev * 256 + a_slot] : 0.0f);
+    if (!HELP) {
+        const float av = tpar == 0 ? dgl[a_slot] : ((T & 1) ? dgl[256 + a_slot] : 0.0f);              // dg(0): buffer 0, dg(1): buffer 1
         const float *hrow = tpar == 0 ? h_init + (size_t)b * LS_H : slab0 + LS_ROWP + 5 * LS_PP;     // slab 0, row 0, h plane
         const float bv0 = hrow[c32], bv1 = hrow[32 + c32];
         const float li = tpar < T ? (probe ? 0.5f : lb[tpar]) : 0.0f, xi = tpar < T ? (probe ? 0.25f : xb[tpar]) : 0.0f;
@@ -501,13 +612,15 @@ __global__ __launch_bounds__(LS_THREADS) void lstm_bwd_kernel(const float *__res
     // one gradient row per clip, state-dict order:
     //   [lstm.weight_ih_l0 (256,2) | lstm.weight_hh_l0 (256,64) | lstm.bias_ih_l0 | lstm.bias_hh_l0 | fc.weight | fc.bias]
     float *pb = part + (size_t)b * LS_NPARAM;
+    if (!HELP) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = 32 * wv + mfma_row(r, lane);
-        pb[512 + row * LS_H + c32] = wacc0[r];
-        pb[512 + row * LS_H + 32 + c32] = wacc1[r];
+        for (int r = 0; r < 16; ++r) {
+            const int row = 32 * wv + mfma_row(r, lane);
+            pb[512 + row * LS_H + c32] = wacc0[r];
+            pb[512 + row * LS_H + 32 + c32] = wacc1[r];
+        }
     }
-    {
+    if (!HELP) {
         const float s0 = dwi0 + __shfl_xor(dwi0, 32, 64), s1 = dwi1 + __shfl_xor(dwi1, 32, 64);
         const float sbias = dbs + __shfl_xor(dbs, 32, 64);
         if (tpar == 0) {
@@ -532,20 +645,24 @@ static int lstm_bwd_l1_launch(const float *x, int64_t x_stride, const float *lfo
     if (!x || !lfo || !y || (!wet && !dy) || !stash || !w_hh || !fc_w || !h_init || !c_init || !part || B <= 0 || T <= 0)
         return MX_ERR_ARG;
     if (T >= (1ll << 30)) return MX_ERR_UNSUPPORTED;
-    const size_t lds = (size_t)(2 * LS_SLAB_FLOATS + 768 + LS_THREADS) * sizeof(float);
-    static MxLdsLatch latch = {}, latch_dg = {};              // per device (common.h)
-    if (dgate) {
-        if (mx_set_dyn_lds(latch_dg, (const void *)lstm_bwd_kernel<true>, lds) != MX_OK) return MX_ERR_LAUNCH;
-        hipLaunchKernelGGL(lstm_bwd_kernel<true>, dim3((unsigned)B), dim3(LS_THREADS), lds, (hipStream_t)stream, x,
-                           (long long)x_stride, lfo, (long long)lfo_stride, y, (long long)y_stride, wet, (long long)wet_stride,
-                           stash, w_hh, fc_w, h_init, c_init, loss_scale, dy, (long long)dy_stride, part, dgate, (int)T, probe);
-        return mx_launch_status();
+    const size_t lds = (size_t)LS_BWD_LDS_FLOATS * sizeof(float);
+    // MODEX_LSTM_HELPERS=0: the round-5 kernel (weight-gradient matrix instructions inside the recurrence waves); default: on helper waves
+    static const bool help = !(getenv("MODEX_LSTM_HELPERS") && atoi(getenv("MODEX_LSTM_HELPERS")) == 0);
+    static MxLdsLatch latch[2][2] = {};                       // per device (common.h), per (DGOUT, HELP) instance
+#define LS_BWD_LAUNCH(DG, HP)                                                                                                       \
+    {                                                                                                                               \
+        if (mx_set_dyn_lds(latch[DG][HP], (const void *)lstm_bwd_kernel<DG, HP>, lds) != MX_OK) return MX_ERR_LAUNCH;               \
+        hipLaunchKernelGGL((lstm_bwd_kernel<DG, HP>), dim3((unsigned)B), dim3(LS_THREADS + (HP ? 64 * LS_HELP_WAVES : 0)), lds,    \
+                           (hipStream_t)stream, x, (long long)x_stride, lfo, (long long)lfo_stride, y, (long long)y_stride, wet,   \
+                           (long long)wet_stride, stash, w_hh, fc_w, h_init, c_init, loss_scale, dy, (long long)dy_stride, part,   \
+                           DG ? dgate : nullptr, (int)T, probe);                                                                    \
+        return mx_launch_status();                                                                                                  \
     }
-    if (mx_set_dyn_lds(latch, (const void *)lstm_bwd_kernel<false>, lds) != MX_OK) return MX_ERR_LAUNCH;
-    hipLaunchKernelGGL(lstm_bwd_kernel<false>, dim3((unsigned)B), dim3(LS_THREADS), lds, (hipStream_t)stream, x,
-                       (long long)x_stride, lfo, (long long)lfo_stride, y, (long long)y_stride, wet, (long long)wet_stride,
-                       stash, w_hh, fc_w, h_init, c_init, loss_scale, dy, (long long)dy_stride, part, nullptr, (int)T, probe);
-    return mx_launch_status();
+    if (dgate) {
+        if (help) LS_BWD_LAUNCH(true, true) else LS_BWD_LAUNCH(true, false)
+    }
+    if (help) LS_BWD_LAUNCH(false, true) else LS_BWD_LAUNCH(false, false)
+#undef LS_BWD_LAUNCH
 }
 
 MX_EXPORT int mx_lstm_bwd_l1(const float *x, int64_t x_stride, const float *lfo, int64_t lfo_stride, const float *y,

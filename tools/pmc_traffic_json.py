@@ -61,3 +61,29 @@ if os.path.exists(p5f) and os.path.exists(p5w):
                        "and read once"},
               open(os.path.join(d, "pmc_mrstft.json"), "w"), indent=1)
     print("mrstft:", (2.0 * fetch + write) * 1000.0 / alg, "x algorithmic")
+
+# vector-pipe counters of the MR-STFT kernels: pmc_c5_b64_valu.txt -> pmc_mrstft_valu.json
+p5v = os.path.join(d, "pmc_c5_b64_valu.txt")
+if os.path.exists(p5v):
+    per = {}
+    tot = {"SQ_INSTS_VALU": 0.0, "SQ_ACTIVE_INST_VALU": 0.0, "SQ_BUSY_CU_CYCLES": 0.0, "SQ_WAVE_CYCLES": 0.0}
+    for line in open(p5v):
+        m = re.match(r"(.{60}) x\s*(\d+)\s+([\d.]+) ms/launch\s+(.*)", line)
+        if not m or "mr_onepass" not in m.group(1):
+            continue
+        vals = {k: float(v) for k, v in (kv.split("=") for kv in m.group(4).split())}
+        per[m.group(1).strip()] = dict(vals, ms_per_launch=float(m.group(3)),
+                                       valu_busy=round(vals["SQ_ACTIVE_INST_VALU"] / vals["SQ_BUSY_CU_CYCLES"], 4),
+                                       valu_share_of_wave_cycles=round(vals["SQ_ACTIVE_INST_VALU"] / vals["SQ_WAVE_CYCLES"], 4))
+        for k in tot:
+            tot[k] += vals[k]
+    if per:
+        json.dump({"kernels": per, "batch_measured": 64,
+                   "valu_busy": round(tot["SQ_ACTIVE_INST_VALU"] / tot["SQ_BUSY_CU_CYCLES"], 4),
+                   "valu_insts_per_call_b64": tot["SQ_INSTS_VALU"],
+                   "note": "rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES over bench.py --config 5 --batch 64; "
+                           "valu_busy = SQ_ACTIVE_INST_VALU (quad-cycles over all waves) / SQ_BUSY_CU_CYCLES (cycles over all CUs) = the "
+                           "fraction of the four SIMDs' vector issue time in use (1.0 on the bare phaser cascade probe); "
+                           "SQ_INSTS_VALU is per wave-instruction (a packed fp32 FMA = 4 flop x 64 lanes)"},
+                  open(os.path.join(d, "pmc_mrstft_valu.json"), "w"), indent=1)
+        print("mrstft valu busy:", tot["SQ_ACTIVE_INST_VALU"] / tot["SQ_BUSY_CU_CYCLES"])

@@ -35,8 +35,10 @@ run_pmc5 fetch FETCH_SIZE
 python tools/pmc_summary.py $O/pmc5_fetch mr_ > $O/pmc_c5_b64_fetch.txt
 run_pmc5 write WRITE_SIZE
 python tools/pmc_summary.py $O/pmc5_write mr_ > $O/pmc_c5_b64_write.txt
+run_pmc5 valu SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES
+python tools/pmc_summary.py $O/pmc5_valu mr_ > $O/pmc_c5_b64_valu.txt
 python tools/pmc_traffic_json.py $O
-rm -rf $O/pmc5_fetch $O/pmc5_write
+rm -rf $O/pmc5_fetch $O/pmc5_write $O/pmc5_valu
 # the sample-recurrent kernels of config 4 (LSTM forward / backward): issue and LDS counters
 rocprofv3 --kernel-trace --pmc SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_lstm -- python3 tools/bench_lstm.py > $O/pmc_lstm.log 2>&1
 python tools/pmc_summary.py $O/pmc_lstm lstm > $O/pmc_lstm_sq.txt
