@@ -40,6 +40,7 @@
 #define LS_STASH 384        // floats per time step: gates 256 (i, f, g, o) + c 64 + h 64
 #define LS_TB 256           // steps per history block (forward)
 #define LS_HP 68            // history row pitch (floats): 17 x 16 B, conflict-free for the per-step row reads
+#define LS_FG 16            // forward: steps per unrolled group (LDS offsets of a group's steps are immediates)
 #define LS_NPARAM 17473     // 512 + 16384 + 256 + 256 + 64 + 1
 #define LS_THREADS 512
 #define LS_SLAB 32          // steps per stash slab (backward)
@@ -110,6 +111,16 @@ __device__ unsigned long long ls_diag[8 * 8];
 #define LS_DIAG_INIT
 #define LS_DIAG_DUMP
 #endif
+// a wave-uniform global pointer pinned to scalar registers: accesses through it take the scalar-base + 32-bit lane offset form
+// (address space 1 kept through the integer round trip: a generic pointer would make them flat_* instructions, which also
+// count on the LDS counter the step waits on)
+typedef __attribute__((address_space(1))) float ls_gfloat;
+__device__ __forceinline__ ls_gfloat *ls_uniform_mut(float *p)
+{
+    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (ls_gfloat *)(((unsigned long long)hi << 32) | lo);
+}
 __device__ __forceinline__ void ls_barrier()      // LDS-only: outstanding global stores keep flying
 {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -131,7 +142,7 @@ __global__ __launch_bounds__(128 * KQ) void lstm_fwd_kernel(const float *__restr
 {
     __shared__ __attribute__((aligned(16))) float hist[(LS_TB + 1) * LS_HP];   // row 0 = state entering the block
     __shared__ __attribute__((aligned(16))) float2 xl[LS_TB];                   // (lfo, x) of the block
-    __shared__ float dummy[LS_THREADS];                                          // sink of the lanes that hold no h
+    __shared__ float dummy[LS_THREADS + LS_FG * LS_HP];                          // sink of the lanes that hold no h (+ a group's row offsets)
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     constexpr int KPL = LS_H / KQ;                  // k values per lane
     const int kq = lane & (KQ - 1), gp = (lane / KQ) & 1, u = wv * (32 / KQ) + lane / (2 * KQ);
@@ -175,6 +186,79 @@ __global__ __launch_bounds__(128 * KQ) void lstm_fwd_kernel(const float *__restr
         float *hwp = hw;
         LS_DIAG_INIT
         float *st = sb + (size_t)t0 * LS_STASH + st_off;       // dereferenced only when sb != NULL (wave-uniform test)
+#if LS_ABL == 0 && !defined(LS_DIAG)
+        // Round 6: blocks whose length is a multiple of LS_FG steps run in unrolled groups -- the row of the h history read and
+        // written, the (lfo, x) pair and the stash row of a step are a per-group base + an immediate, the loop counter is a
+        // scalar, and the stash store of step t is issued at the head of step t + 1 behind its h reads (it sat between the h
+        // write and the barrier: five instructions on every step's critical path).  Same arithmetic, same order.
+        if ((cnt % LS_FG) == 0) {
+          auto run_groups = [&](auto st_tag) {
+            constexpr bool do_st = decltype(st_tag)::value;    // the BPTT stash is written (wave-uniform: two instances of the loop)
+            float pend_a = 0.0f, pend_c = 0.0f, pend_h = 0.0f; // the previous step's stash values
+            const int hw_group = writer ? LS_FG * LS_HP : 0;
+            const float2 *xlg = xl;
+            for (int g = 0; g < cnt; g += LS_FG) {
+                // stash rows of the group: wave-uniform base in scalar registers + the lane's slot
+                ls_gfloat *stg = do_st ? ls_uniform_mut(sb + (size_t)(t0 + g) * LS_STASH) : nullptr;
+#pragma unroll
+                for (int j = 0; j < LS_FG; ++j) {
+                    const float2 in = xlg[j];                  // (first: the input term is then formed while the h reads are in flight)
+                    const float4 h0 = *(const float4 *)(hr + j * LS_HP), h1 = *(const float4 *)(hr + j * LS_HP + 4),
+                                 h2 = *(const float4 *)(hr + j * LS_HP + 8), h3 = *(const float4 *)(hr + j * LS_HP + 12);
+                    float4 h4, h5, h6, h7;
+                    if (KQ == 2) {
+                        h4 = *(const float4 *)(hr + j * LS_HP + 16); h5 = *(const float4 *)(hr + j * LS_HP + 20);
+                        h6 = *(const float4 *)(hr + j * LS_HP + 24); h7 = *(const float4 *)(hr + j * LS_HP + 28);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);         // (the step's reads first; the deferred store rides in their shadow)
+                    if (do_st && (g > 0 || j > 0)) {                   // (the selects live here, not between the barrier and the reads)
+                        if (KQ == 4) stg[(j - 1) * LS_STASH + st_off] = st_c ? pend_c : (st_h ? pend_h : pend_a);
+                        else {
+                            stg[(j - 1) * LS_STASH + st_off] = pend_a;
+                            stg[(j - 1) * LS_STASH + st_off2] = st_c ? pend_c : (st_h ? pend_h : pend_a);
+                        }
+                    }
+                    ls_f2 acc = wi1 * in.y + (wi0 * in.x + bias);
+                    LS_PK16(acc, wp, h0, h1, h2, h3);
+                    if (KQ == 2) {
+                        const ls_f2 *wq = wp + (KQ == 2 ? 16 : 0);
+                        LS_PK16(acc, wq, h4, h5, h6, h7);
+                    }
+                    float pa = acc.x, pb = acc.y;
+                    pa += ls_dpp<0xB1>(pa); pb += ls_dpp<0xB1>(pb);     // quad_perm [1,0,3,2]
+                    if (KQ == 4) { pa += ls_dpp<0x4E>(pa); pb += ls_dpp<0x4E>(pb); }   // quad_perm [2,3,0,1]: all four quarters
+                    const float a = ls_act(odd ? pb : pa, nsl2e, s, oms);
+                    float gi, gf, gg, go;
+                    if (KQ == 4) {
+                        const float m = ls_dpp<0x141>(a);               // row_half_mirror: the other gate pair of the unit
+                        gi = ls_dpp<0x00>(a); gf = ls_dpp<0x55>(a); gg = ls_dpp<0x55>(m); go = ls_dpp<0x00>(m);
+                    } else {
+                        gi = ls_dpp<0x00>(a); gf = ls_dpp<0x55>(a); gg = ls_dpp<0xAA>(a); go = ls_dpp<0xFF>(a);
+                    }
+                    c = fmaf(gf, c, gi * gg);
+                    const float hv = go * ls_tanh(c);
+                    hwp[j * LS_HP] = hv;
+                    pend_a = a; pend_c = c; pend_h = hv;
+                    ls_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                hr += LS_FG * LS_HP;
+                hwp += hw_group;
+                xlg += LS_FG;
+            }
+            if (do_st) {                                       // the block's last step
+                float *stl = sb + (size_t)(t0 + cnt - 1) * LS_STASH;
+                if (KQ == 4) stl[st_off] = st_c ? pend_c : (st_h ? pend_h : pend_a);
+                else {
+                    stl[st_off] = pend_a;
+                    stl[st_off2] = st_c ? pend_c : (st_h ? pend_h : pend_a);
+                }
+            }
+          };
+          if (sb && !probe) run_groups(std::true_type{});
+          else run_groups(std::false_type{});
+        } else
+#endif
         for (int tt = 0; tt < cnt; ++tt) {
             float4 h0, h1, h2, h3;
             if (LS_ABL & 1) {
