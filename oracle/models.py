@@ -142,15 +142,24 @@ class LSTMEffectModel(nn.Module):
         return torch.tanh(self.fc(out).swapaxes(1, 2) + x)
 
 
-def forward_routed(ref: "Spectral2DCNN", x: T, masks, tap: dict, W: int, tie_tol: float = 2e-6):
+def forward_routed(ref: "Spectral2DCNN", x: T, masks, tap: dict, W: int, tie_tol: float = 2e-6, kink_stats: dict = None):
     """Oracle forward that takes the device's decisions at the two non-differentiable points of a block: the
     MaxPool2d((2,1)) argmax (``tap["amax<l>"]``) and the PReLU branch (sign of ``tap["p<l>"]``).  Wherever a
     decision differs from torch's own, the oracle's values must sit on the kink to fp32 rounding (the two pooled
     rows equal, or the pre-activation ~0; ``tie_tol`` relative to the tensor's max): either side is a valid
     sub-gradient there.  Sharing the decisions lets every downstream gradient be compared at fp32 tolerance.
-    Returns (sigmoid output, latent, number of shared kink decisions)."""
+    Returns (sigmoid output, latent, number of shared kink decisions).  ``kink_stats`` (optional dict) accumulates how
+    wide the shared decisions were: ``n`` of them, ``n_wide`` with |delta| above the one-step rule (2e-6 of the tensor's
+    max), ``max_rel`` the widest -- a test that allows a looser ``tie_tol`` prints these."""
     h = ref.log_mel(x, masks)
     n_kinks = 0
+
+    def note(gap: T, scale: float) -> None:
+        if kink_stats is not None and gap.numel():
+            rel = gap / max(scale, 1e-30)
+            kink_stats["n"] = kink_stats.get("n", 0) + int(rel.numel())
+            kink_stats["n_wide"] = kink_stats.get("n_wide", 0) + int((rel > 2e-6).sum())
+            kink_stats["max_rel"] = max(kink_stats.get("max_rel", 0.0), float(rel.max()))
     for i, m in enumerate(ref.cnn):
         blk = i // 4
         if isinstance(m, nn.MaxPool2d):
@@ -160,6 +169,7 @@ def forward_routed(ref: "Spectral2DCNN", x: T, masks, tap: dict, W: int, tie_tol
             if diff.any():
                 assert float((top - bot).abs()[diff].max()) <= tie_tol * float(h.detach().abs().max()), \
                     "argmax differs away from a tie"
+                note((top - bot).detach().abs()[diff], float(h.detach().abs().max()))
                 n_kinks += int(diff.sum())
             h = torch.where(pick, bot, top)
         elif isinstance(m, nn.PReLU):
@@ -168,6 +178,7 @@ def forward_routed(ref: "Spectral2DCNN", x: T, masks, tap: dict, W: int, tie_tol
             if diff.any():
                 assert float(h.detach().abs()[diff].max()) <= tie_tol * float(h.detach().abs().max()), \
                     "PReLU branch differs away from zero"
+                note(h.detach().abs()[diff], float(h.detach().abs().max()))
                 n_kinks += int(diff.sum())
             h = torch.where(pos, h, m.weight.view(1, -1, 1, 1) * h)
         else:

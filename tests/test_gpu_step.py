@@ -152,6 +152,7 @@ def test_lfo_extraction_twenty_step_trajectory_vs_oracle(dev):
     batcher = data_modules.SyntheticFxBatcher(B, n, sr, ("flanger", "chorus", "phaser"), dev, audio_seed=7)
     runner = trainer.Trainer(log_fn=None)
     worst_loss, n_shared = 0.0, 0
+    kinks = {}                                               # how wide the shared decisions were (the tie rule here is 1e-4, the one-step tests' 2e-6)
     losses = []
     for i in range(steps):
         dry, wet, mod, _ = batcher.render(batcher.sample_params())
@@ -168,7 +169,7 @@ def test_lfo_extraction_twenty_step_trajectory_vs_oracle(dev):
         class _Routed:
             def __call__(self, x, _masks=None):
                 nonlocal n_shared
-                out, latent, k = om.forward_routed(ref, x, masks, tap, mine.n_frames, tie_tol=1e-4)
+                out, latent, k = om.forward_routed(ref, x, masks, tap, mine.n_frames, tie_tol=1e-4, kink_stats=kinks)
                 n_shared += k
                 return out, latent
 
@@ -198,8 +199,11 @@ def test_lfo_extraction_twenty_step_trajectory_vs_oracle(dev):
     print(f"20-step trajectory: worst per-step loss rel err {worst_loss:.2e}; ||p_hip - p_oracle|| / ||p_oracle - p_init|| "
           f"overall {overall:.2e}, worst tensor {worst_l2:.2e}; max |diff| / max |param| {worst_max:.2e} (abs {worst_abs:.2e} = "
           f"{worst_abs / lr:.2f} lr); elements beyond 1e-3 of their tensor's max: {n_bad} of {n_all}; "
-          f"decisions shared at ties: {n_shared}; loss {losses[0][0]:.5f} -> {losses[-1][0]:.5f}")
+          f"decisions shared at ties: {n_shared}, of them {kinks.get('n_wide', 0)} with |delta| between 2e-6 and 1e-4 of the tensor's max "
+          f"(widest {kinks.get('max_rel', 0.0):.2e}); loss {losses[0][0]:.5f} -> {losses[-1][0]:.5f}")
     assert worst_loss < 1e-4
+    assert kinks.get("max_rel", 0.0) <= 1e-4                   # (widest decision shared with the device: on record in measured_errors.json)
+    assert kinks.get("n_wide", 0) / max(1, n_shared) <= 1e-0   # share of the shared decisions wider than the one-step rule (2e-6)
     assert overall < 1e-3
     assert worst_l2 < 1e-3
     assert n_bad / n_all < 1e-3

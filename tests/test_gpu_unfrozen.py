@@ -99,6 +99,7 @@ def test_unfrozen_lfo_tbptt_step_vs_oracle(dev):
     assert (n_c - W) // S == 1
     lo = (n - n_c) // 2
     g = torch.Generator().manual_seed(77)
+    kinks = {}                                               # width of the decisions shared with the device (tie rule 1e-4 here)
     for step in range(2):
         dry = torch.rand(B, 1, n, generator=g) * 1.6 - 0.8
         wet = (0.7 * dry + 0.25 * torch.roll(dry, 3, -1)).clamp(-1, 1)
@@ -113,7 +114,7 @@ def test_unfrozen_lfo_tbptt_step_vs_oracle(dev):
         # ---- the reference loop (lightning.py:310-384) on the oracle's modules, the device's decisions shared
         x_in = torch.cat([dry, wet], dim=1)
         def extract():
-            hat, _, _ = om.forward_routed(ref_cnn, x_in, (0, 0, 0, 0), tap, cnn.n_frames, tie_tol=1e-4)
+            hat, _, _ = om.forward_routed(ref_cnn, x_in, (0, 0, 0, 0), tap, cnn.n_frames, tie_tol=1e-4, kink_stats=kinks)
             hs = hat.squeeze(1).unfold(-1, k, 1).mean(-1)
             return F.interpolate(hs.unsqueeze(1), size=n_c, mode="linear", align_corners=True)
         dry_c, wet_c = dry[..., lo:lo + n_c], wet[..., lo:lo + n_c]
@@ -143,6 +144,10 @@ def test_unfrozen_lfo_tbptt_step_vs_oracle(dev):
                                 list(ref_em.parameters()) + list(ref_cnn.parameters())):
             d = float((p.detach().cpu() - q.detach()).abs().max())
             assert d < 2.5e-4 * (step + 1), (step, name, d)           # <= 2 lr per step (Adam's first steps are ~ lr sign(g))
+    print(f"unfrozen step: decisions shared with the device {kinks.get('n', 0)}, of them {kinks.get('n_wide', 0)} with |delta| between "
+          f"2e-6 and 1e-4 of the tensor's max (widest {kinks.get('max_rel', 0.0):.2e})")
+    assert kinks.get("max_rel", 0.0) <= 1e-4                   # widest decision shared with the device (measured_errors.json)
+    assert kinks.get("n_wide", 0) / max(1, kinks.get("n", 0)) <= 1e-0
     assert opt.step_count == 2
 
 
