@@ -674,7 +674,7 @@ __global__ __launch_bounds__(LS_THREADS + (HELP ? 64 * LS_HELP_WAVES : 0)) void 
             n_a = pa[r0]; n_p = pp_[r0]; n_f = pf[r0]; n_o = po[r0]; n_c = pc[r0]; n_z = dzl[cnt - 1];
             n_h = ph[r0];
         }
-        if (cnt == LS_SLAB) {
+        if (!DGOUT && cnt == LS_SLAB) {           // (the gate-gradient variant keeps the rolled loop: unrolled, its per-step store addresses spill)
 #pragma unroll
             for (int s = LS_SLAB - 1; s >= 0; --s) step(s, LS_SLAB, S, t0, sl, dzl, xll, pa, pp_, pf, po, pc, ph);
         } else {
@@ -742,9 +742,7 @@ static int lstm_bwd_l1_launch(const float *x, int64_t x_stride, const float *lfo
                            DG ? dgate : nullptr, (int)T, probe);                                                                    \
         return mx_launch_status();                                                                                                  \
     }
-    if (dgate) {
-        if (help) LS_BWD_LAUNCH(true, true) else LS_BWD_LAUNCH(true, false)
-    }
+    if (dgate) LS_BWD_LAUNCH(true, false)     // (168 registers per wave are not enough for this variant: it stays fused)
     if (help) LS_BWD_LAUNCH(false, true) else LS_BWD_LAUNCH(false, false)
 #undef LS_BWD_LAUNCH
 }
