@@ -532,6 +532,14 @@ int mx_adamw_step(float *param, const float *grad, float *exp_avg, float *exp_av
                   int64_t step, float lr, float beta1, float beta2, float eps, float weight_decay,
                   float grad_scale, void *stream);
 
+/* mx_reduce_rows + mx_adamw_step in ONE launch for small parameter sets whose gradient arrives as one row per clip (the
+ * LSTM-64's 17 473 parameters, 83 optimizer steps per TBPTT batch: lightning.py:355-384 / configs/opt/adam_w.yml):
+ * part (R, n) -> grad (n,) = column sums (fp64, the order of mx_reduce_rows), then the AdamW update of mx_adamw_step on them.
+ * Bit-identical to the two calls. */
+int mx_reduce_rows_adamw_step(const float *part, int64_t R, float *param, float *grad, float *exp_avg, float *exp_avg_sq,
+                              int64_t n, int64_t step, float lr, float beta1, float beta2, float eps, float weight_decay,
+                              float grad_scale, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -105,6 +105,7 @@ SIGNATURES = {
     "mx_mrstft_loss": [_P, _I64, _P, _I64, _I64, _I64, _I32, _P, _P, _P, _P, _F32, _F32, _F32, _P, _P, _P, _P, _P,
                        _I64, _P],
     "mx_adamw_step": [_P, _P, _P, _P, _I64, _I64, _F32, _F32, _F32, _F32, _F32, _F32, _P],
+    "mx_reduce_rows_adamw_step": [_P, _I64, _P, _P, _P, _P, _I64, _I64, _F32, _F32, _F32, _F32, _F32, _F32, _P],
 }
 
 # measurement twins (same signatures): the dependent chain of the sample-recurrent kernels without global traffic

@@ -38,6 +38,55 @@ MX_EXPORT int mx_adamw_step(float *param, const float *grad, float *exp_avg, flo
     return mx_launch_status();
 }
 
+// Column sums of a small (R, C) matrix of per-clip gradient rows AND the AdamW step on them in one launch: the truncated-BPTT loop
+// of the effect model takes 83 optimizer steps per batch on 17 473 parameters (lightning.py:355-384), where mx_reduce_rows and
+// mx_adamw_step were two ~8 us launches each.  Same arithmetic in the same order as the two entry points (fp64 column sums over
+// rows r, r + 16, ... combined in a fixed order; then adamw_kernel's update of element c): bit-identical results.
+__global__ __launch_bounds__(256) void reduce_rows_adamw_kernel(const float *__restrict__ part, int R, int C, float *__restrict__ p,
+                                                                float *__restrict__ g, float *__restrict__ m, float *__restrict__ v,
+                                                                float lr, float beta1, float beta2, float eps, float wd,
+                                                                float bias_c1, float bias_c2_sqrt, float grad_scale)
+{
+    __shared__ double sh[16][17];
+    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
+    double s = 0.0;
+    if (c < C)
+        for (int r = rl; r < R; r += 16) s += (double)part[(size_t)r * C + c];
+    sh[rl][cl] = s;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += sh[k][cl];
+        const float gsum = (float)t;
+        g[c] = gsum;                                            // the flat gradient stays observable (logging, tests)
+        const float step_size = lr / bias_c1;
+        const float gi = gsum * grad_scale;
+        float pi = p[c] * (1.0f - lr * wd);
+        const float mi = m[c] + (gi - m[c]) * (1.0f - beta1);
+        const float vi = v[c] * beta2 + (1.0f - beta2) * gi * gi;
+        const float denom = sqrtf(vi) / bias_c2_sqrt + eps;
+        pi -= step_size * (mi / denom);
+        p[c] = pi; m[c] = mi; v[c] = vi;
+    }
+}
+
+// part (R, n): one gradient row per clip; grad (n,) receives the column sums; then the AdamW step of mx_adamw_step on them.
+MX_EXPORT int mx_reduce_rows_adamw_step(const float *part, int64_t R, float *param, float *grad, float *exp_avg, float *exp_avg_sq,
+                                        int64_t n, int64_t step, float lr, float beta1, float beta2, float eps, float weight_decay,
+                                        float grad_scale, void *stream)
+{
+    if (!part || !param || !grad || !exp_avg || !exp_avg_sq || R <= 0 || n <= 0 || step <= 0) return MX_ERR_ARG;
+    if (n >= (1ll << 31) || R >= (1ll << 31)) return MX_ERR_UNSUPPORTED;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    hipLaunchKernelGGL(reduce_rows_adamw_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, (hipStream_t)stream, part, (int)R,
+                       (int)n, param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2),
+                       grad_scale);
+    return mx_launch_status();
+}
+
 // out[plane] = sum of the H x Wv valid region of plane (B*C planes of (H, 352)); fp64 accumulate.
 __global__ __launch_bounds__(256) void plane_sum_kernel(const float *__restrict__ x, int H, int Wv,
                                                         float *__restrict__ out)

@@ -367,9 +367,9 @@ class TBPTTLFOEffectModeling(BaseLightingModule):
                 raise ValueError("freeze_lfo_model: false re-extracts the LFO of EVERY clip inside the step (lightning.py:344-349): "
                                  "it cannot be combined with clips dropped by discard_invalid_lfos")
             lfo_in = stack_dry_wet(batch[0], batch[1]) if self.use_dry else batch[1]
+        from .models import LSTM_NPARAM
         if relearn and not general:
             g_off = (em.lstm.weight_ih_l0.grad.data_ptr() - optimizer.flat_grad.data_ptr()) // 4
-            from .models import LSTM_NPARAM
             assert em.fc.bias.grad.data_ptr() == optimizer.flat_grad.data_ptr() + 4 * (g_off + LSTM_NPARAM - 1), \
                 "the effect model's parameters must be contiguous in the flat gradient (state-dict order)"
             lstm_grad = optimizer.flat_grad[g_off:g_off + LSTM_NPARAM]
@@ -429,6 +429,13 @@ class TBPTTLFOEffectModeling(BaseLightingModule):
                 elif is_training:
                     y, h0, c0 = em.run_chunk(x, lat, stash)
                     # no zero_grad(): the BPTT launch OVERWRITES the whole flat gradient (one fill kernel less per step)
+                    if self._fused_l1 and world_size == 1 and optimizer.numel == LSTM_NPARAM:
+                        # one process, only the LSTM trained: row sum + AdamW in one launch (bit-identical to the two below)
+                        optimizer.step_from_rows(em.bptt_l1_chunk(x, lat, y, tgt, stash, h0, c0, w_l1 / (B * S), None))
+                        em.detach_hidden()
+                        done += 1
+                        chunks.append(y)
+                        continue
                     if self._fused_l1:
                         em.bptt_l1_chunk(x, lat, y, tgt, stash, h0, c0, w_l1 / (B * S), optimizer.flat_grad)
                     else:       # lightning.py:380-382 with any loss_dict: d loss / d y from the loss kernels, then BPTT

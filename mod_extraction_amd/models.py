@@ -853,11 +853,12 @@ class LSTMEffectModel(HiddenStateModel):
         return y, h0, c0
 
     def bptt_l1_chunk(self, x: T, latent: T, y: T, wet: T, stash: T, h0: T, c0: T, loss_scale: float,
-                      grad_out: T) -> None:
+                      grad_out: Optional[T]) -> Optional[T]:
         """BPTT of one chunk with the L1 loss fused; the summed parameter gradient (17473,) in
-        state-dict order is written to ``grad_out``."""
+        state-dict order is written to ``grad_out``.  ``grad_out=None``: the per-clip gradient rows (B, 17473) are returned
+        unsummed (``FlatAdamW.step_from_rows`` sums them and steps in one launch)."""
         B, _, Tn = x.shape
-        assert grad_out.numel() == LSTM_NPARAM and grad_out.is_contiguous()     # every element is overwritten below
+        assert grad_out is None or (grad_out.numel() == LSTM_NPARAM and grad_out.is_contiguous())     # every element is overwritten below
         part = torch.empty((B, LSTM_NPARAM), device=x.device, dtype=torch.float32)
         xp, xs = _rows(x)
         lp, ls = _rows(latent)
@@ -866,7 +867,10 @@ class LSTMEffectModel(HiddenStateModel):
         _hip.call("mx_lstm_bwd_l1", xp, xs, lp, ls, yp, ys, wp, ws, _hip.ptr(stash),
                   _hip.ptr(self.lstm.weight_hh_l0.detach().contiguous()), _hip.ptr(self.fc.weight.detach().contiguous()),
                   _hip.ptr(h0.contiguous()), _hip.ptr(c0.contiguous()), float(loss_scale), _hip.ptr(part), B, Tn, _hip.stream())
+        if grad_out is None:
+            return part
         _hip.call("mx_reduce_rows", _hip.ptr(part), B, LSTM_NPARAM, 0, _hip.ptr(grad_out), _hip.stream())
+        return None
 
     def bptt_chunk(self, x: T, latent: T, y: T, dy: T, stash: T, h0: T, c0: T, grad_out: T) -> None:
         """BPTT of one chunk for ANY loss: ``dy`` (B,1,T) or (B,T) = d loss / d y (``effect_losses.effect_loss_grad``);

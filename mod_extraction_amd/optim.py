@@ -72,6 +72,16 @@ class FlatAdamW:
                   _hip.ptr(self.exp_avg_sq), self.numel, self.step_count, self.lr, self.betas[0], self.betas[1],
                   self.eps, self.weight_decay, float(grad_scale), _hip.stream())
 
+    def step_from_rows(self, part: torch.Tensor, grad_scale: float = 1.0) -> None:
+        """``flat_grad = part.sum(0)`` (one gradient row per clip, the order of ``mx_reduce_rows``) and the AdamW step in ONE
+        launch -- the TBPTT loop of the effect model takes 83 optimizer steps per batch on 17 473 parameters.  Bit-identical
+        to ``mx_reduce_rows`` followed by ``step()``."""
+        assert part.dim() == 2 and part.size(1) == self.numel and part.is_contiguous() and part.dtype == torch.float32
+        self.step_count += 1
+        _hip.call("mx_reduce_rows_adamw_step", _hip.ptr(part), part.size(0), _hip.ptr(self.flat_param), _hip.ptr(self.flat_grad),
+                  _hip.ptr(self.exp_avg), _hip.ptr(self.exp_avg_sq), self.numel, self.step_count, self.lr, self.betas[0],
+                  self.betas[1], self.eps, self.weight_decay, float(grad_scale), _hip.stream())
+
     def state_dict(self) -> Dict[str, object]:
         return {"step": self.step_count, "exp_avg": self.exp_avg.clone(), "exp_avg_sq": self.exp_avg_sq.clone(),
                 "lr": self.lr, "betas": self.betas, "eps": self.eps, "weight_decay": self.weight_decay}
