@@ -315,3 +315,24 @@ def test_tbptt_training_with_other_losses_vs_oracle(dev, ld, W, S, n):
         d = (v.cpu() - ref.state_dict()[k]).abs()
         moved = (ref.state_dict()[k] - init[k]).abs()
         assert float(d.median()) < 0.02 * max(float(moved.median()), 1e-9), k
+
+
+def test_reduce_rows_adamw_step_is_the_two_launches_in_one(dev):
+    """mx_reduce_rows_adamw_step (the TBPTT loop's 83 optimizer steps per batch, one process, frozen extractor) against
+    mx_reduce_rows followed by mx_adamw_step on the same rows: flat gradient, parameters and both moments bit-identical
+    over three steps (same fp64 column sums in the same order, same update expression)."""
+    from mod_extraction_amd import _hip, optim
+    torch.manual_seed(3)
+    n, rows = 17473, 128
+    pa = [torch.nn.Parameter(torch.randn(n, device=dev) * 0.1)]
+    pb = [torch.nn.Parameter(pa[0].detach().clone())]
+    oa, ob = optim.FlatAdamW(pa, lr=1e-3, betas=(0.8, 0.99)), optim.FlatAdamW(pb, lr=1e-3, betas=(0.8, 0.99))
+    for step in range(3):
+        part = torch.randn(rows, n, device=dev) * (10.0 ** -step)
+        _hip.call("mx_reduce_rows", _hip.ptr(part), rows, n, 0, _hip.ptr(oa.flat_grad), _hip.stream())
+        oa.step(grad_scale=0.5)
+        ob.step_from_rows(part, grad_scale=0.5)
+        assert torch.equal(oa.flat_grad, ob.flat_grad)
+        assert torch.equal(oa.flat_param, ob.flat_param)
+        assert torch.equal(oa.exp_avg, ob.exp_avg) and torch.equal(oa.exp_avg_sq, ob.exp_avg_sq)
+    assert oa.step_count == ob.step_count == 3
