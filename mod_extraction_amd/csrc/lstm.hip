@@ -45,7 +45,7 @@
 #define LS_THREADS 512
 #define LS_SLAB 32          // steps per stash slab (backward)
 #define LS_PP 72            // plane pitch inside a slab row (64 + 8: the four gate planes land on different banks)
-#define LS_ROWP (6 * LS_PP) // slab row pitch (floats)
+#define LS_ROWP (7 * LS_PP) // slab row pitch (floats): the stash's six planes (i, f, g, o, c, h) + tanh(c), formed once per slab (backward)
 #define LS_SLAB_FLOATS ((LS_SLAB + 2) * LS_ROWP + LS_SLAB + 72)   // rows -1 .. 32, dzy, (lfo, x) of 36 steps
 #define LS_DGL_FLOATS 1024                                        // backward: ring of four gate-gradient vectors
 #define LS_BWD_LDS_FLOATS (2 * LS_SLAB_FLOATS + LS_DGL_FLOATS + LS_THREADS + 768)
@@ -399,6 +399,9 @@ __device__ __forceinline__ int ls_dg_slot(int r)   // LDS slot of gate row r: [1
 // join the same ONE barrier per step, so nothing about the hand-over changes; the eight recurrence waves no longer stall in-order
 // behind two 64-cycle matrix instructions and their five operand reads at the top of every second step.
 #define LS_HELP_WAVES 4
+#ifndef LSB_ABL
+#define LSB_ABL 0    // diagnostic builds only (tools/exp_lstm_bwd.py; wrong results): bit 0 helper waves idle, 1 no prefetch reads of the
+#endif               // stash values, 2 no slab staging after the first slab
 template <bool DGOUT, bool HELP>    // DGOUT: also write the gate gradients (B, T, 256) -- the input of mx_lstm_dlfo (an UNFROZEN LFO model, lightning.py:258,361)
 __global__ __launch_bounds__(LS_THREADS + (HELP ? 64 * LS_HELP_WAVES : 0)) void lstm_bwd_kernel(const float *__restrict__ x, long long xs,
                                                               const float *__restrict__ lfo, long long ls,
@@ -432,28 +435,41 @@ __global__ __launch_bounds__(LS_THREADS + (HELP ? 64 * LS_HELP_WAVES : 0)) void 
         float di00 = 0.0f, di01 = 0.0f, di10 = 0.0f, di11 = 0.0f, dbs0 = 0.0f, dbs1 = 0.0f;
         const float *lbh = lfo + (size_t)b * ls, *xbh = x + (size_t)b * xs;
         const int n_slabs_h = (T + LS_SLAB - 1) / LS_SLAB;
+        float dfw_h = 0.0f, dfb_h = 0.0f;                      // helper 0: d fc.weight[lane] = sum_t dzy_t h_t[lane], d fc.bias = sum_t dzy_t
         __syncthreads();                                       // the recurrence waves' first slab is in LDS, dgl is zeroed
+        __syncthreads();                                       // ... and its tanh(c) plane
         for (int S = n_slabs_h - 1; S >= 0; --S) {
             const int t0 = S * LS_SLAB, cnt = min(LS_SLAB, T - t0);
             const float *sl = (S & 1 ? slab1 : slab0) + LS_ROWP;
-            const float *xll = (S & 1 ? slab1 : slab0) + (LS_SLAB + 2) * LS_ROWP + LS_SLAB;
+            const float *dzlh = (S & 1 ? slab1 : slab0) + (LS_SLAB + 2) * LS_ROWP;
+            const float *xll = dzlh + LS_SLAB;
             for (int s_ = cnt - 1; s_ >= 0; --s_) {
-                if ((T - 1 - (t0 + s_)) & 1) {
+                if (!(LSB_ABL & 1) && hw == 0) {               // the output layer's gradients (they were two instructions + one LDS read of every recurrence wave and step)
+                    const float dzy_ = dzlh[s_];
+                    dfw_h = fmaf(dzy_, sl[s_ * LS_ROWP + 5 * LS_PP + lane], dfw_h);
+                    dfb_h += dzy_;
+                }
+                if (!(LSB_ABL & 1) && ((T - 1 - (t0 + s_)) & 1)) {
                     const float *dgb = dgl + ((s_ + 1 + tparh) & 3) * 256;         // dg(t + 1) / dg(t + 2): buffer t & 3, t0 is a multiple of 4
                     const float av0 = dgb[a_slot0], av1 = dgb[a_slot1];
                     const float *hrow = sl + (s_ + tparh) * LS_ROWP + 5 * LS_PP;
                     const float bv0 = hrow[c32h], bv1 = hrow[32 + c32h];
                     const float li = xll[s_ + 1 + tparh], xi = xll[36 + s_ + 1 + tparh];
+#if LSB_ABL & 32     // ablation: the helper's reads and sums, no matrix instructions
+                    dbs0 += bv0 + bv1;
+#else
                     w00 = mfma32(av0, bv0, w00);
                     w10 = mfma32(av1, bv0, w10);
                     w01 = mfma32(av0, bv1, w01);
                     w11 = mfma32(av1, bv1, w11);
+#endif
                     di00 = fmaf(av0, li, di00); di01 = fmaf(av0, xi, di01);
                     di10 = fmaf(av1, li, di10); di11 = fmaf(av1, xi, di11);
                     dbs0 += av0; dbs1 += av1;
                 }
                 ls_barrier();
             }
+            if (S > 0 && cnt == 1) { ls_barrier(); ls_barrier(); }     // (the recurrence waves' one-step slab: store / tanh pass behind the step)
         }
         {   // the steps the pairing left over: dg(0) (x) h_init always, dg(1) (x) h_0 when T is odd
             const float *dgb = dgl + tparh * 256;              // dg(0) in buffer 0, dg(1) in buffer 1
@@ -493,6 +509,10 @@ __global__ __launch_bounds__(LS_THREADS + (HELP ? 64 * LS_HELP_WAVES : 0)) void 
             pbh[512 + 16384 + row + 32] = sb1;
             pbh[512 + 16384 + 256 + row + 32] = sb1;
         }
+        if (hw == 0) {
+            pbh[512 + 16384 + 512 + lane] = dfw_h;
+            if (lane == 0) pbh[LS_NPARAM - 1] = dfb_h;
+        }
         return;
     }
     const int rg = lane & 15, kp = wv * 4 + (lane >> 4);       // 16 gate rows 16 rg .. 16 rg + 15, hidden units 2 kp, 2 kp + 1
@@ -507,7 +527,7 @@ __global__ __launch_bounds__(LS_THREADS + (HELP ? 64 * LS_HELP_WAVES : 0)) void 
     // per-lane slab offsets (floats, relative to the row of the step)
     const int off_a = q * LS_PP + k;
     const int off_p = q == 0 ? 2 * LS_PP + k : (q == 1 ? 4 * LS_PP + k - LS_ROWP : (q == 2 ? k : 3 * LS_PP + k));
-    const int off_f = 1 * LS_PP + k, off_o = 3 * LS_PP + k, off_c = 4 * LS_PP + k;
+    const int off_f = 1 * LS_PP + k, off_o = 3 * LS_PP + k, off_c = 6 * LS_PP + k;     // (off_c: the tanh(c) plane)
     const int dg_rd = rg * 4;                                  // + 64 c: the c-th 16-byte chunk of this lane's run of 16 rows
     const bool owner = rg < 8;
     const int dg_wr = ls_dg_slot(q * LS_H + k);
@@ -592,9 +612,21 @@ __global__ __launch_bounds__(LS_THREADS + (HELP ? 64 * LS_HELP_WAVES : 0)) void 
         if (tid >= 160 && tid < 160 + 72) dst[(LS_SLAB + 2) * LS_ROWP + LS_SLAB + tid - 160] = pre_xl;
     };
 
+    // tanh(c) of a stored slab, once per (step, unit): 32 x 64 values = four per thread (one 16-byte read, one write), a barrier
+    // after slab_store.  Every recurrence wave used to evaluate it in every step for the 8 units it differentiates -- 40 wave
+    // instructions per step and workgroup (two of five transcendental) for 64 distinct values, on SIMDs whose vector issue is what
+    // bounds the backward step (two recurrence waves + one helper per SIMD; the fp32 matrix instructions execute on the vector ALUs).
+    auto slab_tanh = [&](float *dst) {
+        const int r = tid >> 4, u4 = (tid & 15) * 4;
+        float *row = dst + (r + 1) * LS_ROWP;
+        const float4 cv = *(const float4 *)(row + 4 * LS_PP + u4);
+        *(float4 *)(row + 6 * LS_PP + u4) = make_float4(ls_tanh(cv.x), ls_tanh(cv.y), ls_tanh(cv.z), ls_tanh(cv.w));
+    };
     for (int i = tid; i < LS_DGL_FLOATS; i += LS_THREADS) dgl[i] = 0.0f;        // dh from "step T" is zero
     slab_load(n_slabs - 1, std::false_type{});
     slab_store((n_slabs - 1) & 1 ? slab1 : slab0, nullptr);
+    __syncthreads();
+    slab_tanh((n_slabs - 1) & 1 ? slab1 : slab0);
     __syncthreads();
 
     float dc_next = 0.0f;
@@ -621,23 +653,30 @@ __global__ __launch_bounds__(LS_THREADS + (HELP ? 64 * LS_HELP_WAVES : 0)) void 
         }
         // (1) the 16 gate gradients of step t+1 this lane multiplies
         const float *dr = dr_base + bc * 256;
+#if !(LSB_ABL & 8)
         const float4 g0 = *(const float4 *)dr, g1 = *(const float4 *)(dr + 64), g2 = *(const float4 *)(dr + 128),
                      g3 = *(const float4 *)(dr + 192);
+#endif
+#if LSB_ABL & 8      // ablation: ONE 16-byte read per lane instead of four (the critical reads' share of the LDS pipe)
+        const float4 g0 = *(const float4 *)dr, g1 = g0, g2 = g0, g3 = g0;
+#endif
         __builtin_amdgcn_sched_barrier(0);                         // (first thing behind the barrier: these four reads head the step's dependent chain)
         // (2) while they arrive: the local derivatives of step t from the values prefetched last step
         const float a = n_a, pp = n_p, f = n_f, o = n_o, dzy = n_z;
-        dfw = fmaf(dzy, n_h, dfw);                                 // d fc.weight[k] = sum_t dzy_t h_t[k]
-        dfb += dzy;
-        const float tc = ls_tanh(n_c);
+        if (!HELP) {
+            dfw = fmaf(dzy, n_h, dfw);                             // d fc.weight[k] = sum_t dzy_t h_t[k]   (HELP: helper wave 0)
+            dfb += dzy;
+        }
+        const float tc = n_c;                                      // tanh(c_t), from the slab's seventh plane
         const float kc = o * fmaf(-tc, tc, 1.0f);                  // d h / d c = o (1 - tanh^2 c)
         const float der = fmaf(a, beta - a, alpha);
         const float kq = der * (q == 3 ? tc : pp);                 // i: g i(1-i); f: c_prev f(1-f); g: i (1-g^2); o: tanh(c) o(1-o)
         // (3) prefetch the raw values of step t-1 (row -1 of the slab is never used as a step)
-        {   // unconditional (s = 0 re-reads row 0): the compiler can then count these reads behind the four above
+        if (!(LSB_ABL & 2)) {   // unconditional (s = 0 re-reads row 0): the compiler can then count these reads behind the four above
             const int sp = s > 0 ? s - 1 : 0;
             n_a = pa[sp * LS_ROWP]; n_p = pp_[sp * LS_ROWP]; n_f = pf[sp * LS_ROWP]; n_o = po[sp * LS_ROWP]; n_c = pc[sp * LS_ROWP];
             n_z = dzl[sp];
-            n_h = ph[sp * LS_ROWP];
+            if (!HELP) n_h = ph[sp * LS_ROWP];
         }
         __builtin_amdgcn_sched_barrier(0);                         // (the prefetch reads stay in FRONT of the FMA chain: sunk to the end of
                                                                    //  the step they sit between the dg write and the barrier, on the critical path)
@@ -657,7 +696,8 @@ __global__ __launch_bounds__(LS_THREADS + (HELP ? 64 * LS_HELP_WAVES : 0)) void 
         dc_next = dc * f;
         wr_base[bw * 256] = dg;
         if (DGOUT && owner) dgate[((size_t)b * T + (t0 + s)) * 256 + q * LS_H + k] = dg;       // row order of weight_ih_l0: gate * 64 + unit
-        if (S > 0 && s == cnt / 2) slab_store((S - 1) & 1 ? slab1 : slab0, S & 1 ? slab1 : slab0);   // the other buffer is idle
+        if (!(LSB_ABL & 4) && S > 0 && cnt > 1 && s == cnt / 2) slab_store((S - 1) & 1 ? slab1 : slab0, S & 1 ? slab1 : slab0);   // the other buffer is idle
+        if (!(LSB_ABL & 4) && S > 0 && cnt > 1 && s == cnt / 2 - 1) slab_tanh((S - 1) & 1 ? slab1 : slab0);                      // one barrier later
         ls_barrier();
         __builtin_amdgcn_sched_barrier(0);                         // (nothing of the next step is hoisted in front of the barrier)
     };
@@ -667,18 +707,24 @@ __global__ __launch_bounds__(LS_THREADS + (HELP ? 64 * LS_HELP_WAVES : 0)) void 
         const float *dzl = (S & 1 ? slab1 : slab0) + (LS_SLAB + 2) * LS_ROWP;
         const float *xll = dzl + LS_SLAB;                              // lfo[t0 + i] at i, x[t0 + i] at 36 + i
         const float *pa = sl + off_a, *pp_ = sl + off_p, *pf = sl + off_f, *po = sl + off_o, *pc = sl + off_c, *ph = sl + off_h;
-        if (S > 0) slab_load(S - 1, std::true_type{});
+        if (!(LSB_ABL & 4) && S > 0) slab_load(S - 1, std::true_type{});
         // raw stash values of the first step processed (the steps prefetch one step ahead)
         {
             const int r0 = (cnt - 1) * LS_ROWP;
             n_a = pa[r0]; n_p = pp_[r0]; n_f = pf[r0]; n_o = po[r0]; n_c = pc[r0]; n_z = dzl[cnt - 1];
-            n_h = ph[r0];
+            n_h = HELP ? 0.0f : ph[r0];
         }
         if (!DGOUT && cnt == LS_SLAB) {           // (the gate-gradient variant keeps the rolled loop: unrolled, its per-step store addresses spill)
 #pragma unroll
             for (int s = LS_SLAB - 1; s >= 0; --s) step(s, LS_SLAB, S, t0, sl, dzl, xll, pa, pp_, pf, po, pc, ph);
         } else {
             for (int s = cnt - 1; s >= 0; --s) step(s, cnt, S, t0, sl, dzl, xll, pa, pp_, pf, po, pc, ph);
+        }
+        if (S > 0 && cnt == 1) {                   // a one-step slab (only the clip's last): store and tanh pass behind its step
+            slab_store((S - 1) & 1 ? slab1 : slab0, S & 1 ? slab1 : slab0);
+            ls_barrier();
+            slab_tanh((S - 1) & 1 ? slab1 : slab0);
+            ls_barrier();
         }
     }
     // the steps the pairing above left over: dg(0) (x) h_init always, dg(1) (x) h_0 when T is odd
@@ -715,8 +761,10 @@ __global__ __launch_bounds__(LS_THREADS + (HELP ? 64 * LS_HELP_WAVES : 0)) void 
             pb[512 + 16384 + 256 + row] = sbias;
         }
     }
-    if (rg == 0 || rg == 4) pb[512 + 16384 + 512 + k] = dfw;          // lanes e = 0 / 4 hold units 2 kp / 2 kp + 1
-    if (tid == 0) pb[LS_NPARAM - 1] = dfb;
+    if (!HELP) {
+        if (rg == 0 || rg == 4) pb[512 + 16384 + 512 + k] = dfw;      // lanes e = 0 / 4 hold units 2 kp / 2 kp + 1
+        if (tid == 0) pb[LS_NPARAM - 1] = dfb;
+    }
 }
 
 // part: (B, 17473) gradient rows, one per clip, to be summed with mx_reduce_rows(part, B, 17473, ...).
