@@ -457,6 +457,14 @@ __global__ __launch_bounds__(LS_THREADS + (HELP ? 64 * LS_HELP_WAVES : 0)) void 
                     const float li = xll[s_ + 1 + tparh], xi = xll[36 + s_ + 1 + tparh];
 #if LSB_ABL & 32     // ablation: the helper's reads and sums, no matrix instructions
                     dbs0 += bv0 + bv1;
+#elif LSB_ABL & 64   // ablation (wrong results): the matrix-pipe time of a bf16x3 product instead -- three 32-cycle bf16 instructions per step pair
+                    {
+                        typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+                        const bf16x8 a8 = __builtin_bit_cast(bf16x8, make_float4(av0, av1, bv0, bv1));
+                        w00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, a8, w00, 0, 0, 0);
+                        w01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, a8, w01, 0, 0, 0);
+                        w10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, a8, w10, 0, 0, 0);
+                    }
 #else
                     w00 = mfma32(av0, bv0, w00);
                     w10 = mfma32(av1, bv0, w10);
