@@ -133,7 +133,9 @@ def test_unfrozen_lfo_tbptt_step_vs_oracle(dev):
             for name, p in list(ref_em.named_parameters()) + list(ref_cnn.named_parameters()):
                 kk = p.numel()
                 e = _rel(grads_m[off:off + kk], p.grad.reshape(-1))
-                assert e < 1e-4, (name, e)
+                # LSTM parameters: the recurrence's 1e-4; CNN parameters (behind it in the flat buffer): the suite's 2e-5 CNN gate
+                # and then some for the chain through the LSTM's d loss / d lfo (measured 8.2e-6)
+                assert e < (1e-4 if off < 17473 else 3e-5), (name, e)
                 off += kk
             assert off == opt.numel
         ref_opt.step()
