@@ -705,8 +705,8 @@ def run_config4(args, env):
     em.clear_hidden()
     fwd_bytes = B * S * (12.0 + 1536.0)
     bwd_bytes = B * S * (1536.0 + 16.0) + B * 17473 * 4.0
-    note = ("one 512-thread workgroup per clip; a launch lasts T = 1024 x (latency of one step): LDS exchange of h / dg + "
-            "barrier + the dependent FMA / activation chain (csrc/lstm.hip)")
+    note = ("one workgroup per clip (512 recurrence lanes; backward + 256 helper lanes); a launch lasts T = 1024 x (one step): LDS "
+            "exchange of h / dg + barrier + the dependent FMA / activation chain (csrc/lstm.hip)")
     kernels = {
         "lstm_fwd_kernel": hbm_block(f"lstm_fwd_kernel ({B} clips x {S} steps, models.py:325-339)", fwd_bytes,
                                      iso[0]["mx_lstm_fwd"], iso[1]["mx_lstm_fwd"], bound="latency",
@@ -715,7 +715,7 @@ def run_config4(args, env):
             f"lstm_bwd_kernel ({B} clips x {S} steps, BPTT + L1 + weight gradients, lightning.py:355-384)", bwd_bytes,
             iso[0]["mx_lstm_bwd_l1"], iso[1]["mx_lstm_bwd_l1"], bound="latency",
             note="stash read once (1536 B/sample) + x, lfo, y, wet (16 B/sample) + one gradient row per clip; the weight "
-                 "gradients accumulate on the matrix pipes inside the recurrence (fp32 MFMA, operands from LDS); " + note),
+                 "gradients accumulate in the same launch (exact-fp32 MFMA on four helper waves of the workgroup, operands from LDS); " + note),
     }
     # the independent floor: S x one bare dependent step measured by a stand-alone microbenchmark
     for kind, key in ((0, "lstm_fwd_kernel"), (1, "lstm_bwd_kernel")):

@@ -19,14 +19,21 @@
 //            LDS -- rows never collide, hence one barrier per step.  y_t = tanh(fc h_t + b + x_t) is not on the
 //            recurrent path: it is evaluated for 256 steps at a time from the history, one step per thread.
 //  backward  (serial part) lane = (pair of hidden units, group rg of 16 gate rows): dh_prev[k] = sum_r W[r][k] dg[r]
-//            as 16 v_pk_fma_f32 (two units per packed FMA), an all-reduce over the 16 groups by four DPP adds per
-//            unit, and the element-wise gate derivatives computed by the lanes rg < 8 (one (unit, gate) each) from a
-//            slab of the forward stash that is staged through LDS 32 steps at a time (coalesced, double buffered).
+//            as 16 v_pk_fma_f32 (two units per packed FMA), a reduction over the 16 groups by DPP (the first level hands the
+//            partner the unit IT needs: 2 selects + 4 adds), and the element-wise gate derivatives computed by the lanes rg < 8
+//            (one (unit, gate) each) from a slab of the forward stash that is staged through LDS 32 steps at a time (coalesced,
+//            double buffered; tanh(c) is added to the slab as a seventh plane by one pass per slab).  Round 6: the step is
+//            unrolled over a full slab -- every LDS address is a per-slab lane register + an immediate, the gate gradients live
+//            in a ring of four buffers (t & 3) -- and the backward step turned out to be bound by the SIMD's vector ISSUE
+//            (two recurrence waves per SIMD), not by latency.
 //            The weight gradients do not feed the recurrence: dW_hh = sum_t dg_t (x) h_{t-1} accumulates in the SAME
-//            kernel on the matrix pipes, which the recurrence leaves idle -- two v_mfma_f32_32x32x2_f32 (exact fp32) per
-//            wave every second step, on the gate gradients of steps t+1, t+2 that sit in LDS anyway (three rotating
-//            buffers) and the h rows of the stash slab; dW_ih / biases ride along on the A fragment, fc on the unit
-//            lanes.  (First version: gate gradients written to HBM and a separate GEMM kernel per chunk, 0.10-0.14 ms.)
+//            kernel as exact-fp32 products (v_mfma_f32_32x32x2_f32 -- which executes on the SIMD's fp32 vector ALUs), on the
+//            gate gradients of steps t+1, t+2 that sit in LDS anyway and the h rows of the stash slab.  Round 6: FOUR HELPER
+//            WAVES of the workgroup (one per SIMD, 64 gate rows = four tiles each) issue them, so that the in-order recurrence
+//            waves do not stall behind two 64-cycle instructions; dW_ih / biases ride along on the A values, the output layer's
+//            gradients on helper 0.  (First version: gate gradients written to HBM and a separate GEMM kernel per chunk,
+//            0.10-0.14 ms; rounds 2-5: inside the recurrence waves.)  The variant that also leaves the gate gradients
+//            (mx_lstm_bwd_dgate) keeps the round-5 shape: rolled loop, products in the recurrence waves.
 // One gradient row per clip (state-dict order) is summed over the batch by mx_reduce_rows (deterministic, no atomics).
 //
 // Activations use v_exp_f32 / v_rcp_f32 (1 ulp each): sigmoid(x) = 1 / (1 + 2^(-x log2 e)),
