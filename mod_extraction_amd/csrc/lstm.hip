@@ -225,7 +225,10 @@ __global__ __launch_bounds__(128 * KQ) void lstm_fwd_kernel(const float *__restr
                             stg[(j - 1) * LS_STASH + st_off2] = st_c ? pend_c : (st_h ? pend_h : pend_a);
                         }
                     }
-                    ls_f2 acc = wi1 * in.y + (wi0 * in.x + bias);
+                    // input term as two packed FMAs (the rolled loop below keeps the unfused 4-instruction form: same value to 1 ulp)
+                    ls_f2 acc;
+                    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(acc) : "v"(wi0), "v"(in), "v"(bias));
+                    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0]" : "+v"(acc) : "v"(wi1), "v"(in));
                     LS_PK16(acc, wp, h0, h1, h2, h3);
                     if (KQ == 2) {
                         const ls_f2 *wq = wp + (KQ == 2 ? 16 : 0);
