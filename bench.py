@@ -718,7 +718,7 @@ def run_config4(args, env):
                  "gradients accumulate in the same launch (exact-fp32 MFMA on four helper waves of the workgroup, operands from LDS); " + note),
     }
     # the independent floor: S x one bare dependent step measured by a stand-alone microbenchmark
-    for kind, key in ((0, "lstm_fwd_kernel"), (1, "lstm_bwd_kernel")):
+    for kind, key in ((2, "lstm_fwd_kernel"), (1, "lstm_bwd_kernel")):       # (2: the forward step of the 256-lane kernel the product launches)
         try:
             ns = lstm_step_ns(device, kind)
             k_ = kernels[key]
@@ -727,9 +727,10 @@ def run_config4(args, env):
             k_["independent_floor_ms"] = round(S * ns * 1e-6, 4)
             k_["frac_of_independent_floor"] = round(k_["independent_floor_ms"] / k_["avg_launch_ms"], 4)
             k_["independent_floor_note"] = (
-                f"{S} steps x the duration of ONE bare dependent step measured by mx_lstm_step_probe({kind}) on one 512-lane "
-                "workgroup: " + ("LDS broadcast of h -> 16 packed FMAs -> cross-lane adds -> v_exp / v_rcp gate -> exchange -> cell "
-                                 "update -> tanh -> LDS write -> s_barrier" if kind == 0 else
+                f"{S} steps x the duration of ONE bare dependent step measured by mx_lstm_step_probe({kind}) on one "
+                f"{256 if kind == 2 else 512}-lane workgroup: " +
+                                ("LDS broadcast of h -> 32 packed FMAs -> cross-lane add -> v_exp / v_rcp gate -> exchange -> cell "
+                                 "update -> tanh -> LDS write -> s_barrier" if kind != 1 else
                                  "gate gradients from LDS -> 16 packed FMAs -> all-reduce over 16 row groups -> dh, dc, dg (local "
                                  "derivatives from seven LDS values) -> LDS write -> s_barrier") +
                 "; no global memory, input term, stash, output layer or weight gradients")

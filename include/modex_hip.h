@@ -394,8 +394,9 @@ int mx_phaser_cascade_probe(int64_t steps, float *out, void *stream);
 /* Measurement aid (bench.py, `frac_of_independent_floor` of the LSTM kernels): `steps` dependent recurrent steps of the bare
  * shape of models.py:333 (kind 0: LDS broadcast of h -> 16 packed FMAs -> cross-lane adds -> v_exp / v_rcp gate -> exchange ->
  * cell update -> tanh -> LDS write -> s_barrier) or of its BPTT (kind 1: gate gradients from LDS -> 16 packed FMAs -> all-reduce
- * over 16 row groups -> dh, dc, dg -> LDS write -> s_barrier) on ONE 512-lane workgroup: no global memory, no input term, no
- * stash, no output layer, no weight gradients.  Time / steps x T is a floor of a T-step launch that does not come from the
+ * over 16 row groups -> dh, dc, dg -> LDS write -> s_barrier) on ONE 512-lane workgroup, or (kind 2) the forward step in the
+ * 256-lane decomposition that mx_lstm_fwd launches since round 6 (32 packed FMAs per lane, one cross-lane add): no global memory,
+ * no input term, no stash, no output layer, no weight gradients.  Time / steps x T is a floor of a T-step launch that does not come from the
  * product kernels.  out: 1 float (keeps the chain live).  No reference counterpart. */
 int mx_lstm_step_probe(int32_t kind, int64_t steps, float *out, void *stream);
 

@@ -361,11 +361,12 @@ static int lstm_fwd_launch(const float *x, int64_t x_stride, const float *lfo, i
         B <= 0 || T <= 0)
         return MX_ERR_ARG;
     if (T >= (1ll << 30)) return MX_ERR_UNSUPPORTED;
-    // 8 waves (16 k per lane) when the BPTT stash is written -- its spare lanes carry c and h in the one store -- and
-    // 4 waves (32 k per lane, no idle lanes in the cell update) for inference / warm-up: measured 0.349 vs 0.343 ms with
-    // the stash and 0.343 vs 0.322 ms without, per 128 clips x 1024 steps.  MODEX_LSTM_KQ = 2 | 4 forces one (experiments).
+    // 4 waves (32 k per lane, no idle lanes in the cell update, half the waves at the barrier) for both uses.  Rounds 3-5 ran
+    // 8 waves (16 k per lane; the spare lanes carry c and h in the one stash store) when the BPTT stash is written: 0.349 vs
+    // 0.343 ms then; with round 6's unrolled groups and the deferred stash store the 4-wave kernel is ahead with the stash
+    // too: 0.284 vs 0.305 ms per 128 clips x 1024 steps (0.260 vs 0.315 without).  MODEX_LSTM_KQ = 2 | 4 forces one (experiments).
     static const int kq_env = getenv("MODEX_LSTM_KQ") ? atoi(getenv("MODEX_LSTM_KQ")) : 0;
-    const int kq = kq_env ? kq_env : (stash ? 4 : 2);
+    const int kq = kq_env == 4 ? 4 : 2;
     if (kq == 2)
         hipLaunchKernelGGL(lstm_fwd_kernel<2>, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, x,
                            (long long)x_stride, lfo, (long long)lfo_stride, w_ih, w_hh, b_ih, b_hh, fc_w, fc_b, h_in, c_in,
@@ -898,12 +899,18 @@ MX_EXPORT int mx_lstm_dlfo(const float *dgate, const float *w_ih, int64_t B, int
 //   kind 0 (forward step, models.py:333):  broadcast read of h_{t-1} from LDS (4 x 16 B per lane) -> 16 packed FMAs (two
 //          chains of 8) -> 2 + 2 cross-lane adds -> one gate activation (v_exp_f32, v_rcp_f32) -> exchange of i, f, g, o inside
 //          the unit's 8 lanes -> c = f c + i g -> tanh(c) (v_exp_f32, v_rcp_f32) -> h = o tanh(c) -> LDS write -> s_barrier
-//   kind 1 (backward step, lightning.py:380): read of the 16 gate gradients of step t + 1 -> 16 packed FMAs -> 4 + 4 cross-lane
-//          adds (all-reduce over the 16 row groups) -> dh, dc, dg of step t (the local derivatives tanh(c), o (1 - tanh^2),
-//          a (1 - a) from seven LDS values read beside the gradients) -> LDS write -> s_barrier
+//   kind 1 (backward step, lightning.py:380): read of the 16 gate gradients of step t + 1 -> 16 packed FMAs -> reduction over
+//          the 16 row groups (2 selects + 4 cross-lane adds) -> dh, dc, dg of step t (the local derivatives o (1 - tanh^2 c),
+//          a (1 - a) from six LDS values read beside the gradients; tanh c is one of them since round 6) -> LDS write -> s_barrier
+//   kind 2 (forward step in the 256-lane decomposition, 32 k per lane: what mx_lstm_fwd launches since round 6): 8 x 16 B of h
+//          per lane -> 32 packed FMAs -> 1 + 1 cross-lane adds -> gate activation -> exchange inside the unit's quad -> cell
+//          update -> tanh -> LDS write -> s_barrier (four waves)
 // `steps` such steps on ONE workgroup; time / steps x T is a floor of a T-step launch that does not come from the product kernels.
 __global__ __launch_bounds__(LS_THREADS) void lstm_step_probe_kernel(int steps, int kind, int stride, float *__restrict__ out)
 {
+    // Round 6: the loops run two steps per iteration so that the double-buffered row is addressed by immediates, as the
+    // product kernels address their history / ring rows since this round (the probe must not be slower than what it bounds);
+    // `stride` is 0 at run time (the compiler cannot know) and keeps the saved-value reads of the backward step inside the loop.
     __shared__ __attribute__((aligned(16))) float row[2][256 + 16];      // h (64 used) or gate gradients (256) of the previous step
     __shared__ float vals[8 * 64];                                        // stand-in for the saved activations of a step (backward)
     __shared__ float sink[LS_THREADS];
@@ -911,19 +918,21 @@ __global__ __launch_bounds__(LS_THREADS) void lstm_step_probe_kernel(int steps, 
     ls_f2 w[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) w[j] = (ls_f2){0.001f * (float)((tid + 3 * j) % 17) - 0.008f, 0.001f * (float)((tid + 5 * j) % 13) - 0.006f};
-    for (int i = tid; i < 2 * (256 + 16); i += LS_THREADS) (&row[0][0])[i] = 0.01f * (float)(i % 23) - 0.1f;
-    vals[tid] = 0.3f + 0.001f * (float)(tid & 63);
+    for (int i = tid; i < 2 * (256 + 16); i += blockDim.x) (&row[0][0])[i] = 0.01f * (float)(i % 23) - 0.1f;
+    for (int i = tid; i < 8 * 64; i += blockDim.x) vals[i] = 0.3f + 0.001f * (float)(i & 63);
     __syncthreads();
     float acc_out = 0.0f;
+    const int n_pairs = (steps + 1) / 2;
     if (kind == 0) {
         const int kq = lane & 3, gp = (lane >> 2) & 1, u = wv * 8 + (lane >> 3);
         const bool odd = kq & 1, writer = gp == 0;
         const int q = 2 * gp + (kq & 1);
         const float sc = q == 2 ? 2.0f : 1.0f, nsl2e = -sc * 1.4426950408889634f, oms = 1.0f - sc;
         float c = 0.1f;
-        int cur = 0;
-        for (int t = 0; t < steps; ++t) {
-            const float *hr = &row[cur][16 * kq];
+        float *const wr[2] = {writer ? &row[0][u] : &sink[tid], writer ? &row[1][u] : &sink[tid]};
+        const float *const rd[2] = {&row[0][16 * kq], &row[1][16 * kq]};
+        auto step = [&](const int cur) {
+            const float *hr = rd[cur];
             const float4 h0 = *(const float4 *)hr, h1 = *(const float4 *)(hr + 4), h2 = *(const float4 *)(hr + 8), h3 = *(const float4 *)(hr + 12);
             ls_f2 acc = {0.01f, 0.02f};
             LS_PK16(acc, w, h0, h1, h2, h3);
@@ -935,52 +944,88 @@ __global__ __launch_bounds__(LS_THREADS) void lstm_step_probe_kernel(int steps, 
             const float gi = ls_dpp<0x00>(a), gf = ls_dpp<0x55>(a), gg = ls_dpp<0x55>(m), go = ls_dpp<0x00>(m);
             c = fmaf(gf, c, gi * gg);
             const float hv = go * ls_tanh(c);
-            cur = (cur + 1 + stride) & 1;                                 // `stride` is 0 at run time (the compiler cannot know)
-            *(writer ? &row[cur][u] : &sink[tid]) = hv;
+            *wr[cur ^ 1] = hv;
             ls_barrier();
             acc_out = hv;
-        }
+        };
+        for (int t = 0; t < n_pairs; ++t) { step(0); step(1); }
+    } else if (kind == 2) {
+        // forward step of the 256-lane decomposition (32 k per lane: the kernel the product launches since round 6): a quad holds
+        // i, f, g, o of one unit
+        const int kq = lane & 1, gp = (lane >> 1) & 1, u = wv * 16 + (lane >> 2);
+        const bool odd = kq & 1, writer = (lane & 3) == 0;
+        const int q = 2 * gp + kq;
+        const float sc = q == 2 ? 2.0f : 1.0f, nsl2e = -sc * 1.4426950408889634f, oms = 1.0f - sc;
+        ls_f2 w2[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) w2[j] = (ls_f2){0.001f * (float)((tid + 7 * j) % 19) - 0.009f, 0.001f * (float)((tid + 11 * j) % 23) - 0.011f};
+        float c = 0.1f;
+        float *const wr[2] = {writer ? &row[0][u] : &sink[tid], writer ? &row[1][u] : &sink[tid]};
+        const float *const rd[2] = {&row[0][32 * kq], &row[1][32 * kq]};
+        auto step = [&](const int cur) {
+            const float *hr = rd[cur];
+            const float4 h0 = *(const float4 *)hr, h1 = *(const float4 *)(hr + 4), h2 = *(const float4 *)(hr + 8), h3 = *(const float4 *)(hr + 12);
+            const float4 h4 = *(const float4 *)(hr + 16), h5 = *(const float4 *)(hr + 20), h6 = *(const float4 *)(hr + 24), h7 = *(const float4 *)(hr + 28);
+            ls_f2 acc = {0.01f, 0.02f};
+            LS_PK16(acc, w, h0, h1, h2, h3);
+            LS_PK16(acc, w2, h4, h5, h6, h7);
+            float pa = acc.x, pb = acc.y;
+            pa += ls_dpp<0xB1>(pa); pb += ls_dpp<0xB1>(pb);
+            const float a = ls_act(odd ? pb : pa, nsl2e, sc, oms);
+            const float gi = ls_dpp<0x00>(a), gf = ls_dpp<0x55>(a), gg = ls_dpp<0xAA>(a), go = ls_dpp<0xFF>(a);
+            c = fmaf(gf, c, gi * gg);
+            const float hv = go * ls_tanh(c);
+            *wr[cur ^ 1] = hv;
+            ls_barrier();
+            acc_out = hv;
+        };
+        for (int t = 0; t < n_pairs; ++t) { step(0); step(1); }
     } else {
+        // backward step as the round-6 kernel runs it: tanh(c) is a saved value (formed once per slab, off the chain), the
+        // row-group reduction hands over one component in its first level
         const int rg = lane & 15, kp = wv * 4 + (lane >> 4), e = rg & 7, q = e & 3, k = 2 * kp + (e >> 2);
         const bool second = e >> 2, owner = rg < 8;
         const float alpha = q == 2 ? 1.0f : 0.0f, beta = q == 2 ? 0.0f : 1.0f, fcw = 0.01f * (float)k;
         float dc_next = 0.0f;
-        int cur = 0;
-        for (int t = 0; t < steps; ++t) {
-            const float *dr = &row[cur][rg * 4];
+        float *const wr[2] = {owner ? &row[0][ls_dg_slot(q * LS_H + k)] : &sink[tid], owner ? &row[1][ls_dg_slot(q * LS_H + k)] : &sink[tid]};
+        const float *const rd[2] = {&row[0][rg * 4], &row[1][rg * 4]};
+        int t = 0;
+        auto step = [&](const int cur) {
+            const float *dr = rd[cur];
             const float4 g0 = *(const float4 *)dr, g1 = *(const float4 *)(dr + 64), g2 = *(const float4 *)(dr + 128), g3 = *(const float4 *)(dr + 192);
-            // the saved values of step t (a, its partner, f, o, c, d loss / d pre-tanh output, h): seven LDS reads, as from a staged stash slab
-            const float *v = vals + ((t + stride) & 7) * 64 + (k & 63) - (k & 63) + (lane & 7);
-            const float a = v[0], pp = v[8], f = v[16], o = v[24], cc = v[32], dzy = v[40] * 1e-3f;
-            const float tc = ls_tanh(cc);
+            // the saved values of step t (a, its partner, f, o, tanh c, d loss / d pre-tanh output): six LDS reads, as from a staged stash slab
+            const float *v = vals + ((t + stride) & 7) * 64 + (lane & 7);
+            const float a = v[0], pp = v[8], f = v[16], o = v[24], tc = v[32], dzy = v[40] * 1e-3f;
             const float kc = o * fmaf(-tc, tc, 1.0f);
             const float der = fmaf(a, beta - a, alpha);
             const float kqv = der * (q == 3 ? tc : pp);
             ls_f2 acc = {0.0f, 0.0f};
             LS_PK16(acc, w, g0, g1, g2, g3);
-            float da = acc.x, db = acc.y;
-            da += ls_dpp<0xB1>(da); db += ls_dpp<0xB1>(db);
-            da += ls_dpp<0x4E>(da); db += ls_dpp<0x4E>(db);
-            da += ls_dpp<0x141>(da); db += ls_dpp<0x141>(db);
-            da += ls_dpp<0x140>(da); db += ls_dpp<0x140>(db);
-            const float dhn = second ? db : da;
-            const float dh = fmaf(dzy, fcw, dhn);
+            float keep = second ? acc.y : acc.x;
+            const float send = second ? acc.x : acc.y;
+            keep += ls_dpp<0x141>(send);
+            keep += ls_dpp<0xB1>(keep);
+            keep += ls_dpp<0x4E>(keep);
+            keep += ls_dpp<0x128>(keep);
+            const float dh = fmaf(dzy, fcw, keep);
             const float dc = fmaf(dh, kc, dc_next);
             const float dg = (q == 3 ? dh : dc) * kqv;
             dc_next = dc * f;
-            cur = (cur + 1 + stride) & 1;
-            *(owner ? &row[cur][ls_dg_slot(q * LS_H + k)] : &sink[tid]) = dg;
+            *wr[cur ^ 1] = dg;
             ls_barrier();
             acc_out = dg;
-        }
+            ++t;
+        };
+        for (int p = 0; p < n_pairs; ++p) { step(0); step(1); }
     }
     if (tid == 0) out[0] = acc_out;
 }
 
-// kind 0: forward step, 1: backward step (see above); `steps` dependent steps on one 512-lane workgroup; out: 1 float
+// kind 0: forward step of the 512-lane decomposition (16 k per lane), 1: backward step (512 lanes), 2: forward step of the 256-lane
+// decomposition (32 k per lane; what mx_lstm_fwd launches); `steps` dependent steps on one workgroup; out: 1 float
 MX_EXPORT int mx_lstm_step_probe(int32_t kind, int64_t steps, float *out, void *stream)
 {
-    if (!out || steps <= 0 || steps >= (1ll << 30) || kind < 0 || kind > 1) return MX_ERR_ARG;
-    hipLaunchKernelGGL(lstm_step_probe_kernel, dim3(1), dim3(LS_THREADS), 0, (hipStream_t)stream, (int)steps, (int)kind, 0, out);
+    if (!out || steps <= 0 || steps >= (1ll << 30) || kind < 0 || kind > 2) return MX_ERR_ARG;
+    hipLaunchKernelGGL(lstm_step_probe_kernel, dim3(1), dim3(kind == 2 ? 256 : LS_THREADS), 0, (hipStream_t)stream, (int)steps, (int)kind, 0, out);
     return mx_launch_status();
 }
