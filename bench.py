@@ -52,6 +52,9 @@ import sys
 import time
 
 torch = None        # imported by the worker only: the launcher process must never initialise the GPU
+# multi-process GPU work on this pool needs dmabuf IPC (RCCL / sharing device tensors across processes fail with
+# `hipIpcGetMemHandle: invalid argument` otherwise); the image exports it already -- kept here for any environment the ranks are built in
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)

@@ -36,6 +36,7 @@ def init_distributed(backend: Optional[str] = None) -> Dict[str, int]:
     if env["world_size"] > 1 and not dist.is_initialized():
         if backend is None:
             backend = os.environ.get("MODEX_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC (the only mode this pool's driver supports)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend == "nccl":
