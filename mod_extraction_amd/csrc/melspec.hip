@@ -16,7 +16,6 @@
 // HBM-bound by design: 2*N*4 B read + 2*n_mels*frames*4 B written per clip (1.41 MB at N=88200);
 // the FFT is ~17.7 MFLOP per clip.
 #include "wave_fft.h"
-#include <stdlib.h>
 
 #define MEL_NFFT 1024
 #define MEL_FR 16
@@ -338,14 +337,12 @@ MX_EXPORT int mx_logmel_fwd(const float *x, int64_t planes, int64_t N, const flo
     const size_t lds = ((size_t)n_mels * (MEL_FR + 1) + coef_cap + n_mels + 1) * sizeof(float);
     // static (FFT exchange buffers, twiddles) + dynamic (mel tile, packed filter coefficients) LDS must fit the CU's 160 KB:
     // a large n_mels is MX_ERR_UNSUPPORTED here, not a failed launch; above 64 KB the dynamic part needs the function attribute
-    // MODEX_MELSPEC_WF=1: n_fft = 1024 on the shared register-staged wavefront FFT as well (experiment knob)
-    static const bool wf1024 = getenv("MODEX_MELSPEC_WF") && atoi(getenv("MODEX_MELSPEC_WF")) == 1;
-    const void *fn = n_fft == MEL_NFFT ? (wf1024 ? (const void *)melspec_wf_kernel<1024> : (const void *)melspec_kernel)
+    const void *fn = n_fft == MEL_NFFT ? (const void *)melspec_kernel
                      : n_fft == 512    ? (const void *)melspec_wf_kernel<512>
                                        : (const void *)melspec_wf_kernel<2048>;
-    static size_t static_lds[4] = {0, 0, 0, 0};                   // a constant of the code object, cached
-    static MxLdsLatch latch[4] = {};
-    const int ki = n_fft == MEL_NFFT ? (wf1024 ? 3 : 0) : n_fft == 512 ? 1 : 2;
+    static size_t static_lds[3] = {0, 0, 0};                      // a constant of the code object, cached
+    static MxLdsLatch latch[3] = {};
+    const int ki = n_fft == MEL_NFFT ? 0 : n_fft == 512 ? 1 : 2;
     if (!static_lds[ki]) {
         hipFuncAttributes fa;
         if (hipFuncGetAttributes(&fa, fn) != hipSuccess) return MX_ERR_LAUNCH;
@@ -354,12 +351,6 @@ MX_EXPORT int mx_logmel_fwd(const float *x, int64_t planes, int64_t N, const flo
     const size_t lds_cap = 160 * 1024;
     if (static_lds[ki] + lds > lds_cap) return MX_ERR_UNSUPPORTED;
     if (static_lds[ki] + lds > 64 * 1024 && mx_set_dyn_lds(latch[ki], fn, lds_cap - static_lds[ki]) != MX_OK) return MX_ERR_LAUNCH;
-    if (n_fft == MEL_NFFT && wf1024) {
-        hipLaunchKernelGGL((melspec_wf_kernel<1024>), dim3(tiles, (unsigned)planes), dim3(WF<1024>::WAVES * 64), lds, (hipStream_t)stream,
-                           x, (int)N, window, (const float2 *)twiddle, fb, band_lo, band_hi, (int)n_mels, (int)hop, (int)n_frames,
-                           (int)out_pitch, eps, f0, f1, t0, t1, coef_cap, out);
-        return mx_launch_status();
-    }
     if (n_fft != MEL_NFFT) {
         if (n_fft == 512)
             hipLaunchKernelGGL((melspec_wf_kernel<512>), dim3(tiles, (unsigned)planes), dim3(WF<512>::WAVES * 64), lds, (hipStream_t)stream,
