@@ -101,6 +101,24 @@ __device__ __forceinline__ void load_frame_w(cf (&R)[WF<N>::NB][4], const float 
         }
 }
 
+// the same frame UNWINDOWED (the one-pass kernel fetches a frame while the frame before it is transformed: MR_PREFETCH)
+template <int N, bool INTERIOR>
+__device__ __forceinline__ void fetch_frame(cf (&R)[WF<N>::NB][4], const float *xb, const float *yb, int f, int hop, int T, int a)
+{
+    const float *xf = xb + (f * hop - N / 2 + a), *yf = yb + (f * hop - N / 2 + a);     // dereferenced only when INTERIOR
+#pragma unroll
+    for (int b = 0; b < WF<N>::NB; ++b)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (INTERIOR) {
+                R[b][c] = {xf[WF<N>::L * b + (N / 4) * c], yf[WF<N>::L * b + (N / 4) * c]};
+            } else {
+                const int s = reflect_index(f * hop + a + WF<N>::L * b + (N / 4) * c - N / 2, T);
+                R[b][c] = {xb[s], yb[s]};
+            }
+        }
+}
+
 // spectra of the two real signals from Z = FFT(x + i y):  X[k] = (Z[k] + conj Z[N-k]) / 2,
 // Y[k] = (Z[k] - conj Z[N-k]) / (2 i)
 template <int N>
@@ -357,6 +375,21 @@ __global__ __launch_bounds__(MR_OPW * 64) __attribute__((amdgpu_waves_per_eu(N =
     const unsigned ring1_b = (unsigned)(sidx * 2) * 4u * N, ring2_b = ring1_b + 4u * N;
 
     float *m1 = main1 + (size_t)b * n_frames * hop, *m2 = main2 + (size_t)b * n_frames * hop;
+#ifndef MR_PREFETCH
+#define MR_PREFETCH 1     // the samples of a frame are requested while the frame before it is transformed (0: loaded where they are used)
+#endif
+    // Round 6: a wave spent 31 % of its cycles in s_waitcnt (profiles/r06): every frame began with 2 E global loads whose L2 round trip
+    // nothing covered.  `raw` holds the next frame's unwindowed samples; the window multiplication is the same one, a frame later.
+    cf raw[NB][4];
+    auto fetch = [&](int f, int a) {
+        const int fl_ = f < f_end ? f : (n_frames - 1);                        // dead slots transform a valid frame and contribute nothing
+        // interior (decided for the whole wavefront: a per-position test would put every load in a basic block of its own):
+        // no position of the frame needs the reflection arithmetic, the loads are one base pointer + constant offsets
+        const bool inter_lane = fl_ * hop - N / 2 >= 0 && fl_ * hop + N / 2 <= T;
+        if (__ballot(!inter_lane) == 0ull) fetch_frame<N, true>(raw, xb, yb, fl_, hop, T, a);
+        else fetch_frame<N, false>(raw, xb, yb, fl_, hop, T, a);
+    };
+    if (MR_PREFETCH) fetch(f_begin, a_);
     for (int fp = 0; fp < F; fp += 2) {
         // the lane's position is made opaque to the optimiser again before every transform: the ~100 twiddle / exchange /
         // window addresses built from it would otherwise be shared by the iteration's four transforms (and hoisted out of the
@@ -381,7 +414,13 @@ __global__ __launch_bounds__(MR_OPW * 64) __attribute__((amdgpu_waves_per_eu(N =
             const int f = u ? f1 : f0;
             const bool live = u ? live1 : live0;
             const int fl_ = live ? f : (n_frames - 1);                         // dead slots transform a valid frame and contribute nothing
-            {
+            if (MR_PREFETCH) {
+#pragma unroll
+                for (int bq = 0; bq < NB; ++bq)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) R[bq][c] = raw[bq][c] * wv[bq + (N / 4 / L) * c];
+                fetch(u ? f0 + 2 : f1, a);                                     // the frame after this one, in flight during this transform
+            } else {
                 // interior (decided for the whole wavefront: a per-position test would put every load in a basic block of its own):
                 // no position of the frame needs the reflection arithmetic, the loads are one base pointer + constant offsets
                 const bool inter_lane = fl_ * hop - N / 2 >= 0 && fl_ * hop + N / 2 <= T;
