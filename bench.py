@@ -14,10 +14,17 @@
         --master-port P bench.py --gpus N --steps K --warmup W
 
 Outside torchrun the first form is a LAUNCHER: it never touches the GPU itself, starts the N rank processes (fresh
-children; through torch.distributed.run when N > 1) and relays rank 0's JSON line.  At N = 1 on the headline config it
+children; through torch.distributed.run when N > 1) and relays rank 0's result.  At N = 1 on the headline config it
 then measures configs 2 / 4 / 5 the same way (one fresh process each) and appends them as `other_configs`, so a single
 driver run carries every BASELINE configuration.  `--worker` runs one measurement in the calling process (use that
 form under rocprofv3).
+
+OUTPUT (round 6).  The LAST stdout line is ONE short JSON object (< 6 KB: `compact()` below) -- metric, value, unit,
+n_gpus, steps, warmup, ms_per_step, dtype, config, `roofline` (numbers + one short note), `cpu_baseline`, step statistics,
+floor fractions of the sample-recurrent kernels, and a five-number summary per other config.  Everything else (per-kernel
+tables, notes, floors, the other configs in full) goes to `bench_detail.json` next to this file (`--detail-out PATH`) and,
+as one `BENCH_DETAIL {...}` line, to stderr.  N > 1: the line also carries `allreduce_ms`, `step_ms_per_rank`,
+`rank_median_spread_ms`.
 
 One step of config 2 / 3 = on-device batch synthesis (LFO synth, flanger/chorus, phaser; inputs are generated in
 HBM) -> log-mel -> 6-block 2D-CNN forward -> L1 + 5*FDL1 + 10*SDL1 loss -> backward -> gradient all-reduce (RCCL)
