@@ -13,7 +13,10 @@ from oracle import fx as ofx, losses as olosses, models as om, modulations as om
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("B,T", [(1, 1), (2, 2), (1, 31), (2, 33), (1, 64), (2, 255), (1, 257), (3, 300), (1, 513)])
+@pytest.mark.parametrize("B,T", [(1, 1), (2, 2), (1, 31), (2, 33), (1, 64), (2, 255), (1, 257), (3, 300), (1, 513),
+                                 # round 6: the forward's unrolled groups of 16 and the backward's unrolled 32-step slabs, alone and
+                                 # next to a partial group / slab, a one-slab chunk, a second 256-step block of one group
+                                 (1, 16), (2, 32), (1, 48), (2, 272), (1, 1056)])
 def test_lstm_chunk_lengths_around_the_slab_and_block_sizes(dev, B, T):
     from mod_extraction_amd import models as am
     torch.manual_seed(100 * B + T)
