@@ -325,7 +325,11 @@ def timed_loop(step, steps, world, device, timer_names, key_fn=None):
                 "allreduce_ms": None if not ar else {"mean": round(mean(ar), 4), "max": round(max(ar), 4),
                                                       "per_step": round(sum(ar) / steps, 4), "calls_per_step": len(ar) / steps}}
         ranks = [None] * world
-        torch.distributed.all_gather_object(ranks, mine)
+        try:                                        # (never lose the bench line over the diagnostic gather)
+            torch.distributed.all_gather_object(ranks, mine)
+        except Exception as e:
+            ranks = [mine]
+            stats = dict(stats, per_rank_error=repr(e)[:200])
         stats = dict(stats, per_rank=ranks)
     return float(dt_t), kt.results(), stats, out
 
